@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the upscale hot path (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one batch of --frames-per-step synthetic 2048x1024 RGB frames pushed through the whole
+path (R2C rows -> column FFT/zero-pad/iFFT -> C2R rows -> sharpen) on each GPU, inputs resident in HBM
+(a ring of --ring distinct frames per GPU).  Frames are independent, so N GPUs = N independent shards,
+no data-path collective ("weak" scaling: per-GPU work fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-step", type=int, default=64)
+    ap.add_argument("--ring", type=int, default=4, help="distinct resident input/output frame slots per GPU")
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--upscale", type=float, default=2.0)
+    ap.add_argument("--precision", type=int, default=0, help="0 = fp32 (headline), 2 = fp16 memory")
+    ap.add_argument("--fuse-u8", action="store_true", help="row kernel reads uint8 RGB directly")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--profile-iters", type=int, default=50)
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
+                    help="per-launch HBM bytes of the dominant kernel from a committed rocprofv3 --pmc run")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement, `kind: port`) timed on this host, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib as O
+    from vkresample_amd import synth
+    frames = [synth.frame(k, args.width, args.height, "U") for k in range(args.cpu_frames)]
+    O.upscale_rgb8(synth.frame(99, 64, 32), args.upscale, args.precision)     # load + warm the library
+    t0 = time.perf_counter()
+    for f in frames:
+        O.upscale_rgb8(f, args.upscale, args.precision)
+    dt = time.perf_counter() - t0
+    return {"value": len(frames) / dt, "unit": "frames/s", "cores": O.num_threads(), "kind": "port",
+            "sample": "%d synthetic %dx%d frames through oracle/fftup_oracle.c (fp64, OpenMP), %.1f s"
+                      % (len(frames), args.width, args.height, dt)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+
+    import vkresample_amd as v
+    from vkresample_amd import synth
+    if v.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+    dev = local_rank % v.device_count()
+    flags = v.FLAG_FUSE_U8_LOAD if args.fuse_u8 else 0
+    up = v.Upscaler(args.width, args.height, args.upscale, args.precision, 0.2, dev, flags, args.ring)
+    # distinct frames per rank and slot: rank r owns frames r*ring .. r*ring+ring-1 of the job
+    for s in range(args.ring):
+        up.upload_rgb8(synth.frame(rank * args.ring + s, args.width, args.height, "U"), slot=s)
+
+    def barrier():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    slot = 0
+    for _ in range(args.warmup):
+        up.execute_ring(args.frames_per_step, slot)
+        slot = (slot + args.frames_per_step) % args.ring
+    barrier()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    for _ in range(args.steps):
+        dev_ms += up.execute_ring(args.frames_per_step, slot)      # blocks until the batch has finished
+        slot = (slot + args.frames_per_step) % args.ring
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    frames_total = world * args.steps * args.frames_per_step
+    fps = frames_total / dt
+    line = None
+    if rank == 0:
+        # per-kernel durations with HIP events on the plan's own stream (same process, right after the
+        # timed region, same resident inputs)
+        kms = up.profile_kernels(args.profile_iters)
+        dom = max(range(len(kms)), key=lambda i: kms[i])
+        achieved = up.kernel_alg_bytes[dom] / (kms[dom] * 1e-3) / 1e9
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                tj = json.load(open(args.traffic_json))
+                traffic = tj.get(up.kernel_names[dom], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        frame_ms = dev_ms / (args.steps * args.frames_per_step)
+        line = {
+            "metric": "frames/s, 2048x1024->4096x2048 fp32 FFT upscale (R2C+zero-pad+C2R+sharpen)",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.precision == 0 else "f16-memory/f32-math",
+            "data": "synthetic",
+            "config": {"workload": "%dx%d->%dx%d -u %g -p %d, %d frames/step/GPU, ring of %d resident %s frames/GPU"
+                                   % (args.width, args.height, up.out_width, up.out_height, args.upscale,
+                                      args.precision, args.frames_per_step, args.ring,
+                                      "uint8 RGB (fused load)" if args.fuse_u8 else "planar fp%d" % (16 if args.precision == 2 else 32)),
+                       "frames_per_step": args.frames_per_step, "sharding": "independent frames, no collective",
+                       "kernels": "tuned" if up.tuned else "generic", "device": up.device_name},
+            "ms_per_frame": frame_ms,
+            "frame_alg_bytes": up.alg_bytes_per_frame,
+            "frame_roofline_frac": up.alg_bytes_per_frame / (frame_ms * 1e-3) / 8e12,
+            "kernel_ms": dict(zip(up.kernel_names, kms)),
+            "roofline": {"bound": "hbm", "kernel": up.kernel_names[dom], "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+    up.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+/*
+ * fftup.h -- C ABI of the MI355X-native FFT upscaler (drop-in for VkResample's upscale path).
+ *
+ * The reference (DTolm/VkResample, one translation unit, no plugin layer) exposes the hot path as
+ * the call sequence inside launchResample() (VkResample.cpp, "VR"); vkFFT/vkFFT.h is "VF".
+ * Each entry point below replaces the reference calls cited next to it.  Plain pointers and
+ * sizes only; no C++/torch types.  0 = success, non-zero = FFTUP_E_* (text: fftup_strerror).
+ * The library never exits the process and never falls back to a CPU path: without a usable HIP
+ * device every compute entry point fails with FFTUP_E_NO_DEVICE / FFTUP_E_HIP.
+ *
+ * Threading (mirrors VR:1282-1320, 1959-1969): one plan per host thread; a plan is used by one
+ * thread at a time; distinct plans are independent (own stream, own device buffers).
+ */
+#ifndef FFTUP_H
+#define FFTUP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define FFTUP_API __attribute__((visibility("default")))
+#else
+#define FFTUP_API
+#endif
+
+/* ---- error codes (reference: VkResult ints, 0 = VK_SUCCESS; VR:1286-1320, 1364-1367) ---- */
+enum {
+    FFTUP_OK = 0,
+    FFTUP_E_INVALID_ARG = 1,    /* null pointer, bad slot, odd size, channels != 3 (VR:1368)            */
+    FFTUP_E_UNSUPPORTED_SIZE = 2, /* a dimension is not 2,3,5,7-smooth: VF:4719-4726
+                                     (VK_ERROR_FORMAT_NOT_SUPPORTED), or exceeds the R2C limit VR:1424  */
+    FFTUP_E_UNSUPPORTED_PRECISION = 3, /* -p 1 (double) is not implemented; 0 and 2 are              */
+    FFTUP_E_NO_DEVICE = 4,      /* no HIP device / bad device id (VR:1292-1296)                         */
+    FFTUP_E_HIP = 5,            /* a HIP runtime call failed (message in fftup_last_error)              */
+    FFTUP_E_OUT_OF_MEMORY = 6,  /* device allocation failed (allocateFFTBuffer VR:361-384)              */
+    FFTUP_E_NO_INPUT = 7,       /* execute/download before any upload                                   */
+    FFTUP_E_INCOMPLETE = 8      /* "Image not found" class of errors in the host mirror (VR:1366)       */
+};
+
+/* ---- flags ---- */
+enum {
+    FFTUP_FLAG_U8_WRAP = 1u,       /* u8 store wraps like the x86 C cast of VR:1715 instead of saturating */
+    FFTUP_FLAG_FUSE_U8_LOAD = 2u,  /* row-FFT kernel reads the uint8 RGB image directly (README.md:31
+                                      roadmap item); otherwise upload converts to the reference's planar
+                                      float/half inputBuffer first (VR:1636-1688 semantics)               */
+    FFTUP_FLAG_GENERIC_KERNELS = 4u /* force the size-generic kernels even where a tuned plan exists     */
+};
+
+/* Replaces VkResampleConfiguration (VR:45-59) + the part of VkFFTConfiguration (VF:22-94) that
+ * launchResample() derives from it (VR:1409-1503). */
+typedef struct fftup_config {
+    uint32_t width, height;   /* input image size; both even                                         */
+    uint32_t channels;        /* must be 3 (stbi_load(...,3) VR:1362, channels = 3 VR:1368)           */
+    float    upscale;         /* -u; output = (uint32_t)(upscale*size) (VR:1417-1418)                */
+    uint32_t precision;       /* -p: 0 single, 2 half-memory/fp32-math (VR:1420-1421); 1 unsupported */
+    float    sharpen;         /* -s sharpening constant (VR:1616)                                    */
+    int32_t  device;          /* -d HIP device ordinal                                               */
+    uint32_t flags;           /* FFTUP_FLAG_*                                                        */
+    uint32_t ring;            /* resident input/output frame slots (0 or 1 = one, like the reference) */
+} fftup_config;
+
+typedef struct fftup_plan fftup_plan;   /* opaque; replaces VkGPU + 2x VkFFTApplication +
+                                           2x VkShiftApplication + the three device buffers      */
+
+enum { FFTUP_NUM_KERNELS = 4 };          /* row R2C, column fwd+pad+inv, row C2R, sharpen        */
+
+typedef struct fftup_info {
+    uint32_t out_width, out_height;      /* uW, uH                                                */
+    uint32_t num_kernels;                /* launches per frame                                    */
+    uint32_t tuned;                      /* 1 if size-specialised kernels are in use              */
+    double   alg_bytes_per_frame;        /* B_alg of SURVEY 8(d) for this plan's I/O types        */
+    double   kernel_alg_bytes[FFTUP_NUM_KERNELS]; /* algorithmic bytes moved by each kernel      */
+    uint64_t device_bytes;               /* device memory owned by the plan ("VRAM per thread")   */
+    char     device_name[256];
+    char     kernel_names[FFTUP_NUM_KERNELS][64];
+} fftup_info;
+
+/* devices_list() VR:239-268 */
+FFTUP_API int fftup_device_count(void);
+FFTUP_API int fftup_device_name(int device, char* buf, size_t buflen);
+
+/* initializeVulkanFFT x2 + createShiftApp + createSharpenApp + 3x allocateFFTBuffer
+ * (VR:1437-1448, 1506-1509, 1562, 1617) */
+FFTUP_API int fftup_plan_create(fftup_plan** out, const fftup_config* cfg);
+/* deleteVulkanFFT x2, deleteShiftApp x2, buffer frees (VR:1759-1771) */
+FFTUP_API void fftup_plan_destroy(fftup_plan* plan);
+FFTUP_API int fftup_plan_info(const fftup_plan* plan, fftup_info* info);
+
+/* host pack loop + transferDataFromCPU (VR:1636-1688).  rgb: interleaved 8-bit RGB, H rows of
+ * row_stride_bytes (>= 3*W).  Blocking, like the reference. */
+FFTUP_API int fftup_upload_rgb8(fftup_plan* plan, const uint8_t* rgb, size_t row_stride_bytes);
+FFTUP_API int fftup_upload_rgb8_slot(fftup_plan* plan, uint32_t slot, const uint8_t* rgb, size_t row_stride_bytes);
+/* transferDataFromCPU of an already packed planar buffer: float (precision 0) or IEEE half
+ * (precision 2) planes, 3 planes of H rows; strides in elements (the reference's inputBuffer uses
+ * row stride W and plane stride (W+2)*H, VR:1644). */
+FFTUP_API int fftup_upload_planar(fftup_plan* plan, uint32_t slot, const void* planes,
+                                  size_t row_stride_elems, size_t plane_stride_elems);
+
+/* performVulkanUpscale (VR:1249-1279): enqueue n_iter full pipelines back to back on the plan's
+ * stream, one synchronisation, returns device-timed milliseconds per iteration. */
+FFTUP_API int fftup_execute(fftup_plan* plan, uint32_t n_iter, double* ms_per_iter);
+/* batched mode: n_frames pipelines, frame i reads input slot (first_slot+i) % ring and writes
+ * output slot (first_slot+i) % ring; returns total device milliseconds. */
+FFTUP_API int fftup_execute_ring(fftup_plan* plan, uint32_t n_frames, uint32_t first_slot, double* ms_total);
+/* measurement aid: runs n_iter frames with a HIP event pair around every kernel launch on the
+ * plan's stream and returns the average duration (ms) of each of the FFTUP_NUM_KERNELS kernels. */
+FFTUP_API int fftup_profile_kernels(fftup_plan* plan, uint32_t n_iter, double* ms_per_kernel);
+
+/* transferDataToCPU + unpack loop (VR:1697-1748).  rgb8: u8 = trunc(255*x), saturating unless
+ * FFTUP_FLAG_U8_WRAP.  planar: dense [3][uH][uW] float (precision 0) or half (precision 2). */
+FFTUP_API int fftup_download_rgb8(fftup_plan* plan, uint32_t slot, uint8_t* rgb, size_t row_stride_bytes);
+FFTUP_API int fftup_download_planar(fftup_plan* plan, uint32_t slot, void* planes);
+/* parity-test taps: the C2R output before sharpening (the reference's tempBuffer contents,
+ * dense [3][uH][uW]) of the last executed frame, and the converted input planes [3][H][W]. */
+FFTUP_API int fftup_download_presharpen(fftup_plan* plan, void* planes);
+FFTUP_API int fftup_download_input_planar(fftup_plan* plan, uint32_t slot, void* planes);
+
+FFTUP_API const char* fftup_strerror(int code);
+FFTUP_API const char* fftup_last_error(void);   /* thread-local detail of the last failure */
+FFTUP_API const char* fftup_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFTUP_H */

@@ -1,0 +1,460 @@
+/*
+ * fftup_oracle.c -- CPU ORACLE for the FFT-upscale hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ *   *** PARITY UNPINNED ***  The reference (DTolm/VkResample) ships no tests, no golden
+ *   outputs (its FFT_upscaled*.png are missing, .MISSING_LARGE_BLOBS:1-4) and cannot be built
+ *   or run in this image (needs Vulkan + glslang).  This file is therefore a RESTATEMENT of the
+ *   reference's algorithm, pinned only by analytic known-answer tests (tests/test_oracle_kat.py),
+ *   by numpy.fft, and by an independent index-faithful emulation of the reference's buffer
+ *   layout (oracle/ref_layout_emulation.py).
+ *
+ *   Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call into this file.
+ *   The product (libfftup.so, HIP) never links or loads it.
+ *
+ * What is restated (VR = /root/reference/VkResample.cpp, VF = /root/reference/vkFFT/vkFFT.h):
+ *   load      u8 -> real planes                         VR:1636-1685  (fp32: float(double(v)/255.0) VR:1644,
+ *                                                                      fp16: half((float)half(v)/255.0) VR:1676)
+ *   F0        R2C row FFT, two rows packed as one complex VF:1945-2058 (read), VF:4274-4377 (unpack/write)
+ *   F1,F2     column FFT (DC column + columns 1..W/2)    VF:5190-6040, VF:1656-1717, dispatch VF:7740-7789
+ *   S         in-place shift of rows [H/2,H) to the top  VR:514-526 (R2C branch), sizes VR:1511-1562
+ *   I0,I1     column inverse FFT with frequency zero-pad VF:1670-1695, VF:5751-5758; ranges VR:1491-1495
+ *   I2        C2R row inverse (pair packing, DC leak)    VF:2059-2201 (read), VF:4378-4491 (write)
+ *   norm      1/N folded into the inverse stages         VF:2921-2923
+ *   sign      forward = exp(+2 pi i nk/N), inverse = exp(-...)   VF:4545, VF:751
+ *   C         CAS-like sharpen                           VR:819-925, constants VR:1564-1617
+ *   store     (unsigned char)(255.0*x)                   VR:1708-1748 (C cast; saturating variant is ours)
+ *
+ * Arithmetic: IEEE double everywhere ("ideal" semantics of the reference's fp32 math); storage
+ * roundings of `-p 2` (fp16 memory: input, C2R output, and the sharpen shader evaluated in
+ * float16_t) are emulated exactly with round-to-nearest-even half rounding after every operation.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+typedef struct { double re, im; } cpx;
+
+typedef struct {
+    uint32_t width, height;   /* input size                                          */
+    float    upscale;         /* -u (float, VR:1886)                                 */
+    uint32_t precision;       /* 0 = fp32 semantics, 2 = fp16 memory (VR:1420-1421)  */
+    float    sharpen;         /* -s (VR:1875)                                        */
+    uint32_t u8_wrap;         /* 0 = saturating u8 store, 1 = x86 wrap of VR:1715    */
+} orc_config;
+
+/* ------------------------------------------------------------------ small helpers */
+
+/* round a double to the nearest IEEE binary16 value (ties to even); result returned as double */
+static double round_half(double x)
+{
+    if (x != x || isinf(x)) return x;
+    double ax = fabs(x);
+    if (ax == 0.0) return x;
+    if (ax >= 65520.0) return x > 0 ? INFINITY : -INFINITY;   /* overflow threshold of RN */
+    int e;
+    frexp(ax, &e);            /* ax = m * 2^e, m in [0.5,1)  ->  floor(log2 ax) = e-1 */
+    int E = e - 1;
+    if (E < -14) E = -14;     /* subnormal range: fixed quantum 2^-24 */
+    double q = ldexp(1.0, E - 10);
+    double r = nearbyint(ax / q) * q;   /* default rounding mode = RN-even */
+    return x < 0 ? -r : r;
+}
+
+static double round_f32(double x) { return (double)(float)x; }
+
+/* VF:4719-4726: only 2,3,5,7-smooth sizes are accepted */
+static int is_smooth(uint32_t n)
+{
+    if (n == 0) return 0;
+    const uint32_t p[4] = {2, 3, 5, 7};
+    for (int i = 0; i < 4; i++) while (n % p[i] == 0) n /= p[i];
+    return n == 1;
+}
+
+ORC_API int orc_out_dims(const orc_config* c, uint32_t* uW, uint32_t* uH)
+{
+    /* VR:1417-1418: bufferStride = (uint32_t)(config.upscale * size) evaluated in float */
+    *uW = (uint32_t)(c->upscale * (float)c->width);
+    *uH = (uint32_t)(c->upscale * (float)c->height);
+    return 0;
+}
+
+/* returns 0 if the configuration is one the reference's R2C path would run */
+ORC_API int orc_check(const orc_config* c)
+{
+    uint32_t uW, uH;
+    orc_out_dims(c, &uW, &uH);
+    if (c->width < 2 || c->height < 2 || (c->width & 1) || (c->height & 1)) return 1;
+    if (uW < c->width || uH < c->height || (uW & 1) || (uH & 1)) return 1;
+    if (!is_smooth(c->width) || !is_smooth(c->height) || !is_smooth(uW) || !is_smooth(uH)) return 2;
+    if (c->precision != 0 && c->precision != 2) return 3;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ 1-D FFT (double) */
+
+typedef struct {
+    uint32_t n;
+    cpx* tw;            /* tw[k] = exp(+2 pi i k / n) */
+    uint32_t nfac;
+    uint32_t fac[32];
+} fft_plan;
+
+static void plan_init(fft_plan* p, uint32_t n)
+{
+    p->n = n;
+    p->tw = (cpx*)malloc(sizeof(cpx) * n);
+    for (uint32_t k = 0; k < n; k++) {
+        /* octant-symmetric evaluation is unnecessary in double; 1e-16 is far below need */
+        double a = 2.0 * M_PI * (double)k / (double)n;
+        p->tw[k].re = cos(a);
+        p->tw[k].im = sin(a);
+    }
+    p->nfac = 0;
+    uint32_t m = n;
+    const uint32_t pr[4] = {2, 3, 5, 7};
+    for (int i = 0; i < 4; i++) while (m % pr[i] == 0) { p->fac[p->nfac++] = pr[i]; m /= pr[i]; }
+}
+static void plan_free(fft_plan* p) { free(p->tw); p->tw = NULL; }
+
+/* Stockham autosort, decimation in time.  sign=+1: exp(+2 pi i nk/N) ("forward" of the
+ * reference, VF:4545), sign=-1: exp(-...) ("inverse").  No normalisation here.
+ * x: n elements, contiguous.  work: n elements scratch.  Result in x. */
+static void fft1d(const fft_plan* p, cpx* x, cpx* work, int sign)
+{
+    const uint32_t n = p->n;
+    cpx* in = x;
+    cpx* out = work;
+    uint32_t Ns = 1;
+    for (uint32_t s = 0; s < p->nfac; s++) {
+        const uint32_t R = p->fac[s];
+        const uint32_t nb = n / R;
+        const uint32_t tstep = n / (Ns * R);
+        for (uint32_t j = 0; j < nb; j++) {
+            const uint32_t k = j % Ns;
+            cpx v[7];
+            for (uint32_t m = 0; m < R; m++) {
+                cpx a = in[j + m * nb];
+                uint32_t ti = (uint32_t)(((uint64_t)k * m * tstep) % n);
+                double wr = p->tw[ti].re, wi = sign * p->tw[ti].im;
+                v[m].re = a.re * wr - a.im * wi;
+                v[m].im = a.re * wi + a.im * wr;
+            }
+            const uint32_t j0 = (j - k) * R + k;
+            for (uint32_t q = 0; q < R; q++) {
+                double sr = 0, si = 0;
+                for (uint32_t m = 0; m < R; m++) {
+                    uint32_t ti = (uint32_t)(((uint64_t)m * q * nb) % n);   /* exp(2 pi i m q / R) */
+                    double wr = p->tw[ti].re, wi = sign * p->tw[ti].im;
+                    sr += v[m].re * wr - v[m].im * wi;
+                    si += v[m].re * wi + v[m].im * wr;
+                }
+                out[j0 + q * Ns].re = sr;
+                out[j0 + q * Ns].im = si;
+            }
+        }
+        Ns *= R;
+        cpx* t = in; in = out; out = t;
+    }
+    if (in != x) memcpy(x, in, sizeof(cpx) * n);
+}
+
+/* exported for unit tests against numpy.fft: interleaved re/im doubles, in place */
+ORC_API int orc_fft1d(double* data, uint32_t n, int sign)
+{
+    if (!is_smooth(n)) return 2;
+    fft_plan p;
+    plan_init(&p, n);
+    cpx* w = (cpx*)malloc(sizeof(cpx) * n);
+    fft1d(&p, (cpx*)data, w, sign);
+    free(w);
+    plan_free(&p);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ load (A.1) */
+
+/* VR:1644  buffer_input[...] = (float)png_input[...] / 255.0;   (double division, float store)
+ * VR:1676  buffer_input[...] = (half)png_input[...] / 255.0;     (half -> float -> double / -> half) */
+ORC_API double orc_load_u8(uint32_t precision, uint8_t v)
+{
+    if (precision == 2) {
+        double h = round_half((double)v);          /* (half)v : exact for 0..255 */
+        float f = (float)h;                        /* half.hpp arithmetic promotes to float */
+        return round_half((double)f / 255.0);      /* double quotient, RN to half (half.hpp:373-374) */
+    }
+    return (double)(float)((double)(float)v / 255.0);
+}
+
+/* ------------------------------------------------------------------ sharpen (A.4) */
+
+/* the constants reach the shader as "%f" text (VR:893-901, VR:920): 6 decimals, then the GLSL
+ * compiler parses them as float (or float16_t with the HF suffix) */
+static double const_via_percent_f(double v, uint32_t precision)
+{
+    char buf[64];
+    snprintf(buf, sizeof buf, "%f", v);
+    double t = strtod(buf, NULL);
+    return precision == 2 ? round_half(t) : round_f32(t);
+}
+
+/* rounding applied after every shader operation */
+#define RQ(x) (half ? round_half(x) : (x))
+
+static void sharpen_plane(const double* R, double* out, uint32_t uW, uint32_t uH,
+                          double upsq, double coef, int half)
+{
+    const uint64_t plane = (uint64_t)uW * uH;
+#pragma omp parallel for schedule(static)
+    for (int64_t y = 0; y < (int64_t)uH; y++) {
+        for (uint32_t x = 0; x < uW; x++) {
+            /* VR:889-892: lower clamps only; upper comparisons are against size, never true */
+            uint32_t xs[3] = { x > 0 ? x - 1 : x, x, x + 1 };
+            uint32_t ys[3] = { y > 0 ? (uint32_t)y - 1 : (uint32_t)y, (uint32_t)y, (uint32_t)y + 1 };
+            double len[9];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) {
+                    uint64_t f = (uint64_t)xs[b] + (uint64_t)ys[a] * uW;   /* index(): x + y*stride */
+                    /* Reads at/after the end of the plane's written data hit the 2*uH padding
+                     * elements = stale memory in the reference (quirk B5).  Defined here as
+                     * "same column, last written row"; the last row is excluded from parity. */
+                    while (f >= plane) f -= uW;
+                    double t = RQ(upsq * R[f]);            /* tex = upscale * inputs[...]      */
+                    double l = fabs(t);                     /* length(scalar)                   */
+                    if (l > 1.0) l = 1.0;
+                    if (l < 0.0) l = 0.0;
+                    len[a * 3 + b] = l;
+                }
+            double mn0 = fmin(len[1], fmin(len[3], fmin(len[4], fmin(len[5], len[7]))));
+            double mn1 = fmin(mn0, fmin(len[0], fmin(len[2], fmin(len[6], len[8]))));
+            double mx0 = fmax(len[1], fmax(len[3], fmax(len[4], fmax(len[5], len[7]))));
+            double mx1 = fmax(mx0, fmax(len[0], fmax(len[2], fmax(len[6], len[8]))));
+            double minlen = RQ(0.5 * RQ(mn0 + mn1));
+            double maxlen = RQ(0.5 * RQ(mx0 + mx1));
+            minlen = RQ(minlen / RQ(1.0 - minlen));
+            maxlen = RQ(RQ(1.0 - maxlen) / maxlen);
+            double scale = (minlen < maxlen) ? minlen : maxlen;      /* NaN -> maxlen, as the ternary */
+            scale = RQ(-coef * RQ(sqrt(scale)));
+            /* (len[4]+scale*(len[1]+len[3]+len[5]+len[7]))/(1.0+scale*4.0), left-to-right */
+            double s4 = RQ(RQ(RQ(len[1] + len[3]) + len[5]) + len[7]);
+            double num = RQ(len[4] + RQ(scale * s4));
+            double den = RQ(1.0 + RQ(scale * 4.0));
+            out[(uint64_t)y * uW + x] = RQ(num / den);
+        }
+    }
+}
+
+ORC_API int orc_sharpen(const orc_config* c, const double* R, double* out, uint32_t uW, uint32_t uH)
+{
+    const int half = c->precision == 2;
+    double upsq = const_via_percent_f((double)(c->upscale * c->upscale), c->precision); /* VR:1615 float product */
+    double coef = const_via_percent_f((double)c->sharpen, c->precision);
+    for (int ch = 0; ch < 3; ch++)
+        sharpen_plane(R + (uint64_t)ch * uW * uH, out + (uint64_t)ch * uW * uH, uW, uH, upsq, coef, half);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ the pipeline */
+
+/* in_planes: [3][H][W] real (already load-converted).  pre / out: [3][uH][uW] (either may be NULL).
+ * poison_reads (may be NULL) counts spectrum elements read without ever having been written
+ * (the reference would read stale memory there); 0 for every supported configuration. */
+ORC_API int orc_upscale_planes(const orc_config* c, const double* in_planes, double* pre, double* out,
+                               uint64_t* poison_reads)
+{
+    int rc = orc_check(c);
+    if (rc) return rc;
+    const uint32_t W = c->width, H = c->height;
+    uint32_t uW, uH;
+    orc_out_dims(c, &uW, &uH);
+    const uint32_t HX = W / 2 + 1;              /* kx = 0 .. W/2 kept */
+    const int half = c->precision == 2;
+
+    /* zero-pad ranges, VR:1491-1495, evaluated like the reference: uint / float -> float -> uint32 */
+    const uint32_t zlx = W / 2;                                    /* fft_zeropad_left[0]  (column index space) */
+    const uint32_t zrx = uW / 2;                                   /* fft_zeropad_right[0] */
+    const uint32_t zly = (uint32_t)((float)uH / (2 * c->upscale));
+    const uint32_t zry = (uint32_t)((2 * c->upscale - 1) * (float)uH / (2 * c->upscale));
+
+    fft_plan pW, pH, puW, puH;
+    plan_init(&pW, W); plan_init(&pH, H); plan_init(&puW, uW); plan_init(&puH, uH);
+
+    double* Rbuf = pre ? pre : (double*)malloc(sizeof(double) * 3ull * uW * uH);
+    uint64_t poison_total = 0;
+
+    for (int ch = 0; ch < 3; ch++) {
+        const double* x = in_planes + (uint64_t)ch * W * H;
+        /* "buffer": uH rows x HX columns; column kx.  NaN = never written. */
+        cpx* buf = (cpx*)malloc(sizeof(cpx) * (uint64_t)uH * HX);
+        for (uint64_t i = 0; i < (uint64_t)uH * HX; i++) { buf[i].re = NAN; buf[i].im = NAN; }
+
+        /* F0: R2C rows, two real rows as one complex FFT (VF:1945-2058, 4274-4377) */
+#pragma omp parallel
+        {
+            cpx* z = (cpx*)malloc(sizeof(cpx) * W);
+            cpx* w = (cpx*)malloc(sizeof(cpx) * W);
+#pragma omp for schedule(static)
+            for (int64_t j = 0; j < (int64_t)(H / 2); j++) {
+                for (uint32_t n = 0; n < W; n++) { z[n].re = x[(2 * j) * W + n]; z[n].im = x[(2 * j + 1) * W + n]; }
+                fft1d(&pW, z, w, +1);
+                cpx* rowA = buf + (uint64_t)(2 * j) * HX;
+                cpx* rowB = buf + (uint64_t)(2 * j + 1) * HX;
+                /* VF:4292-4312: DC of both rows */
+                rowA[0].re = z[0].re; rowA[0].im = 0.0;
+                rowB[0].re = z[0].im; rowB[0].im = 0.0;
+                for (uint32_t k = 1; k <= W / 2; k++) {           /* VF:4320-4323 */
+                    cpx a = z[k], b = z[W - k];
+                    rowA[k].re = 0.5 * (a.re + b.re);
+                    rowA[k].im = 0.5 * (a.im - b.im);
+                    rowB[k].re = 0.5 * (a.im + b.im);
+                    rowB[k].im = 0.5 * (-a.re + b.re);
+                }
+            }
+            free(z); free(w);
+        }
+
+        /* F1 + F2: forward column FFT of length H on rows [0,H) */
+#pragma omp parallel
+        {
+            cpx* z = (cpx*)malloc(sizeof(cpx) * (H > uH ? H : uH));
+            cpx* w = (cpx*)malloc(sizeof(cpx) * (H > uH ? H : uH));
+#pragma omp for schedule(static)
+            for (int64_t kx = 0; kx < (int64_t)HX; kx++) {
+                for (uint32_t ky = 0; ky < H; ky++) z[ky] = buf[(uint64_t)ky * HX + kx];
+                fft1d(&pH, z, w, +1);
+                for (uint32_t ky = 0; ky < H; ky++) buf[(uint64_t)ky * HX + kx] = z[ky];
+            }
+            free(z); free(w);
+        }
+
+        /* S: rows [H/2,H) -> +uH-H, in place, source rows not cleared (VR:514-526).  For
+         * uH < 1.5 H source and destination overlap and the reference races (quirk B6); here the
+         * copy is taken from the pristine source (descending order is overlap-safe for uH >= H). */
+        if (uH != H)
+            for (int64_t ky = (int64_t)H - 1; ky >= (int64_t)(H / 2); ky--)
+                memcpy(buf + (uint64_t)(ky + uH - H) * HX, buf + (uint64_t)ky * HX, sizeof(cpx) * HX);
+
+        /* I0 + I1: inverse column FFT of length uH with read guards (VF:1670-1695): rows in
+         * [zly,zry) are taken as zero; 1/uH folded in (VF:2921-2923). */
+        uint64_t poison = 0;
+#pragma omp parallel reduction(+:poison)
+        {
+            cpx* z = (cpx*)malloc(sizeof(cpx) * uH);
+            cpx* w = (cpx*)malloc(sizeof(cpx) * uH);
+#pragma omp for schedule(static)
+            for (int64_t kx = 0; kx < (int64_t)HX; kx++) {
+                for (uint32_t ky = 0; ky < uH; ky++) {
+                    if (ky >= zly && ky < zry) { z[ky].re = 0; z[ky].im = 0; continue; }
+                    cpx v = buf[(uint64_t)ky * HX + kx];
+                    if (v.re != v.re) { poison++; v.re = 0; v.im = 0; }
+                    z[ky] = v;
+                }
+                fft1d(&puH, z, w, -1);
+                for (uint32_t ky = 0; ky < uH; ky++) {
+                    buf[(uint64_t)ky * HX + kx].re = z[ky].re / uH;
+                    buf[(uint64_t)ky * HX + kx].im = z[ky].im / uH;
+                }
+            }
+            free(z); free(w);
+        }
+        poison_total += poison;
+
+        /* I2: C2R rows (VF:2059-2201).  Column index c <-> kx = c+1; columns in [zlx,zrx) read as 0. */
+        double* R = Rbuf + (uint64_t)ch * uW * uH;
+#pragma omp parallel
+        {
+            cpx* z = (cpx*)malloc(sizeof(cpx) * uW);
+            cpx* w = (cpx*)malloc(sizeof(cpx) * uW);
+#pragma omp for schedule(static)
+            for (int64_t j = 0; j < (int64_t)(uH / 2); j++) {
+                const cpx* rowA = buf + (uint64_t)(2 * j) * HX;
+                const cpx* rowB = buf + (uint64_t)(2 * j + 1) * HX;
+                for (uint32_t n = 0; n < uW; n++) { z[n].re = 0; z[n].im = 0; }
+                for (uint32_t cidx = 0; cidx < uW / 2; cidx++) {
+                    cpx a = {0, 0}, b = {0, 0};
+                    if (cidx < zlx || cidx >= zrx) {
+                        /* only reachable columns: cidx < W/2 (or all of them when uW == W) */
+                        a = rowA[cidx + 1];
+                        b = rowB[cidx + 1];
+                    }
+                    const uint32_t k = cidx + 1;
+                    z[k].re = a.re - b.im;        z[k].im = a.im + b.re;        /* A + iB           */
+                    z[uW - k].re = a.re + b.im;   z[uW - k].im = -a.im + b.re;  /* conj A + i conj B */
+                }
+                /* VF:2110-2131: DC element from the DC column of BOTH rows, imaginary parts kept */
+                z[0].re = rowA[0].re - rowB[0].im;
+                z[0].im = rowA[0].im + rowB[0].re;
+                fft1d(&puW, z, w, -1);
+                for (uint32_t n = 0; n < uW; n++) {
+                    double r0 = z[n].re / uW, r1 = z[n].im / uW;
+                    if (half) { r0 = round_half(r0); r1 = round_half(r1); }   /* VF:7289-7290 */
+                    R[(uint64_t)(2 * j) * uW + n] = r0;
+                    R[(uint64_t)(2 * j + 1) * uW + n] = r1;
+                }
+            }
+            free(z); free(w);
+        }
+        free(buf);
+    }
+    if (poison_reads) *poison_reads = poison_total;
+
+    if (out) orc_sharpen(c, Rbuf, out, uW, uH);
+    if (!pre) free(Rbuf);
+    plan_free(&pW); plan_free(&pH); plan_free(&puW); plan_free(&puH);
+    return 0;
+}
+
+/* VR:1715: png_output[...] = 255.0 * buffer_output[...]  (double product, C cast to unsigned char) */
+ORC_API uint8_t orc_store_u8(double x, uint32_t wrap)
+{
+    double v = 255.0 * x;
+    if (wrap) {                       /* x86-64 gcc: cvttsd2si then low byte */
+        if (!(v > -2147483648.0 && v < 2147483648.0)) return 0;
+        return (uint8_t)((int32_t)v & 0xFF);
+    }
+    if (!(v > 0.0)) return 0;         /* also NaN */
+    if (v >= 255.0) return 255;
+    return (uint8_t)v;                /* truncation */
+}
+
+/* rgb: [H][W][3] interleaved; pre/out: [3][uH][uW] doubles (NULL ok); rgb_out: [uH][uW][3] (NULL ok) */
+ORC_API int orc_upscale_rgb8(const orc_config* c, const uint8_t* rgb, double* pre, double* out, uint8_t* rgb_out)
+{
+    int rc = orc_check(c);
+    if (rc) return rc;
+    const uint32_t W = c->width, H = c->height;
+    uint32_t uW, uH;
+    orc_out_dims(c, &uW, &uH);
+    double lut[256];
+    for (int v = 0; v < 256; v++) lut[v] = orc_load_u8(c->precision, (uint8_t)v);
+    double* in = (double*)malloc(sizeof(double) * 3ull * W * H);
+    for (int ch = 0; ch < 3; ch++)
+        for (uint64_t i = 0; i < (uint64_t)W * H; i++) in[(uint64_t)ch * W * H + i] = lut[rgb[i * 3 + ch]];
+    double* o = out;
+    if (!o && rgb_out) o = (double*)malloc(sizeof(double) * 3ull * uW * uH);
+    rc = orc_upscale_planes(c, in, pre, o, NULL);
+    if (!rc && rgb_out)
+        for (int ch = 0; ch < 3; ch++)
+            for (uint64_t i = 0; i < (uint64_t)uW * uH; i++)
+                rgb_out[i * 3 + ch] = orc_store_u8(o[(uint64_t)ch * uW * uH + i], c->u8_wrap);
+    if (o != out) free(o);
+    free(in);
+    return rc;
+}
+
+ORC_API int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

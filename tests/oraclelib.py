@@ -1,0 +1,108 @@
+"""ctypes binding of the CPU oracle (oracle/libfftup_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ORACLE_DIR, "libfftup_oracle.so")
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("upscale", C.c_float),
+                ("precision", C.c_uint32), ("sharpen", C.c_float), ("u8_wrap", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(ORACLE_DIR, "fftup_oracle.c")
+        if not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "libfftup_oracle.so"])
+        _lib = C.CDLL(SO)
+        _lib.orc_load_u8.restype = C.c_double
+        _lib.orc_load_u8.argtypes = [C.c_uint32, C.c_uint8]
+        _lib.orc_store_u8.restype = C.c_uint8
+        _lib.orc_store_u8.argtypes = [C.c_double, C.c_uint32]
+    return _lib
+
+
+def _cfg(W, H, upscale=2.0, precision=0, sharpen=0.2, u8_wrap=0):
+    return OrcConfig(W, H, upscale, precision, sharpen, u8_wrap)
+
+
+def out_dims(W, H, upscale):
+    uW, uH = C.c_uint32(), C.c_uint32()
+    cfg = _cfg(W, H, upscale)
+    lib().orc_out_dims(C.byref(cfg), C.byref(uW), C.byref(uH))
+    return uW.value, uH.value
+
+
+def check(W, H, upscale=2.0, precision=0):
+    cfg = _cfg(W, H, upscale, precision)
+    return lib().orc_check(C.byref(cfg))
+
+
+def fft1d(x, sign):
+    x = np.ascontiguousarray(x, dtype=np.complex128).copy()
+    rc = lib().orc_fft1d(x.ctypes.data_as(C.c_void_p), C.c_uint32(x.size), C.c_int(sign))
+    if rc:
+        raise ValueError("oracle fft1d rc=%d" % rc)
+    return x
+
+
+def load_lut(precision):
+    return np.array([lib().orc_load_u8(precision, v) for v in range(256)])
+
+
+def upscale_planes(planes, upscale=2.0, precision=0, sharpen=0.2):
+    """planes: [3][H][W] float64 -> (pre [3][uH][uW], out [3][uH][uW], poison_reads)"""
+    planes = np.ascontiguousarray(planes, dtype=np.float64)
+    _, H, W = planes.shape
+    cfg = _cfg(W, H, upscale, precision, sharpen)
+    uW, uH = out_dims(W, H, upscale)
+    pre = np.empty((3, uH, uW))
+    out = np.empty((3, uH, uW))
+    poison = C.c_uint64(0)
+    rc = lib().orc_upscale_planes(C.byref(cfg), planes.ctypes.data_as(C.c_void_p),
+                                  pre.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                  C.byref(poison))
+    if rc:
+        raise ValueError("oracle rc=%d" % rc)
+    return pre, out, poison.value
+
+
+def upscale_rgb8(rgb, upscale=2.0, precision=0, sharpen=0.2, u8_wrap=0):
+    """rgb: [H][W][3] uint8 -> (pre, out, rgb_out[uH][uW][3])"""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    H, W, _ = rgb.shape
+    cfg = _cfg(W, H, upscale, precision, sharpen, u8_wrap)
+    uW, uH = out_dims(W, H, upscale)
+    pre = np.empty((3, uH, uW))
+    out = np.empty((3, uH, uW))
+    rgb_out = np.empty((uH, uW, 3), dtype=np.uint8)
+    rc = lib().orc_upscale_rgb8(C.byref(cfg), rgb.ctypes.data_as(C.c_void_p),
+                                pre.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                rgb_out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise ValueError("oracle rc=%d" % rc)
+    return pre, out, rgb_out
+
+
+def sharpen(R, upscale=2.0, precision=0, sharpen=0.2):
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    _, uH, uW = R.shape
+    cfg = _cfg(0, 0, upscale, precision, sharpen)
+    out = np.empty_like(R)
+    lib().orc_sharpen(C.byref(cfg), R.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                      C.c_uint32(uW), C.c_uint32(uH))
+    return out
+
+
+def num_threads():
+    return lib().orc_num_threads()

@@ -1,0 +1,71 @@
+"""ctypes loader of the C-ABI library (include/fftup.h).  No fallback: if libfftup.so is missing or
+fails to load, importing the product path raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfftup.so")
+
+FFTUP_NUM_KERNELS = 4
+
+FLAG_U8_WRAP = 1
+FLAG_FUSE_U8_LOAD = 2
+FLAG_GENERIC_KERNELS = 4
+
+# every symbol include/fftup.h declares
+EXPORTS = [
+    "fftup_device_count", "fftup_device_name", "fftup_plan_create", "fftup_plan_destroy", "fftup_plan_info",
+    "fftup_upload_rgb8", "fftup_upload_rgb8_slot", "fftup_upload_planar", "fftup_execute", "fftup_execute_ring",
+    "fftup_profile_kernels", "fftup_download_rgb8", "fftup_download_planar", "fftup_download_presharpen",
+    "fftup_download_input_planar", "fftup_strerror", "fftup_last_error", "fftup_version",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint32), ("upscale", C.c_float),
+                ("precision", C.c_uint32), ("sharpen", C.c_float), ("device", C.c_int32), ("flags", C.c_uint32),
+                ("ring", C.c_uint32)]
+
+
+class Info(C.Structure):
+    _fields_ = [("out_width", C.c_uint32), ("out_height", C.c_uint32), ("num_kernels", C.c_uint32),
+                ("tuned", C.c_uint32), ("alg_bytes_per_frame", C.c_double),
+                ("kernel_alg_bytes", C.c_double * FFTUP_NUM_KERNELS), ("device_bytes", C.c_uint64),
+                ("device_name", C.c_char * 256), ("kernel_names", (C.c_char * 64) * FFTUP_NUM_KERNELS)]
+
+
+_lib = None
+
+
+def load():
+    """Load libfftup.so (built by __graft_entry__.build()).  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
+    lib.fftup_device_count.restype = C.c_int
+    lib.fftup_device_name.argtypes = [C.c_int, C.c_char_p, sz]
+    lib.fftup_plan_create.argtypes = [C.POINTER(vp), C.POINTER(Config)]
+    lib.fftup_plan_destroy.argtypes = [vp]
+    lib.fftup_plan_destroy.restype = None
+    lib.fftup_plan_info.argtypes = [vp, C.POINTER(Info)]
+    lib.fftup_upload_rgb8.argtypes = [vp, vp, sz]
+    lib.fftup_upload_rgb8_slot.argtypes = [vp, u32, vp, sz]
+    lib.fftup_upload_planar.argtypes = [vp, u32, vp, sz, sz]
+    lib.fftup_execute.argtypes = [vp, u32, C.POINTER(C.c_double)]
+    lib.fftup_execute_ring.argtypes = [vp, u32, u32, C.POINTER(C.c_double)]
+    lib.fftup_profile_kernels.argtypes = [vp, u32, C.POINTER(C.c_double)]
+    lib.fftup_download_rgb8.argtypes = [vp, u32, vp, sz]
+    lib.fftup_download_planar.argtypes = [vp, u32, vp]
+    lib.fftup_download_presharpen.argtypes = [vp, vp]
+    lib.fftup_download_input_planar.argtypes = [vp, u32, vp]
+    lib.fftup_strerror.argtypes = [C.c_int]
+    lib.fftup_strerror.restype = C.c_char_p
+    lib.fftup_last_error.restype = C.c_char_p
+    lib.fftup_version.restype = C.c_char_p
+    _lib = lib
+    return lib

@@ -1,0 +1,134 @@
+"""Host-side mirror of the reference's per-image pipeline surface, on top of the C ABI.
+
+Reference (VkResample.cpp): launchResample() VR:1280-1780 builds the plan and runs, per file,
+pack+upload (VR:1636-1688) -> performVulkanUpscale(numIter) (VR:1249-1279, VR:1692) -> download+unpack
+(VR:1697-1748).  `Upscaler` keeps those three steps and their argument meaning (`upscale`, `precision`,
+`sharpen`, `num_iter` = -u/-p/-s/-n).  All compute happens in libfftup.so (HIP); there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class FftupError(RuntimeError):
+    def __init__(self, code, where):
+        lib = _lib.load()
+        self.code = code
+        detail = lib.fftup_last_error().decode(errors="replace")
+        super().__init__("%s failed: %s (%d)%s" % (where, lib.fftup_strerror(code).decode(), code,
+                                                   ": " + detail if detail else ""))
+
+
+def _check(code, where):
+    if code != 0:
+        raise FftupError(code, where)
+
+
+def device_count():
+    return _lib.load().fftup_device_count()
+
+
+def device_name(device=0):
+    buf = C.create_string_buffer(256)
+    _check(_lib.load().fftup_device_name(device, buf, 256), "fftup_device_name")
+    return buf.value.decode()
+
+
+class Upscaler:
+    """One plan = one (width, height, upscale, precision, sharpen, device) configuration."""
+
+    def __init__(self, width, height, upscale=2.0, precision=0, sharpen=0.2, device=0, flags=0, ring=1):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        cfg = _lib.Config(width, height, 3, upscale, precision, sharpen, device, flags, ring)
+        _check(self._lib.fftup_plan_create(C.byref(self._h), C.byref(cfg)), "fftup_plan_create")
+        info = _lib.Info()
+        _check(self._lib.fftup_plan_info(self._h, C.byref(info)), "fftup_plan_info")
+        self.width, self.height = width, height
+        self.out_width, self.out_height = info.out_width, info.out_height
+        self.precision = precision
+        self.ring = max(1, ring)
+        self.alg_bytes_per_frame = info.alg_bytes_per_frame
+        self.kernel_alg_bytes = list(info.kernel_alg_bytes)
+        self.kernel_names = [bytes(n).split(b"\0")[0].decode() for n in info.kernel_names]
+        self.device_name = info.device_name.decode()
+        self.device_bytes = info.device_bytes
+        self.tuned = bool(info.tuned)
+        self._dtype = np.float16 if precision == 2 else np.float32
+
+    def close(self):
+        if self._h:
+            self._lib.fftup_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- pack + transferDataFromCPU (VR:1636-1688)
+    def upload_rgb8(self, rgb, slot=0):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        assert rgb.shape == (self.height, self.width, 3), rgb.shape
+        _check(self._lib.fftup_upload_rgb8_slot(self._h, slot, rgb.ctypes.data, rgb.strides[0]), "fftup_upload_rgb8")
+
+    def upload_planar(self, planes, slot=0):
+        planes = np.ascontiguousarray(planes, dtype=self._dtype)
+        assert planes.shape == (3, self.height, self.width), planes.shape
+        _check(self._lib.fftup_upload_planar(self._h, slot, planes.ctypes.data, self.width, self.width * self.height),
+               "fftup_upload_planar")
+
+    # ---- performVulkanUpscale (VR:1249-1279): returns ms per iteration
+    def execute(self, num_iter=1):
+        ms = C.c_double()
+        _check(self._lib.fftup_execute(self._h, num_iter, C.byref(ms)), "fftup_execute")
+        return ms.value
+
+    def execute_ring(self, n_frames, first_slot=0):
+        ms = C.c_double()
+        _check(self._lib.fftup_execute_ring(self._h, n_frames, first_slot, C.byref(ms)), "fftup_execute_ring")
+        return ms.value
+
+    def profile_kernels(self, num_iter=10):
+        ms = (C.c_double * _lib.FFTUP_NUM_KERNELS)()
+        _check(self._lib.fftup_profile_kernels(self._h, num_iter, ms), "fftup_profile_kernels")
+        return list(ms)
+
+    # ---- transferDataToCPU + unpack (VR:1697-1748)
+    def download_planar(self, slot=0):
+        out = np.empty((3, self.out_height, self.out_width), dtype=self._dtype)
+        _check(self._lib.fftup_download_planar(self._h, slot, out.ctypes.data), "fftup_download_planar")
+        return out
+
+    def download_presharpen(self):
+        out = np.empty((3, self.out_height, self.out_width), dtype=self._dtype)
+        _check(self._lib.fftup_download_presharpen(self._h, out.ctypes.data), "fftup_download_presharpen")
+        return out
+
+    def download_input_planar(self, slot=0):
+        out = np.empty((3, self.height, self.width), dtype=self._dtype)
+        _check(self._lib.fftup_download_input_planar(self._h, slot, out.ctypes.data), "fftup_download_input_planar")
+        return out
+
+    def download_rgb8(self, slot=0):
+        out = np.empty((self.out_height, self.out_width, 3), dtype=np.uint8)
+        _check(self._lib.fftup_download_rgb8(self._h, slot, out.ctypes.data, out.strides[0]), "fftup_download_rgb8")
+        return out
+
+
+def upscale_image(rgb, upscale=2.0, precision=0, sharpen=0.2, num_iter=1, device=0, flags=0):
+    """Single-image path of launchResample(): returns (rgb_out uint8 [uH][uW][3], ms_per_iter)."""
+    rgb = np.asarray(rgb)
+    with Upscaler(rgb.shape[1], rgb.shape[0], upscale, precision, sharpen, device, flags) as up:
+        up.upload_rgb8(rgb)
+        ms = up.execute(num_iter)
+        return up.download_rgb8(), ms

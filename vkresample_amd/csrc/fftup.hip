@@ -1,0 +1,584 @@
+// fftup.hip -- host side of the C ABI (include/fftup.h): plan construction, device buffers,
+// kernel launches, timing.  Mirrors the plan semantics of launchResample() (VkResample.cpp:1409-1617)
+// and the frame executor performVulkanUpscale() (VkResample.cpp:1249-1279) on one HIP stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fftup.h"
+#include "kernels_generic.hpp"
+#include "kernels_pow2.hpp"
+
+using namespace fftup;
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(_e == hipErrorOutOfMemory ? FFTUP_E_OUT_OF_MEMORY : FFTUP_E_HIP,           \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                        \
+    } while (0)
+
+struct fftup_plan {
+    fftup_config cfg{};
+    uint32_t W = 0, H = 0, uW = 0, uH = 0;
+    uint32_t ring = 1;
+    bool half = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipDeviceProp_t prop{};
+
+    // geometry
+    int TK = 8, NT = 0;
+    int zlx = 0, zrx = 0, zly = 0, zry = 0;
+    StagePlan planW{}, planH{}, planUW{}, planUH{};
+    int thrW = 0, thrCol = 0, thrUW = 0;
+    size_t ldsRowF = 0, ldsCol = 0, ldsRowI = 0;
+    float upsq = 0, coef = 0;
+    bool tuned = false;
+
+    // device memory
+    std::vector<void*> in_planar;     // per slot: planar float/half, row stride W, plane stride (W+2)*H
+    std::vector<uint8_t*> in_u8;      // per slot: RGB u8 [H][W][3] (staging and fused-load source)
+    std::vector<int> in_kind;         // per slot: 0 none, 1 planar valid, 2 u8 valid (fused)
+    float2 *S1 = nullptr, *S2 = nullptr;
+    void* R = nullptr;                // pre-sharpen, dense [3][uH][uW]
+    std::vector<void*> out;           // per slot: dense [3][uH][uW]
+    uint8_t* out_u8 = nullptr;        // staging for download_rgb8
+    float2 *twW = nullptr, *twH = nullptr, *twUW = nullptr, *twUH = nullptr;
+    uint64_t device_bytes = 0;
+    size_t in_plane_stride = 0;
+    int executed = 0;
+
+    std::vector<void*> allocs;
+};
+
+// ------------------------------------------------------------------------------------------------
+static bool is_smooth(uint32_t n)
+{
+    if (n == 0) return false;
+    for (uint32_t p : {2u, 3u, 5u, 7u})
+        while (n % p == 0) n /= p;
+    return n == 1;
+}
+
+// radix sequence: as many 8s as possible, then 4/2, then 3,5,7 (VkFFTScheduler vkFFT.h:4707-5189
+// makes the same kind of choice; order only affects speed)
+static StagePlan make_stage_plan(uint32_t n)
+{
+    StagePlan p{};
+    p.n = (int)n;
+    uint32_t m = n;
+    int e2 = 0;
+    while (m % 2 == 0) { m /= 2; e2++; }
+    int ns = 0;
+    while (e2 >= 3) { p.radix[ns++] = 8; e2 -= 3; }
+    if (e2 == 2) p.radix[ns++] = 4;
+    if (e2 == 1) p.radix[ns++] = 2;
+    for (uint32_t q : {3u, 5u, 7u})
+        while (m % q == 0) { p.radix[ns++] = (uint8_t)q; m /= q; }
+    p.nstages = ns;
+    return p;
+}
+
+static int dev_alloc(fftup_plan* P, void** ptr, size_t bytes)
+{
+    hipError_t e = hipMalloc(ptr, bytes);
+    if (e != hipSuccess) {
+        *ptr = nullptr;
+        return fail(FFTUP_E_OUT_OF_MEMORY, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    }
+    P->allocs.push_back(*ptr);
+    P->device_bytes += bytes;
+    return FFTUP_OK;
+}
+
+static int make_twiddles(fftup_plan* P, float2** dptr, uint32_t n)
+{
+    std::vector<float2> h(n);
+    for (uint32_t k = 0; k < n; k++) {
+        // exact octant reduction is unnecessary in double; rounded once to fp32
+        double a = 2.0 * M_PI * (double)k / (double)n;
+        h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    int rc = dev_alloc(P, (void**)dptr, sizeof(float2) * n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(*dptr, h.data(), sizeof(float2) * n, hipMemcpyHostToDevice));
+    return FFTUP_OK;
+}
+
+// the sharpen constants reach the reference's shader as "%f" text (VkResample.cpp:893-901, 920)
+static float const_via_percent_f(double v, bool half)
+{
+    char buf[64];
+    snprintf(buf, sizeof buf, "%f", v);
+    float f = (float)strtod(buf, nullptr);
+    if (half) f = __half2float(__float2half_rn(f));
+    return f;
+}
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int fftup_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fftup_device_name(int device, char* buf, size_t buflen)
+{
+    if (!buf || buflen == 0) return fail(FFTUP_E_INVALID_ARG, "null buffer");
+    hipDeviceProp_t prop;
+    if (device < 0 || device >= fftup_device_count()) return fail(FFTUP_E_NO_DEVICE, "bad device id");
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s", prop.name);
+    return FFTUP_OK;
+}
+
+void fftup_plan_destroy(fftup_plan* P)
+{
+    if (!P) return;
+    (void)hipSetDevice(P->device);
+    if (P->stream) (void)hipStreamSynchronize(P->stream);
+    for (void* p : P->allocs) (void)hipFree(p);
+    if (P->ev0) (void)hipEventDestroy(P->ev0);
+    if (P->ev1) (void)hipEventDestroy(P->ev1);
+    if (P->stream) (void)hipStreamDestroy(P->stream);
+    delete P;
+}
+
+int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
+{
+    if (!out || !cfg) return fail(FFTUP_E_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->channels != 3) return fail(FFTUP_E_INVALID_ARG, "channels must be 3 (VkResample.cpp:1368)");
+    if (cfg->precision == 1) return fail(FFTUP_E_UNSUPPORTED_PRECISION, "double precision (-p 1) is not implemented");
+    if (cfg->precision != 0 && cfg->precision != 2) return fail(FFTUP_E_UNSUPPORTED_PRECISION, "precision must be 0 or 2");
+    const uint32_t W = cfg->width, H = cfg->height;
+    const uint32_t uW = (uint32_t)(cfg->upscale * (float)W);     // VkResample.cpp:1417-1418
+    const uint32_t uH = (uint32_t)(cfg->upscale * (float)H);
+    if (W < 2 || H < 2 || (W & 1) || (H & 1) || (uW & 1) || (uH & 1) || uW < W || uH < H)
+        return fail(FFTUP_E_INVALID_ARG, "width/height (and upscaled sizes) must be even, upscale >= 1");
+    if (!is_smooth(W) || !is_smooth(H) || !is_smooth(uW) || !is_smooth(uH))
+        return fail(FFTUP_E_UNSUPPORTED_SIZE, "sizes must factor into 2,3,5,7 (vkFFT.h:4719-4726)");
+    // R2C rule of the reference: uW <= maxComputeSharedMemorySize/8 with 64 KB (VkResample.cpp:1424);
+    // beyond it the reference switches to its complex path, which is out of scope here.
+    if (uW > 8192) return fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width > 8192: non-R2C path not implemented (VkResample.cpp:1424)");
+
+    int ndev = fftup_device_count();
+    if (ndev <= 0) return fail(FFTUP_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(FFTUP_E_NO_DEVICE, "device id out of range");
+
+    fftup_plan* P = new fftup_plan();
+    P->cfg = *cfg;
+    P->W = W; P->H = H; P->uW = uW; P->uH = uH;
+    P->ring = cfg->ring ? cfg->ring : 1;
+    P->half = cfg->precision == 2;
+    P->device = cfg->device;
+    int rc = FFTUP_OK;
+#define PLAN_TRY(expr)                                                                             \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            rc = fail(FFTUP_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+            goto bad;                                                                              \
+        }                                                                                          \
+    } while (0)
+#define PLAN_RC(expr)                                                                              \
+    do {                                                                                           \
+        rc = (expr);                                                                               \
+        if (rc) goto bad;                                                                          \
+    } while (0)
+
+    {
+        PLAN_TRY(hipSetDevice(P->device));
+        PLAN_TRY(hipGetDeviceProperties(&P->prop, P->device));
+        PLAN_TRY(hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking));
+        PLAN_TRY(hipEventCreate(&P->ev0));
+        PLAN_TRY(hipEventCreate(&P->ev1));
+
+        // zero-padding ranges exactly as launchResample computes them (float math, uint32 store)
+        const float u = cfg->upscale;
+        P->zlx = (int)(W / 2);
+        P->zrx = (int)(uW / 2);
+        P->zly = (int)(uint32_t)((float)uH / (2 * u));
+        P->zry = (int)(uint32_t)((2 * u - 1) * (float)uH / (2 * u));
+
+        P->planW = make_stage_plan(W);
+        P->planH = make_stage_plan(H);
+        P->planUW = make_stage_plan(uW);
+        P->planUH = make_stage_plan(uH);
+
+        const size_t lds_max = P->prop.sharedMemPerBlock ? P->prop.sharedMemPerBlock : 65536;
+        // column tile width: widest of 8,4,2,1 whose ping-pong buffers fit in LDS
+        P->TK = 0;
+        for (int tk : {8, 4, 2, 1}) {
+            size_t need = 2 * sizeof(float2) * (size_t)lpad_size((int)uH * tk);
+            if (need <= lds_max) { P->TK = tk; P->ldsCol = need; break; }
+        }
+        if (!P->TK) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled height too large for LDS"); goto bad; }
+        P->NT = ((int)(W / 2 + 1) + P->TK - 1) / P->TK;
+        P->ldsRowF = 2 * sizeof(float2) * (size_t)lpad_size((int)W);
+        P->ldsRowI = 2 * sizeof(float2) * (size_t)lpad_size((int)uW);
+        if (P->ldsRowI > lds_max) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width too large for LDS"); goto bad; }
+        P->thrW = std::min(1024, std::max(64, round_up((int)W / 8, 64)));
+        P->thrUW = std::min(1024, std::max(64, round_up((int)uW / 8, 64)));
+        P->thrCol = std::min(1024, std::max(64, round_up((int)uH * P->TK / 8, 64)));
+
+        P->upsq = const_via_percent_f((double)(cfg->upscale * cfg->upscale), P->half);   // VkResample.cpp:1615
+        P->coef = const_via_percent_f((double)cfg->sharpen, P->half);                    // VkResample.cpp:1616
+
+        PLAN_RC(make_twiddles(P, &P->twW, W));
+        PLAN_RC(make_twiddles(P, &P->twH, H));
+        PLAN_RC(make_twiddles(P, &P->twUW, uW));
+        PLAN_RC(make_twiddles(P, &P->twUH, uH));
+
+        const size_t esz = P->half ? 2 : 4;
+        P->in_plane_stride = (size_t)(W + 2) * H;                    // VkResample.cpp:1644
+        P->in_planar.assign(P->ring, nullptr);
+        P->in_u8.assign(P->ring, nullptr);
+        P->in_kind.assign(P->ring, 0);
+        P->out.assign(P->ring, nullptr);
+        for (uint32_t s = 0; s < P->ring; s++) {
+            PLAN_RC(dev_alloc(P, &P->in_planar[s], 3 * P->in_plane_stride * esz));
+            PLAN_RC(dev_alloc(P, (void**)&P->in_u8[s], (size_t)3 * W * H));
+            PLAN_RC(dev_alloc(P, &P->out[s], (size_t)3 * uW * uH * esz));
+        }
+        PLAN_RC(dev_alloc(P, (void**)&P->S1, sizeof(float2) * 3 * (size_t)P->NT * H * P->TK));
+        PLAN_RC(dev_alloc(P, (void**)&P->S2, sizeof(float2) * 3 * (size_t)P->NT * uH * P->TK));
+        PLAN_RC(dev_alloc(P, &P->R, (size_t)3 * uW * uH * esz));
+        PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH));
+
+        // allow > 64 KB dynamic LDS
+#define SET_LDS(kern, bytes) PLAN_TRY(hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
+        SET_LDS(k_row_r2c<IN_F32>, P->ldsRowF);
+        SET_LDS(k_row_r2c<IN_F16>, P->ldsRowF);
+        SET_LDS(k_row_r2c<IN_U8_F32>, P->ldsRowF);
+        SET_LDS(k_row_r2c<IN_U8_F16>, P->ldsRowF);
+        SET_LDS(k_col<8>, P->ldsCol);
+        SET_LDS(k_col<4>, P->ldsCol);
+        SET_LDS(k_col<2>, P->ldsCol);
+        SET_LDS(k_col<1>, P->ldsCol);
+        SET_LDS(k_row_c2r<false>, P->ldsRowI);
+        SET_LDS(k_row_c2r<true>, P->ldsRowI);
+#undef SET_LDS
+        P->tuned = false;
+    }
+    *out = P;
+    return FFTUP_OK;
+bad:
+    fftup_plan_destroy(P);
+    return rc;
+#undef PLAN_TRY
+#undef PLAN_RC
+}
+
+int fftup_plan_info(const fftup_plan* P, fftup_info* info)
+{
+    if (!P || !info) return fail(FFTUP_E_INVALID_ARG, "null argument");
+    memset(info, 0, sizeof *info);
+    info->out_width = P->uW;
+    info->out_height = P->uH;
+    info->num_kernels = FFTUP_NUM_KERNELS;
+    info->tuned = P->tuned ? 1 : 0;
+    // B_alg = in + 2*S1 + 2*S2 + 2*R + out
+    const double C = 3.0, W = P->W, H = P->H, uW = P->uW, uH = P->uH;
+    const bool fused_u8 = (P->cfg.flags & FFTUP_FLAG_FUSE_U8_LOAD) != 0;
+    const double b_in = fused_u8 ? 1.0 : (P->half ? 2.0 : 4.0);
+    const double b_r = P->half ? 2.0 : 4.0, b_out = b_r;
+    const double in = C * W * H * b_in;
+    const double S1 = C * (W / 2 + 1) * H * 8.0;
+    const double S2 = C * (W / 2 + 1) * uH * 8.0;
+    const double R = C * uW * uH * b_r;
+    const double o = C * uW * uH * b_out;
+    info->alg_bytes_per_frame = in + 2 * S1 + 2 * S2 + 2 * R + o;
+    info->kernel_alg_bytes[0] = in + S1;
+    info->kernel_alg_bytes[1] = S1 + S2;
+    info->kernel_alg_bytes[2] = S2 + R;
+    info->kernel_alg_bytes[3] = R + o;
+    info->device_bytes = P->device_bytes;
+    snprintf(info->device_name, sizeof info->device_name, "%s", P->prop.name);
+    snprintf(info->kernel_names[0], 64, "row_r2c");
+    snprintf(info->kernel_names[1], 64, "col_fwd_pad_inv");
+    snprintf(info->kernel_names[2], 64, "row_c2r");
+    snprintf(info->kernel_names[3], 64, "sharpen");
+    return FFTUP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int check_slot(fftup_plan* P, uint32_t slot)
+{
+    if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
+    if (slot >= P->ring) return fail(FFTUP_E_INVALID_ARG, "slot out of range");
+    return FFTUP_OK;
+}
+
+int fftup_upload_rgb8_slot(fftup_plan* P, uint32_t slot, const uint8_t* rgb, size_t row_stride_bytes)
+{
+    int rc = check_slot(P, slot);
+    if (rc) return rc;
+    if (!rgb || row_stride_bytes < (size_t)3 * P->W) return fail(FFTUP_E_INVALID_ARG, "bad rgb pointer/stride");
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipMemcpy2DAsync(P->in_u8[slot], (size_t)3 * P->W, rgb, row_stride_bytes, (size_t)3 * P->W, P->H,
+                             hipMemcpyHostToDevice, P->stream));
+    if (P->cfg.flags & FFTUP_FLAG_FUSE_U8_LOAD) {
+        P->in_kind[slot] = 2;
+    } else {
+        dim3 grid((P->W + 255) / 256, P->H);
+        if (P->half)
+            hipLaunchKernelGGL(k_unpack_u8<true>, grid, dim3(256), 0, P->stream, P->in_u8[slot], (long)3 * P->W,
+                               P->in_planar[slot], (int)P->W, (int)P->H, (long)P->in_plane_stride);
+        else
+            hipLaunchKernelGGL(k_unpack_u8<false>, grid, dim3(256), 0, P->stream, P->in_u8[slot], (long)3 * P->W,
+                               P->in_planar[slot], (int)P->W, (int)P->H, (long)P->in_plane_stride);
+        HIP_TRY(hipGetLastError());
+        P->in_kind[slot] = 1;
+    }
+    HIP_TRY(hipStreamSynchronize(P->stream));   // blocking, like transferDataFromCPU (VkResample.cpp:385-429)
+    return FFTUP_OK;
+}
+
+int fftup_upload_rgb8(fftup_plan* P, const uint8_t* rgb, size_t row_stride_bytes)
+{
+    return fftup_upload_rgb8_slot(P, 0, rgb, row_stride_bytes);
+}
+
+int fftup_upload_planar(fftup_plan* P, uint32_t slot, const void* planes, size_t row_stride, size_t plane_stride)
+{
+    int rc = check_slot(P, slot);
+    if (rc) return rc;
+    if (!planes || row_stride < P->W || plane_stride < row_stride * (P->H - 1) + P->W)
+        return fail(FFTUP_E_INVALID_ARG, "bad planes pointer/strides");
+    HIP_TRY(hipSetDevice(P->device));
+    const size_t esz = P->half ? 2 : 4;
+    for (int c = 0; c < 3; c++)
+        HIP_TRY(hipMemcpy2DAsync((char*)P->in_planar[slot] + c * P->in_plane_stride * esz, P->W * esz,
+                                 (const char*)planes + c * plane_stride * esz, row_stride * esz, P->W * esz, P->H,
+                                 hipMemcpyHostToDevice, P->stream));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    P->in_kind[slot] = 1;
+    return FFTUP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// one frame: 4 launches on the plan's stream.  `which` < 0 launches all, otherwise only that one.
+static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
+{
+    const int kind = P->in_kind[in_slot];
+    if (kind == 0) return fail(FFTUP_E_NO_INPUT, "no input uploaded for this slot");
+    if (which < 0 || which == 0) {
+        RowR2CParams p{};
+        p.S1 = P->S1; p.tw = P->twW; p.plan = P->planW; p.W = (int)P->W; p.H = (int)P->H;
+        p.TK = P->TK; p.NT = P->NT;
+        dim3 grid(P->H / 2, 3), block(P->thrW);
+        if (kind == 2) {
+            p.in = P->in_u8[in_slot]; p.in_row_stride = 3l * P->W; p.in_plane_stride = 0;
+            if (P->half) hipLaunchKernelGGL(k_row_r2c<IN_U8_F16>, grid, block, P->ldsRowF, P->stream, p);
+            else hipLaunchKernelGGL(k_row_r2c<IN_U8_F32>, grid, block, P->ldsRowF, P->stream, p);
+        } else {
+            p.in = P->in_planar[in_slot]; p.in_row_stride = P->W; p.in_plane_stride = (long)P->in_plane_stride;
+            if (P->half) hipLaunchKernelGGL(k_row_r2c<IN_F16>, grid, block, P->ldsRowF, P->stream, p);
+            else hipLaunchKernelGGL(k_row_r2c<IN_F32>, grid, block, P->ldsRowF, P->stream, p);
+        }
+    }
+    if (which < 0 || which == 1) {
+        ColParams p{};
+        p.S1 = P->S1; p.S2 = P->S2; p.twH = P->twH; p.twUH = P->twUH; p.planH = P->planH; p.planUH = P->planUH;
+        p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.zly = P->zly; p.zry = P->zry;
+        p.inv_norm = 1.0f / (float)P->uH;
+        dim3 grid(P->NT, 3), block(P->thrCol);
+        switch (P->TK) {
+        case 8: hipLaunchKernelGGL(k_col<8>, grid, block, P->ldsCol, P->stream, p); break;
+        case 4: hipLaunchKernelGGL(k_col<4>, grid, block, P->ldsCol, P->stream, p); break;
+        case 2: hipLaunchKernelGGL(k_col<2>, grid, block, P->ldsCol, P->stream, p); break;
+        default: hipLaunchKernelGGL(k_col<1>, grid, block, P->ldsCol, P->stream, p); break;
+        }
+    }
+    if (which < 0 || which == 2) {
+        RowC2RParams p{};
+        p.S2 = P->S2; p.R = P->R; p.tw = P->twUW; p.plan = P->planUW; p.W = (int)P->W; p.uW = (int)P->uW;
+        p.uH = (int)P->uH; p.TK = P->TK; p.NT = P->NT; p.zlx = P->zlx; p.zrx = P->zrx;
+        p.inv_norm = 1.0f / (float)P->uW;
+        dim3 grid(P->uH / 2, 3), block(P->thrUW);
+        if (P->half) hipLaunchKernelGGL(k_row_c2r<true>, grid, block, P->ldsRowI, P->stream, p);
+        else hipLaunchKernelGGL(k_row_c2r<false>, grid, block, P->ldsRowI, P->stream, p);
+    }
+    if (which < 0 || which == 3) {
+        SharpenParams p{};
+        p.R = P->R; p.out = P->out[out_slot]; p.uW = (int)P->uW; p.uH = (int)P->uH; p.upsq = P->upsq; p.coef = P->coef;
+        dim3 grid((P->uW / 4 + 255) / 256, P->uH, 3), block(256);
+        if (P->half) hipLaunchKernelGGL(k_sharpen<true>, grid, block, 0, P->stream, p);
+        else hipLaunchKernelGGL(k_sharpen<false>, grid, block, 0, P->stream, p);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FFTUP_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return FFTUP_OK;
+}
+
+int fftup_execute_ring(fftup_plan* P, uint32_t n_frames, uint32_t first_slot, double* ms_total)
+{
+    if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
+    if (n_frames == 0) return fail(FFTUP_E_INVALID_ARG, "n_frames must be > 0");
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipEventRecord(P->ev0, P->stream));
+    for (uint32_t i = 0; i < n_frames; i++) {
+        uint32_t s = (first_slot + i) % P->ring;
+        int rc = launch_frame(P, s, s, -1);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(P->ev1, P->stream));
+    HIP_TRY(hipEventSynchronize(P->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, P->ev0, P->ev1));
+    if (ms_total) *ms_total = ms;
+    P->executed = 1;
+    return FFTUP_OK;
+}
+
+int fftup_execute(fftup_plan* P, uint32_t n_iter, double* ms_per_iter)
+{
+    if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
+    if (n_iter == 0) return fail(FFTUP_E_INVALID_ARG, "n_iter must be > 0");
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipEventRecord(P->ev0, P->stream));
+    for (uint32_t i = 0; i < n_iter; i++) {
+        int rc = launch_frame(P, 0, 0, -1);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(P->ev1, P->stream));
+    HIP_TRY(hipEventSynchronize(P->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, P->ev0, P->ev1));
+    if (ms_per_iter) *ms_per_iter = (double)ms / n_iter;
+    P->executed = 1;
+    return FFTUP_OK;
+}
+
+int fftup_profile_kernels(fftup_plan* P, uint32_t n_iter, double* ms_per_kernel)
+{
+    if (!P || !ms_per_kernel) return fail(FFTUP_E_INVALID_ARG, "null argument");
+    if (n_iter == 0) return fail(FFTUP_E_INVALID_ARG, "n_iter must be > 0");
+    HIP_TRY(hipSetDevice(P->device));
+    std::vector<hipEvent_t> ev((size_t)n_iter * (FFTUP_NUM_KERNELS + 1));
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    int rc = FFTUP_OK;
+    for (uint32_t i = 0; i < n_iter && !rc; i++) {
+        hipEvent_t* e = &ev[(size_t)i * (FFTUP_NUM_KERNELS + 1)];
+        (void)hipEventRecord(e[0], P->stream);
+        for (int k = 0; k < FFTUP_NUM_KERNELS && !rc; k++) {
+            rc = launch_frame(P, i % P->ring, i % P->ring, k);
+            (void)hipEventRecord(e[k + 1], P->stream);
+        }
+    }
+    hipError_t se = hipStreamSynchronize(P->stream);
+    if (!rc && se != hipSuccess) rc = fail(FFTUP_E_HIP, std::string("sync: ") + hipGetErrorString(se));
+    if (!rc) {
+        for (int k = 0; k < FFTUP_NUM_KERNELS; k++) ms_per_kernel[k] = 0;
+        for (uint32_t i = 0; i < n_iter; i++) {
+            hipEvent_t* e = &ev[(size_t)i * (FFTUP_NUM_KERNELS + 1)];
+            for (int k = 0; k < FFTUP_NUM_KERNELS; k++) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, e[k], e[k + 1]);
+                ms_per_kernel[k] += ms;
+            }
+        }
+        for (int k = 0; k < FFTUP_NUM_KERNELS; k++) ms_per_kernel[k] /= n_iter;
+        P->executed = 1;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+int fftup_download_planar(fftup_plan* P, uint32_t slot, void* planes)
+{
+    int rc = check_slot(P, slot);
+    if (rc) return rc;
+    if (!planes) return fail(FFTUP_E_INVALID_ARG, "null destination");
+    if (!P->executed) return fail(FFTUP_E_NO_INPUT, "nothing executed yet");
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipMemcpyAsync(planes, P->out[slot], (size_t)3 * P->uW * P->uH * (P->half ? 2 : 4), hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    return FFTUP_OK;
+}
+
+int fftup_download_presharpen(fftup_plan* P, void* planes)
+{
+    if (!P || !planes) return fail(FFTUP_E_INVALID_ARG, "null argument");
+    if (!P->executed) return fail(FFTUP_E_NO_INPUT, "nothing executed yet");
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipMemcpyAsync(planes, P->R, (size_t)3 * P->uW * P->uH * (P->half ? 2 : 4), hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    return FFTUP_OK;
+}
+
+int fftup_download_input_planar(fftup_plan* P, uint32_t slot, void* planes)
+{
+    int rc = check_slot(P, slot);
+    if (rc) return rc;
+    if (!planes) return fail(FFTUP_E_INVALID_ARG, "null destination");
+    if (P->in_kind[slot] != 1) return fail(FFTUP_E_NO_INPUT, "slot holds no planar input");
+    HIP_TRY(hipSetDevice(P->device));
+    const size_t esz = P->half ? 2 : 4;
+    for (int c = 0; c < 3; c++)
+        HIP_TRY(hipMemcpyAsync((char*)planes + (size_t)c * P->W * P->H * esz, (char*)P->in_planar[slot] + c * P->in_plane_stride * esz,
+                               (size_t)P->W * P->H * esz, hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    return FFTUP_OK;
+}
+
+int fftup_download_rgb8(fftup_plan* P, uint32_t slot, uint8_t* rgb, size_t row_stride_bytes)
+{
+    int rc = check_slot(P, slot);
+    if (rc) return rc;
+    if (!rgb || row_stride_bytes < (size_t)3 * P->uW) return fail(FFTUP_E_INVALID_ARG, "bad rgb pointer/stride");
+    if (!P->executed) return fail(FFTUP_E_NO_INPUT, "nothing executed yet");
+    HIP_TRY(hipSetDevice(P->device));
+    dim3 grid((P->uW + 255) / 256, P->uH);
+    const int wrap = (P->cfg.flags & FFTUP_FLAG_U8_WRAP) ? 1 : 0;
+    if (P->half) hipLaunchKernelGGL(k_pack_u8<true>, grid, dim3(256), 0, P->stream, P->out[slot], P->out_u8, (int)P->uW, (int)P->uH, wrap);
+    else hipLaunchKernelGGL(k_pack_u8<false>, grid, dim3(256), 0, P->stream, P->out[slot], P->out_u8, (int)P->uW, (int)P->uH, wrap);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2DAsync(rgb, row_stride_bytes, P->out_u8, (size_t)3 * P->uW, (size_t)3 * P->uW, P->uH, hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    return FFTUP_OK;
+}
+
+const char* fftup_strerror(int code)
+{
+    switch (code) {
+    case FFTUP_OK: return "success";
+    case FFTUP_E_INVALID_ARG: return "invalid argument";
+    case FFTUP_E_UNSUPPORTED_SIZE: return "unsupported size (not 2,3,5,7-smooth, or beyond the R2C limit)";
+    case FFTUP_E_UNSUPPORTED_PRECISION: return "unsupported precision";
+    case FFTUP_E_NO_DEVICE: return "no usable HIP device";
+    case FFTUP_E_HIP: return "HIP runtime error";
+    case FFTUP_E_OUT_OF_MEMORY: return "out of device memory";
+    case FFTUP_E_NO_INPUT: return "no input uploaded / nothing executed";
+    case FFTUP_E_INCOMPLETE: return "incomplete (image not found)";
+    default: return "unknown error";
+    }
+}
+
+const char* fftup_last_error(void) { return g_last_error.c_str(); }
+const char* fftup_version(void) { return "fftup 0.1.0 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,306 @@
+// kernels_generic.hpp -- size-generic HIP kernels of the upscale path (any 2,3,5,7-smooth size).
+//
+// Three FFT kernels + sharpen per frame (the reference records 20 dispatches):
+//   k_row_r2c   replaces F0        (VkFFT type 5, vkFFT.h:1945-2058 / 4274-4377)
+//   k_col       replaces F1,F2,S,I0,I1 (vkFFT.h:1656-1717, VkResample.cpp:514-526, vkFFT.h:1670-1695)
+//   k_row_c2r   replaces I2        (VkFFT type 6, vkFFT.h:2059-2201 / 4378-4491)
+//   k_sharpen   replaces C         (VkResample.cpp:819-925)
+// Spectrum layout in HBM ("blocked half-spectrum"): S[c][tile][ky][TK] float2, tile = kx / TK,
+// kx = 0..W/2.  A column tile is one contiguous block for k_col; a row pair (2j,2j+1) of a tile
+// is one contiguous 2*TK*8-byte segment for the row kernels.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "fft_engine.hpp"
+
+namespace fftup {
+
+enum InMode { IN_F32 = 0, IN_F16 = 1, IN_U8_F32 = 2, IN_U8_F16 = 3 };
+
+// VkResample.cpp:1644  x = float(double(v)/255.0)   -- fp32 division is correctly rounded here
+// and agrees with the double-rounded reference expression for all 256 inputs (tests check it).
+__device__ __forceinline__ float cvt_u8_f32(uint8_t v) { return __fdiv_rn((float)v, 255.0f); }
+// VkResample.cpp:1676  x = half((float)half(v)/255.0)  (round to nearest even)
+__device__ __forceinline__ float cvt_u8_f16(uint8_t v) { return __half2float(__float2half_rn(__fdiv_rn((float)v, 255.0f))); }
+
+struct RowR2CParams {
+    const void* in;          // planar float/half (row stride, plane stride in elements) or u8 RGB (row stride bytes)
+    float2* S1;              // blocked half spectrum, H rows
+    const float2* tw;        // W-th roots
+    StagePlan plan;          // n = W
+    int W, H;
+    long in_row_stride, in_plane_stride;
+    int TK, NT;              // tile width (complex), number of tiles = ceil((W/2+1)/TK)
+};
+
+template <int MODE> __device__ __forceinline__ float load_px(const RowR2CParams& p, int c, int y, int x)
+{
+    if constexpr (MODE == IN_F32) {
+        return ((const float*)p.in)[c * p.in_plane_stride + y * p.in_row_stride + x];
+    } else if constexpr (MODE == IN_F16) {
+        return __half2float(((const __half*)p.in)[c * p.in_plane_stride + y * p.in_row_stride + x]);
+    } else if constexpr (MODE == IN_U8_F32) {
+        return cvt_u8_f32(((const uint8_t*)p.in)[y * p.in_row_stride + 3l * x + c]);
+    } else {
+        return cvt_u8_f16(((const uint8_t*)p.in)[y * p.in_row_stride + 3l * x + c]);
+    }
+}
+
+// grid (H/2, 3); dynamic LDS = 2 * lpad_size(W) float2
+template <int MODE>
+__global__ void __launch_bounds__(1024) k_row_r2c(RowR2CParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* a = (float2*)smem;
+    float2* b = a + lpad_size(p.W);
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int j = blockIdx.x, c = blockIdx.y;
+    const int W = p.W;
+    for (int n = tid; n < W; n += T)
+        a[lpad(n)] = make_float2(load_px<MODE>(p, c, 2 * j, n), load_px<MODE>(p, c, 2 * j + 1, n));
+    __syncthreads();
+    const float2* Z = fft_lds<+1, 1>(a, b, p.plan, p.tw, tid, T);
+    // unpack two real rows (vkFFT.h:4292-4323): A = (Z[k]+conj Z[W-k])/2, B = (Z[k]-conj Z[W-k])/(2i)
+    const long tile_stride = (long)p.H * p.TK;
+    float2* base = p.S1 + (long)c * p.NT * tile_stride;
+    for (int k = tid; k <= W / 2; k += T) {
+        float2 zk = Z[lpad(k)];
+        float2 zn = Z[lpad(k == 0 ? 0 : W - k)];
+        float2 A = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        float2 B = make_float2(0.5f * (zk.y + zn.y), 0.5f * (-zk.x + zn.x));
+        float2* dst = base + (long)(k / p.TK) * tile_stride + (long)(2 * j) * p.TK + (k % p.TK);
+        dst[0] = A;
+        dst[p.TK] = B;
+    }
+}
+
+struct ColParams {
+    const float2* S1;
+    float2* S2;
+    const float2 *twH, *twUH;
+    StagePlan planH, planUH;
+    int W, H, uH;
+    int NT;
+    int zly, zry;            // inverse read guard: rows [zly,zry) read as zero (VkResample.cpp:1494-1495)
+    float inv_norm;          // 1/uH
+};
+
+// grid (NT, 3); dynamic LDS = 2 * lpad_size(uH*TK) float2
+template <int TK>
+__global__ void __launch_bounds__(1024) k_col(ColParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* a = (float2*)smem;
+    float2* b = a + lpad_size(p.uH * TK);
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int tile = blockIdx.x, c = blockIdx.y;
+    const int H = p.H, uH = p.uH;
+    const int ncol_valid = min(TK, p.W / 2 + 1 - tile * TK);
+    const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
+    for (int e = tid; e < H * TK; e += T) {
+        float2 v = make_float2(0.f, 0.f);
+        if ((e % TK) < ncol_valid) v = src[e];
+        a[lpad(e)] = v;
+    }
+    __syncthreads();
+    float2* F = fft_lds<+1, TK>(a, b, p.planH, p.twH, tid, T);
+    float2* G = (F == a) ? b : a;
+    // shift (VkResample.cpp:514-526): buffer row ky' holds F[ky'-(uH-H)] for ky' >= uH-H/2, else the
+    // un-shifted F[ky'] while ky' < H; then the zero-padding read guard of the inverse plan.
+    for (int e = tid; e < uH * TK; e += T) {
+        const int ky = e / TK, col = e % TK;
+        float2 v = make_float2(0.f, 0.f);
+        if (!(ky >= p.zly && ky < p.zry)) {
+            if (ky >= uH - H / 2) v = F[lpad((ky - (uH - H)) * TK + col)];
+            else if (ky < H) v = F[lpad(e)];
+        }
+        G[lpad(e)] = v;
+    }
+    __syncthreads();
+    const float2* D = fft_lds<-1, TK>(G, F, p.planUH, p.twUH, tid, T);
+    float2* dst = p.S2 + ((long)c * p.NT + tile) * uH * TK;
+    for (int e = tid; e < uH * TK; e += T)
+        if ((e % TK) < ncol_valid) dst[e] = cscale(D[lpad(e)], p.inv_norm);
+}
+
+struct RowC2RParams {
+    const float2* S2;
+    void* R;                 // dense [3][uH][uW] float or half
+    const float2* tw;        // uW-th roots
+    StagePlan plan;          // n = uW
+    int W, uW, uH;
+    int TK, NT;
+    int zlx, zrx;            // column-index read guard [zlx,zrx) (VkResample.cpp:1492-1493)
+    float inv_norm;          // 1/uW
+};
+
+// grid (uH/2, 3); dynamic LDS = 2 * lpad_size(uW) float2
+template <bool HALF_OUT>
+__global__ void __launch_bounds__(1024) k_row_c2r(RowC2RParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* a = (float2*)smem;
+    float2* b = a + lpad_size(p.uW);
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int j = blockIdx.x, c = blockIdx.y;
+    const int uW = p.uW;
+    const long tile_stride = (long)p.uH * p.TK;
+    const float2* base = p.S2 + (long)c * p.NT * tile_stride + (long)(2 * j) * p.TK;
+    // vkFFT.h:2059-2131: Z[k] = A + iB, Z[uW-k] = conj(A) + i conj(B); column index cidx = k-1
+    for (int cidx = tid; cidx < uW / 2; cidx += T) {
+        const int k = cidx + 1;
+        float2 A = make_float2(0.f, 0.f), B = A;
+        if ((cidx < p.zlx || cidx >= p.zrx) && k <= p.W / 2) {
+            const float2* s = base + (long)(k / p.TK) * tile_stride + (k % p.TK);
+            A = s[0];
+            B = s[p.TK];
+        }
+        a[lpad(k)] = make_float2(A.x - B.y, A.y + B.x);
+        a[lpad(uW - k)] = make_float2(A.x + B.y, -A.y + B.x);
+    }
+    if (tid == 0) {
+        float2 A = base[0], B = base[p.TK];
+        a[lpad(0)] = make_float2(A.x - B.y, A.y + B.x);
+    }
+    __syncthreads();
+    const float2* z = fft_lds<-1, 1>(a, b, p.plan, p.tw, tid, T);
+    const long plane = (long)uW * p.uH;
+    for (int n = tid; n < uW; n += T) {
+        float2 v = cscale(z[lpad(n)], p.inv_norm);
+        if constexpr (HALF_OUT) {
+            __half* R = (__half*)p.R + c * plane + (long)(2 * j) * uW;
+            R[n] = __float2half_rn(v.x);
+            R[uW + n] = __float2half_rn(v.y);
+        } else {
+            float* R = (float*)p.R + c * plane + (long)(2 * j) * uW;
+            R[n] = v.x;
+            R[uW + n] = v.y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- sharpen (VkResample.cpp:819-925)
+struct SharpenParams {
+    const void* R;           // dense [3][uH][uW]
+    void* out;               // dense [3][uH][uW]
+    int uW, uH;
+    float upsq, coef;        // constants as the shader sees them ("%f" text, VkResample.cpp:893-920)
+};
+
+// arithmetic policy: fp32, or "every operation rounded to binary16" (GLSL float16_t, -p 2)
+template <bool HALF> struct Arith {
+    static __device__ __forceinline__ float r(float x)
+    {
+        if constexpr (HALF) return __half2float(__float2half_rn(x));
+        else return x;
+    }
+};
+
+template <bool HALF>
+__device__ __forceinline__ float sharpen_px(const float* len, float coef)
+{
+    using A = Arith<HALF>;
+    float mn0 = fminf(len[1], fminf(len[3], fminf(len[4], fminf(len[5], len[7]))));
+    float mn1 = fminf(mn0, fminf(len[0], fminf(len[2], fminf(len[6], len[8]))));
+    float mx0 = fmaxf(len[1], fmaxf(len[3], fmaxf(len[4], fmaxf(len[5], len[7]))));
+    float mx1 = fmaxf(mx0, fmaxf(len[0], fmaxf(len[2], fmaxf(len[6], len[8]))));
+    float minlen = A::r(0.5f * A::r(mn0 + mn1));
+    float maxlen = A::r(0.5f * A::r(mx0 + mx1));
+    minlen = A::r(__fdiv_rn(minlen, A::r(1.0f - minlen)));
+    maxlen = A::r(__fdiv_rn(A::r(1.0f - maxlen), maxlen));
+    float scale = (minlen < maxlen) ? minlen : maxlen;
+    scale = A::r(-coef * A::r(__fsqrt_rn(scale)));
+    float s4 = A::r(A::r(A::r(len[1] + len[3]) + len[5]) + len[7]);
+    float num = A::r(len[4] + A::r(scale * s4));
+    float den = A::r(1.0f + A::r(scale * 4.0f));
+    return A::r(__fdiv_rn(num, den));
+}
+
+// one thread = 4 consecutive pixels of one row; grid (ceil(uW/4/256), uH, 3)
+template <bool HALF>
+__global__ void __launch_bounds__(256) k_sharpen(SharpenParams p)
+{
+    using A = Arith<HALF>;
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y, c = blockIdx.z;
+    const int uW = p.uW, uH = p.uH;
+    if (x0 >= uW) return;
+    const long plane = (long)uW * uH;
+    const int ym = y > 0 ? y - 1 : y;
+    const int rows[3] = {ym, y, y + 1};          // no upper clamp (VkResample.cpp:891-892)
+    float L[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            int x = x0 - 1 + i;
+            if (x < 0) x = 0;                    // id_x_m clamp (VkResample.cpp:889)
+            long f = (long)rows[r] * uW + x;     // x == uW wraps to the next row (quirk B5)
+            while (f >= plane) f -= uW;          // reads past the plane: same column, last row (see oracle)
+            float t;
+            if constexpr (HALF) t = __half2float(((const __half*)p.R)[c * plane + f]);
+            else t = ((const float*)p.R)[c * plane + f];
+            t = fabsf(A::r(p.upsq * t));
+            L[r][i] = fminf(fmaxf(t, 0.0f), 1.0f);
+        }
+    }
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float len[9] = {L[0][i], L[0][i + 1], L[0][i + 2], L[1][i], L[1][i + 1], L[1][i + 2],
+                        L[2][i], L[2][i + 1], L[2][i + 2]};
+        o[i] = sharpen_px<HALF>(len, p.coef);
+    }
+    const long of = c * plane + (long)y * uW + x0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (x0 + i < uW) {
+            if constexpr (HALF) ((__half*)p.out)[of + i] = __float2half_rn(o[i]);
+            else ((float*)p.out)[of + i] = o[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host-loop replacements
+// VkResample.cpp:1636-1685: u8 interleaved -> planar float/half (row stride W, plane stride ps)
+template <bool HALF>
+__global__ void __launch_bounds__(256) k_unpack_u8(const uint8_t* rgb, long row_stride_bytes, void* planes,
+                                                    int W, int H, long plane_stride)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t* s = rgb + (long)y * row_stride_bytes + 3l * x;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        if constexpr (HALF) ((__half*)planes)[c * plane_stride + (long)y * W + x] = __float2half_rn(__fdiv_rn((float)s[c], 255.0f));
+        else ((float*)planes)[c * plane_stride + (long)y * W + x] = cvt_u8_f32(s[c]);
+    }
+}
+
+// VkResample.cpp:1708-1748: planar float/half -> u8 interleaved, u8 = (unsigned char)(255.0*x)
+template <bool HALF>
+__global__ void __launch_bounds__(256) k_pack_u8(const void* planes, uint8_t* rgb, int uW, int uH, int wrap)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= uW) return;
+    const long plane = (long)uW * uH;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float v;
+        if constexpr (HALF) v = __half2float(((const __half*)planes)[c * plane + (long)y * uW + x]);
+        else v = ((const float*)planes)[c * plane + (long)y * uW + x];
+        double d = 255.0 * (double)v;            // the reference multiplies in double
+        uint8_t o;
+        if (wrap) {
+            o = (d > -2147483648.0 && d < 2147483648.0) ? (uint8_t)(((int)d) & 0xFF) : 0;
+        } else {
+            o = !(d > 0.0) ? 0 : (d >= 255.0 ? 255 : (uint8_t)d);
+        }
+        rgb[((long)y * uW + x) * 3 + c] = o;
+    }
+}
+
+}  // namespace fftup
