@@ -16,6 +16,8 @@
 
 using namespace fftup;
 
+static constexpr int TUNED_TK = 4;     // column tile width of the size-specialised kernels
+
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 
@@ -228,11 +230,19 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         P->planUH = make_stage_plan(uH);
 
         const size_t lds_max = P->prop.sharedMemPerBlock ? P->prop.sharedMemPerBlock : 65536;
-        // column tile width: widest of 8,4,2,1 whose ping-pong buffers fit in LDS
+        // size-specialised kernels: u == 2 and power-of-two sizes with instantiated plans
+        P->tuned = !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && uW == 2 * W && uH == 2 * H &&
+                   (W == 512 || W == 1024 || W == 2048) && (H == 256 || H == 512 || H == 1024);
         P->TK = 0;
-        for (int tk : {8, 4, 2, 1}) {
-            size_t need = 2 * sizeof(float2) * (size_t)lpad_size((int)uH * tk);
-            if (need <= lds_max) { P->TK = tk; P->ldsCol = need; break; }
+        if (P->tuned) {
+            P->TK = TUNED_TK;
+            P->ldsCol = sizeof(float2) * (size_t)lpad_size((int)uH * TUNED_TK);
+        } else {
+            // column tile width: widest of 8,4,2,1 whose ping-pong buffers fit in LDS
+            for (int tk : {8, 4, 2, 1}) {
+                size_t need = 2 * sizeof(float2) * (size_t)lpad_size((int)uH * tk);
+                if (need <= lds_max) { P->TK = tk; P->ldsCol = need; break; }
+            }
         }
         if (!P->TK) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled height too large for LDS"); goto bad; }
         P->NT = ((int)(W / 2 + 1) + P->TK - 1) / P->TK;
@@ -279,8 +289,14 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         SET_LDS(k_col<1>, P->ldsCol);
         SET_LDS(k_row_c2r<false>, P->ldsRowI);
         SET_LDS(k_row_c2r<true>, P->ldsRowI);
+        if (P->tuned) {
+            switch (H) {
+            case 256: SET_LDS((k_col_t<256, TUNED_TK>), P->ldsCol); break;
+            case 512: SET_LDS((k_col_t<512, TUNED_TK>), P->ldsCol); break;
+            default: SET_LDS((k_col_t<1024, TUNED_TK>), P->ldsCol); break;
+            }
+        }
 #undef SET_LDS
-        P->tuned = false;
     }
     *out = P;
     return FFTUP_OK;
@@ -380,10 +396,88 @@ int fftup_upload_planar(fftup_plan* P, uint32_t slot, const void* planes, size_t
 
 // ------------------------------------------------------------------------------------------------
 // one frame: 4 launches on the plan's stream.  `which` < 0 launches all, otherwise only that one.
+}  // extern "C"
+
+template <int W> static void launch_r2c_t(fftup_plan* P, const RowR2CTParams& p, int mode)
+{
+    dim3 grid(P->H / 2, 3), block(W / 8);
+    switch (mode) {
+    case IN_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F32, TUNED_TK>), grid, block, 0, P->stream, p); break;
+    case IN_F16: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F16, TUNED_TK>), grid, block, 0, P->stream, p); break;
+    case IN_U8_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_U8_F32, TUNED_TK>), grid, block, 0, P->stream, p); break;
+    default: hipLaunchKernelGGL((k_row_r2c_t<W, IN_U8_F16, TUNED_TK>), grid, block, 0, P->stream, p); break;
+    }
+}
+template <int H> static void launch_col_t(fftup_plan* P, const ColTParams& p)
+{
+    dim3 grid(P->NT, 3), block(TUNED_TK * H / 8);
+    hipLaunchKernelGGL((k_col_t<H, TUNED_TK>), grid, block, P->ldsCol, P->stream, p);
+}
+template <int UW> static void launch_c2r_t(fftup_plan* P, const RowC2RTParams& p)
+{
+    dim3 grid(P->uH / 2, 3), block(UW / 8);
+    if (P->half) hipLaunchKernelGGL((k_row_c2r_t<UW, true, TUNED_TK, true>), grid, block, 0, P->stream, p);
+    else hipLaunchKernelGGL((k_row_c2r_t<UW, false, TUNED_TK, true>), grid, block, 0, P->stream, p);
+}
+
+static bool fast_sharpen_ok(const fftup_plan* P) { return P->uW % 256 == 0 && P->uH % 16 == 0; }
+
+static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
+{
+    const int kind = P->in_kind[in_slot];
+    if (which < 0 || which == 0) {
+        RowR2CTParams p{};
+        p.S1 = P->S1; p.tw = P->twW; p.H = (int)P->H; p.NT = P->NT;
+        int mode;
+        if (kind == 2) { p.in = P->in_u8[in_slot]; p.in_row_stride = 3l * P->W; p.in_plane_stride = 0; mode = P->half ? IN_U8_F16 : IN_U8_F32; }
+        else { p.in = P->in_planar[in_slot]; p.in_row_stride = P->W; p.in_plane_stride = (long)P->in_plane_stride; mode = P->half ? IN_F16 : IN_F32; }
+        switch (P->W) {
+        case 512: launch_r2c_t<512>(P, p, mode); break;
+        case 1024: launch_r2c_t<1024>(P, p, mode); break;
+        default: launch_r2c_t<2048>(P, p, mode); break;
+        }
+    }
+    if (which < 0 || which == 1) {
+        ColTParams p{};
+        p.S1 = P->S1; p.S2 = P->S2; p.twH = P->twH; p.twUH = P->twUH; p.W = (int)P->W; p.NT = P->NT;
+        switch (P->H) {
+        case 256: launch_col_t<256>(P, p); break;
+        case 512: launch_col_t<512>(P, p); break;
+        default: launch_col_t<1024>(P, p); break;
+        }
+    }
+    if (which < 0 || which == 2) {
+        RowC2RTParams p{};
+        p.S2 = P->S2; p.R = P->R; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
+        switch (P->uW) {
+        case 1024: launch_c2r_t<1024>(P, p); break;
+        case 2048: launch_c2r_t<2048>(P, p); break;
+        default: launch_c2r_t<4096>(P, p); break;
+        }
+    }
+    return FFTUP_OK;
+}
+
+static void launch_sharpen_fast(fftup_plan* P, uint32_t out_slot)
+{
+    SharpenTParams p{};
+    p.R = P->R; p.out = P->out[out_slot]; p.uW = (int)P->uW; p.uH = (int)P->uH; p.upsq = P->upsq; p.coef = P->coef;
+    dim3 grid(P->uW / 256, P->uH / 16, 3), block(64, 4);
+    if (P->half) hipLaunchKernelGGL((k_sharpen_t<true, 4>), grid, block, 0, P->stream, p);
+    else hipLaunchKernelGGL((k_sharpen_t<false, 4>), grid, block, 0, P->stream, p);
+}
+
 static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
 {
     const int kind = P->in_kind[in_slot];
     if (kind == 0) return fail(FFTUP_E_NO_INPUT, "no input uploaded for this slot");
+    if (P->tuned) {
+        launch_frame_tuned(P, in_slot, out_slot, which);
+        if (which < 0 || which == 3) launch_sharpen_fast(P, out_slot);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(FFTUP_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+        return FFTUP_OK;
+    }
     if (which < 0 || which == 0) {
         RowR2CParams p{};
         p.S1 = P->S1; p.tw = P->twW; p.plan = P->planW; p.W = (int)P->W; p.H = (int)P->H;
@@ -421,7 +515,9 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         if (P->half) hipLaunchKernelGGL(k_row_c2r<true>, grid, block, P->ldsRowI, P->stream, p);
         else hipLaunchKernelGGL(k_row_c2r<false>, grid, block, P->ldsRowI, P->stream, p);
     }
-    if (which < 0 || which == 3) {
+    if ((which < 0 || which == 3) && fast_sharpen_ok(P)) {
+        launch_sharpen_fast(P, out_slot);
+    } else if (which < 0 || which == 3) {
         SharpenParams p{};
         p.R = P->R; p.out = P->out[out_slot]; p.uW = (int)P->uW; p.uH = (int)P->uH; p.upsq = P->upsq; p.coef = P->coef;
         dim3 grid((P->uW / 4 + 255) / 256, P->uH, 3), block(256);
@@ -432,6 +528,8 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
     if (e != hipSuccess) return fail(FFTUP_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return FFTUP_OK;
 }
+
+extern "C" {
 
 int fftup_execute_ring(fftup_plan* P, uint32_t n_frames, uint32_t first_slot, double* ms_total)
 {
