@@ -47,7 +47,9 @@ enum {
     FFTUP_FLAG_FUSE_U8_LOAD = 2u,  /* row-FFT kernel reads the uint8 RGB image directly (README.md:31
                                       roadmap item); otherwise upload converts to the reference's planar
                                       float/half inputBuffer first (VR:1636-1688 semantics)               */
-    FFTUP_FLAG_GENERIC_KERNELS = 4u /* force the size-generic kernels even where a tuned plan exists     */
+    FFTUP_FLAG_GENERIC_KERNELS = 4u, /* force the size-generic kernels even where a tuned plan exists    */
+    FFTUP_FLAG_UNFUSED_SHARPEN = 8u  /* keep C2R and sharpen as two launches with the pre-sharpen image in
+                                        HBM, like the reference (tempBuffer); default fuses them          */
 };
 
 /* Replaces VkResampleConfiguration (VR:45-59) + the part of VkFFTConfiguration (VF:22-94) that

@@ -57,9 +57,13 @@ def test_fp32_parity_small(W, H, u, dist):
     assert np.abs(pre - opre).max() * usq <= 1e-4
     assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-4
     assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1e-3
-    # sharpen kernel in isolation: same (device) input on both sides
-    sh = O.sharpen(pre, u, 0, 0.2)
-    assert np.abs(out[:, :-1] - sh[:, :-1]).max() <= 2e-6 + 1e-3 * (np.abs(out - sh) > 2e-6).mean()
+    # sharpen kernel in isolation: same (device) input on both sides (two-launch path, where the
+    # pre-sharpen planes are exactly what the sharpen kernel read)
+    from vkresample_amd import FLAG_UNFUSED_SHARPEN
+    (pre_u, out_u, _), _ = _run(W, H, u, 0, dist, flags=FLAG_UNFUSED_SHARPEN)
+    sh = O.sharpen(pre_u, u, 0, 0.2)
+    # 5e-5: n = 1 - mx cancels in fp32 for near-saturated neighbourhoods (as in the reference's fp32 shader)
+    assert np.abs(out_u[:, :-1] - sh[:, :-1]).max() <= 5e-5
     # u8 = trunc(255*x): a float error can flip the truncation by one code; for u == 1 every exact
     # output sits ON a code boundary (x = k/255), so only the magnitude is asserted there
     d = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
@@ -83,12 +87,14 @@ def test_fp16_parity_small(W, H, u, dist):
     # pre-sharpen: both sides are fp16 values; fp32-vs-fp64 FFT noise can flip a rounding -> <= 1 ulp
     ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
     assert (np.abs(pre - opre) <= ulp * 1.0001).all()
-    assert (pre != opre).mean() <= 0.02
+    assert (pre != opre).mean() <= 0.05      # ringing around zero: fp16 ulp shrinks with |g|, fp32 noise does not
     assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-3
     assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 8e-3
-    # the half-arithmetic sharpen is bit-exact given the same fp16 input
-    sh = O.sharpen(pre, u, 2, 0.2)
-    assert np.array_equal(out[:, :-1], sh[:, :-1])
+    # the half-arithmetic sharpen is bit-exact given the same fp16 input (two-launch path)
+    from vkresample_amd import FLAG_UNFUSED_SHARPEN
+    (pre_u, out_u, _), _ = _run(W, H, u, 2, dist, flags=FLAG_UNFUSED_SHARPEN)
+    sh = O.sharpen(pre_u, u, 2, 0.2)
+    assert np.array_equal(out_u[:, :-1], sh[:, :-1])
 
 
 @pytest.mark.parametrize("precision", [0, 2])
@@ -221,8 +227,6 @@ def test_full_size_vs_oracle(W, H, precision):
         assert np.abs(pre - opre).max() * 4 <= 1e-4
         assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-4
         assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1e-3
-        sh = O.sharpen(pre, 2.0, 0, 0.2)
-        assert np.abs(out[:, :-1] - sh[:, :-1]).max() <= 5e-5
     else:
         ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
         assert (np.abs(pre - opre) <= ulp * 1.0001).all()
@@ -249,3 +253,24 @@ def test_full_size_properties():
     assert np.abs(res[2] - lin).max() <= 2e-5
     for r, p in zip(res[:2], (pa, pb)):
         assert np.abs(r.mean(axis=(1, 2)) - p.astype(np.float64).mean(axis=(1, 2))).max() <= 1e-6
+
+
+@pytest.mark.parametrize("precision", [0, 2])
+@pytest.mark.parametrize("pps", [1, 5, 6, 7, 256, 300, 1000])
+def test_fused_sharpen_equals_unfused(precision, pps, monkeypatch):
+    """The fused C2R+sharpen kernel (strips, one halo pair, explicit DC-leak, deferred last pixel, corner
+    sample) against the two-launch path on the same frame, for strip lengths that do / do not divide the
+    plane, cross plane boundaries, or swallow whole planes."""
+    from vkresample_amd import FLAG_UNFUSED_SHARPEN
+    monkeypatch.setenv("FFTUP_PAIRS_PER_STRIP", str(pps))
+    (pre, out, u8), _ = _run(512, 256, 2.0, precision, "U", seed=3)
+    (pre2, out2, u82), _ = _run(512, 256, 2.0, precision, "U", flags=FLAG_UNFUSED_SHARPEN, seed=3)
+    if precision == 0:
+        # different row pairing -> different fp32 rounding of the same numbers
+        assert np.abs(out - out2).max() <= 1e-4
+        assert _rel_l2(out, out2) <= 2e-6
+        # the quirk column x = uW-1 and the strip-boundary rows are where the bookkeeping lives
+        assert np.abs(out[:, :, -1] - out2[:, :, -1]).max() <= 1e-4
+    else:
+        assert np.abs(out - out2).max() <= 8e-3
+        assert (out != out2).mean() <= 0.02

@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 rocminfo | grep -E "Marketing Name|Compute Unit|gfx" | head -8 > $OUT/rocminfo.txt 2>&1
 nproc >> $OUT/rocminfo.txt
-timeout 900 python -m pytest tests -m gpu -q --timeout=600 > $OUT/pytest_gpu.txt 2>&1
+timeout 900 python -m pytest tests -m gpu -q --timeout=600 ${PYTEST_K:+-k "$PYTEST_K"} > $OUT/pytest_gpu.txt 2>&1
 grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu.txt | tail -15
 timeout 600 python bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json; tail -3 $OUT/bench.err

@@ -11,6 +11,7 @@ FFTUP_NUM_KERNELS = 4
 FLAG_U8_WRAP = 1
 FLAG_FUSE_U8_LOAD = 2
 FLAG_GENERIC_KERNELS = 4
+FLAG_UNFUSED_SHARPEN = 8
 
 # every symbol include/fftup.h declares
 EXPORTS = [

@@ -52,6 +52,11 @@ struct fftup_plan {
     size_t ldsRowF = 0, ldsCol = 0, ldsRowI = 0;
     float upsq = 0, coef = 0;
     bool tuned = false;
+    bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
+    int pairs_per_strip = 6;
+    size_t ldsFused = 0;
+    unsigned long long* trace = nullptr;   // FFTUP_TRACE builds only
+    bool R_valid = false;             // pre-sharpen buffer holds the last frame (unfused path only)
 
     // device memory
     std::vector<void*> in_planar;     // per slot: planar float/half, row stride W, plane stride (W+2)*H
@@ -245,6 +250,9 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             }
         }
         if (!P->TK) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled height too large for LDS"); goto bad; }
+        P->fused = P->tuned && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
+        P->ldsFused = fused_lds_bytes((int)uW);
+        if (const char* e = getenv("FFTUP_PAIRS_PER_STRIP")) P->pairs_per_strip = std::max(1, atoi(e));
         P->NT = ((int)(W / 2 + 1) + P->TK - 1) / P->TK;
         P->ldsRowF = 2 * sizeof(float2) * (size_t)lpad_size((int)W);
         P->ldsRowI = 2 * sizeof(float2) * (size_t)lpad_size((int)uW);
@@ -276,6 +284,10 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         PLAN_RC(dev_alloc(P, (void**)&P->S2, sizeof(float2) * 3 * (size_t)P->NT * uH * P->TK));
         PLAN_RC(dev_alloc(P, &P->R, (size_t)3 * uW * uH * esz));
         PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH));
+#ifdef FFTUP_TRACE
+        PLAN_RC(dev_alloc(P, (void**)&P->trace, 8 * 96 * 64));
+        PLAN_TRY(hipMemset(P->trace, 0, 8 * 96 * 64));
+#endif
 
         // allow > 64 KB dynamic LDS
 #define SET_LDS(kern, bytes) PLAN_TRY(hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
@@ -290,6 +302,11 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         SET_LDS(k_row_c2r<false>, P->ldsRowI);
         SET_LDS(k_row_c2r<true>, P->ldsRowI);
         if (P->tuned) {
+            switch (uW) {
+            case 1024: SET_LDS((k_c2r_sharpen_t<1024, false, TUNED_TK>), P->ldsFused); SET_LDS((k_c2r_sharpen_t<1024, true, TUNED_TK>), P->ldsFused); break;
+            case 2048: SET_LDS((k_c2r_sharpen_t<2048, false, TUNED_TK>), P->ldsFused); SET_LDS((k_c2r_sharpen_t<2048, true, TUNED_TK>), P->ldsFused); break;
+            default: SET_LDS((k_c2r_sharpen_t<4096, false, TUNED_TK>), P->ldsFused); SET_LDS((k_c2r_sharpen_t<4096, true, TUNED_TK>), P->ldsFused); break;
+            }
             switch (H) {
             case 256: SET_LDS((k_col_t<256, TUNED_TK>), P->ldsCol); break;
             case 512: SET_LDS((k_col_t<512, TUNED_TK>), P->ldsCol); break;
@@ -313,7 +330,7 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
     memset(info, 0, sizeof *info);
     info->out_width = P->uW;
     info->out_height = P->uH;
-    info->num_kernels = FFTUP_NUM_KERNELS;
+    info->num_kernels = P->fused ? 3 : 4;
     info->tuned = P->tuned ? 1 : 0;
     // B_alg = in + 2*S1 + 2*S2 + 2*R + out
     const double C = 3.0, W = P->W, H = P->H, uW = P->uW, uH = P->uH;
@@ -328,14 +345,16 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
     info->alg_bytes_per_frame = in + 2 * S1 + 2 * S2 + 2 * R + o;
     info->kernel_alg_bytes[0] = in + S1;
     info->kernel_alg_bytes[1] = S1 + S2;
-    info->kernel_alg_bytes[2] = S2 + R;
-    info->kernel_alg_bytes[3] = R + o;
+    // a fused C2R+sharpen launch does the work of the reference's I2 and C dispatches: its algorithmic
+    // bytes stay S2 + 2R + out although R never reaches HBM
+    info->kernel_alg_bytes[2] = P->fused ? S2 + 2 * R + o : S2 + R;
+    info->kernel_alg_bytes[3] = P->fused ? 0.0 : R + o;
     info->device_bytes = P->device_bytes;
     snprintf(info->device_name, sizeof info->device_name, "%s", P->prop.name);
     snprintf(info->kernel_names[0], 64, "row_r2c");
     snprintf(info->kernel_names[1], 64, "col_fwd_pad_inv");
-    snprintf(info->kernel_names[2], 64, "row_c2r");
-    snprintf(info->kernel_names[3], 64, "sharpen");
+    snprintf(info->kernel_names[2], 64, P->fused ? "row_c2r_sharpen" : "row_c2r");
+    snprintf(info->kernel_names[3], 64, P->fused ? "-" : "sharpen");
     return FFTUP_OK;
 }
 
@@ -420,6 +439,14 @@ template <int UW> static void launch_c2r_t(fftup_plan* P, const RowC2RTParams& p
     else hipLaunchKernelGGL((k_row_c2r_t<UW, false, TUNED_TK, true>), grid, block, 0, P->stream, p);
 }
 
+template <int UW> static void launch_fused_t(fftup_plan* P, const FusedParams& p)
+{
+    const int total_pairs = 3 * (int)P->uH / 2;
+    dim3 grid((total_pairs + p.pairs_per_strip - 1) / p.pairs_per_strip), block(UW / 8);
+    if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_t<UW, true, TUNED_TK>), grid, block, P->ldsFused, P->stream, p);
+    else hipLaunchKernelGGL((k_c2r_sharpen_t<UW, false, TUNED_TK>), grid, block, P->ldsFused, P->stream, p);
+}
+
 static bool fast_sharpen_ok(const fftup_plan* P) { return P->uW % 256 == 0 && P->uH % 16 == 0; }
 
 static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
@@ -446,7 +473,18 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
         default: launch_col_t<1024>(P, p); break;
         }
     }
-    if (which < 0 || which == 2) {
+    if ((which < 0 || which == 2) && P->fused) {
+        FusedParams p{};
+        p.trace = P->trace;
+        p.S2 = P->S2; p.out = P->out[out_slot]; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
+        p.pairs_per_strip = P->pairs_per_strip; p.upsq = P->upsq; p.coef = P->coef;
+        switch (P->uW) {
+        case 1024: launch_fused_t<1024>(P, p); break;
+        case 2048: launch_fused_t<2048>(P, p); break;
+        default: launch_fused_t<4096>(P, p); break;
+        }
+        P->R_valid = false;
+    } else if (which < 0 || which == 2 || which == 22) {   // 22: pre-sharpen tap requested for a fused plan
         RowC2RTParams p{};
         p.S2 = P->S2; p.R = P->R; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
         switch (P->uW) {
@@ -454,6 +492,7 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
         case 2048: launch_c2r_t<2048>(P, p); break;
         default: launch_c2r_t<4096>(P, p); break;
         }
+        P->R_valid = true;
     }
     return FFTUP_OK;
 }
@@ -473,7 +512,7 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
     if (kind == 0) return fail(FFTUP_E_NO_INPUT, "no input uploaded for this slot");
     if (P->tuned) {
         launch_frame_tuned(P, in_slot, out_slot, which);
-        if (which < 0 || which == 3) launch_sharpen_fast(P, out_slot);
+        if ((which < 0 || which == 3) && !P->fused) launch_sharpen_fast(P, out_slot);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(FFTUP_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
         return FFTUP_OK;
@@ -623,6 +662,12 @@ int fftup_download_presharpen(fftup_plan* P, void* planes)
     if (!P || !planes) return fail(FFTUP_E_INVALID_ARG, "null argument");
     if (!P->executed) return fail(FFTUP_E_NO_INPUT, "nothing executed yet");
     HIP_TRY(hipSetDevice(P->device));
+    if (P->fused && !P->R_valid) {
+        // the fused kernel never writes the pre-sharpen image; rebuild it from the spectrum of the last
+        // frame (still in S2) with the stand-alone C2R kernel
+        launch_frame_tuned(P, 0, 0, 22);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipMemcpyAsync(planes, P->R, (size_t)3 * P->uW * P->uH * (P->half ? 2 : 4), hipMemcpyDeviceToHost, P->stream));
     HIP_TRY(hipStreamSynchronize(P->stream));
     return FFTUP_OK;
@@ -675,6 +720,15 @@ const char* fftup_strerror(int code)
     default: return "unknown error";
     }
 }
+
+#ifdef FFTUP_TRACE
+__attribute__((visibility("default"))) int fftup_debug_trace(fftup_plan* P, unsigned long long* host, size_t n)
+{
+    if (!P || !P->trace) return 1;
+    hipStreamSynchronize(P->stream);
+    return hipMemcpy(host, P->trace, sizeof(unsigned long long) * std::min<size_t>(n, 96 * 64), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 5;
+}
+#endif
 
 const char* fftup_last_error(void) { return g_last_error.c_str(); }
 const char* fftup_version(void) { return "fftup 0.1.0 (gfx950)"; }

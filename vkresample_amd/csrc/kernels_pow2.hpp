@@ -24,26 +24,85 @@ constexpr int stage_radix(int N, int Ns) { return (N / Ns >= 8) ? 8 : (N / Ns); 
 // LDS element index of point idx of sequence col (TK interleaved sequences)
 template <int TK> __device__ __forceinline__ int lidx(int idx, int col) { return lpad(idx * TK + col); }
 
-// ---- one stage on registers: E/R butterflies of radix R, twiddles for Ns > 1
-template <int N, int E, int R, int Ns, int DIR>
-__device__ __forceinline__ void reg_butterflies(float2 (&v)[E], int p, const float2* __restrict__ tw)
+// ---- twiddles.  Stage with Ns > 1 of butterfly j needs exp(DIR*2 pi i*m*k/(Ns*R)), k = j % Ns,
+// m < R.  Every thread fetches ONE base twiddle per stage from the table, all of them up front
+// (TwSet::load, issued next to the first-stage input loads so that no stage waits on memory), and
+// forms the powers by multiplication (<= 3 roundings, ~2e-7).  A thread's butterflies b > 0 of one
+// stage differ from b = 0 by a compile-time rotation (only in the last stage, where Ns > Tc).
+constexpr int num_stages(int N, int Ns = 1) { return Ns >= N ? 0 : 1 + num_stages(N, Ns * stage_radix(N, Ns)); }
+constexpr int stage_ns(int N, int s) { return s == 0 ? 1 : stage_ns(N, s - 1) * stage_radix(N, stage_ns(N, s - 1)); }
+
+template <int N, int E> struct TwSet {
+    static constexpr int S = num_stages(N);
+    float2 w[S > 1 ? S - 1 : 1];                 // base twiddle of stages 1..S-1 (table sign: exp(+i..))
+    template <int s> __device__ __forceinline__ void load_stage(const float2* __restrict__ tw, int p)
+    {
+        if constexpr (s < S) {
+            constexpr int Ns = stage_ns(N, s);
+            constexpr int R = stage_radix(N, Ns);
+            constexpr int tstep = N / (Ns * R);
+            w[s - 1] = tw[(p & (Ns - 1)) * tstep];
+            load_stage<s + 1>(tw, p);
+        }
+    }
+    __device__ __forceinline__ void load(const float2* __restrict__ tw, int p) { load_stage<1>(tw, p); }
+};
+
+// exp(2 pi i q/16), q = 0..15, as compile-time constants
+constexpr float kCos16[16] = {1.f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.f,
+                              -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.f,
+                              -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f, 0.f,
+                              0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
+template <int Q> __device__ __forceinline__ float2 rot16()
+{
+    constexpr float cr = kCos16[Q & 15], ci = kCos16[(Q + 12) & 15];
+    return make_float2(cr, ci);
+}
+
+template <int R> __device__ __forceinline__ void twiddle_powers(float2* v, float2 w1)
+{
+    if constexpr (R == 2) {
+        v[1] = cmul(v[1], w1);
+    } else if constexpr (R == 4) {
+        float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+        v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3);
+    } else {
+        float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+        float2 w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+        v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
+        v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7);
+    }
+}
+
+// ---- one stage on registers: E/R butterflies of radix R (compile-time recursion over b)
+template <int N, int E, int R, int Ns, int DIR, int B>
+__device__ __forceinline__ void butterfly_b(float2 (&v)[E], float2 wbase)
 {
     constexpr int Tc = N / E;
     constexpr int NB = E / R;
-    constexpr int tstep = N / (Ns * R);
-#pragma unroll
-    for (int b = 0; b < NB; b++) {
+    if constexpr (B < NB) {
         float2 w[R];
 #pragma unroll
-        for (int m = 0; m < R; m++) w[m] = v[b + m * NB];
+        for (int m = 0; m < R; m++) w[m] = v[B + m * NB];
         if constexpr (Ns > 1) {
-            const int k = (p + b * Tc) & (Ns - 1);
-            apply_twiddles<R, DIR>(w, tw, k * tstep);
+            float2 w1 = twid<DIR>(wbase);
+            // last stage (Ns > Tc): k_b = p + b*Tc, i.e. an extra b/E of a revolution
+            if constexpr (Ns > Tc && B > 0) w1 = cmul(w1, twid<DIR>(rot16<B * (16 / E)>()));
+            twiddle_powers<R>(w, w1);
         }
         bfly<R, DIR>(w);
 #pragma unroll
-        for (int m = 0; m < R; m++) v[b + m * NB] = w[m];
+        for (int m = 0; m < R; m++) v[B + m * NB] = w[m];
+        butterfly_b<N, E, R, Ns, DIR, B + 1>(v, wbase);
     }
+}
+
+template <int N, int E, int R, int Ns, int DIR>
+__device__ __forceinline__ void reg_butterflies(float2 (&v)[E], float2 wbase)
+{
+    constexpr int Tc = N / E;
+    static_assert(Ns <= Tc || Ns * R == N, "per-butterfly twiddle offsets are only derived for the last stage");
+    butterfly_b<N, E, R, Ns, DIR, 0>(v, wbase);
 }
 
 // ---- Stockham autosort scatter of a stage's outputs into LDS
@@ -73,13 +132,14 @@ __device__ __forceinline__ void reg_gather(float2 (&v)[E], const float2* __restr
 // ---- all stages.  On entry v[i] = x[p + Tc*i].  If FINAL_TO_LDS the result X is left in LDS in
 // natural order (valid after the trailing barrier); otherwise v[i] = X[p + Tc*i] on return.
 // `buf` must not be in use by anyone on entry (callers barrier before re-using it).
-template <int N, int E, int DIR, int TK, bool FINAL_TO_LDS, int Ns = 1>
+template <int N, int E, int DIR, int TK, bool FINAL_TO_LDS, int S = 0>
 __device__ __forceinline__ void reg_fft(float2 (&v)[E], float2* __restrict__ buf, int p, int col,
-                                        const float2* __restrict__ tw)
+                                        const TwSet<N, E>& tws)
 {
+    constexpr int Ns = stage_ns(N, S);
     constexpr int R = stage_radix(N, Ns);
     static_assert(E % R == 0, "radix must divide the per-thread point count");
-    reg_butterflies<N, E, R, Ns, DIR>(v, p, tw);
+    reg_butterflies<N, E, R, Ns, DIR>(v, tws.w[S > 0 ? S - 1 : 0]);
     constexpr bool last = (Ns * R == N);
     if constexpr (!last || FINAL_TO_LDS) {
         reg_scatter<N, E, R, Ns, TK>(v, buf, p, col);
@@ -88,7 +148,7 @@ __device__ __forceinline__ void reg_fft(float2 (&v)[E], float2* __restrict__ buf
     if constexpr (!last) {
         reg_gather<N, E, TK>(v, buf, p, col);
         __syncthreads();
-        reg_fft<N, E, DIR, TK, FINAL_TO_LDS, Ns * R>(v, buf, p, col, tw);
+        reg_fft<N, E, DIR, TK, FINAL_TO_LDS, S + 1>(v, buf, p, col, tws);
     }
 }
 
@@ -117,10 +177,12 @@ __global__ void __launch_bounds__(W / 8) k_row_r2c_t(RowR2CTParams p)
     __shared__ float2 buf[lpad_size(W)];
     const int tid = threadIdx.x, j = blockIdx.x, c = blockIdx.y;
     float2 v[E];
+    TwSet<W, E> tws;
+    tws.load(p.tw, tid);
 #pragma unroll
     for (int i = 0; i < E; i++)
         v[i] = make_float2(load_px_t<MODE>(p, c, 2 * j, tid + T * i), load_px_t<MODE>(p, c, 2 * j + 1, tid + T * i));
-    reg_fft<W, E, +1, 1, true>(v, buf, tid, 0, p.tw);
+    reg_fft<W, E, +1, 1, true>(v, buf, tid, 0, tws);
     // unpack (vkFFT.h:4292-4323).  8 consecutive lanes cover one tile segment [A(TK)|B(TK)] of
     // 2*TK float2; each lane stores 16 bytes (two complex values).
     static_assert(TK == 4 || TK == 8, "tile width");
@@ -173,9 +235,13 @@ __global__ void __launch_bounds__(TK* H / 8) k_col_t(ColTParams p)
     const bool valid = tile * TK + col <= p.W / 2;
     const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
     float2 v[8];
+    TwSet<H, 8> twsF;
+    TwSet<UH, 16> twsI;
+    twsF.load(p.twH, pp);
+    twsI.load(p.twUH, pp);
 #pragma unroll
     for (int i = 0; i < 8; i++) v[i] = valid ? src[(pp + Tc * i) * TK + col] : make_float2(0.f, 0.f);
-    reg_fft<H, 8, +1, TK, true>(v, buf, pp, col, p.twH);          // F[ky] natural order in LDS
+    reg_fft<H, 8, +1, TK, true>(v, buf, pp, col, twsF);           // F[ky] natural order in LDS
     // inverse input (shift VkResample.cpp:514-526 + zero-pad guard vkFFT.h:1670-1695, u = 2):
     //   G[ky'] = F[ky'] (ky' < H/2), F[ky' - H] (ky' >= 3H/2), 0 otherwise.
     // Thread owns G[pp + Tc*i], i < 16 (UH/16 = Tc): i<4 -> F[pp+Tc*i]; i>=12 -> F[pp+Tc*(i-8)].
@@ -187,7 +253,7 @@ __global__ void __launch_bounds__(TK* H / 8) k_col_t(ColTParams p)
         else g[i] = make_float2(0.f, 0.f);
     }
     __syncthreads();
-    reg_fft<UH, 16, -1, TK, false>(g, buf, pp, col, p.twUH);
+    reg_fft<UH, 16, -1, TK, false>(g, buf, pp, col, twsI);
     float2* dst = p.S2 + ((long)c * p.NT + tile) * UH * TK;
     constexpr float inv = 1.0f / (float)UH;
     if (valid) {
@@ -222,6 +288,8 @@ __global__ void __launch_bounds__(UW / 8) k_row_c2r_t(RowC2RTParams p)
     // i=3..5 zero; i=6: mirror of k' = 2T - tid; i=7: mirror of k' = T - tid  (vkFFT.h:2096-2106)
     float2 v[E];
     float2 A, B;
+    TwSet<UW, E> tws;
+    tws.load(p.tw, tid);
     ldAB(tid, A, B);
     v[0] = make_float2(A.x - B.y, A.y + B.x);        // tid 0: DC element, same formula (vkFFT.h:2110-2131)
     ldAB(tid + T, A, B);
@@ -235,7 +303,7 @@ __global__ void __launch_bounds__(UW / 8) k_row_c2r_t(RowC2RTParams p)
     const long plane = (long)UW * p.uH;
     constexpr float inv = 1.0f / (float)UW;
     if constexpr (!WIDE) {
-        reg_fft<UW, E, -1, 1, false>(v, buf, tid, 0, p.tw);
+        reg_fft<UW, E, -1, 1, false>(v, buf, tid, 0, tws);
 #pragma unroll
         for (int i = 0; i < E; i++) {
             const int n = tid + T * i;
@@ -250,7 +318,7 @@ __global__ void __launch_bounds__(UW / 8) k_row_c2r_t(RowC2RTParams p)
             }
         }
     } else {
-        reg_fft<UW, E, -1, 1, true>(v, buf, tid, 0, p.tw);
+        reg_fft<UW, E, -1, 1, true>(v, buf, tid, 0, tws);
         // natural order in LDS: each thread takes 4 consecutive points twice -> 16-byte stores
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -271,6 +339,16 @@ __global__ void __launch_bounds__(UW / 8) k_row_c2r_t(RowC2RTParams p)
             }
         }
     }
+}
+
+// lane i <- lane i-1 / lane i+1 of the wave (gfx9 DPP wave shifts); lane 0 / 63 keep `edge`
+__device__ __forceinline__ float lane_from_below(float v, float edge)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_from_above(float v, float edge)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
 // =================================================================================== sharpen
@@ -396,6 +474,303 @@ __global__ void __launch_bounds__(256) k_sharpen_t(SharpenTParams p)
         }
         ra = rb;
         rb = rc;
+    }
+}
+
+
+// =================================================================================== fused C2R + sharpen
+// One workgroup = one strip of output rows [y0,y1) of one plane (a strip that crosses a plane boundary
+// is processed as two segments).  Row pairs are transformed one after the other; the clamped
+// |u^2 g| rows ("L rows") of a pair are parked in the FFT exchange buffer that just produced them, and
+// the next pair uses the OTHER of two exchange buffers, so the previous pair's rows stay put: no copy,
+// no extra registers.  After each pair the two rows whose 3x3 neighbourhood is complete are sharpened
+// and stored.  The pre-sharpen image never goes to HBM (the reference writes and re-reads it:
+// tempBuffer, 2 x 100 MB per frame).  The next pair's spectrum rows are fetched before the sharpen
+// phase, the per-stage twiddles once per workgroup.
+//
+// Pairing: a strip needs rows y0-1 .. y1, so it pairs (y0-1,y0),(y0+1,y0+2),.. -- one pair more than
+// it outputs.  The reference pairs (2j,2j+1) and its C2R leaks Im(DC column) between the two rows of a
+// pair (vkFFT.h:2110-2131); with any other pairing the same result is obtained by
+// adding that leak explicitly: row y gets -Im D[y+1] (y even) or +Im D[y-1] (y odd) on its DC term.
+//
+// Quirk B5 (VkResample.cpp:891-892): the right neighbour of x = uW-1 is x = 0 of the NEXT row, so pixel
+// (y, uW-1) needs L(y+2, 0).  For the newest sharpened row that value arrives with the next pair: the
+// pixel is finished one iteration later by the thread that owns it; for the last row of a strip the one
+// missing sample g[y1+1][0] = (sum over k of Z[k])/uW is evaluated directly from the spectrum row.
+// optional phase timeline (s_memtime) of wave 0 of every 64th workgroup: build with -DFFTUP_TRACE
+#ifdef FFTUP_TRACE
+#define FTRACE(slot) do { if (p.trace && tid == 0 && (blockIdx.x & 63) == 0 && tr_n < 96) { p.trace[(blockIdx.x >> 6) * 96 + tr_n++] = ((unsigned long long)(slot) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); } } while (0)
+#else
+#define FTRACE(slot) do { } while (0)
+#endif
+
+struct FusedParams {
+    unsigned long long* trace;
+    const float2* S2;
+    void* out;               // dense [3][uH][uW] float / half
+    const float2* tw;
+    int uH, NT;
+    int pairs_per_strip;
+    float upsq, coef;
+};
+
+__host__ __device__ constexpr size_t fused_buf_bytes(int uw) { return (sizeof(float2) * lpad_size(uw) + 15) & ~(size_t)15; }
+__host__ __device__ constexpr size_t fused_lds_bytes(int uw) { return 2 * fused_buf_bytes(uw) + 64; }
+
+template <bool HALF> __device__ __forceinline__ float to_L(float g, float upsq)
+{
+    using A = Arith<HALF>;
+    // C2R output is stored as half for -p 2 (vkFFT.h:7289-7290) before the sharpen shader scales it
+    if constexpr (HALF) g = __half2float(__float2half_rn(g));
+    return fminf(fmaxf(fabsf(A::r(upsq * g)), 0.0f), 1.0f);
+}
+
+// fp32 fast form of VkResample.cpp:909-922.  a < b  <=>  mn + mx < 1 (both denominators positive), so
+// one quotient n/d with d in [0.5,1] is formed; sqrt(n/d) = n * rsq(n*d).  2 transcendental ops/pixel.
+__device__ __forceinline__ float sharpen_eval_fast(float s4, float C, float mn0, float mn1, float mx0, float mx1, float coef)
+{
+    const float mn = 0.5f * (mn0 + mn1), mx = 0.5f * (mx0 + mx1);
+    const bool lo = (mn + mx) < 1.0f;
+    const float n = lo ? mn : 1.0f - mx;
+    const float d = lo ? 1.0f - mn : mx;
+    const float scale = -coef * n * __builtin_amdgcn_rsqf(fmaxf(n * d, 1e-30f));
+    return fmaf(scale, s4, C) * __builtin_amdgcn_rcpf(fmaf(scale, 4.0f, 1.0f));
+}
+
+// 4 output pixels from 3 tap rows of 6 values each (t[r][0] = left neighbour .. t[r][5] = right)
+template <bool HALF>
+__device__ __forceinline__ void sharpen_quad(const float (&t)[3][6], float coef, float (&o)[4])
+{
+    float hmn[3][4], hmx[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            hmn[r][i] = fminf(fminf(t[r][i], t[r][i + 1]), t[r][i + 2]);
+            hmx[r][i] = fmaxf(fmaxf(t[r][i], t[r][i + 1]), t[r][i + 2]);
+        }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float N = t[0][i + 1], S = t[2][i + 1], Wv = t[1][i], C = t[1][i + 1], E = t[1][i + 2];
+        const float mn0 = fminf(fminf(N, S), hmn[1][i]);           // cross = N, S and the centre row triple
+        const float mx0 = fmaxf(fmaxf(N, S), hmx[1][i]);
+        const float mn1 = fminf(fminf(hmn[0][i], hmn[2][i]), mn0);  // full 3x3 (min/max are exact: any order)
+        const float mx1 = fmaxf(fmaxf(hmx[0][i], hmx[2][i]), mx0);
+        if constexpr (HALF) o[i] = sharpen_eval<true>(N, S, Wv, E, C, mn1, mx1, mn0, mx0, coef);
+        else o[i] = sharpen_eval_fast(((N + Wv) + E) + S, C, mn0, mn1, mx0, mx1, coef);
+    }
+}
+
+template <int UW, bool HALF, int TK>
+__global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 / 256 : 1) k_c2r_sharpen_t(FusedParams p)
+{
+    constexpr int E = 8, T = UW / E;
+    constexpr float inv = 1.0f / (float)UW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)(smem + 2 * fused_buf_bytes(UW));     // [T/64] reduction scratch
+    const int tid = threadIdx.x;
+    const int uH = p.uH;
+    const int pairs_per_plane = uH / 2;
+    const long tile_stride = (long)uH * TK;
+    const long plane = (long)UW * uH;
+#ifdef FFTUP_TRACE
+    int tr_n = 0;
+#endif
+    FTRACE(0);
+    int f0 = blockIdx.x * p.pairs_per_strip;
+    const int f1 = min(f0 + p.pairs_per_strip, 3 * pairs_per_plane);
+    while (f0 < f1) {
+        // ---- one segment: plane c, output rows [y0,y1)
+        const int c = f0 / pairs_per_plane;
+        const int j0 = f0 - c * pairs_per_plane;
+        const int j1 = min(j0 + (f1 - f0), pairs_per_plane);
+        f0 += j1 - j0;
+        const int y0 = 2 * j0, y1 = 2 * j1;
+        const bool top = (y0 == 0);
+        const int a0 = top ? 0 : y0 - 1;
+        const int npairs = (j1 - j0) + 1;
+        const float2* base = p.S2 + (long)c * p.NT * tile_stride;
+        auto S2at = [&](int k, int row) -> float2 { return base[(long)(k / TK) * tile_stride + (long)row * TK + (k % TK)]; };
+        // DC term of row y including the reference's pair leak
+        auto dc_term = [&](int y) -> float {
+            float2 d = S2at(0, y);
+            float2 dp = S2at(0, y ^ 1);
+            return (y & 1) ? d.x + dp.y : d.x - dp.y;
+        };
+        // raw spectrum values of a pair: A from row ya, B from row yb at k = tid, tid+T, 2T-tid, T-tid;
+        // thread 0 also fetches the imaginary parts of the DC column of the reference partners (leak)
+        float2 rawA[4], rawB[4];
+        float lkA = 0.f, lkB = 0.f;
+        auto fetch = [&](int a) {
+            const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);   // rows past the plane: duplicate of the last row
+            const int ks[4] = {tid, tid + T, 2 * T - tid, T - tid};
+#pragma unroll
+            for (int q = 0; q < 4; q++) { rawA[q] = S2at(ks[q], ya); rawB[q] = S2at(ks[q], yb); }
+            // raw loads only: any arithmetic here would make the wave wait for the data at the prefetch point
+            if (tid == 0) { lkA = S2at(0, ya ^ 1).y; lkB = S2at(0, yb ^ 1).y; }
+        };
+        fetch(a0);
+        // ---- corner sample L(y1+1, 0) for the last pixel of row y1-1 (interior, non-bottom strips):
+        // g[rs][0] = (DC term + 2 * sum_{k=1..W/2} Re A_rs[k]) / uW.  The loads are issued here, behind
+        // the first pair's, and consumed after the first sharpen phase.
+        const bool need_corner = !top && (y1 + 1 < uH);
+        static_assert(UW / 4 == 2 * T, "two spectrum samples per thread");
+        float cs0 = 0.f, cs1 = 0.f, cd0 = 0.f, cd1 = 0.f;      // raw loads, combined after the first sharpen phase
+        const int rs = y1 + 1;
+        if (need_corner) {
+            cs0 = S2at(tid + 1, rs).x;
+            cs1 = S2at(tid + 1 + T, rs).x;
+            if (tid == T - 1) { cd0 = S2at(0, rs).x; cd1 = S2at(0, rs ^ 1).y; }
+        }
+
+        for (int it = 0; it < npairs; it++) {
+            const int a = a0 + 2 * it;
+            // exchange buffer of this pair; the other one still holds the previous pair's L rows
+            float2* buf = (float2*)(smem + (it & 1) * fused_buf_bytes(UW));
+            float* cur = (float*)buf;                                            // [2][UW] rows a, a+1
+            const float* ring = (const float*)(smem + ((it + 1) & 1) * fused_buf_bytes(UW));   // [2][UW] rows a-2, a-1
+            // ---- first-stage inputs (vkFFT.h:2059-2131): Z[k] = A + iB, Z[UW-k] = conj A + i conj B
+            FTRACE(1);
+            float2 v[E];
+            v[0] = make_float2(rawA[0].x - rawB[0].y, rawA[0].y + rawB[0].x);
+            v[1] = make_float2(rawA[1].x - rawB[1].y, rawA[1].y + rawB[1].x);
+            v[6] = make_float2(rawA[2].x + rawB[2].y, -rawA[2].y + rawB[2].x);
+            v[7] = make_float2(rawA[3].x + rawB[3].y, -rawA[3].y + rawB[3].x);
+            v[2] = make_float2(0.f, 0.f);
+            if (tid == 0) {
+                v[2] = make_float2(rawA[2].x - rawB[2].y, rawA[2].y + rawB[2].x);       // k = 2T = W/2
+                // DC terms incl. the pair leak: row y gets -Im D[y+1] (y even) / +Im D[y-1] (y odd)
+                const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);
+                v[0] = make_float2(rawA[0].x + ((ya & 1) ? lkA : -lkA), rawB[0].x + ((yb & 1) ? lkB : -lkB));
+            }
+            v[3] = v[4] = v[5] = make_float2(0.f, 0.f);
+#ifdef FFTUP_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            FTRACE(2);
+            {
+                TwSet<UW, E> tws;                 // L1-resident after the first pair; not kept live across the sharpen phase
+                tws.load(p.tw, tid);
+#ifdef FFTUP_PRIO
+                __builtin_amdgcn_s_setprio(FFTUP_PRIO);   // latency-bound FFT bursts go ahead of the other strip's sharpen arithmetic
+#endif
+                reg_fft<UW, E, -1, 1, false>(v, buf, tid, 0, tws);
+#ifdef FFTUP_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            }
+            FTRACE(3);
+            // ---- L rows of the new pair into the (now idle) exchange buffer
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                cur[tid + T * i] = to_L<HALF>(v[i].x * inv, p.upsq);
+                cur[UW + tid + T * i] = to_L<HALF>(v[i].y * inv, p.upsq);
+            }
+            if (it + 1 < npairs) fetch(a + 2);               // in flight during the sharpen phase
+            __syncthreads();
+            FTRACE(4);
+            auto rowp = [&](int r) -> const float* {      // r relative to a: -2,-1 (ring), 0,1 (cur)
+                return r < 0 ? ring + (r + 2) * UW : cur + r * UW;
+            };
+#pragma unroll 1
+            for (int w = 0; w < 2; w++) {                  // output row y = a-1 (w=0) and y = a (w=1)
+                const int y = a - 1 + w;
+                if (y < y0 || y >= y1) continue;           // uniform over the workgroup
+                const int rN = (y == 0) ? 0 : w - 2;       // tap rows relative to a; row -1 clamps to row 0
+                const float* pN = rowp(rN);
+                const float* pC = rowp(w - 1);
+                const float* pS = rowp(w);
+                // x = UW wraps to x = 0 of the next row: rows after N, C, S
+                const float* pNn = (y == 0) ? rowp(rN + 1) : pC;
+                const float* pCn = pS;
+                const bool have_Sn = (w == 0);             // row y+2 present only for y = a-1
+                const float* pSn = rowp(have_Sn ? w + 1 : w);
+#pragma unroll 1
+                for (int h = 0; h < 2; h++) {
+                    const int x0 = 4 * (tid + T * h);
+                    float t[3][6];
+                    const float* rows[3] = {pN, pC, pS};
+                    const float* nxt[3] = {pNn, pCn, pSn};
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        float4 q = *(const float4*)(rows[r] + x0);
+                        t[r][1] = q.x; t[r][2] = q.y; t[r][3] = q.z; t[r][4] = q.w;
+                        // neighbours live in the adjacent lanes; only the wave-edge lanes read LDS
+                        float el = q.x, er = 0.f;
+                        if ((tid & 63) == 0 && x0 != 0) el = rows[r][x0 - 1];
+                        if ((tid & 63) == 63) er = (x0 + 4 == UW) ? nxt[r][0] : rows[r][x0 + 4];
+                        t[r][0] = lane_from_below(q.w, el);
+                        t[r][5] = lane_from_above(q.x, er);
+                    }
+                    const bool last_chunk = (x0 + 4 == UW);
+                    bool defer = false;
+                    if (last_chunk && !have_Sn) {
+                        // SE tap of pixel (a, UW-1) is L(a+2, 0).  Past the plane it clamps to row uH-1
+                        // (held as row a or a+1); in the last iteration it is the corner sample;
+                        // otherwise the pixel is finished by the next iteration.
+                        const int r2 = min(y + 2, uH - 1) - a;
+                        if (r2 <= 1) t[2][5] = rowp(r2)[0];
+                        else if (it != npairs - 1) defer = true;
+                        else {                                 // it >= 1: partial sums were published by iteration 0
+                            float sum = 0.f;
+                            for (int w2 = 0; w2 < T / 64; w2++) sum += red[w2];
+                            t[2][5] = to_L<HALF>((red[8] + 2.0f * sum) * inv, p.upsq);
+                        }
+                    }
+                    float o[4];
+                    sharpen_quad<HALF>(t, p.coef, o);
+                    const long of = c * plane + (long)y * UW + x0;
+                    if constexpr (HALF) {
+                        __half* op = (__half*)p.out + of;
+                        if (defer) {
+                            *(__half2*)op = __floats2half2_rn(o[0], o[1]);
+                            op[2] = __float2half_rn(o[2]);
+                        } else {
+                            __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
+                            *(float2*)op = make_float2(*(float*)&h0, *(float*)&h1);
+                        }
+                    } else {
+                        float* op = (float*)p.out + of;
+                        if (defer) { op[0] = o[0]; op[1] = o[1]; op[2] = o[2]; }
+                        else *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+            }
+            FTRACE(5);
+            if (it == 0 && need_corner) {                 // uniform; published by this iteration's closing barrier
+                float part = cs0 + cs1;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+                if ((tid & 63) == 0) red[tid >> 6] = part;
+                if (tid == T - 1) red[8] = cd0 + ((rs & 1) ? cd1 : -cd1);
+            }
+            if (tid == T - 1) {
+                // ---- finish the pixel deferred by the previous iteration: (a-2, UW-1); L(a,0) is known now
+                if (it > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1) {
+                    const float* r2 = rowp(-2);
+                    const float* r1 = rowp(-1);
+                    const float* r0 = rowp(0);
+                    // N row of pixel (a-2, UW-1) is row a-3, whose wrap neighbour is (a-2, 0); for row 0
+                    // the N row is row 0 itself and wraps to (1, 0)
+                    const float ne = (a - 2 == 0) ? r1[0] : r2[0];
+                    const float pn0 = red[9], pn1 = red[10];
+                    const float t[3][6] = {{pn0, pn0, pn1, ne, ne, ne},
+                                           {r2[UW - 2], r2[UW - 2], r2[UW - 1], r1[0], r1[0], r1[0]},
+                                           {r1[UW - 2], r1[UW - 2], r1[UW - 1], r0[0], r0[0], r0[0]}};
+                    float o[4];
+                    sharpen_quad<HALF>(t, p.coef, o);       // o[1]: centre = column 2 = pixel UW-1
+                    const long of = c * plane + (long)(a - 2) * UW + (UW - 1);
+                    if constexpr (HALF) ((__half*)p.out)[of] = __float2half_rn(o[1]);
+                    else ((float*)p.out)[of] = o[1];
+                }
+                // N-row taps of the pixel (a, UW-1) deferred by this iteration: row a-1 (row 0 clamps to itself)
+                const float* rn = (a == 0) ? rowp(0) : rowp(-1);
+                red[9] = rn[UW - 2];
+                red[10] = rn[UW - 1];
+            }
+            __syncthreads();
+            FTRACE(6);
+        }
     }
 }
 
