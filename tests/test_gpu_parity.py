@@ -274,3 +274,20 @@ def test_fused_sharpen_equals_unfused(precision, pps, monkeypatch):
     else:
         assert np.abs(out - out2).max() <= 8e-3
         assert (out != out2).mean() <= 0.02
+
+
+@pytest.mark.parametrize("name", ["g16x8_u2_p0", "g20x12_u2_p0", "g64x32_u2_p0", "g64x32_u2_p2", "gsample64_u2_p0"])
+def test_golden_vectors_gpu(name):
+    """HIP path against the committed golden fixtures (tests/golden/make_golden.py)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    precision = int(d["precision"])
+    (pre, out, u8), _ = _run_rgb(d["rgb"], float(d["upscale"]), precision, float(d["sharpen"]))
+    if precision == 0:
+        assert np.abs(pre - d["pre"]).max() * 4 <= 1e-4 and _rel_l2(pre, d["pre"]) <= 1e-5
+        assert np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 1e-3 and _rel_l2(out[:, :-1], d["out"][:, :-1]) <= 1e-4
+        assert np.abs(u8[:-1].astype(int) - d["u8"][:-1].astype(int)).max() <= 1
+    else:
+        ulp = np.maximum(np.abs(d["pre"]), 2.0 ** -14) * 2.0 ** -10
+        assert (np.abs(pre - d["pre"]) <= ulp * 1.0001).all()
+        assert np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 8e-3

@@ -1,0 +1,144 @@
+"""CPU suite: the C ABI library loads and exports every declared symbol, structs match the header, error
+behaviour without a GPU, host-side sharding logic incl. a world_size-2 gloo run.  No GPU compute."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "fftup.h")
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    return sorted(set(re.findall(r"FFTUP_API\s+[\w\s\*]+?\b(fftup_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vkresample_amd import _lib
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.EXPORTS) == names          # the Python binding covers the whole header
+
+
+def test_struct_layout_matches_header(tmp_path):
+    """ctypes mirrors of fftup_config / fftup_info have the compiler's sizes and offsets."""
+    from vkresample_amd import _lib
+    prog = tmp_path / "layout.c"
+    prog.write_text(textwrap.dedent("""
+        #include <stdio.h>
+        #include <stddef.h>
+        #include "fftup.h"
+        int main(void) {
+            printf("%zu %zu %zu %zu %zu\\n", sizeof(fftup_config), offsetof(fftup_config, upscale),
+                   offsetof(fftup_config, device), offsetof(fftup_config, ring), sizeof(fftup_info));
+            printf("%zu %zu %zu\\n", offsetof(fftup_info, alg_bytes_per_frame), offsetof(fftup_info, device_name),
+                   offsetof(fftup_info, kernel_names));
+            return 0;
+        }"""))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    a, b = subprocess.check_output([str(exe)]).decode().split("\n")[:2]
+    a = [int(x) for x in a.split()]
+    b = [int(x) for x in b.split()]
+    assert a == [C.sizeof(_lib.Config), _lib.Config.upscale.offset, _lib.Config.device.offset, _lib.Config.ring.offset,
+                 C.sizeof(_lib.Info)]
+    assert b == [_lib.Info.alg_bytes_per_frame.offset, _lib.Info.device_name.offset, _lib.Info.kernel_names.offset]
+
+
+def test_header_compiles_as_c_and_cxx(tmp_path):
+    for comp, std, ext in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "cpp")):
+        f = tmp_path / ("t." + ext)
+        f.write_text('#include "fftup.h"\nint main(void){ return FFTUP_OK; }\n')
+        subprocess.check_call([comp, std, "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(f),
+                               "-o", str(tmp_path / "t.o")])
+
+
+def test_error_paths_without_device():
+    """argument validation happens before any device access; without a GPU the product refuses to run."""
+    import vkresample_amd as v
+    from vkresample_amd import _lib
+    lib = _lib.load()
+    assert lib.fftup_strerror(0) == b"success"
+    assert b"unsupported size" in lib.fftup_strerror(2)
+    assert lib.fftup_version().startswith(b"fftup")
+    for kwargs, code in ((dict(width=2 * 11 * 64, height=64), 2), (dict(width=63, height=64), 1),
+                         (dict(width=64, height=64, precision=1), 3), (dict(width=64, height=64, upscale=0.5), 1),
+                         (dict(width=8192, height=64), 2)):
+        with pytest.raises(v.FftupError) as e:
+            v.Upscaler(**kwargs)
+        assert e.value.code == code, kwargs
+    h = C.c_void_p()
+    cfg = _lib.Config(64, 32, 4, 2.0, 0, 0.2, 0, 0, 1)          # 4 channels
+    assert lib.fftup_plan_create(C.byref(h), C.byref(cfg)) == 1
+    assert lib.fftup_plan_create(None, C.byref(cfg)) == 1
+    if v.device_count() == 0:
+        with pytest.raises(v.FftupError) as e:
+            v.Upscaler(64, 32)
+        assert e.value.code == 4                                   # FFTUP_E_NO_DEVICE: no CPU fallback
+    assert lib.fftup_execute(None, 1, None) == 1
+    lib.fftup_plan_destroy(None)                                   # no-op
+
+
+def test_product_does_not_touch_the_oracle():
+    """the shipped path (package + csrc + CLI) never references oracle/ (tests, smoke and bench's cpu_baseline may)."""
+    pkg = os.path.join(ROOT, "vkresample_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(base, f), errors="replace").read()
+                assert "oraclelib" not in txt and "libfftup_oracle" not in txt and "orc_" not in txt, f
+    ldd = subprocess.check_output(["ldd", os.path.join(pkg, "libfftup.so")]).decode()
+    assert "oracle" not in ldd
+
+
+def test_reference_stripe_semantics():
+    from vkresample_amd.shard import frames_for_rank, local_frame_count
+    for n, t in ((512, 8), (10, 3), (7, 8), (1, 1), (9, 4)):
+        seen = []
+        for r in range(t):
+            fr = frames_for_rank(n, t, r)
+            assert len(fr) == local_frame_count(n, t, r)
+            assert all(f % t == r for f in fr)
+            seen += fr
+        assert sorted(seen) == list(range(n))                      # every frame exactly once
+    assert frames_for_rank(10, 3, 0) == [0, 3, 6, 9] and frames_for_rank(10, 3, 2) == [2, 5, 8]
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from vkresample_amd import synth
+from vkresample_amd.shard import frames_for_rank, reduce_summary
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+frames = frames_for_rank(11, world, rank)
+chk = sum(int(synth.frame(k, 32, 16).astype(np.int64).sum()) for k in frames)
+n, total, tmax = reduce_summary(dist, len(frames), chk, 0.5 + rank)
+if rank == 0:
+    print("RESULT", n, total, tmax)
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_sharding(tmp_path):
+    """world_size 2 on CPU (gloo): the shards cover the job exactly once and the end-of-run reduction is right."""
+    import numpy as np
+    from vkresample_amd import synth
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741")
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                                   "--master-addr", "127.0.0.1", "--master-port", "29741", str(script)],
+                                  env=env, stderr=subprocess.STDOUT, timeout=240).decode()
+    line = [l for l in out.splitlines() if l.startswith("RESULT")][0].split()
+    expect = sum(int(synth.frame(k, 32, 16).astype(np.int64).sum()) for k in range(11))
+    assert int(line[1]) == 11 and int(line[2]) == expect and float(line[3]) == 1.5

@@ -1,0 +1,184 @@
+"""CPU suite: the oracle against numpy.fft, the index-faithful layout emulation, analytic known-answer
+tests and the committed golden vectors.  No GPU."""
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+from oracle import ref_layout_emulation as E
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 12, 30, 64, 210, 1080, 2048, 2160])
+def test_fft1d_vs_numpy(n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    assert np.abs(O.fft1d(x, -1) - np.fft.fft(x)).max() <= 1e-11
+    assert np.abs(O.fft1d(x, +1) - np.fft.ifft(x) * n).max() <= 1e-11   # reference "forward" = exp(+i..)
+
+
+@pytest.mark.parametrize("W,H,u", [(16, 8, 2.0), (20, 12, 2.0), (24, 30, 2.0), (16, 8, 1.5), (16, 8, 1.0),
+                                   (12, 10, 3.0), (32, 16, 2.5)])
+def test_oracle_equals_layout_emulation_and_closed_form(W, H, u):
+    """C restatement == replay of the reference's buffers/strides/guards == SURVEY App. A.3 closed form."""
+    rng = np.random.default_rng(W * 1000 + H)
+    planes = rng.random((3, H, W))
+    pre, _, poison = O.upscale_planes(planes, u)
+    R, temp = E.emulate(planes, u)
+    assert poison == 0 and not np.isnan(R).any()       # nothing stale is ever read
+    assert np.abs(pre - R).max() <= 1e-14
+    assert np.abs(R - E.closed_form(planes, u)).max() <= 1e-14
+
+
+def test_out_dims_and_checks():
+    assert O.out_dims(2048, 1024, 2.0) == (4096, 2048)
+    assert O.out_dims(1920, 1080, 2.0) == (3840, 2160)
+    assert O.out_dims(16, 8, 1.5) == (24, 12)
+    assert O.check(2048, 1024) == 0
+    assert O.check(2 * 11 * 64, 64) == 2          # KAT8: not 2,3,5,7-smooth (vkFFT.h:4719-4726)
+    assert O.check(63, 64) == 1
+    assert O.check(64, 64, precision=1) == 3
+
+
+def test_load_conversion_table():
+    """VkResample.cpp:1644 / 1676 for all 256 codes, against independent numpy float32/float16 arithmetic."""
+    v = np.arange(256)
+    f32 = (v.astype(np.float32).astype(np.float64) / 255.0).astype(np.float32).astype(np.float64)
+    assert np.array_equal(O.load_lut(0), f32)
+    f16 = (v.astype(np.float16).astype(np.float32).astype(np.float64) / 255.0).astype(np.float32).astype(np.float16)
+    assert np.array_equal(O.load_lut(2), f16.astype(np.float64))
+    # fused device conversion = fp32 division (checked on the GPU side too)
+    assert np.array_equal(O.load_lut(0), (v.astype(np.float32) / np.float32(255)).astype(np.float64))
+
+
+def test_store_u8():
+    L = O.lib()
+    assert L.orc_store_u8(0.5, 0) == 127 and L.orc_store_u8(1.0, 0) == 255 and L.orc_store_u8(0.999, 0) == 254
+    assert L.orc_store_u8(-0.1, 0) == 0 and L.orc_store_u8(1.2, 0) == 255          # saturating (ours)
+    assert L.orc_store_u8(-1.6 / 255, 1) == 255 and L.orc_store_u8(256.3 / 255, 1) == 0   # x86 wrap of VR:1715
+
+
+# ------------------------------------------------------------------ known-answer tests (pre-sharpen, t = u^2 g)
+def _pre(planes, u=2.0):
+    pre, _, _ = O.upscale_planes(np.asarray(planes, dtype=np.float64), u)
+    return pre * u * u
+
+
+def test_kat1_constant():
+    planes = np.stack([np.full((8, 16), c) for c in (0.25, 0.5, 1.0)])
+    pre, out, _ = O.upscale_planes(planes, 2.0)
+    for c, v in enumerate((0.25, 0.5, 1.0)):
+        assert np.abs(pre[c] * 4 - v).max() <= 1e-14
+        assert np.abs(out[c] - v).max() <= 1e-14           # sharpen of a constant is the constant
+
+
+def test_kat2_kat3_kat5_cosines():
+    W, H, u = 32, 16, 2.0
+    x = np.arange(W)[None, :]
+    y = np.arange(H)[:, None]
+    X = np.arange(int(u * W))[None, :]
+    Y = np.arange(int(u * H))[:, None]
+    k0 = 5
+    planes = np.stack([0.5 + 0.25 * np.cos(2 * np.pi * k0 * x / W) + 0 * y,
+                       0.5 + 0.1 * (-1.0) ** x + 0 * y,
+                       0.5 + 0.1 * (-1.0) ** y * np.cos(2 * np.pi * 3 * x / W)])
+    t = _pre(planes, u)
+    assert np.abs(t[0] - (0.5 + 0.25 * np.cos(2 * np.pi * k0 * X / (u * W)) + 0 * Y)).max() <= 1e-14   # KAT2
+    assert np.abs(t[1] - (0.5 + 0.2 * np.cos(np.pi * X / u) + 0 * Y)).max() <= 1e-14                   # KAT3 (quirk B1)
+    assert np.abs(t[2] - (0.5 + 0.1 * np.cos(2 * np.pi * 3 * X / (u * W) - np.pi * Y / u))).max() <= 1e-14   # KAT5
+
+
+def test_kat4_nyquist_row_cancelled_by_leak():
+    """0.5 + a(-1)^y, u = 2: the (kx=0, ky=H/2) component is cancelled exactly by the row-pair DC leak (B2+B3)."""
+    W, H = 16, 8
+    y = np.arange(H)[:, None]
+    p = 0.5 + 0.1 * (-1.0) ** y + np.zeros((H, W))
+    t = _pre(np.stack([p, p, p]))
+    assert np.abs(t - 0.5).max() <= 1e-14
+
+
+def test_kat6_impulse():
+    W, H, u = 16, 8, 2
+    p = np.zeros((H, W))
+    p[0, 0] = 1.0
+    t = _pre(np.stack([p, p, p]))[0]
+    S = np.ones((H, W // 2 + 1), dtype=complex)
+    S[H // 2, 0] = 0.0                                        # u = 2: leak == zeroing S[H/2,0]
+    G = np.zeros((u * H, u * W // 2 + 1), dtype=complex)
+    G[:H // 2, :W // 2 + 1] = S[:H // 2]
+    G[u * H - H // 2:, :W // 2 + 1] = S[H // 2:]
+    assert np.abs(t - u * u * np.fft.irfft2(G, s=(u * H, u * W))).max() <= 1e-14
+
+
+def _sharpen_ref(L, coef):
+    """direct numpy transcription of App. A.4 for interior pixels of one plane (already clamped |t|)"""
+    out = np.zeros_like(L)
+    Hh, Ww = L.shape
+    for yy in range(1, Hh - 1):
+        for xx in range(1, Ww - 1):
+            n = L[yy - 1:yy + 2, xx - 1:xx + 2]
+            cross = [n[0, 1], n[1, 0], n[1, 1], n[1, 2], n[2, 1]]
+            mn0, mx0 = min(cross), max(cross)
+            mn1, mx1 = min(mn0, n[0, 0], n[0, 2], n[2, 0], n[2, 2]), max(mx0, n[0, 0], n[0, 2], n[2, 0], n[2, 2])
+            mn, mx = 0.5 * (mn0 + mn1), 0.5 * (mx0 + mx1)
+            a = mn / (1 - mn) if mn < 1 else np.inf
+            b = (1 - mx) / mx if mx > 0 else np.inf
+            sc = -coef * np.sqrt(min(a, b))
+            out[yy, xx] = (n[1, 1] + sc * (n[0, 1] + n[1, 0] + n[1, 2] + n[2, 1])) / (1 + 4 * sc)
+    return out
+
+
+def test_kat7_sharpen_step_edge_and_quirks():
+    uW, uH = 24, 10
+    R = np.zeros((3, uH, uW))
+    R[0, :, uW // 2:] = 0.2                       # step edge, t = 0.8
+    R[1] = np.linspace(-0.05, 0.3, uW)[None, :]    # negative -> abs (quirk B4), > 0.25 -> clamp
+    R[2] = np.random.default_rng(5).random((uH, uW)) * 0.25
+    out = O.sharpen(R, 2.0, 0, 0.2)
+    coef = float(np.float32(0.2))
+    for c in range(3):
+        L = np.clip(np.abs(4.0 * R[c]), 0, 1)
+        ref = _sharpen_ref(L, coef)
+        assert np.abs(out[c, 1:-1, 1:-1] - ref[1:-1, 1:-1]).max() <= 1e-14
+    # quirk B5: right neighbour of x = uW-1 is x = 0 of the next row; left/top clamp
+    L = np.clip(np.abs(4.0 * R[2]), 0, 1)
+    y = 4
+    ext = np.column_stack([L[:, uW - 2], L[:, uW - 1], np.roll(L[:, 0], -1)])   # (y, uW) -> (y+1, 0)
+    n = ext[y - 1:y + 2]
+    cross = [n[0, 1], n[1, 0], n[1, 1], n[1, 2], n[2, 1]]
+    mn0, mx0 = min(cross), max(cross)
+    mn1, mx1 = min(mn0, n[0, 0], n[0, 2], n[2, 0], n[2, 2]), max(mx0, n[0, 0], n[0, 2], n[2, 0], n[2, 2])
+    mn, mx = 0.5 * (mn0 + mn1), 0.5 * (mx0 + mx1)
+    sc = -coef * np.sqrt(min(mn / (1 - mn), (1 - mx) / mx))
+    expect = (n[1, 1] + sc * (n[0, 1] + n[1, 0] + n[1, 2] + n[2, 1])) / (1 + 4 * sc)
+    assert abs(out[2, y, uW - 1] - expect) <= 1e-14
+
+
+def test_sharpen_constants_via_percent_f():
+    """the shader sees its constants as '%f' text (VkResample.cpp:893-920): s = 0.123456789 acts as 0.123457"""
+    R = np.random.default_rng(1).random((3, 8, 8)) * 0.25
+    a = O.sharpen(R, 2.0, 0, 0.123456789)
+    b = O.sharpen(R, 2.0, 0, 0.123457)
+    assert np.array_equal(a, b)
+
+
+def test_fp16_mode_values_are_halves():
+    from vkresample_amd import synth
+    rgb = synth.frame(3, 32, 16, "N")
+    pre, out, u8 = O.upscale_rgb8(rgb, 2.0, 2)
+    assert np.array_equal(pre, pre.astype(np.float16).astype(np.float64))
+    assert np.array_equal(out, out.astype(np.float16).astype(np.float64))
+    pre0, out0, _ = O.upscale_rgb8(rgb, 2.0, 0)
+    assert np.abs(pre - pre0).max() <= 2e-4 and np.abs(out - out0).max() <= 2e-2
+
+
+# ------------------------------------------------------------------ golden vectors (tests/golden/make_golden.py)
+@pytest.mark.parametrize("name", ["g16x8_u2_p0", "g20x12_u2_p0", "g64x32_u2_p0", "g64x32_u2_p2", "gsample64_u2_p0"])
+def test_golden_vectors(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    pre, out, u8 = O.upscale_rgb8(d["rgb"], float(d["upscale"]), int(d["precision"]), float(d["sharpen"]))
+    assert np.abs(pre - d["pre"]).max() <= 1e-13
+    assert np.abs(out - d["out"]).max() <= 1e-12
+    assert np.array_equal(u8, d["u8"])

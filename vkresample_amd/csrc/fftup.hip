@@ -54,6 +54,8 @@ struct fftup_plan {
     bool tuned = false;
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
     int pairs_per_strip = 6;
+    int fused_version = 2;            // 1: two independent strips per CU, 2: one strip per CU with role-swapping halves
+    size_t ldsFused2 = 0;
     size_t ldsFused = 0;
     unsigned long long* trace = nullptr;   // FFTUP_TRACE builds only
     bool R_valid = false;             // pre-sharpen buffer holds the last frame (unfused path only)
@@ -252,7 +254,14 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         if (!P->TK) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled height too large for LDS"); goto bad; }
         P->fused = P->tuned && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
         P->ldsFused = fused_lds_bytes((int)uW);
+        if (const char* e = getenv("FFTUP_FUSED_V")) P->fused_version = atoi(e) == 1 ? 1 : 2;
+        {
+            const int total_pairs = 3 * (int)uH / 2, cus = std::max(1, P->prop.multiProcessorCount);
+            const int per_cu = (total_pairs + cus - 1) / cus;
+            P->pairs_per_strip = P->fused_version == 2 ? std::max(2, per_cu) : std::max(1, per_cu / 2);
+        }
         if (const char* e = getenv("FFTUP_PAIRS_PER_STRIP")) P->pairs_per_strip = std::max(1, atoi(e));
+        P->ldsFused2 = uW == 1024 ? Fused2Lds<1024>::TOTAL : uW == 2048 ? Fused2Lds<2048>::TOTAL : Fused2Lds<4096>::TOTAL;
         P->NT = ((int)(W / 2 + 1) + P->TK - 1) / P->TK;
         P->ldsRowF = 2 * sizeof(float2) * (size_t)lpad_size((int)W);
         P->ldsRowI = 2 * sizeof(float2) * (size_t)lpad_size((int)uW);
@@ -306,6 +315,11 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             case 1024: SET_LDS((k_c2r_sharpen_t<1024, false, TUNED_TK>), P->ldsFused); SET_LDS((k_c2r_sharpen_t<1024, true, TUNED_TK>), P->ldsFused); break;
             case 2048: SET_LDS((k_c2r_sharpen_t<2048, false, TUNED_TK>), P->ldsFused); SET_LDS((k_c2r_sharpen_t<2048, true, TUNED_TK>), P->ldsFused); break;
             default: SET_LDS((k_c2r_sharpen_t<4096, false, TUNED_TK>), P->ldsFused); SET_LDS((k_c2r_sharpen_t<4096, true, TUNED_TK>), P->ldsFused); break;
+            }
+            switch (uW) {
+            case 1024: SET_LDS((k_c2r_sharpen2_t<1024, false, TUNED_TK>), P->ldsFused2); SET_LDS((k_c2r_sharpen2_t<1024, true, TUNED_TK>), P->ldsFused2); break;
+            case 2048: SET_LDS((k_c2r_sharpen2_t<2048, false, TUNED_TK>), P->ldsFused2); SET_LDS((k_c2r_sharpen2_t<2048, true, TUNED_TK>), P->ldsFused2); break;
+            default: SET_LDS((k_c2r_sharpen2_t<4096, false, TUNED_TK>), P->ldsFused2); SET_LDS((k_c2r_sharpen2_t<4096, true, TUNED_TK>), P->ldsFused2); break;
             }
             switch (H) {
             case 256: SET_LDS((k_col_t<256, TUNED_TK>), P->ldsCol); break;
@@ -442,7 +456,14 @@ template <int UW> static void launch_c2r_t(fftup_plan* P, const RowC2RTParams& p
 template <int UW> static void launch_fused_t(fftup_plan* P, const FusedParams& p)
 {
     const int total_pairs = 3 * (int)P->uH / 2;
-    dim3 grid((total_pairs + p.pairs_per_strip - 1) / p.pairs_per_strip), block(UW / 8);
+    dim3 grid((total_pairs + p.pairs_per_strip - 1) / p.pairs_per_strip);
+    if (P->fused_version == 2) {
+        dim3 block(UW / 4);
+        if (P->half) hipLaunchKernelGGL((k_c2r_sharpen2_t<UW, true, TUNED_TK>), grid, block, P->ldsFused2, P->stream, p);
+        else hipLaunchKernelGGL((k_c2r_sharpen2_t<UW, false, TUNED_TK>), grid, block, P->ldsFused2, P->stream, p);
+        return;
+    }
+    dim3 block(UW / 8);
     if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_t<UW, true, TUNED_TK>), grid, block, P->ldsFused, P->stream, p);
     else hipLaunchKernelGGL((k_c2r_sharpen_t<UW, false, TUNED_TK>), grid, block, P->ldsFused, P->stream, p);
 }

@@ -16,6 +16,10 @@
 #include "fft_engine.hpp"
 #include "kernels_generic.hpp"
 
+#ifndef FFTUP_ABL
+#define FFTUP_ABL 0      // ablation builds (tools/): 1 no sharpen math, 2 no FFT, 3 no output stores
+#endif
+
 namespace fftup {
 
 constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n / 2); }
@@ -577,6 +581,11 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
     int tr_n = 0;
 #endif
     FTRACE(0);
+    // per-stage base twiddles: once per workgroup.  No load other than the spectrum prefetch may sit in
+    // the pair loop: vmcnt retires in order, so waiting for ANY load also waits for every older output
+    // store of the previous sharpen phase.
+    TwSet<UW, E> tws;
+    tws.load(p.tw, tid);
     int f0 = blockIdx.x * p.pairs_per_strip;
     const int f1 = min(f0 + p.pairs_per_strip, 3 * pairs_per_plane);
     while (f0 < f1) {
@@ -648,17 +657,15 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
             FTRACE(2);
-            {
-                TwSet<UW, E> tws;                 // L1-resident after the first pair; not kept live across the sharpen phase
-                tws.load(p.tw, tid);
-#ifdef FFTUP_PRIO
-                __builtin_amdgcn_s_setprio(FFTUP_PRIO);   // latency-bound FFT bursts go ahead of the other strip's sharpen arithmetic
+            // the next pair's spectrum rows are requested now (their registers were just consumed) and fly
+            // during the whole transform; they are made to land before the first output store below
+            if (it + 1 < npairs) fetch(a + 2);
+#if FFTUP_ABL != 2
+            reg_fft<UW, E, -1, 1, false>(v, buf, tid, 0, tws);
+#else
+#pragma unroll
+            for (int i = 0; i < E; i++) v[i].x += tws.w[0].x;
 #endif
-                reg_fft<UW, E, -1, 1, false>(v, buf, tid, 0, tws);
-#ifdef FFTUP_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
-            }
             FTRACE(3);
             // ---- L rows of the new pair into the (now idle) exchange buffer
 #pragma unroll
@@ -666,7 +673,11 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
                 cur[tid + T * i] = to_L<HALF>(v[i].x * inv, p.upsq);
                 cur[UW + tid + T * i] = to_L<HALF>(v[i].y * inv, p.upsq);
             }
-            if (it + 1 < npairs) fetch(a + 2);               // in flight during the sharpen phase
+            // landing point of the prefetch: the empty asm makes the compiler wait for these registers HERE,
+            // before any output store is issued, so that no later wait has stores in front of it
+#pragma unroll
+            for (int q = 0; q < 4; q++) asm volatile("" :: "v"(rawA[q].x), "v"(rawA[q].y), "v"(rawB[q].x), "v"(rawB[q].y));
+            asm volatile("" :: "v"(lkA), "v"(lkB));
             __syncthreads();
             FTRACE(4);
             auto rowp = [&](int r) -> const float* {      // r relative to a: -2,-1 (ring), 0,1 (cur)
@@ -718,21 +729,25 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
                         }
                     }
                     float o[4];
+#if FFTUP_ABL != 1
                     sharpen_quad<HALF>(t, p.coef, o);
+#else
+                    o[0] = t[0][1] + t[1][0] + t[2][5]; o[1] = t[0][2] + t[1][2]; o[2] = t[0][3] + t[2][3]; o[3] = t[0][4] + t[1][5];
+#endif
                     const long of = c * plane + (long)y * UW + x0;
+                    // one 16-byte (8-byte for half) store per lane, always: a deferred last pixel is written
+                    // with a placeholder now and overwritten by the same thread one iteration later
+                    (void)defer;
                     if constexpr (HALF) {
                         __half* op = (__half*)p.out + of;
-                        if (defer) {
-                            *(__half2*)op = __floats2half2_rn(o[0], o[1]);
-                            op[2] = __float2half_rn(o[2]);
-                        } else {
-                            __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
-                            *(float2*)op = make_float2(*(float*)&h0, *(float*)&h1);
-                        }
+                        __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
+                        *(float2*)op = make_float2(*(float*)&h0, *(float*)&h1);
                     } else {
                         float* op = (float*)p.out + of;
-                        if (defer) { op[0] = o[0]; op[1] = o[1]; op[2] = o[2]; }
-                        else *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
+#if FFTUP_ABL == 3
+                        if (o[0] == 12345.f)
+#endif
+                        *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
                     }
                 }
             }
@@ -770,6 +785,232 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
             }
             __syncthreads();
             FTRACE(6);
+        }
+    }
+}
+
+// =================================================================================== fused C2R + sharpen, v2
+// Same strip algorithm as k_c2r_sharpen_t, but ONE workgroup of 2*T threads per compute unit in which the
+// two halves swap roles every step: while one half transforms row pair s (LDS exchange buffer X[s%3]), the
+// other half sharpens the rows of pair s-1 (X[(s-1)%3] and X[(s-2)%3]) and stages the spectrum rows of
+// pair s+1 into LDS.  Both halves pass the same 8 workgroup barriers per step, so in every barrier interval
+// each SIMD holds latency-bound FFT waves next to arithmetic-bound sharpen waves.  Strips are twice as long
+// as in v1 (one strip per CU), which halves the halo overhead.
+template <int UW> struct Fused2Lds {
+    static constexpr int KH = UW / 4;                                        // highest non-zero kx (= W/2)
+    static constexpr size_t XB = fused_buf_bytes(UW);                        // exchange buffer / two L rows
+    static constexpr size_t SB = (sizeof(float2) * (2 * (KH + 1) + 2) + 15) & ~(size_t)15;   // A row, B row, leak terms
+    static constexpr size_t RED = 3 * XB + 2 * SB;
+    static constexpr size_t TOTAL = RED + 32 * sizeof(float);
+};
+
+template <int UW, bool HALF, int TK>
+__global__ void __launch_bounds__(UW / 4) k_c2r_sharpen2_t(FusedParams p)
+{
+    constexpr int E = 8, T = UW / E;
+    constexpr int KH = UW / 4;
+    constexpr float inv = 1.0f / (float)UW;
+    using L = Fused2Lds<UW>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)(smem + L::RED);      // [0..15] corner partial sums, [16] corner DC term, [20..21] deferred-pixel taps
+    const int tid = threadIdx.x;
+    const int grp = __builtin_amdgcn_readfirstlane(tid / T);      // 0 / 1, wave-uniform
+    const int lt = tid - grp * T;
+    const int uH = p.uH;
+    const int pairs_per_plane = uH / 2;
+    const long tile_stride = (long)uH * TK;
+    const long plane = (long)UW * uH;
+    // Loads and stores retire through ONE in-order counter (vmcnt): a wave that waits for a load also waits
+    // for every output store it issued before it.  Hence all loads belong to the FFT role (which stores
+    // nothing, and whose previous stores are a whole step old): twiddles first (L1/L2 hits, needed at stage
+    // 1), then the staging loads (a whole step to land); the sharpen role never waits on memory at all.
+
+    int f0 = blockIdx.x * p.pairs_per_strip;
+    const int f1 = min(f0 + p.pairs_per_strip, 3 * pairs_per_plane);
+    while (f0 < f1) {
+        const int c = f0 / pairs_per_plane;
+        const int j0 = f0 - c * pairs_per_plane;
+        const int j1 = min(j0 + (f1 - f0), pairs_per_plane);
+        f0 += j1 - j0;
+        const int y0 = 2 * j0, y1 = 2 * j1;
+        const bool top = (y0 == 0);
+        const int a0 = top ? 0 : y0 - 1;
+        const int npairs = (j1 - j0) + 1;
+        const float2* base = p.S2 + (long)c * p.NT * tile_stride;
+        auto S2at = [&](int k, int row) -> float2 { return base[(long)(k / TK) * tile_stride + (long)row * TK + (k % TK)]; };
+        const bool need_corner = !top && (y1 + 1 < uH);
+        const int rs = y1 + 1;
+
+        // ---- staging of the spectrum rows of pair i: issue (registers) and commit (LDS slot i&1)
+        struct Stage { float2 a0, a1, b0, b1, x0, x1; };
+        auto stage_issue = [&](int i) -> Stage {
+            Stage st;
+            const int a = a0 + 2 * i;
+            const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);       // rows past the plane: duplicate of the last row
+            st.a0 = S2at(lt, ya); st.a1 = S2at(lt + T, ya);
+            st.b0 = S2at(lt, yb); st.b1 = S2at(lt + T, yb);
+            // lane 0: k = W/2; lane 1: DC column of the reference partners (leak); others: a harmless re-read
+            const int kx = (lt == 0) ? KH : 0;
+            st.x0 = S2at(kx, (lt == 1) ? (ya ^ 1) : ya);
+            st.x1 = S2at(kx, (lt == 1) ? (yb ^ 1) : yb);
+            return st;
+        };
+        auto stage_commit = [&](int i, const Stage& st) {
+            float2* SA = (float2*)(smem + 3 * L::XB + (i & 1) * L::SB);
+            float2* SBp = SA + (KH + 1);
+            SA[lt] = st.a0; SA[lt + T] = st.a1;
+            SBp[lt] = st.b0; SBp[lt + T] = st.b1;
+            if (lt == 0) { SA[KH] = st.x0; SBp[KH] = st.x1; }
+            if (lt == 1) {
+                const int a = a0 + 2 * i;
+                const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);
+                // leak: row y gets -Im D[y+1] (y even) / +Im D[y-1] (y odd)
+                SBp[KH + 1] = make_float2((ya & 1) ? st.x0.y : -st.x0.y, (yb & 1) ? st.x1.y : -st.x1.y);
+            }
+        };
+
+        // ---- prologue: each half stages the first pair it will transform (pair 0 by half 0, pair 1 by
+        // half 1); half 1 also evaluates the corner sums; one barrier publishes everything
+        if (grp < npairs) {
+            const Stage st = stage_issue(grp);
+            stage_commit(grp, st);
+        }
+        if (grp == 1 && need_corner) {
+            float part = S2at(lt + 1, rs).x + S2at(lt + 1 + T, rs).x;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+            if ((lt & 63) == 0) red[lt >> 6] = part;
+            if (lt == T - 1) {
+                float2 d = S2at(0, rs), dp = S2at(0, rs ^ 1);
+                red[16] = (rs & 1) ? d.x + dp.y : d.x - dp.y;
+            }
+        }
+        __syncthreads();
+
+        for (int s = 0; s <= npairs; s++) {
+            if (grp == (s & 1)) {
+                // ================= FFT role: pair s
+                if (s < npairs) {
+                    const float2* SA = (const float2*)(smem + 3 * L::XB + (s & 1) * L::SB);
+                    const float2* SBp = SA + (KH + 1);
+                    float2* buf = (float2*)(smem + (s % 3) * L::XB);
+                    float* cur = (float*)buf;
+                    TwSet<UW, E> tws;
+                    tws.load(p.tw, lt);
+                    float2 v[E];
+                    {
+                        float2 A = SA[lt], B = SBp[lt];
+                        v[0] = make_float2(A.x - B.y, A.y + B.x);
+                        A = SA[lt + T]; B = SBp[lt + T];
+                        v[1] = make_float2(A.x - B.y, A.y + B.x);
+                        A = SA[2 * T - lt]; B = SBp[2 * T - lt];
+                        v[6] = make_float2(A.x + B.y, -A.y + B.x);
+                        v[2] = make_float2(0.f, 0.f);
+                        if (lt == 0) {
+                            v[2] = make_float2(A.x - B.y, A.y + B.x);                       // k = 2T = W/2
+                            const float2 lk = SBp[KH + 1];
+                            v[0] = make_float2(SA[0].x + lk.x, SBp[0].x + lk.y);              // DC terms incl. the pair leak
+                        }
+                        A = SA[T - lt]; B = SBp[T - lt];
+                        v[7] = make_float2(A.x + B.y, -A.y + B.x);
+                        v[3] = v[4] = v[5] = make_float2(0.f, 0.f);
+                    }
+                    // this half's next transform is pair s+2 (clamped re-read when there is none)
+                    const bool do_stage = (s + 2 < npairs);
+                    const Stage st = stage_issue(do_stage ? s + 2 : s);
+                    reg_fft<UW, E, -1, 1, false>(v, buf, lt, 0, tws);                           // 6 barriers
+#pragma unroll
+                    for (int i = 0; i < E; i++) {
+                        cur[lt + T * i] = to_L<HALF>(v[i].x * inv, p.upsq);
+                        cur[UW + lt + T * i] = to_L<HALF>(v[i].y * inv, p.upsq);
+                    }
+                    if (do_stage) stage_commit(s + 2, st);        // same slot (s&1) that was consumed above
+                    __syncthreads();                                                            // 7
+                    __syncthreads();                                                            // 8
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 8; b++) __syncthreads();
+                }
+            } else {
+                // ================= sharpen role: rows of pair i = s-1; stage pair s+1
+                const int i = s - 1;
+                const int a = a0 + 2 * i;
+                const float* cur = (const float*)(smem + ((i + 3) % 3) * L::XB);               // rows a, a+1
+                const float* ring = (const float*)(smem + ((i + 2) % 3) * L::XB);              // rows a-2, a-1
+                auto rowp = [&](int r) -> const float* { return r < 0 ? ring + (r + 2) * UW : cur + r * UW; };
+#pragma unroll 1
+                for (int ch = 0; ch < 4; ch++) {
+                    const int w = ch >> 1, h = ch & 1;
+                    const int y = a - 1 + w;
+                    if (i >= 0 && y >= y0 && y < y1) {                     // uniform over the half
+                        const int rN = (y == 0) ? 0 : w - 2;              // tap rows relative to a; row -1 clamps to row 0
+                        const float* rows[3] = {rowp(rN), rowp(w - 1), rowp(w)};
+                        const bool have_Sn = (w == 0);                    // row y+2 present only for y = a-1
+                        const float* nxt[3] = {(y == 0) ? rowp(rN + 1) : rows[1], rows[2], rowp(have_Sn ? w + 1 : w)};
+                        const int x0 = 4 * (lt + T * h);
+                        float t[3][6];
+#pragma unroll
+                        for (int r = 0; r < 3; r++) {
+                            float4 q = *(const float4*)(rows[r] + x0);
+                            t[r][1] = q.x; t[r][2] = q.y; t[r][3] = q.z; t[r][4] = q.w;
+                            float el = q.x, er = 0.f;
+                            if ((lt & 63) == 0 && x0 != 0) el = rows[r][x0 - 1];
+                            if ((lt & 63) == 63) er = (x0 + 4 == UW) ? nxt[r][0] : rows[r][x0 + 4];
+                            t[r][0] = lane_from_below(q.w, el);
+                            t[r][5] = lane_from_above(q.x, er);
+                        }
+                        const bool last_chunk = (x0 + 4 == UW);
+                        bool defer = false;
+                        if (last_chunk && !have_Sn) {
+                            const int r2 = min(y + 2, uH - 1) - a;
+                            if (r2 <= 1) t[2][5] = rowp(r2)[0];
+                            else if (i != npairs - 1) defer = true;
+                            else {
+                                float sum = 0.f;
+                                for (int w2 = 0; w2 < T / 64; w2++) sum += red[w2];
+                                t[2][5] = to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq);
+                            }
+                        }
+                        float o[4];
+                        sharpen_quad<HALF>(t, p.coef, o);
+                        const long of = c * plane + (long)y * UW + x0;
+                        // one 16-byte (8-byte for half) store per lane, always: a deferred last pixel gets a
+                        // placeholder now and is overwritten by the owning thread of the other half next step
+                        (void)defer;
+                        if constexpr (HALF) {
+                            __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
+                            *(float2*)((__half*)p.out + of) = make_float2(*(float*)&h0, *(float*)&h1);
+                        } else {
+                            *(float4*)((float*)p.out + of) = make_float4(o[0], o[1], o[2], o[3]);
+                        }
+                    }
+                    __syncthreads();
+                    if (ch < 2) __syncthreads();                                               // 6 in total
+                }
+                if (i >= 0 && lt == T - 1) {
+                    // finish the pixel deferred by the previous pair: (a-2, UW-1); L(a,0) is known now
+                    if (i > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1) {
+                        const float* r2 = rowp(-2);
+                        const float* r1 = rowp(-1);
+                        const float* r0 = rowp(0);
+                        const float ne = (a - 2 == 0) ? r1[0] : r2[0];
+                        const float pn0 = red[20], pn1 = red[21];
+                        const float t[3][6] = {{pn0, pn0, pn1, ne, ne, ne},
+                                               {r2[UW - 2], r2[UW - 2], r2[UW - 1], r1[0], r1[0], r1[0]},
+                                               {r1[UW - 2], r1[UW - 2], r1[UW - 1], r0[0], r0[0], r0[0]}};
+                        float o[4];
+                        sharpen_quad<HALF>(t, p.coef, o);
+                        const long of = c * plane + (long)(a - 2) * UW + (UW - 1);
+                        if constexpr (HALF) ((__half*)p.out)[of] = __float2half_rn(o[1]);
+                        else ((float*)p.out)[of] = o[1];
+                    }
+                    const float* rn = (a == 0) ? rowp(0) : rowp(-1);
+                    red[20] = rn[UW - 2];
+                    red[21] = rn[UW - 1];
+                }
+                __syncthreads();                                                               // 7
+                __syncthreads();                                                               // 8
+            }
         }
     }
 }
