@@ -1,0 +1,248 @@
+// vkresample -- command-line front end of the MI355X FFT upscaler; drop-in for the VkResample binary.
+//
+// Mirrors the reference's process entry and per-thread pipeline (VkResample.cpp "VR"):
+//   main()            VR:1795-1977   same flags, defaults, messages and exit codes
+//   launchResample()  VR:1280-1780   plan once per thread, then per file: PNG decode -> upload ->
+//                                    upscale x numIter -> download -> PNG encode
+// All compute goes through the C ABI of include/fftup.h (HIP); PNG I/O is pngio (zlib).
+// Extensions (do not change the reference behaviour when absent):
+//   -alldevices   batched mode: thread t uses device (d + t) % device_count instead of all threads on -d
+//   -fuseu8       the row kernel reads the uint8 image directly (README.md:31 roadmap item)
+//   -wrapu8       u8 store wraps like the reference's C cast instead of saturating
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fftup.h"
+#include "png_codec.hpp"
+
+struct ResampleConfiguration {           // VkResampleConfiguration, VR:45-59
+    const char* png_input_name = nullptr;
+    const char* png_output_name = nullptr;
+    float upscale = 1;
+    uint32_t precision = 0;
+    uint32_t numIter = 1;
+    int device_id = 0;
+    uint32_t fileUpload = 0;
+    const char* ifolder_prefix = nullptr;
+    const char* ofolder_prefix = nullptr;
+    int numFiles = 0;
+    int numThreads = 1;
+    int threadId = 0;
+    float sharpenConst = 0.2f;
+    bool allDevices = false;
+    uint32_t flags = 0;
+};
+
+static bool findFlag(char** start, char** end, const std::string& flag)      // VR:1782-1784: exact token match
+{
+    return std::find_if(start, end, [&](char* a) { return flag == a; }) != end;
+}
+static char* getFlagValue(char** start, char** end, const std::string& flag)  // VR:1785-1794
+{
+    char** value = std::find_if(start, end, [&](char* a) { return flag == a; });
+    if (value == end) return nullptr;
+    value++;
+    return value != end ? *value : nullptr;
+}
+
+static int devices_list()                                                     // VR:239-268
+{
+    const int n = fftup_device_count();
+    for (int i = 0; i < n; i++) {
+        char name[256] = "";
+        fftup_device_name(i, name, sizeof name);
+        printf("Device id: %d name: %s API:HIP\n", i, name);
+    }
+    return n > 0 ? 0 : FFTUP_E_NO_DEVICE;
+}
+
+static int launchResample(ResampleConfiguration config)                      // VR:1280-1780
+{
+    if (config.threadId == 0) printf("VkResample - FFT based upscaling\n");
+    char fileName[1024];
+    if (config.fileUpload) snprintf(fileName, sizeof fileName, "%s/%06d.png", config.ifolder_prefix, config.threadId + 1);   // VR:1357
+    else snprintf(fileName, sizeof fileName, "%s", config.png_input_name);
+
+    std::vector<uint8_t> png_input;
+    int width = 0, height = 0, channels = 0;
+    std::string err;
+    if (!pngio::load_rgb8(fileName, png_input, width, height, channels, err)) {
+        printf("Image not found\n");                                           // VR:1364-1367
+        return FFTUP_E_INCOMPLETE;
+    }
+    int device = config.device_id;
+    if (config.allDevices) {
+        const int nd = fftup_device_count();
+        if (nd > 0) device = (config.device_id + config.threadId) % nd;
+    }
+    fftup_config cfg{};
+    cfg.width = (uint32_t)width; cfg.height = (uint32_t)height; cfg.channels = 3;
+    cfg.upscale = config.upscale; cfg.precision = config.precision; cfg.sharpen = config.sharpenConst;
+    cfg.device = device; cfg.flags = config.flags; cfg.ring = 1;
+    fftup_plan* plan = nullptr;
+    int res = fftup_plan_create(&plan, &cfg);
+    if (res != FFTUP_OK) {
+        printf("Plan creation failed: %s (%s)\n", fftup_strerror(res), fftup_last_error());
+        return res;
+    }
+    fftup_info info{};
+    fftup_plan_info(plan, &info);
+    if (config.threadId == 0)
+        printf("VRAM per thread: %d MB Total: %d MB\n", (int)(info.device_bytes / 1024 / 1024),
+               (int)(config.numThreads * (info.device_bytes / 1024 / 1024)));  // VR:1450
+    const uint32_t uW = info.out_width, uH = info.out_height;
+    std::vector<uint8_t> png_output((size_t)uW * uH * 3);
+
+    int numLocalFiles = 1;
+    if (config.fileUpload) {                                                   // VR:1622-1625
+        numLocalFiles = (int)std::ceil(config.numFiles / (float)config.numThreads);
+        if ((numLocalFiles - 1) * config.numThreads + config.threadId > config.numFiles - 1) numLocalFiles--;
+    }
+    for (int f = 0; f < numLocalFiles; f++) {
+        if (f > 0) {
+            snprintf(fileName, sizeof fileName, "%s/%06d.png", config.ifolder_prefix, f * config.numThreads + config.threadId + 1);
+            int w2 = 0, h2 = 0;
+            if (!pngio::load_rgb8(fileName, png_input, w2, h2, channels, err) || w2 != width || h2 != height) {
+                printf("Image not found\n");                                   // VR:1631-1634 (all files share one size)
+                fftup_plan_destroy(plan);
+                return FFTUP_E_INCOMPLETE;
+            }
+        }
+        res = fftup_upload_rgb8(plan, png_input.data(), (size_t)width * 3);   // pack loop + transferDataFromCPU
+        double totTime = 0;
+        if (res == FFTUP_OK) res = fftup_execute(plan, config.numIter, &totTime);   // performVulkanUpscale, VR:1692
+        if (res != FFTUP_OK) {
+            printf("Upscale failed: %s (%s)\n", fftup_strerror(res), fftup_last_error());
+            fftup_plan_destroy(plan);
+            return res;
+        }
+        if (!config.fileUpload)
+            printf("VkResample %0.1fx upscale: %dx%d to %dx%d Time: %0.3f ms\n", config.upscale, width, height, uW, uH, totTime);   // VR:1694
+        res = fftup_download_rgb8(plan, 0, png_output.data(), (size_t)uW * 3);  // transferDataToCPU + unpack loop
+        if (res != FFTUP_OK) {
+            printf("Download failed: %s (%s)\n", fftup_strerror(res), fftup_last_error());
+            fftup_plan_destroy(plan);
+            return res;
+        }
+        char outName[1024];
+        if (config.fileUpload) snprintf(outName, sizeof outName, "%s/%06d.png", config.ofolder_prefix, f * config.numThreads + config.threadId + 1);
+        else if (config.png_output_name) snprintf(outName, sizeof outName, "%s", config.png_output_name);
+        else snprintf(outName, sizeof outName, "%d_%d_upscaled.png", width, (int)uW);   // VR:1706
+        if (!pngio::write_rgb8(outName, png_output.data(), (int)uW, (int)uH, (size_t)uW * 3, err))
+            printf("Could not write %s: %s\n", outName, err.c_str());
+    }
+    fftup_plan_destroy(plan);
+    printf("Thread %d finished. Device name: %s API:HIP\n", config.threadId, info.device_name);   // VR:1773
+    return FFTUP_OK;
+}
+
+int main(int argc, char* argv[])
+{
+    ResampleConfiguration config;
+    char** B = argv;
+    char** E = argv + argc;
+    if (findFlag(B, E, "-h")) {
+        printf("vkresample (MI355X/HIP build, %s) -- command line of VkResample v1.0.2\n", fftup_version());
+        printf("PNG images only.\n");
+        printf("	-h: this help\n");
+        printf("	-devices: list the available GPUs\n");
+        printf("	-d X: GPU to use (default 0)\n");
+        printf("	-u X: upscale factor (float; the upscaled sizes must factor into 2s, 3s, 5s and 7s)\n");
+        printf("	-p X: precision (0 - single, 2 - half storage with single arithmetic; 1 - double is not implemented)\n");
+        printf("	-s X: sharpening factor, 0.0-0.2 (default 0.2)\n");
+        printf("	-n X: how many times to run the upscale; removes launch overhead from the reported time (default 1)\n");
+        printf("Single image mode:\n");
+        printf("	-i NAME: input png\n");
+        printf("	-o NAME: output png (default <width>_<upscaled width>_upscaled.png)\n");
+        printf("Batched mode:\n");
+        printf("	-ifolder X: input folder; files are X/000001.png, X/000002.png, ...\n");
+        printf("	-ofolder X: output folder, same naming\n");
+        printf("	-numfiles X: number of images\n");
+        printf("	-numthreads X: host threads, each with its own plan; thread t takes files t+1, t+1+X, ...\n");
+        printf("Extensions:\n");
+        printf("	-alldevices: thread t runs on GPU (d + t) %% count\n");
+        printf("	-fuseu8: FFT kernel reads the 8-bit image directly\n");
+        printf("	-wrapu8: 8-bit store wraps like the original's C cast instead of saturating\n");
+        return 0;
+    }
+    if (findFlag(B, E, "-devices")) return devices_list();
+    if (findFlag(B, E, "-d")) {
+        char* v = getFlagValue(B, E, "-d");
+        if (v) sscanf(v, "%d", &config.device_id);
+        else { printf("No device is selected with -d flag\n"); return 1; }
+    }
+    if (findFlag(B, E, "-n")) {
+        char* v = getFlagValue(B, E, "-n");
+        if (v) sscanf(v, "%u", &config.numIter);
+        else { printf("No number is selected with -n flag\n"); return 1; }
+        if (config.numIter == 0) config.numIter = 1;
+    }
+    if (findFlag(B, E, "-p")) {
+        char* v = getFlagValue(B, E, "-p");
+        if (v) sscanf(v, "%u", &config.precision);
+        else { printf("No precision is selected with -p flag\n"); return 1; }
+    }
+    if (findFlag(B, E, "-s")) {
+        char* v = getFlagValue(B, E, "-s");
+        if (v) sscanf(v, "%f", &config.sharpenConst);
+        else { printf("No sharpening parameter is selected with -s flag\n"); return 1; }
+    }
+    if (findFlag(B, E, "-u")) {
+        char* v = getFlagValue(B, E, "-u");
+        if (v) sscanf(v, "%f", &config.upscale);
+        else printf("No proper upscale factor is selected with -u flag, default 1\n");
+    } else {
+        printf("No upscale factor is selected with -u flag, default 1\n");
+    }
+    config.allDevices = findFlag(B, E, "-alldevices");
+    if (findFlag(B, E, "-fuseu8")) config.flags |= FFTUP_FLAG_FUSE_U8_LOAD;
+    if (findFlag(B, E, "-wrapu8")) config.flags |= FFTUP_FLAG_U8_WRAP;
+
+    if (!findFlag(B, E, "-ifolder")) {
+        config.fileUpload = 0;
+        config.png_input_name = getFlagValue(B, E, "-i");
+        if (!config.png_input_name) { printf("No input file is selected with -i flag\n"); return 1; }
+        if (findFlag(B, E, "-o")) {
+            config.png_output_name = getFlagValue(B, E, "-o");
+            if (!config.png_output_name) { printf("No output file is selected with -o flag\n"); return 1; }
+        }
+    } else {
+        config.fileUpload = 1;
+        config.ifolder_prefix = getFlagValue(B, E, "-ifolder");
+        if (!config.ifolder_prefix) { printf("No input folder+prefix is selected with -ifolder flag\n"); return 1; }
+        config.ofolder_prefix = getFlagValue(B, E, "-ofolder");
+        if (!config.ofolder_prefix) { printf("No output folder+prefix is selected with -ofolder flag\n"); return 1; }
+        if (findFlag(B, E, "-numthreads")) {
+            char* v = getFlagValue(B, E, "-numthreads");
+            if (v) sscanf(v, "%d", &config.numThreads);
+            else { printf("No numThreads is selected with -numthreads flag\n"); return 1; }
+        }
+        char* v = getFlagValue(B, E, "-numfiles");                // the reference leaves numFiles uninitialised when
+        if (v) sscanf(v, "%d", &config.numFiles);                  // the flag is missing (quirk B10): required here
+        else { printf("No numFiles is selected with -numfiles flag\n"); return 1; }
+        if (config.numThreads < 1) config.numThreads = 1;
+        if (config.numFiles < 1) { printf("No numFiles is selected with -numfiles flag\n"); return 1; }
+    }
+    auto timeSubmit = std::chrono::system_clock::now();
+    std::vector<std::thread> threads;
+    std::vector<int> results((size_t)config.numThreads, 0);
+    for (int i = 0; i < config.numThreads; i++) {
+        ResampleConfiguration loc = config;
+        loc.threadId = i;
+        threads.emplace_back([loc, i, &results]() { results[(size_t)i] = launchResample(loc); });
+    }
+    for (auto& t : threads) t.join();
+    auto timeEnd = std::chrono::system_clock::now();
+    double totTime = std::chrono::duration_cast<std::chrono::microseconds>(timeEnd - timeSubmit).count() * 0.001;
+    printf("Total time: %0.3f s\n", totTime / 1000);
+    // the reference returns VK_SUCCESS whatever its threads did (VR:1975); a failing thread is reported here
+    for (int r : results) if (r != FFTUP_OK) return r;
+    return 0;
+}

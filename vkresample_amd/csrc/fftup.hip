@@ -54,10 +54,7 @@ struct fftup_plan {
     bool tuned = false;
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
     int pairs_per_strip = 6;
-    int fused_version = 2;            // 1: two independent strips per CU, 2: one strip per CU with role-swapping halves
     size_t ldsFused2 = 0;
-    size_t ldsFused = 0;
-    unsigned long long* trace = nullptr;   // FFTUP_TRACE builds only
     bool R_valid = false;             // pre-sharpen buffer holds the last frame (unfused path only)
 
     // device memory
@@ -253,12 +250,10 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         }
         if (!P->TK) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled height too large for LDS"); goto bad; }
         P->fused = P->tuned && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
-        P->ldsFused = fused_lds_bytes((int)uW);
-        if (const char* e = getenv("FFTUP_FUSED_V")) P->fused_version = atoi(e) == 1 ? 1 : 2;
         {
+            // one strip (workgroup) per compute unit
             const int total_pairs = 3 * (int)uH / 2, cus = std::max(1, P->prop.multiProcessorCount);
-            const int per_cu = (total_pairs + cus - 1) / cus;
-            P->pairs_per_strip = P->fused_version == 2 ? std::max(2, per_cu) : std::max(1, per_cu / 2);
+            P->pairs_per_strip = std::max(2, (total_pairs + cus - 1) / cus);
         }
         if (const char* e = getenv("FFTUP_PAIRS_PER_STRIP")) P->pairs_per_strip = std::max(1, atoi(e));
         P->ldsFused2 = uW == 1024 ? Fused2Lds<1024>::TOTAL : uW == 2048 ? Fused2Lds<2048>::TOTAL : Fused2Lds<4096>::TOTAL;
@@ -293,10 +288,6 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         PLAN_RC(dev_alloc(P, (void**)&P->S2, sizeof(float2) * 3 * (size_t)P->NT * uH * P->TK));
         PLAN_RC(dev_alloc(P, &P->R, (size_t)3 * uW * uH * esz));
         PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH));
-#ifdef FFTUP_TRACE
-        PLAN_RC(dev_alloc(P, (void**)&P->trace, 8 * 96 * 64));
-        PLAN_TRY(hipMemset(P->trace, 0, 8 * 96 * 64));
-#endif
 
         // allow > 64 KB dynamic LDS
 #define SET_LDS(kern, bytes) PLAN_TRY(hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
@@ -312,14 +303,9 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         SET_LDS(k_row_c2r<true>, P->ldsRowI);
         if (P->tuned) {
             switch (uW) {
-            case 1024: SET_LDS((k_c2r_sharpen_t<1024, false, TUNED_TK>), P->ldsFused); SET_LDS((k_c2r_sharpen_t<1024, true, TUNED_TK>), P->ldsFused); break;
-            case 2048: SET_LDS((k_c2r_sharpen_t<2048, false, TUNED_TK>), P->ldsFused); SET_LDS((k_c2r_sharpen_t<2048, true, TUNED_TK>), P->ldsFused); break;
-            default: SET_LDS((k_c2r_sharpen_t<4096, false, TUNED_TK>), P->ldsFused); SET_LDS((k_c2r_sharpen_t<4096, true, TUNED_TK>), P->ldsFused); break;
-            }
-            switch (uW) {
-            case 1024: SET_LDS((k_c2r_sharpen2_t<1024, false, TUNED_TK>), P->ldsFused2); SET_LDS((k_c2r_sharpen2_t<1024, true, TUNED_TK>), P->ldsFused2); break;
-            case 2048: SET_LDS((k_c2r_sharpen2_t<2048, false, TUNED_TK>), P->ldsFused2); SET_LDS((k_c2r_sharpen2_t<2048, true, TUNED_TK>), P->ldsFused2); break;
-            default: SET_LDS((k_c2r_sharpen2_t<4096, false, TUNED_TK>), P->ldsFused2); SET_LDS((k_c2r_sharpen2_t<4096, true, TUNED_TK>), P->ldsFused2); break;
+            case 1024: SET_LDS((k_c2r_sharpen_t<1024, false, TUNED_TK>), P->ldsFused2); SET_LDS((k_c2r_sharpen_t<1024, true, TUNED_TK>), P->ldsFused2); break;
+            case 2048: SET_LDS((k_c2r_sharpen_t<2048, false, TUNED_TK>), P->ldsFused2); SET_LDS((k_c2r_sharpen_t<2048, true, TUNED_TK>), P->ldsFused2); break;
+            default: SET_LDS((k_c2r_sharpen_t<4096, false, TUNED_TK>), P->ldsFused2); SET_LDS((k_c2r_sharpen_t<4096, true, TUNED_TK>), P->ldsFused2); break;
             }
             switch (H) {
             case 256: SET_LDS((k_col_t<256, TUNED_TK>), P->ldsCol); break;
@@ -457,15 +443,9 @@ template <int UW> static void launch_fused_t(fftup_plan* P, const FusedParams& p
 {
     const int total_pairs = 3 * (int)P->uH / 2;
     dim3 grid((total_pairs + p.pairs_per_strip - 1) / p.pairs_per_strip);
-    if (P->fused_version == 2) {
-        dim3 block(UW / 4);
-        if (P->half) hipLaunchKernelGGL((k_c2r_sharpen2_t<UW, true, TUNED_TK>), grid, block, P->ldsFused2, P->stream, p);
-        else hipLaunchKernelGGL((k_c2r_sharpen2_t<UW, false, TUNED_TK>), grid, block, P->ldsFused2, P->stream, p);
-        return;
-    }
-    dim3 block(UW / 8);
-    if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_t<UW, true, TUNED_TK>), grid, block, P->ldsFused, P->stream, p);
-    else hipLaunchKernelGGL((k_c2r_sharpen_t<UW, false, TUNED_TK>), grid, block, P->ldsFused, P->stream, p);
+    dim3 block(UW / 4);
+    if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_t<UW, true, TUNED_TK>), grid, block, P->ldsFused2, P->stream, p);
+    else hipLaunchKernelGGL((k_c2r_sharpen_t<UW, false, TUNED_TK>), grid, block, P->ldsFused2, P->stream, p);
 }
 
 static bool fast_sharpen_ok(const fftup_plan* P) { return P->uW % 256 == 0 && P->uH % 16 == 0; }
@@ -496,7 +476,6 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
     }
     if ((which < 0 || which == 2) && P->fused) {
         FusedParams p{};
-        p.trace = P->trace;
         p.S2 = P->S2; p.out = P->out[out_slot]; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
         p.pairs_per_strip = P->pairs_per_strip; p.upsq = P->upsq; p.coef = P->coef;
         switch (P->uW) {
@@ -741,15 +720,6 @@ const char* fftup_strerror(int code)
     default: return "unknown error";
     }
 }
-
-#ifdef FFTUP_TRACE
-__attribute__((visibility("default"))) int fftup_debug_trace(fftup_plan* P, unsigned long long* host, size_t n)
-{
-    if (!P || !P->trace) return 1;
-    hipStreamSynchronize(P->stream);
-    return hipMemcpy(host, P->trace, sizeof(unsigned long long) * std::min<size_t>(n, 96 * 64), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 5;
-}
-#endif
 
 const char* fftup_last_error(void) { return g_last_error.c_str(); }
 const char* fftup_version(void) { return "fftup 0.1.0 (gfx950)"; }

@@ -16,9 +16,6 @@
 #include "fft_engine.hpp"
 #include "kernels_generic.hpp"
 
-#ifndef FFTUP_ABL
-#define FFTUP_ABL 0      // ablation builds (tools/): 1 no sharpen math, 2 no FFT, 3 no output stores
-#endif
 
 namespace fftup {
 
@@ -483,14 +480,11 @@ __global__ void __launch_bounds__(256) k_sharpen_t(SharpenTParams p)
 
 
 // =================================================================================== fused C2R + sharpen
-// One workgroup = one strip of output rows [y0,y1) of one plane (a strip that crosses a plane boundary
-// is processed as two segments).  Row pairs are transformed one after the other; the clamped
-// |u^2 g| rows ("L rows") of a pair are parked in the FFT exchange buffer that just produced them, and
-// the next pair uses the OTHER of two exchange buffers, so the previous pair's rows stay put: no copy,
-// no extra registers.  After each pair the two rows whose 3x3 neighbourhood is complete are sharpened
-// and stored.  The pre-sharpen image never goes to HBM (the reference writes and re-reads it:
-// tempBuffer, 2 x 100 MB per frame).  The next pair's spectrum rows are fetched before the sharpen
-// phase, the per-stage twiddles once per workgroup.
+// A strip = output rows [y0,y1) of one plane (a strip that crosses a plane boundary is processed as two
+// segments).  Its row pairs are transformed one after the other; the clamped |u^2 g| rows ("L rows") of a
+// pair are parked in the LDS exchange buffer that just produced them, three such buffers rotate, and after
+// each pair the two rows whose 3x3 neighbourhood is complete are sharpened and stored.  The pre-sharpen
+// image never goes to HBM (the reference writes and re-reads it: tempBuffer, 2 x 100 MB per frame).
 //
 // Pairing: a strip needs rows y0-1 .. y1, so it pairs (y0-1,y0),(y0+1,y0+2),.. -- one pair more than
 // it outputs.  The reference pairs (2j,2j+1) and its C2R leaks Im(DC column) between the two rows of a
@@ -499,17 +493,10 @@ __global__ void __launch_bounds__(256) k_sharpen_t(SharpenTParams p)
 //
 // Quirk B5 (VkResample.cpp:891-892): the right neighbour of x = uW-1 is x = 0 of the NEXT row, so pixel
 // (y, uW-1) needs L(y+2, 0).  For the newest sharpened row that value arrives with the next pair: the
-// pixel is finished one iteration later by the thread that owns it; for the last row of a strip the one
+// pixel is finished one step later (placeholder first, then the final value, ordered by the step barriers);
+// for the last row of a strip the one
 // missing sample g[y1+1][0] = (sum over k of Z[k])/uW is evaluated directly from the spectrum row.
-// optional phase timeline (s_memtime) of wave 0 of every 64th workgroup: build with -DFFTUP_TRACE
-#ifdef FFTUP_TRACE
-#define FTRACE(slot) do { if (p.trace && tid == 0 && (blockIdx.x & 63) == 0 && tr_n < 96) { p.trace[(blockIdx.x >> 6) * 96 + tr_n++] = ((unsigned long long)(slot) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); } } while (0)
-#else
-#define FTRACE(slot) do { } while (0)
-#endif
-
 struct FusedParams {
-    unsigned long long* trace;
     const float2* S2;
     void* out;               // dense [3][uH][uW] float / half
     const float2* tw;
@@ -519,7 +506,6 @@ struct FusedParams {
 };
 
 __host__ __device__ constexpr size_t fused_buf_bytes(int uw) { return (sizeof(float2) * lpad_size(uw) + 15) & ~(size_t)15; }
-__host__ __device__ constexpr size_t fused_lds_bytes(int uw) { return 2 * fused_buf_bytes(uw) + 64; }
 
 template <bool HALF> __device__ __forceinline__ float to_L(float g, float upsq)
 {
@@ -565,237 +551,12 @@ __device__ __forceinline__ void sharpen_quad(const float (&t)[3][6], float coef,
     }
 }
 
-template <int UW, bool HALF, int TK>
-__global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 / 256 : 1) k_c2r_sharpen_t(FusedParams p)
-{
-    constexpr int E = 8, T = UW / E;
-    constexpr float inv = 1.0f / (float)UW;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = (float*)(smem + 2 * fused_buf_bytes(UW));     // [T/64] reduction scratch
-    const int tid = threadIdx.x;
-    const int uH = p.uH;
-    const int pairs_per_plane = uH / 2;
-    const long tile_stride = (long)uH * TK;
-    const long plane = (long)UW * uH;
-#ifdef FFTUP_TRACE
-    int tr_n = 0;
-#endif
-    FTRACE(0);
-    // per-stage base twiddles: once per workgroup.  No load other than the spectrum prefetch may sit in
-    // the pair loop: vmcnt retires in order, so waiting for ANY load also waits for every older output
-    // store of the previous sharpen phase.
-    TwSet<UW, E> tws;
-    tws.load(p.tw, tid);
-    int f0 = blockIdx.x * p.pairs_per_strip;
-    const int f1 = min(f0 + p.pairs_per_strip, 3 * pairs_per_plane);
-    while (f0 < f1) {
-        // ---- one segment: plane c, output rows [y0,y1)
-        const int c = f0 / pairs_per_plane;
-        const int j0 = f0 - c * pairs_per_plane;
-        const int j1 = min(j0 + (f1 - f0), pairs_per_plane);
-        f0 += j1 - j0;
-        const int y0 = 2 * j0, y1 = 2 * j1;
-        const bool top = (y0 == 0);
-        const int a0 = top ? 0 : y0 - 1;
-        const int npairs = (j1 - j0) + 1;
-        const float2* base = p.S2 + (long)c * p.NT * tile_stride;
-        auto S2at = [&](int k, int row) -> float2 { return base[(long)(k / TK) * tile_stride + (long)row * TK + (k % TK)]; };
-        // DC term of row y including the reference's pair leak
-        auto dc_term = [&](int y) -> float {
-            float2 d = S2at(0, y);
-            float2 dp = S2at(0, y ^ 1);
-            return (y & 1) ? d.x + dp.y : d.x - dp.y;
-        };
-        // raw spectrum values of a pair: A from row ya, B from row yb at k = tid, tid+T, 2T-tid, T-tid;
-        // thread 0 also fetches the imaginary parts of the DC column of the reference partners (leak)
-        float2 rawA[4], rawB[4];
-        float lkA = 0.f, lkB = 0.f;
-        auto fetch = [&](int a) {
-            const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);   // rows past the plane: duplicate of the last row
-            const int ks[4] = {tid, tid + T, 2 * T - tid, T - tid};
-#pragma unroll
-            for (int q = 0; q < 4; q++) { rawA[q] = S2at(ks[q], ya); rawB[q] = S2at(ks[q], yb); }
-            // raw loads only: any arithmetic here would make the wave wait for the data at the prefetch point
-            if (tid == 0) { lkA = S2at(0, ya ^ 1).y; lkB = S2at(0, yb ^ 1).y; }
-        };
-        fetch(a0);
-        // ---- corner sample L(y1+1, 0) for the last pixel of row y1-1 (interior, non-bottom strips):
-        // g[rs][0] = (DC term + 2 * sum_{k=1..W/2} Re A_rs[k]) / uW.  The loads are issued here, behind
-        // the first pair's, and consumed after the first sharpen phase.
-        const bool need_corner = !top && (y1 + 1 < uH);
-        static_assert(UW / 4 == 2 * T, "two spectrum samples per thread");
-        float cs0 = 0.f, cs1 = 0.f, cd0 = 0.f, cd1 = 0.f;      // raw loads, combined after the first sharpen phase
-        const int rs = y1 + 1;
-        if (need_corner) {
-            cs0 = S2at(tid + 1, rs).x;
-            cs1 = S2at(tid + 1 + T, rs).x;
-            if (tid == T - 1) { cd0 = S2at(0, rs).x; cd1 = S2at(0, rs ^ 1).y; }
-        }
-
-        for (int it = 0; it < npairs; it++) {
-            const int a = a0 + 2 * it;
-            // exchange buffer of this pair; the other one still holds the previous pair's L rows
-            float2* buf = (float2*)(smem + (it & 1) * fused_buf_bytes(UW));
-            float* cur = (float*)buf;                                            // [2][UW] rows a, a+1
-            const float* ring = (const float*)(smem + ((it + 1) & 1) * fused_buf_bytes(UW));   // [2][UW] rows a-2, a-1
-            // ---- first-stage inputs (vkFFT.h:2059-2131): Z[k] = A + iB, Z[UW-k] = conj A + i conj B
-            FTRACE(1);
-            float2 v[E];
-            v[0] = make_float2(rawA[0].x - rawB[0].y, rawA[0].y + rawB[0].x);
-            v[1] = make_float2(rawA[1].x - rawB[1].y, rawA[1].y + rawB[1].x);
-            v[6] = make_float2(rawA[2].x + rawB[2].y, -rawA[2].y + rawB[2].x);
-            v[7] = make_float2(rawA[3].x + rawB[3].y, -rawA[3].y + rawB[3].x);
-            v[2] = make_float2(0.f, 0.f);
-            if (tid == 0) {
-                v[2] = make_float2(rawA[2].x - rawB[2].y, rawA[2].y + rawB[2].x);       // k = 2T = W/2
-                // DC terms incl. the pair leak: row y gets -Im D[y+1] (y even) / +Im D[y-1] (y odd)
-                const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);
-                v[0] = make_float2(rawA[0].x + ((ya & 1) ? lkA : -lkA), rawB[0].x + ((yb & 1) ? lkB : -lkB));
-            }
-            v[3] = v[4] = v[5] = make_float2(0.f, 0.f);
-#ifdef FFTUP_TRACE
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            FTRACE(2);
-            // the next pair's spectrum rows are requested now (their registers were just consumed) and fly
-            // during the whole transform; they are made to land before the first output store below
-            if (it + 1 < npairs) fetch(a + 2);
-#if FFTUP_ABL != 2
-            reg_fft<UW, E, -1, 1, false>(v, buf, tid, 0, tws);
-#else
-#pragma unroll
-            for (int i = 0; i < E; i++) v[i].x += tws.w[0].x;
-#endif
-            FTRACE(3);
-            // ---- L rows of the new pair into the (now idle) exchange buffer
-#pragma unroll
-            for (int i = 0; i < E; i++) {
-                cur[tid + T * i] = to_L<HALF>(v[i].x * inv, p.upsq);
-                cur[UW + tid + T * i] = to_L<HALF>(v[i].y * inv, p.upsq);
-            }
-            // landing point of the prefetch: the empty asm makes the compiler wait for these registers HERE,
-            // before any output store is issued, so that no later wait has stores in front of it
-#pragma unroll
-            for (int q = 0; q < 4; q++) asm volatile("" :: "v"(rawA[q].x), "v"(rawA[q].y), "v"(rawB[q].x), "v"(rawB[q].y));
-            asm volatile("" :: "v"(lkA), "v"(lkB));
-            __syncthreads();
-            FTRACE(4);
-            auto rowp = [&](int r) -> const float* {      // r relative to a: -2,-1 (ring), 0,1 (cur)
-                return r < 0 ? ring + (r + 2) * UW : cur + r * UW;
-            };
-#pragma unroll 1
-            for (int w = 0; w < 2; w++) {                  // output row y = a-1 (w=0) and y = a (w=1)
-                const int y = a - 1 + w;
-                if (y < y0 || y >= y1) continue;           // uniform over the workgroup
-                const int rN = (y == 0) ? 0 : w - 2;       // tap rows relative to a; row -1 clamps to row 0
-                const float* pN = rowp(rN);
-                const float* pC = rowp(w - 1);
-                const float* pS = rowp(w);
-                // x = UW wraps to x = 0 of the next row: rows after N, C, S
-                const float* pNn = (y == 0) ? rowp(rN + 1) : pC;
-                const float* pCn = pS;
-                const bool have_Sn = (w == 0);             // row y+2 present only for y = a-1
-                const float* pSn = rowp(have_Sn ? w + 1 : w);
-#pragma unroll 1
-                for (int h = 0; h < 2; h++) {
-                    const int x0 = 4 * (tid + T * h);
-                    float t[3][6];
-                    const float* rows[3] = {pN, pC, pS};
-                    const float* nxt[3] = {pNn, pCn, pSn};
-#pragma unroll
-                    for (int r = 0; r < 3; r++) {
-                        float4 q = *(const float4*)(rows[r] + x0);
-                        t[r][1] = q.x; t[r][2] = q.y; t[r][3] = q.z; t[r][4] = q.w;
-                        // neighbours live in the adjacent lanes; only the wave-edge lanes read LDS
-                        float el = q.x, er = 0.f;
-                        if ((tid & 63) == 0 && x0 != 0) el = rows[r][x0 - 1];
-                        if ((tid & 63) == 63) er = (x0 + 4 == UW) ? nxt[r][0] : rows[r][x0 + 4];
-                        t[r][0] = lane_from_below(q.w, el);
-                        t[r][5] = lane_from_above(q.x, er);
-                    }
-                    const bool last_chunk = (x0 + 4 == UW);
-                    bool defer = false;
-                    if (last_chunk && !have_Sn) {
-                        // SE tap of pixel (a, UW-1) is L(a+2, 0).  Past the plane it clamps to row uH-1
-                        // (held as row a or a+1); in the last iteration it is the corner sample;
-                        // otherwise the pixel is finished by the next iteration.
-                        const int r2 = min(y + 2, uH - 1) - a;
-                        if (r2 <= 1) t[2][5] = rowp(r2)[0];
-                        else if (it != npairs - 1) defer = true;
-                        else {                                 // it >= 1: partial sums were published by iteration 0
-                            float sum = 0.f;
-                            for (int w2 = 0; w2 < T / 64; w2++) sum += red[w2];
-                            t[2][5] = to_L<HALF>((red[8] + 2.0f * sum) * inv, p.upsq);
-                        }
-                    }
-                    float o[4];
-#if FFTUP_ABL != 1
-                    sharpen_quad<HALF>(t, p.coef, o);
-#else
-                    o[0] = t[0][1] + t[1][0] + t[2][5]; o[1] = t[0][2] + t[1][2]; o[2] = t[0][3] + t[2][3]; o[3] = t[0][4] + t[1][5];
-#endif
-                    const long of = c * plane + (long)y * UW + x0;
-                    // one 16-byte (8-byte for half) store per lane, always: a deferred last pixel is written
-                    // with a placeholder now and overwritten by the same thread one iteration later
-                    (void)defer;
-                    if constexpr (HALF) {
-                        __half* op = (__half*)p.out + of;
-                        __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
-                        *(float2*)op = make_float2(*(float*)&h0, *(float*)&h1);
-                    } else {
-                        float* op = (float*)p.out + of;
-#if FFTUP_ABL == 3
-                        if (o[0] == 12345.f)
-#endif
-                        *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
-                    }
-                }
-            }
-            FTRACE(5);
-            if (it == 0 && need_corner) {                 // uniform; published by this iteration's closing barrier
-                float part = cs0 + cs1;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
-                if ((tid & 63) == 0) red[tid >> 6] = part;
-                if (tid == T - 1) red[8] = cd0 + ((rs & 1) ? cd1 : -cd1);
-            }
-            if (tid == T - 1) {
-                // ---- finish the pixel deferred by the previous iteration: (a-2, UW-1); L(a,0) is known now
-                if (it > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1) {
-                    const float* r2 = rowp(-2);
-                    const float* r1 = rowp(-1);
-                    const float* r0 = rowp(0);
-                    // N row of pixel (a-2, UW-1) is row a-3, whose wrap neighbour is (a-2, 0); for row 0
-                    // the N row is row 0 itself and wraps to (1, 0)
-                    const float ne = (a - 2 == 0) ? r1[0] : r2[0];
-                    const float pn0 = red[9], pn1 = red[10];
-                    const float t[3][6] = {{pn0, pn0, pn1, ne, ne, ne},
-                                           {r2[UW - 2], r2[UW - 2], r2[UW - 1], r1[0], r1[0], r1[0]},
-                                           {r1[UW - 2], r1[UW - 2], r1[UW - 1], r0[0], r0[0], r0[0]}};
-                    float o[4];
-                    sharpen_quad<HALF>(t, p.coef, o);       // o[1]: centre = column 2 = pixel UW-1
-                    const long of = c * plane + (long)(a - 2) * UW + (UW - 1);
-                    if constexpr (HALF) ((__half*)p.out)[of] = __float2half_rn(o[1]);
-                    else ((float*)p.out)[of] = o[1];
-                }
-                // N-row taps of the pixel (a, UW-1) deferred by this iteration: row a-1 (row 0 clamps to itself)
-                const float* rn = (a == 0) ? rowp(0) : rowp(-1);
-                red[9] = rn[UW - 2];
-                red[10] = rn[UW - 1];
-            }
-            __syncthreads();
-            FTRACE(6);
-        }
-    }
-}
-
-// =================================================================================== fused C2R + sharpen, v2
-// Same strip algorithm as k_c2r_sharpen_t, but ONE workgroup of 2*T threads per compute unit in which the
-// two halves swap roles every step: while one half transforms row pair s (LDS exchange buffer X[s%3]), the
+// ---------------------------------------------------------------------------------------------------
+// The kernel: ONE workgroup of 2*T threads per compute unit in which the two halves swap roles every step: while one half transforms row pair s (LDS exchange buffer X[s%3]), the
 // other half sharpens the rows of pair s-1 (X[(s-1)%3] and X[(s-2)%3]) and stages the spectrum rows of
 // pair s+1 into LDS.  Both halves pass the same 8 workgroup barriers per step, so in every barrier interval
-// each SIMD holds latency-bound FFT waves next to arithmetic-bound sharpen waves.  Strips are twice as long
-// as in v1 (one strip per CU), which halves the halo overhead.
+// each SIMD holds latency-bound FFT waves next to arithmetic-bound sharpen waves.  One strip per CU keeps
+// the halo overhead at one pair in thirteen for the headline size.
 template <int UW> struct Fused2Lds {
     static constexpr int KH = UW / 4;                                        // highest non-zero kx (= W/2)
     static constexpr size_t XB = fused_buf_bytes(UW);                        // exchange buffer / two L rows
@@ -805,7 +566,7 @@ template <int UW> struct Fused2Lds {
 };
 
 template <int UW, bool HALF, int TK>
-__global__ void __launch_bounds__(UW / 4) k_c2r_sharpen2_t(FusedParams p)
+__global__ void __launch_bounds__(UW / 4) k_c2r_sharpen_t(FusedParams p)
 {
     constexpr int E = 8, T = UW / E;
     constexpr int KH = UW / 4;
