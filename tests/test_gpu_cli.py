@@ -1,0 +1,66 @@
+"""GPU: the drop-in CLI end to end (PNG in -> PNG out), single-image and batched modes, against the oracle."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "vkresample_amd", "vkresample")
+
+
+def _png_write(path, rgb):
+    from PIL import Image
+    Image.fromarray(rgb).save(path)
+
+
+def _png_read(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"))
+
+
+def test_cli_single_image_1080p(tmp_path):
+    """BASELINE config 1 shape: 1920x1080 (radix 3/5 path) -u 2 -p 0 -n 1, default output name (quirk B11)."""
+    from vkresample_amd import synth
+    rgb = synth.frame(11, 1920, 1080, "N")
+    _png_write(tmp_path / "in.png", rgb)
+    r = subprocess.run([CLI, "-i", "in.png", "-u", "2", "-p", "0", "-n", "1"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "VkResample - FFT based upscaling" in r.stdout
+    assert re.search(r"VkResample 2\.0x upscale: 1920x1080 to 3840x2160 Time: [0-9.]+ ms", r.stdout)
+    assert "Thread 0 finished." in r.stdout and "Total time:" in r.stdout
+    out = _png_read(tmp_path / "1920_3840_upscaled.png")
+    _, _, ou8 = O.upscale_rgb8(rgb, 2.0, 0, 0.2)
+    d = np.abs(out[:-1].astype(int) - ou8[:-1].astype(int))
+    assert out.shape == (2160, 3840, 3) and d.max() <= 1 and (d != 0).mean() <= 5e-3
+
+
+def test_cli_batched_two_threads(tmp_path):
+    from vkresample_amd import synth
+    os.makedirs(tmp_path / "inp")
+    os.makedirs(tmp_path / "outp")
+    frames = [synth.frame(20 + k, 256, 128, "N") for k in range(5)]
+    for k, f in enumerate(frames):
+        _png_write(tmp_path / "inp" / ("%06d.png" % (k + 1)), f)
+    r = subprocess.run([CLI, "-ifolder", "inp", "-ofolder", "outp", "-numfiles", "5", "-numthreads", "2", "-u", "2",
+                        "-p", "2", "-s", "0.1", "-alldevices"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("finished.") == 2
+    for k, f in enumerate(frames):
+        out = _png_read(tmp_path / "outp" / ("%06d.png" % (k + 1)))
+        _, _, ou8 = O.upscale_rgb8(f, 2.0, 2, 0.1)
+        d = np.abs(out[:-1].astype(int) - ou8[:-1].astype(int))
+        assert d.max() <= 2 and (d > 1).mean() <= 1e-3          # fp16 storage: a one-ulp flip can move a code by 2
+
+
+def test_cli_devices_and_errors(tmp_path):
+    r = subprocess.run([CLI, "-devices"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Device id: 0 name:" in r.stdout
+    from vkresample_amd import synth
+    _png_write(tmp_path / "odd.png", synth.frame(1, 22 * 11, 64, "U"))       # 242 = 2*11*11: not 2,3,5,7-smooth
+    r = subprocess.run([CLI, "-i", "odd.png", "-u", "2"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 2 and "unsupported size" in r.stdout

@@ -86,7 +86,8 @@ def test_fp16_parity_small(W, H, u, dist):
     (pre, out, u8), (opre, oout, ou8) = _run(W, H, u, 2, dist)
     # pre-sharpen: both sides are fp16 values; fp32-vs-fp64 FFT noise can flip a rounding -> <= 1 ulp
     ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
-    assert (np.abs(pre - opre) <= ulp * 1.0001).all()
+    # (+5e-7: below |g| ~ 2^-14 the fp16 grid (2^-24) is finer than the fp32 transform's own noise)
+    assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
     assert (pre != opre).mean() <= 0.05      # ringing around zero: fp16 ulp shrinks with |g|, fp32 noise does not
     assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-3
     assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 8e-3
@@ -229,7 +230,7 @@ def test_full_size_vs_oracle(W, H, precision):
         assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1e-3
     else:
         ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
-        assert (np.abs(pre - opre) <= ulp * 1.0001).all()
+        assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
         assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-3
         assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 8e-3
 
@@ -289,5 +290,5 @@ def test_golden_vectors_gpu(name):
         assert np.abs(u8[:-1].astype(int) - d["u8"][:-1].astype(int)).max() <= 1
     else:
         ulp = np.maximum(np.abs(d["pre"]), 2.0 ** -14) * 2.0 ** -10
-        assert (np.abs(pre - d["pre"]) <= ulp * 1.0001).all()
+        assert (np.abs(pre - d["pre"]) <= ulp * 1.0001 + 5e-7).all()
         assert np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 8e-3
