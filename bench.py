@@ -33,7 +33,7 @@ def parse_args():
     ap.add_argument("--precision", type=int, default=0, help="0 = fp32 (headline), 2 = fp16 memory")
     ap.add_argument("--fuse-u8", action="store_true", help="row kernel reads uint8 RGB directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--profile-iters", type=int, default=50)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
                     help="per-launch HBM bytes of the dominant kernel from a committed rocprofv3 --pmc run")
