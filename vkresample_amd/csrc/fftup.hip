@@ -63,6 +63,11 @@ struct fftup_plan {
     std::vector<int> in_kind;         // per slot: 0 none, 1 planar valid, 2 u8 valid (fused)
     float2 *S1 = nullptr, *S2 = nullptr;
     void* R = nullptr;                // pre-sharpen, dense [3][uH][uW]
+    // batched mode runs consecutive frames on `nlanes` streams (the reference's -numthreads does the same with
+    // several queues on one device); every lane owns its scratch spectra.  Lane 0 = the members above.
+    struct Lane { hipStream_t stream = nullptr; float2 *S1 = nullptr, *S2 = nullptr; void* R = nullptr; hipEvent_t done = nullptr; };
+    std::vector<Lane> lanes;
+    int nlanes = 1, cur = 0, last_lane = 0;
     std::vector<void*> out;           // per slot: dense [3][uH][uW]
     uint8_t* out_u8 = nullptr;        // staging for download_rgb8
     float2 *twW = nullptr, *twH = nullptr, *twUW = nullptr, *twUH = nullptr;
@@ -164,6 +169,10 @@ void fftup_plan_destroy(fftup_plan* P)
     if (!P) return;
     (void)hipSetDevice(P->device);
     if (P->stream) (void)hipStreamSynchronize(P->stream);
+    for (size_t l = 1; l < P->lanes.size(); l++) {
+        if (P->lanes[l].stream) { (void)hipStreamSynchronize(P->lanes[l].stream); (void)hipStreamDestroy(P->lanes[l].stream); }
+        if (P->lanes[l].done) (void)hipEventDestroy(P->lanes[l].done);
+    }
     for (void* p : P->allocs) (void)hipFree(p);
     if (P->ev0) (void)hipEventDestroy(P->ev0);
     if (P->ev1) (void)hipEventDestroy(P->ev1);
@@ -288,6 +297,20 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         PLAN_RC(dev_alloc(P, (void**)&P->S2, sizeof(float2) * 3 * (size_t)P->NT * uH * P->TK));
         PLAN_RC(dev_alloc(P, &P->R, (size_t)3 * uW * uH * esz));
         PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH));
+        {
+            int nl = 2;
+            if (const char* e = getenv("FFTUP_STREAMS")) nl = atoi(e);
+            P->nlanes = std::max(1, std::min(nl, 4));
+            P->lanes.resize(P->nlanes);
+            P->lanes[0].stream = P->stream; P->lanes[0].S1 = P->S1; P->lanes[0].S2 = P->S2; P->lanes[0].R = P->R;
+            for (int l = 1; l < P->nlanes; l++) {
+                PLAN_TRY(hipStreamCreateWithFlags(&P->lanes[l].stream, hipStreamNonBlocking));
+                PLAN_TRY(hipEventCreateWithFlags(&P->lanes[l].done, hipEventDisableTiming));
+                PLAN_RC(dev_alloc(P, (void**)&P->lanes[l].S1, sizeof(float2) * 3 * (size_t)P->NT * H * P->TK));
+                PLAN_RC(dev_alloc(P, (void**)&P->lanes[l].S2, sizeof(float2) * 3 * (size_t)P->NT * uH * P->TK));
+                PLAN_RC(dev_alloc(P, &P->lanes[l].R, (size_t)3 * uW * uH * esz));
+            }
+        }
 
         // allow > 64 KB dynamic LDS
 #define SET_LDS(kern, bytes) PLAN_TRY(hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
@@ -421,22 +444,22 @@ template <int W> static void launch_r2c_t(fftup_plan* P, const RowR2CTParams& p,
 {
     dim3 grid(P->H / 2, 3), block(W / 8);
     switch (mode) {
-    case IN_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F32, TUNED_TK>), grid, block, 0, P->stream, p); break;
-    case IN_F16: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F16, TUNED_TK>), grid, block, 0, P->stream, p); break;
-    case IN_U8_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_U8_F32, TUNED_TK>), grid, block, 0, P->stream, p); break;
-    default: hipLaunchKernelGGL((k_row_r2c_t<W, IN_U8_F16, TUNED_TK>), grid, block, 0, P->stream, p); break;
+    case IN_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F32, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
+    case IN_F16: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F16, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
+    case IN_U8_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_U8_F32, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
+    default: hipLaunchKernelGGL((k_row_r2c_t<W, IN_U8_F16, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
     }
 }
 template <int H> static void launch_col_t(fftup_plan* P, const ColTParams& p)
 {
     dim3 grid(P->NT, 3), block(TUNED_TK * H / 8);
-    hipLaunchKernelGGL((k_col_t<H, TUNED_TK>), grid, block, P->ldsCol, P->stream, p);
+    hipLaunchKernelGGL((k_col_t<H, TUNED_TK>), grid, block, P->ldsCol, P->lanes[P->cur].stream, p);
 }
 template <int UW> static void launch_c2r_t(fftup_plan* P, const RowC2RTParams& p)
 {
     dim3 grid(P->uH / 2, 3), block(UW / 8);
-    if (P->half) hipLaunchKernelGGL((k_row_c2r_t<UW, true, TUNED_TK, true>), grid, block, 0, P->stream, p);
-    else hipLaunchKernelGGL((k_row_c2r_t<UW, false, TUNED_TK, true>), grid, block, 0, P->stream, p);
+    if (P->half) hipLaunchKernelGGL((k_row_c2r_t<UW, true, TUNED_TK, true>), grid, block, 0, P->lanes[P->cur].stream, p);
+    else hipLaunchKernelGGL((k_row_c2r_t<UW, false, TUNED_TK, true>), grid, block, 0, P->lanes[P->cur].stream, p);
 }
 
 template <int UW> static void launch_fused_t(fftup_plan* P, const FusedParams& p)
@@ -444,8 +467,8 @@ template <int UW> static void launch_fused_t(fftup_plan* P, const FusedParams& p
     const int total_pairs = 3 * (int)P->uH / 2;
     dim3 grid((total_pairs + p.pairs_per_strip - 1) / p.pairs_per_strip);
     dim3 block(UW / 4);
-    if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_t<UW, true, TUNED_TK>), grid, block, P->ldsFused2, P->stream, p);
-    else hipLaunchKernelGGL((k_c2r_sharpen_t<UW, false, TUNED_TK>), grid, block, P->ldsFused2, P->stream, p);
+    if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_t<UW, true, TUNED_TK>), grid, block, P->ldsFused2, P->lanes[P->cur].stream, p);
+    else hipLaunchKernelGGL((k_c2r_sharpen_t<UW, false, TUNED_TK>), grid, block, P->ldsFused2, P->lanes[P->cur].stream, p);
 }
 
 static bool fast_sharpen_ok(const fftup_plan* P) { return P->uW % 256 == 0 && P->uH % 16 == 0; }
@@ -455,7 +478,7 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
     const int kind = P->in_kind[in_slot];
     if (which < 0 || which == 0) {
         RowR2CTParams p{};
-        p.S1 = P->S1; p.tw = P->twW; p.H = (int)P->H; p.NT = P->NT;
+        p.S1 = P->lanes[P->cur].S1; p.tw = P->twW; p.H = (int)P->H; p.NT = P->NT;
         int mode;
         if (kind == 2) { p.in = P->in_u8[in_slot]; p.in_row_stride = 3l * P->W; p.in_plane_stride = 0; mode = P->half ? IN_U8_F16 : IN_U8_F32; }
         else { p.in = P->in_planar[in_slot]; p.in_row_stride = P->W; p.in_plane_stride = (long)P->in_plane_stride; mode = P->half ? IN_F16 : IN_F32; }
@@ -467,7 +490,7 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
     }
     if (which < 0 || which == 1) {
         ColTParams p{};
-        p.S1 = P->S1; p.S2 = P->S2; p.twH = P->twH; p.twUH = P->twUH; p.W = (int)P->W; p.NT = P->NT;
+        p.S1 = P->lanes[P->cur].S1; p.S2 = P->lanes[P->cur].S2; p.twH = P->twH; p.twUH = P->twUH; p.W = (int)P->W; p.NT = P->NT;
         switch (P->H) {
         case 256: launch_col_t<256>(P, p); break;
         case 512: launch_col_t<512>(P, p); break;
@@ -476,7 +499,7 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
     }
     if ((which < 0 || which == 2) && P->fused) {
         FusedParams p{};
-        p.S2 = P->S2; p.out = P->out[out_slot]; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
+        p.S2 = P->lanes[P->cur].S2; p.out = P->out[out_slot]; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
         p.pairs_per_strip = P->pairs_per_strip; p.upsq = P->upsq; p.coef = P->coef;
         switch (P->uW) {
         case 1024: launch_fused_t<1024>(P, p); break;
@@ -486,7 +509,7 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
         P->R_valid = false;
     } else if (which < 0 || which == 2 || which == 22) {   // 22: pre-sharpen tap requested for a fused plan
         RowC2RTParams p{};
-        p.S2 = P->S2; p.R = P->R; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
+        p.S2 = P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
         switch (P->uW) {
         case 1024: launch_c2r_t<1024>(P, p); break;
         case 2048: launch_c2r_t<2048>(P, p); break;
@@ -500,10 +523,10 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
 static void launch_sharpen_fast(fftup_plan* P, uint32_t out_slot)
 {
     SharpenTParams p{};
-    p.R = P->R; p.out = P->out[out_slot]; p.uW = (int)P->uW; p.uH = (int)P->uH; p.upsq = P->upsq; p.coef = P->coef;
+    p.R = P->lanes[P->cur].R; p.out = P->out[out_slot]; p.uW = (int)P->uW; p.uH = (int)P->uH; p.upsq = P->upsq; p.coef = P->coef;
     dim3 grid(P->uW / 256, P->uH / 16, 3), block(64, 4);
-    if (P->half) hipLaunchKernelGGL((k_sharpen_t<true, 4>), grid, block, 0, P->stream, p);
-    else hipLaunchKernelGGL((k_sharpen_t<false, 4>), grid, block, 0, P->stream, p);
+    if (P->half) hipLaunchKernelGGL((k_sharpen_t<true, 4>), grid, block, 0, P->lanes[P->cur].stream, p);
+    else hipLaunchKernelGGL((k_sharpen_t<false, 4>), grid, block, 0, P->lanes[P->cur].stream, p);
 }
 
 static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
@@ -519,49 +542,49 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
     }
     if (which < 0 || which == 0) {
         RowR2CParams p{};
-        p.S1 = P->S1; p.tw = P->twW; p.plan = P->planW; p.W = (int)P->W; p.H = (int)P->H;
+        p.S1 = P->lanes[P->cur].S1; p.tw = P->twW; p.plan = P->planW; p.W = (int)P->W; p.H = (int)P->H;
         p.TK = P->TK; p.NT = P->NT;
         dim3 grid(P->H / 2, 3), block(P->thrW);
         if (kind == 2) {
             p.in = P->in_u8[in_slot]; p.in_row_stride = 3l * P->W; p.in_plane_stride = 0;
-            if (P->half) hipLaunchKernelGGL(k_row_r2c<IN_U8_F16>, grid, block, P->ldsRowF, P->stream, p);
-            else hipLaunchKernelGGL(k_row_r2c<IN_U8_F32>, grid, block, P->ldsRowF, P->stream, p);
+            if (P->half) hipLaunchKernelGGL(k_row_r2c<IN_U8_F16>, grid, block, P->ldsRowF, P->lanes[P->cur].stream, p);
+            else hipLaunchKernelGGL(k_row_r2c<IN_U8_F32>, grid, block, P->ldsRowF, P->lanes[P->cur].stream, p);
         } else {
             p.in = P->in_planar[in_slot]; p.in_row_stride = P->W; p.in_plane_stride = (long)P->in_plane_stride;
-            if (P->half) hipLaunchKernelGGL(k_row_r2c<IN_F16>, grid, block, P->ldsRowF, P->stream, p);
-            else hipLaunchKernelGGL(k_row_r2c<IN_F32>, grid, block, P->ldsRowF, P->stream, p);
+            if (P->half) hipLaunchKernelGGL(k_row_r2c<IN_F16>, grid, block, P->ldsRowF, P->lanes[P->cur].stream, p);
+            else hipLaunchKernelGGL(k_row_r2c<IN_F32>, grid, block, P->ldsRowF, P->lanes[P->cur].stream, p);
         }
     }
     if (which < 0 || which == 1) {
         ColParams p{};
-        p.S1 = P->S1; p.S2 = P->S2; p.twH = P->twH; p.twUH = P->twUH; p.planH = P->planH; p.planUH = P->planUH;
+        p.S1 = P->lanes[P->cur].S1; p.S2 = P->lanes[P->cur].S2; p.twH = P->twH; p.twUH = P->twUH; p.planH = P->planH; p.planUH = P->planUH;
         p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.zly = P->zly; p.zry = P->zry;
         p.inv_norm = 1.0f / (float)P->uH;
         dim3 grid(P->NT, 3), block(P->thrCol);
         switch (P->TK) {
-        case 8: hipLaunchKernelGGL(k_col<8>, grid, block, P->ldsCol, P->stream, p); break;
-        case 4: hipLaunchKernelGGL(k_col<4>, grid, block, P->ldsCol, P->stream, p); break;
-        case 2: hipLaunchKernelGGL(k_col<2>, grid, block, P->ldsCol, P->stream, p); break;
-        default: hipLaunchKernelGGL(k_col<1>, grid, block, P->ldsCol, P->stream, p); break;
+        case 8: hipLaunchKernelGGL(k_col<8>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
+        case 4: hipLaunchKernelGGL(k_col<4>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
+        case 2: hipLaunchKernelGGL(k_col<2>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
+        default: hipLaunchKernelGGL(k_col<1>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
         }
     }
     if (which < 0 || which == 2) {
         RowC2RParams p{};
-        p.S2 = P->S2; p.R = P->R; p.tw = P->twUW; p.plan = P->planUW; p.W = (int)P->W; p.uW = (int)P->uW;
+        p.S2 = P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = P->twUW; p.plan = P->planUW; p.W = (int)P->W; p.uW = (int)P->uW;
         p.uH = (int)P->uH; p.TK = P->TK; p.NT = P->NT; p.zlx = P->zlx; p.zrx = P->zrx;
         p.inv_norm = 1.0f / (float)P->uW;
         dim3 grid(P->uH / 2, 3), block(P->thrUW);
-        if (P->half) hipLaunchKernelGGL(k_row_c2r<true>, grid, block, P->ldsRowI, P->stream, p);
-        else hipLaunchKernelGGL(k_row_c2r<false>, grid, block, P->ldsRowI, P->stream, p);
+        if (P->half) hipLaunchKernelGGL(k_row_c2r<true>, grid, block, P->ldsRowI, P->lanes[P->cur].stream, p);
+        else hipLaunchKernelGGL(k_row_c2r<false>, grid, block, P->ldsRowI, P->lanes[P->cur].stream, p);
     }
     if ((which < 0 || which == 3) && fast_sharpen_ok(P)) {
         launch_sharpen_fast(P, out_slot);
     } else if (which < 0 || which == 3) {
         SharpenParams p{};
-        p.R = P->R; p.out = P->out[out_slot]; p.uW = (int)P->uW; p.uH = (int)P->uH; p.upsq = P->upsq; p.coef = P->coef;
+        p.R = P->lanes[P->cur].R; p.out = P->out[out_slot]; p.uW = (int)P->uW; p.uH = (int)P->uH; p.upsq = P->upsq; p.coef = P->coef;
         dim3 grid((P->uW / 4 + 255) / 256, P->uH, 3), block(256);
-        if (P->half) hipLaunchKernelGGL(k_sharpen<true>, grid, block, 0, P->stream, p);
-        else hipLaunchKernelGGL(k_sharpen<false>, grid, block, 0, P->stream, p);
+        if (P->half) hipLaunchKernelGGL(k_sharpen<true>, grid, block, 0, P->lanes[P->cur].stream, p);
+        else hipLaunchKernelGGL(k_sharpen<false>, grid, block, 0, P->lanes[P->cur].stream, p);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FFTUP_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -576,10 +599,20 @@ int fftup_execute_ring(fftup_plan* P, uint32_t n_frames, uint32_t first_slot, do
     if (n_frames == 0) return fail(FFTUP_E_INVALID_ARG, "n_frames must be > 0");
     HIP_TRY(hipSetDevice(P->device));
     HIP_TRY(hipEventRecord(P->ev0, P->stream));
+    // consecutive frames go to distinct lanes; they must then also write distinct output slots
+    const int nl = std::max(1, std::min(P->nlanes, (int)P->ring));
+    for (int l = 1; l < nl; l++) HIP_TRY(hipStreamWaitEvent(P->lanes[l].stream, P->ev0, 0));
     for (uint32_t i = 0; i < n_frames; i++) {
         uint32_t s = (first_slot + i) % P->ring;
+        P->cur = (int)(i % (uint32_t)nl);
         int rc = launch_frame(P, s, s, -1);
+        P->last_lane = P->cur;
+        P->cur = 0;
         if (rc) return rc;
+    }
+    for (int l = 1; l < nl; l++) {
+        HIP_TRY(hipEventRecord(P->lanes[l].done, P->lanes[l].stream));
+        HIP_TRY(hipStreamWaitEvent(P->stream, P->lanes[l].done, 0));
     }
     HIP_TRY(hipEventRecord(P->ev1, P->stream));
     HIP_TRY(hipEventSynchronize(P->ev1));
@@ -595,10 +628,20 @@ int fftup_execute(fftup_plan* P, uint32_t n_iter, double* ms_per_iter)
     if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
     if (n_iter == 0) return fail(FFTUP_E_INVALID_ARG, "n_iter must be > 0");
     HIP_TRY(hipSetDevice(P->device));
+    // The reference records n_iter identical pipelines on one queue (VR:1260-1265).  They are independent
+    // (same input, bit-identical output), so they are spread over the plan's lanes like batched frames.
     HIP_TRY(hipEventRecord(P->ev0, P->stream));
+    for (int l = 1; l < P->nlanes; l++) HIP_TRY(hipStreamWaitEvent(P->lanes[l].stream, P->ev0, 0));
     for (uint32_t i = 0; i < n_iter; i++) {
+        P->cur = (int)(i % (uint32_t)P->nlanes);
         int rc = launch_frame(P, 0, 0, -1);
+        P->last_lane = P->cur;
+        P->cur = 0;
         if (rc) return rc;
+    }
+    for (int l = 1; l < P->nlanes; l++) {
+        HIP_TRY(hipEventRecord(P->lanes[l].done, P->lanes[l].stream));
+        HIP_TRY(hipStreamWaitEvent(P->stream, P->lanes[l].done, 0));
     }
     HIP_TRY(hipEventRecord(P->ev1, P->stream));
     HIP_TRY(hipEventSynchronize(P->ev1));
@@ -665,10 +708,13 @@ int fftup_download_presharpen(fftup_plan* P, void* planes)
     if (P->fused && !P->R_valid) {
         // the fused kernel never writes the pre-sharpen image; rebuild it from the spectrum of the last
         // frame (still in S2) with the stand-alone C2R kernel
+        P->cur = P->last_lane;
         launch_frame_tuned(P, 0, 0, 22);
+        P->cur = 0;
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(P->lanes[P->last_lane].stream));
     }
-    HIP_TRY(hipMemcpyAsync(planes, P->R, (size_t)3 * P->uW * P->uH * (P->half ? 2 : 4), hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipMemcpyAsync(planes, P->lanes[P->last_lane].R, (size_t)3 * P->uW * P->uH * (P->half ? 2 : 4), hipMemcpyDeviceToHost, P->stream));
     HIP_TRY(hipStreamSynchronize(P->stream));
     return FFTUP_OK;
 }
