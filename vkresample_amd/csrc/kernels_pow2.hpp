@@ -17,6 +17,7 @@
 #include "kernels_generic.hpp"
 
 
+
 namespace fftup {
 
 constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n / 2); }
@@ -176,7 +177,8 @@ __global__ void __launch_bounds__(W / 8) k_row_r2c_t(RowR2CTParams p)
 {
     constexpr int E = 8, T = W / E;
     __shared__ float2 buf[lpad_size(W)];
-    const int tid = threadIdx.x, j = blockIdx.x, c = blockIdx.y;
+    const int tid = threadIdx.x, c = blockIdx.y;
+    const int j = blockIdx.x;      // (an XCD-aware pair order -- pairs 2i, 2i+1 on one XCD -- measured no gain)
     float2 v[E];
     TwSet<W, E> tws;
     tws.load(p.tw, tid);
@@ -527,6 +529,44 @@ __device__ __forceinline__ float sharpen_eval_fast(float s4, float C, float mn0,
     return fmaf(scale, s4, C) * __builtin_amdgcn_rcpf(fmaf(scale, 4.0f, 1.0f));
 }
 
+// -p 2 form for the fused kernel: the reference evaluates this shader in float16_t (VkResample.cpp:823-826).
+// Additions and multiplications use the native binary16 instructions (correctly rounded, identical to the
+// oracle's per-operation rounding); the quotient is selected first (a < b <=> mn + mx < 1, as above) and formed
+// from v_rcp_f32 plus one Newton step, the root from v_rsq_f32 plus one step, each rounded once to binary16:
+// within one fp16 ulp of the exactly rounded sequence (which k_sharpen_t keeps, bit for bit) -- the Vulkan
+// spec allows the reference's own fp16 division 2.5 ulp.
+__device__ __forceinline__ float div_f32_newton(float a, float b)
+{
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float q = a * r;
+    return fmaf(fmaf(-q, b, a), r, q);
+}
+__device__ __forceinline__ float sharpen_eval_half_fast(float N, float S, float Wv, float E, float C,
+                                                        float mn0, float mn1, float mx0, float mx1, float coef)
+{
+    const __half one = __float2half_rn(1.0f), hlf = __float2half_rn(0.5f);
+    const __half mn = __hmul(hlf, __hadd(__float2half_rn(mn0), __float2half_rn(mn1)));
+    const __half mx = __hmul(hlf, __hadd(__float2half_rn(mx0), __float2half_rn(mx1)));
+    const bool lo = (__half2float(mn) + __half2float(mx)) < 1.0f;           // exact in fp32
+    const float n = __half2float(lo ? mn : __hsub(one, mx));
+    const float d = __half2float(lo ? __hsub(one, mn) : mx);                // in [0.5, 1]
+    const float q = __half2float(__float2half_rn(div_f32_newton(n, d)));
+    float rt = 0.f;
+    if (q > 0.f) {
+        const float rs = __builtin_amdgcn_rsqf(q);
+        const float s0 = q * rs;
+        rt = fmaf(fmaf(-s0, s0, q), 0.5f * rs, s0);
+    }
+    const __half scale = __hmul(__float2half_rn(-coef), __float2half_rn(rt));
+    const __half s4 = __hadd(__hadd(__hadd(__float2half_rn(N), __float2half_rn(Wv)), __float2half_rn(E)), __float2half_rn(S));
+    // the product must round on its own: keep the compiler from contracting it with the add into v_fma_f16
+    __half prod = __hmul(scale, s4);
+    asm volatile("" : "+v"(prod));
+    const __half num = __hadd(__float2half_rn(C), prod);
+    const __half den = __hadd(one, __hmul(scale, __float2half_rn(4.0f)));
+    return __half2float(__float2half_rn(div_f32_newton(__half2float(num), __half2float(den))));
+}
+
 // 4 output pixels from 3 tap rows of 6 values each (t[r][0] = left neighbour .. t[r][5] = right)
 template <bool HALF>
 __device__ __forceinline__ void sharpen_quad(const float (&t)[3][6], float coef, float (&o)[4])
@@ -546,7 +586,7 @@ __device__ __forceinline__ void sharpen_quad(const float (&t)[3][6], float coef,
         const float mx0 = fmaxf(fmaxf(N, S), hmx[1][i]);
         const float mn1 = fminf(fminf(hmn[0][i], hmn[2][i]), mn0);  // full 3x3 (min/max are exact: any order)
         const float mx1 = fmaxf(fmaxf(hmx[0][i], hmx[2][i]), mx0);
-        if constexpr (HALF) o[i] = sharpen_eval<true>(N, S, Wv, E, C, mn1, mx1, mn0, mx0, coef);
+        if constexpr (HALF) o[i] = sharpen_eval_half_fast(N, S, Wv, E, C, mn0, mn1, mx0, mx1, coef);
         else o[i] = sharpen_eval_fast(((N + Wv) + E) + S, C, mn0, mn1, mx0, mx1, coef);
     }
 }
@@ -738,11 +778,17 @@ __global__ void __launch_bounds__(UW / 4) k_c2r_sharpen_t(FusedParams p)
                         // one 16-byte (8-byte for half) store per lane, always: a deferred last pixel gets a
                         // placeholder now and is overwritten by the owning thread of the other half next step
                         (void)defer;
+                        // non-temporal: the output is written once and never re-read on the device; keeping it
+                        // out of L2 leaves the spectra there (-3 us/frame measured)
                         if constexpr (HALF) {
                             __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
-                            *(float2*)((__half*)p.out + of) = make_float2(*(float*)&h0, *(float*)&h1);
+                            typedef float f2v __attribute__((ext_vector_type(2)));
+                            f2v val = {*(float*)&h0, *(float*)&h1};
+                            __builtin_nontemporal_store(val, (f2v*)((__half*)p.out + of));
                         } else {
-                            *(float4*)((float*)p.out + of) = make_float4(o[0], o[1], o[2], o[3]);
+                            typedef float f4v __attribute__((ext_vector_type(4)));
+                            f4v val = {o[0], o[1], o[2], o[3]};
+                            __builtin_nontemporal_store(val, (f4v*)((float*)p.out + of));
                         }
                     }
                     __syncthreads();
