@@ -66,9 +66,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # RCCL (backend "nccl") over xGMI; FFTUP_BENCH_BACKEND=gloo lets two ranks share one GPU in a dry run
+        backend = os.environ.get("FFTUP_BENCH_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     import vkresample_amd as v
@@ -103,7 +104,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -143,7 +144,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": up.kernel_names[dom], "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args)
     up.close()
     if dist is not None:
