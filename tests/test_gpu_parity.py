@@ -292,3 +292,12 @@ def test_golden_vectors_gpu(name):
         ulp = np.maximum(np.abs(d["pre"]), 2.0 ** -14) * 2.0 ** -10
         assert (np.abs(pre - d["pre"]) <= ulp * 1.0001 + 5e-7).all()
         assert np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 8e-3
+
+
+def test_mixed_radix_plans_equal_generic():
+    """compile-time 1920x1080 plans (radix 8/4/3/5) vs the size-generic kernels on the same frame"""
+    from vkresample_amd import FLAG_GENERIC_KERNELS
+    (pre, out, u8), _ = _run(1920, 1080, 2.0, 0, "N", seed=5)
+    (pre2, out2, u82), _ = _run(1920, 1080, 2.0, 0, "N", seed=5, flags=FLAG_GENERIC_KERNELS)
+    assert np.abs(pre - pre2).max() * 4 <= 2e-6
+    assert np.abs(out - out2).max() <= 1e-4

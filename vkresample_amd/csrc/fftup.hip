@@ -13,6 +13,7 @@
 #include "../../include/fftup.h"
 #include "kernels_generic.hpp"
 #include "kernels_pow2.hpp"
+#include "kernels_mixed.hpp"
 
 using namespace fftup;
 
@@ -53,6 +54,7 @@ struct fftup_plan {
     float upsq = 0, coef = 0;
     bool tuned = false;
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
+    bool mixed1080 = false;           // compile-time mixed-radix plans (1920x1080 -> 3840x2160)
     int pairs_per_strip = 6;
     size_t ldsFused2 = 0;
     bool R_valid = false;             // pre-sharpen buffer holds the last frame (unfused path only)
@@ -258,6 +260,8 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             }
         }
         if (!P->TK) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled height too large for LDS"); goto bad; }
+        P->mixed1080 = !P->tuned && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && W == 1920 && H == 1080 && uW == 3840 &&
+                       uH == 2160 && P->TK == 4;
         P->fused = P->tuned && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
         {
             // one strip (workgroup) per compute unit
@@ -324,6 +328,15 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         SET_LDS(k_col<1>, P->ldsCol);
         SET_LDS(k_row_c2r<false>, P->ldsRowI);
         SET_LDS(k_row_c2r<true>, P->ldsRowI);
+        if (P->mixed1080) {
+            SET_LDS((k_row_r2c_ct<Plan1920, IN_F32>), P->ldsRowF);
+            SET_LDS((k_row_r2c_ct<Plan1920, IN_F16>), P->ldsRowF);
+            SET_LDS((k_row_r2c_ct<Plan1920, IN_U8_F32>), P->ldsRowF);
+            SET_LDS((k_row_r2c_ct<Plan1920, IN_U8_F16>), P->ldsRowF);
+            SET_LDS((k_col_ct<Plan1080, Plan2160, 4>), P->ldsCol);
+            SET_LDS((k_row_c2r_ct<Plan3840, false>), P->ldsRowI);
+            SET_LDS((k_row_c2r_ct<Plan3840, true>), P->ldsRowI);
+        }
         if (P->tuned) {
             switch (uW) {
             case 1024: SET_LDS((k_c2r_sharpen_t<1024, false, TUNED_TK>), P->ldsFused2); SET_LDS((k_c2r_sharpen_t<1024, true, TUNED_TK>), P->ldsFused2); break;
@@ -354,7 +367,7 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
     info->out_width = P->uW;
     info->out_height = P->uH;
     info->num_kernels = P->fused ? 3 : 4;
-    info->tuned = P->tuned ? 1 : 0;
+    info->tuned = (P->tuned || P->mixed1080) ? 1 : 0;
     // B_alg = in + 2*S1 + 2*S2 + 2*R + out
     const double C = 3.0, W = P->W, H = P->H, uW = P->uW, uH = P->uH;
     const bool fused_u8 = (P->cfg.flags & FFTUP_FLAG_FUSE_U8_LOAD) != 0;
@@ -545,7 +558,18 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         p.S1 = P->lanes[P->cur].S1; p.tw = P->twW; p.plan = P->planW; p.W = (int)P->W; p.H = (int)P->H;
         p.TK = P->TK; p.NT = P->NT;
         dim3 grid(P->H / 2, 3), block(P->thrW);
-        if (kind == 2) {
+        if (P->mixed1080) {
+            dim3 blk(Plan1920::T);
+            if (kind == 2) {
+                p.in = P->in_u8[in_slot]; p.in_row_stride = 3l * P->W; p.in_plane_stride = 0;
+                if (P->half) hipLaunchKernelGGL((k_row_r2c_ct<Plan1920, IN_U8_F16>), grid, blk, P->ldsRowF, P->lanes[P->cur].stream, p);
+                else hipLaunchKernelGGL((k_row_r2c_ct<Plan1920, IN_U8_F32>), grid, blk, P->ldsRowF, P->lanes[P->cur].stream, p);
+            } else {
+                p.in = P->in_planar[in_slot]; p.in_row_stride = P->W; p.in_plane_stride = (long)P->in_plane_stride;
+                if (P->half) hipLaunchKernelGGL((k_row_r2c_ct<Plan1920, IN_F16>), grid, blk, P->ldsRowF, P->lanes[P->cur].stream, p);
+                else hipLaunchKernelGGL((k_row_r2c_ct<Plan1920, IN_F32>), grid, blk, P->ldsRowF, P->lanes[P->cur].stream, p);
+            }
+        } else if (kind == 2) {
             p.in = P->in_u8[in_slot]; p.in_row_stride = 3l * P->W; p.in_plane_stride = 0;
             if (P->half) hipLaunchKernelGGL(k_row_r2c<IN_U8_F16>, grid, block, P->ldsRowF, P->lanes[P->cur].stream, p);
             else hipLaunchKernelGGL(k_row_r2c<IN_U8_F32>, grid, block, P->ldsRowF, P->lanes[P->cur].stream, p);
@@ -561,7 +585,8 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.zly = P->zly; p.zry = P->zry;
         p.inv_norm = 1.0f / (float)P->uH;
         dim3 grid(P->NT, 3), block(P->thrCol);
-        switch (P->TK) {
+        if (P->mixed1080) hipLaunchKernelGGL((k_col_ct<Plan1080, Plan2160, 4>), grid, dim3(Plan2160::T), P->ldsCol, P->lanes[P->cur].stream, p);
+        else switch (P->TK) {
         case 8: hipLaunchKernelGGL(k_col<8>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
         case 4: hipLaunchKernelGGL(k_col<4>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
         case 2: hipLaunchKernelGGL(k_col<2>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
@@ -574,7 +599,10 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         p.uH = (int)P->uH; p.TK = P->TK; p.NT = P->NT; p.zlx = P->zlx; p.zrx = P->zrx;
         p.inv_norm = 1.0f / (float)P->uW;
         dim3 grid(P->uH / 2, 3), block(P->thrUW);
-        if (P->half) hipLaunchKernelGGL(k_row_c2r<true>, grid, block, P->ldsRowI, P->lanes[P->cur].stream, p);
+        if (P->mixed1080) {
+            if (P->half) hipLaunchKernelGGL((k_row_c2r_ct<Plan3840, true>), grid, dim3(Plan3840::T), P->ldsRowI, P->lanes[P->cur].stream, p);
+            else hipLaunchKernelGGL((k_row_c2r_ct<Plan3840, false>), grid, dim3(Plan3840::T), P->ldsRowI, P->lanes[P->cur].stream, p);
+        } else if (P->half) hipLaunchKernelGGL(k_row_c2r<true>, grid, block, P->ldsRowI, P->lanes[P->cur].stream, p);
         else hipLaunchKernelGGL(k_row_c2r<false>, grid, block, P->ldsRowI, P->lanes[P->cur].stream, p);
     }
     if ((which < 0 || which == 3) && fast_sharpen_ok(P)) {

@@ -381,8 +381,8 @@ __device__ __forceinline__ void sharpen_load_row(PxRow<HALF>& r, const void* Rp,
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) r.L[1 + i] = fminf(fmaxf(fabsf(A::r(upsq * t[i])), 0.0f), 1.0f);
-    float left = __shfl_up(r.L[4], 1);
-    float right = __shfl_down(r.L[1], 1);
+    float left = lane_from_below(r.L[4], 0.f);
+    float right = lane_from_above(r.L[1], 0.f);
     if (lane == 0) {
         if (x0 == 0) left = r.L[1];                   // id_x_m clamp (VkResample.cpp:889)
         else {
@@ -433,6 +433,18 @@ __device__ __forceinline__ float sharpen_eval(float N, float S, float Wv, float 
     }
 }
 
+// fp32 fast form of VkResample.cpp:909-922.  a < b  <=>  mn + mx < 1 (both denominators positive), so
+// one quotient n/d with d in [0.5,1] is formed; sqrt(n/d) = n * rsq(n*d).  2 transcendental ops/pixel.
+__device__ __forceinline__ float sharpen_eval_fast(float s4, float C, float mn0, float mn1, float mx0, float mx1, float coef)
+{
+    const float mn = 0.5f * (mn0 + mn1), mx = 0.5f * (mx0 + mx1);
+    const bool lo = (mn + mx) < 1.0f;
+    const float n = lo ? mn : 1.0f - mx;
+    const float d = lo ? 1.0f - mn : mx;
+    const float scale = -coef * n * __builtin_amdgcn_rsqf(fmaxf(n * d, 1e-30f));
+    return fmaf(scale, s4, C) * __builtin_amdgcn_rcpf(fmaf(scale, 4.0f, 1.0f));
+}
+
 struct SharpenTParams {
     const void* R;
     void* out;
@@ -466,14 +478,20 @@ __global__ void __launch_bounds__(256) k_sharpen_t(SharpenTParams p)
             float mx0 = fmaxf(fmaxf(N, S), fmaxf(fmaxf(Wv, C), E));
             float mn1 = fminf(mn0, fminf(fminf(ra.L[i], ra.L[2 + i]), fminf(rc.L[i], rc.L[2 + i])));
             float mx1 = fmaxf(mx0, fmaxf(fmaxf(ra.L[i], ra.L[2 + i]), fmaxf(rc.L[i], rc.L[2 + i])));
-            o[i] = sharpen_eval<HALF>(N, S, Wv, E, C, mn1, mx1, mn0, mx0, p.coef);
+            // -p 2 keeps the exactly rounded binary16 sequence here (bit-exact against the oracle)
+            if constexpr (HALF) o[i] = sharpen_eval<true>(N, S, Wv, E, C, mn1, mx1, mn0, mx0, p.coef);
+            else o[i] = sharpen_eval_fast(((N + Wv) + E) + S, C, mn0, mn1, mx0, mx1, p.coef);
         }
         const long of = poff + (long)y * uW + x0;
         if constexpr (HALF) {
             __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
-            *(float2*)((__half*)p.out + of) = make_float2(*(float*)&h0, *(float*)&h1);
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            f2v val = {*(float*)&h0, *(float*)&h1};
+            __builtin_nontemporal_store(val, (f2v*)((__half*)p.out + of));
         } else {
-            *(float4*)((float*)p.out + of) = make_float4(o[0], o[1], o[2], o[3]);
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            f4v val = {o[0], o[1], o[2], o[3]};
+            __builtin_nontemporal_store(val, (f4v*)((float*)p.out + of));
         }
         ra = rb;
         rb = rc;
@@ -515,18 +533,6 @@ template <bool HALF> __device__ __forceinline__ float to_L(float g, float upsq)
     // C2R output is stored as half for -p 2 (vkFFT.h:7289-7290) before the sharpen shader scales it
     if constexpr (HALF) g = __half2float(__float2half_rn(g));
     return fminf(fmaxf(fabsf(A::r(upsq * g)), 0.0f), 1.0f);
-}
-
-// fp32 fast form of VkResample.cpp:909-922.  a < b  <=>  mn + mx < 1 (both denominators positive), so
-// one quotient n/d with d in [0.5,1] is formed; sqrt(n/d) = n * rsq(n*d).  2 transcendental ops/pixel.
-__device__ __forceinline__ float sharpen_eval_fast(float s4, float C, float mn0, float mn1, float mx0, float mx1, float coef)
-{
-    const float mn = 0.5f * (mn0 + mn1), mx = 0.5f * (mx0 + mx1);
-    const bool lo = (mn + mx) < 1.0f;
-    const float n = lo ? mn : 1.0f - mx;
-    const float d = lo ? 1.0f - mn : mx;
-    const float scale = -coef * n * __builtin_amdgcn_rsqf(fmaxf(n * d, 1e-30f));
-    return fmaf(scale, s4, C) * __builtin_amdgcn_rcpf(fmaf(scale, 4.0f, 1.0f));
 }
 
 // -p 2 form for the fused kernel: the reference evaluates this shader in float16_t (VkResample.cpp:823-826).
