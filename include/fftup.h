@@ -108,6 +108,12 @@ FFTUP_API int fftup_execute(fftup_plan* plan, uint32_t n_iter, double* ms_per_it
 /* batched mode: n_frames pipelines, frame i reads input slot (first_slot+i) % ring and writes
  * output slot (first_slot+i) % ring; returns total device milliseconds. */
 FFTUP_API int fftup_execute_ring(fftup_plan* plan, uint32_t n_frames, uint32_t first_slot, double* ms_total);
+/* the same batch with a HIP event before and after every kernel launch of every `stride`-th frame, recorded on
+ * the stream that runs the kernel: also returns the average duration (ms) of each of the plan's kernels.  Consecutive
+ * frames run on two streams, so a kernel's duration includes the time it shares the GPU with the other
+ * stream's kernels (fftup_profile_kernels gives the isolated durations). */
+FFTUP_API int fftup_execute_ring_timed(fftup_plan* plan, uint32_t n_frames, uint32_t first_slot, uint32_t stride,
+                                       double* ms_total, double* ms_per_kernel);
 /* measurement aid: runs n_iter frames with a HIP event pair around every kernel launch on the
  * plan's stream and returns the average duration (ms) of each of the FFTUP_NUM_KERNELS kernels. */
 FFTUP_API int fftup_profile_kernels(fftup_plan* plan, uint32_t n_iter, double* ms_per_kernel);

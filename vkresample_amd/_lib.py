@@ -16,7 +16,7 @@ FLAG_UNFUSED_SHARPEN = 8
 # every symbol include/fftup.h declares
 EXPORTS = [
     "fftup_device_count", "fftup_device_name", "fftup_plan_create", "fftup_plan_destroy", "fftup_plan_info",
-    "fftup_upload_rgb8", "fftup_upload_rgb8_slot", "fftup_upload_planar", "fftup_execute", "fftup_execute_ring",
+    "fftup_upload_rgb8", "fftup_upload_rgb8_slot", "fftup_upload_planar", "fftup_execute", "fftup_execute_ring", "fftup_execute_ring_timed",
     "fftup_profile_kernels", "fftup_download_rgb8", "fftup_download_planar", "fftup_download_presharpen",
     "fftup_download_input_planar", "fftup_strerror", "fftup_last_error", "fftup_version",
 ]
@@ -59,6 +59,7 @@ def load():
     lib.fftup_upload_planar.argtypes = [vp, u32, vp, sz, sz]
     lib.fftup_execute.argtypes = [vp, u32, C.POINTER(C.c_double)]
     lib.fftup_execute_ring.argtypes = [vp, u32, u32, C.POINTER(C.c_double)]
+    lib.fftup_execute_ring_timed.argtypes = [vp, u32, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.fftup_profile_kernels.argtypes = [vp, u32, C.POINTER(C.c_double)]
     lib.fftup_download_rgb8.argtypes = [vp, u32, vp, sz]
     lib.fftup_download_planar.argtypes = [vp, u32, vp]

@@ -98,6 +98,14 @@ class Upscaler:
         _check(self._lib.fftup_execute_ring(self._h, n_frames, first_slot, C.byref(ms)), "fftup_execute_ring")
         return ms.value
 
+    def execute_ring_timed(self, n_frames, first_slot=0, stride=1):
+        """-> (total ms, [ms per kernel]); events around every launch of every stride-th frame, on the launching stream"""
+        ms = C.c_double()
+        km = (C.c_double * _lib.FFTUP_NUM_KERNELS)()
+        _check(self._lib.fftup_execute_ring_timed(self._h, n_frames, first_slot, stride, C.byref(ms), km),
+               "fftup_execute_ring_timed")
+        return ms.value, list(km)
+
     def profile_kernels(self, num_iter=10):
         ms = (C.c_double * _lib.FFTUP_NUM_KERNELS)()
         _check(self._lib.fftup_profile_kernels(self._h, num_iter, ms), "fftup_profile_kernels")

@@ -621,34 +621,82 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
 
 extern "C" {
 
-int fftup_execute_ring(fftup_plan* P, uint32_t n_frames, uint32_t first_slot, double* ms_total)
+// shared body of fftup_execute_ring / fftup_execute_ring_timed.  With kernel_ms != NULL a HIP event is recorded
+// before and after every kernel launch ON THE STREAM THAT RUNS IT (one event chain per lane) and the average
+// duration of each of the plan's kernels over this very batch is returned.
+static int execute_ring_impl(fftup_plan* P, uint32_t n_frames, uint32_t first_slot, double* ms_total, double* kernel_ms,
+                             uint32_t stride)
 {
     if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
     if (n_frames == 0) return fail(FFTUP_E_INVALID_ARG, "n_frames must be > 0");
     HIP_TRY(hipSetDevice(P->device));
+    const int nk = P->fused ? 3 : 4;
+    // every `stride`-th frame is bracketed with events (an event record costs ~1 us of queue time each)
+    if (stride == 0) stride = 1;
+    const uint32_t n_timed = kernel_ms ? (n_frames + stride - 1) / stride : 0;
+    std::vector<hipEvent_t> ev;
+    if (kernel_ms) {
+        ev.resize((size_t)n_timed * (nk + 1));
+        for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    }
     HIP_TRY(hipEventRecord(P->ev0, P->stream));
     // consecutive frames go to distinct lanes; they must then also write distinct output slots
     const int nl = std::max(1, std::min(P->nlanes, (int)P->ring));
     for (int l = 1; l < nl; l++) HIP_TRY(hipStreamWaitEvent(P->lanes[l].stream, P->ev0, 0));
-    for (uint32_t i = 0; i < n_frames; i++) {
+    int rc = FFTUP_OK;
+    for (uint32_t i = 0; i < n_frames && !rc; i++) {
         uint32_t s = (first_slot + i) % P->ring;
         P->cur = (int)(i % (uint32_t)nl);
-        int rc = launch_frame(P, s, s, -1);
+        if (kernel_ms && i % stride == 0) {
+            hipEvent_t* e = &ev[(size_t)(i / stride) * (nk + 1)];
+            (void)hipEventRecord(e[0], P->lanes[P->cur].stream);
+            for (int k = 0; k < nk && !rc; k++) {
+                rc = launch_frame(P, s, s, k);
+                (void)hipEventRecord(e[k + 1], P->lanes[P->cur].stream);
+            }
+        } else {
+            rc = launch_frame(P, s, s, -1);
+        }
         P->last_lane = P->cur;
         P->cur = 0;
-        if (rc) return rc;
     }
     for (int l = 1; l < nl; l++) {
-        HIP_TRY(hipEventRecord(P->lanes[l].done, P->lanes[l].stream));
-        HIP_TRY(hipStreamWaitEvent(P->stream, P->lanes[l].done, 0));
+        (void)hipEventRecord(P->lanes[l].done, P->lanes[l].stream);
+        (void)hipStreamWaitEvent(P->stream, P->lanes[l].done, 0);
     }
-    HIP_TRY(hipEventRecord(P->ev1, P->stream));
-    HIP_TRY(hipEventSynchronize(P->ev1));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, P->ev0, P->ev1));
-    if (ms_total) *ms_total = ms;
-    P->executed = 1;
-    return FFTUP_OK;
+    hipError_t e1 = hipEventRecord(P->ev1, P->stream);
+    hipError_t e2 = hipEventSynchronize(P->ev1);
+    if (!rc && (e1 != hipSuccess || e2 != hipSuccess)) rc = fail(FFTUP_E_HIP, std::string("sync: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    if (!rc) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, P->ev0, P->ev1);
+        if (ms_total) *ms_total = ms;
+        if (kernel_ms) {
+            for (int k = 0; k < FFTUP_NUM_KERNELS; k++) kernel_ms[k] = 0;
+            for (uint32_t i = 0; i < n_timed; i++)
+                for (int k = 0; k < nk; k++) {
+                    float d = 0;
+                    (void)hipEventElapsedTime(&d, ev[(size_t)i * (nk + 1) + k], ev[(size_t)i * (nk + 1) + k + 1]);
+                    kernel_ms[k] += d;
+                }
+            for (int k = 0; k < nk; k++) kernel_ms[k] /= n_timed;
+        }
+        P->executed = 1;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+int fftup_execute_ring(fftup_plan* P, uint32_t n_frames, uint32_t first_slot, double* ms_total)
+{
+    return execute_ring_impl(P, n_frames, first_slot, ms_total, nullptr, 1);
+}
+
+int fftup_execute_ring_timed(fftup_plan* P, uint32_t n_frames, uint32_t first_slot, uint32_t stride, double* ms_total,
+                             double* ms_per_kernel)
+{
+    if (!ms_per_kernel) return fail(FFTUP_E_INVALID_ARG, "null argument");
+    return execute_ring_impl(P, n_frames, first_slot, ms_total, ms_per_kernel, stride);
 }
 
 int fftup_execute(fftup_plan* P, uint32_t n_iter, double* ms_per_iter)

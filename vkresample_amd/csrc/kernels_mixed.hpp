@@ -42,7 +42,6 @@ __global__ void __launch_bounds__(PW::T) k_row_r2c_ct(RowR2CParams p)
     float2* a = (float2*)smem;
     float2* b = a + lpad_size(W);
     const int tid = threadIdx.x, j = blockIdx.x, c = blockIdx.y;
-#pragma unroll
     for (int n = tid; n < W; n += T)
         a[lpad(n)] = make_float2(load_px<MODE>(p, c, 2 * j, n), load_px<MODE>(p, c, 2 * j + 1, n));
     __syncthreads();
@@ -50,7 +49,6 @@ __global__ void __launch_bounds__(PW::T) k_row_r2c_ct(RowR2CParams p)
     const int TK = p.TK;
     const long tile_stride = (long)p.H * TK;
     float2* base = p.S1 + (long)c * p.NT * tile_stride + (long)(2 * j) * TK;
-#pragma unroll
     for (int k = tid; k <= W / 2; k += T) {
         float2 zk = Z[lpad(k)];
         float2 zn = Z[lpad(k == 0 ? 0 : W - k)];
@@ -74,7 +72,6 @@ __global__ void __launch_bounds__(PUH::T) k_col_ct(ColParams p)
     const int tid = threadIdx.x, tile = blockIdx.x, c = blockIdx.y;
     const int ncol_valid = min(TK, p.W / 2 + 1 - tile * TK);
     const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
-#pragma unroll
     for (int e = tid; e < H * TK; e += T) {
         float2 v = make_float2(0.f, 0.f);
         if ((e % TK) < ncol_valid) v = src[e];
@@ -84,7 +81,6 @@ __global__ void __launch_bounds__(PUH::T) k_col_ct(ColParams p)
     float2* F = run_plan<+1, TK>(PH{}, a, b, p.twH, tid);
     float2* G = (F == a) ? b : a;
     // shift + zero-pad guard for u = 2: G[ky] = F[ky] (ky < H/2), F[ky-H] (ky >= 3H/2), else 0
-#pragma unroll
     for (int e = tid; e < UH * TK; e += T) {
         const int ky = e / TK, col = e % TK;
         float2 v = make_float2(0.f, 0.f);
@@ -96,7 +92,6 @@ __global__ void __launch_bounds__(PUH::T) k_col_ct(ColParams p)
     const float2* D = run_plan<-1, TK>(PUH{}, G, F, p.twUH, tid);
     float2* dst = p.S2 + ((long)c * p.NT + tile) * UH * TK;
     constexpr float inv = 1.0f / (float)UH;
-#pragma unroll
     for (int e = tid; e < UH * TK; e += T)
         if ((e % TK) < ncol_valid) dst[e] = cscale(D[lpad(e)], inv);
 }
@@ -113,7 +108,6 @@ __global__ void __launch_bounds__(PUW::T) k_row_c2r_ct(RowC2RParams p)
     const int TK = p.TK;
     const long tile_stride = (long)p.uH * TK;
     const float2* base = p.S2 + (long)c * p.NT * tile_stride + (long)(2 * j) * TK;
-#pragma unroll
     for (int k = tid + 1; k <= UW / 2; k += T) {
         float2 A = make_float2(0.f, 0.f), B = A;
         if (k <= KH) {
@@ -133,7 +127,6 @@ __global__ void __launch_bounds__(PUW::T) k_row_c2r_ct(RowC2RParams p)
     const long plane = (long)UW * p.uH;
     constexpr float inv = 1.0f / (float)UW;
     // 4 consecutive points per thread: 16-byte (8-byte for half) stores
-#pragma unroll
     for (int n0 = tid * 4; n0 < UW; n0 += T * 4) {
         float2 q[4];
 #pragma unroll
