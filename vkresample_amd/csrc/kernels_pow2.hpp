@@ -18,6 +18,7 @@
 
 
 
+
 namespace fftup {
 
 constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n / 2); }
@@ -745,60 +746,82 @@ __global__ void __launch_bounds__(UW / 4) k_c2r_sharpen_t(FusedParams p)
                 const float* cur = (const float*)(smem + ((i + 3) % 3) * L::XB);               // rows a, a+1
                 const float* ring = (const float*)(smem + ((i + 2) % 3) * L::XB);              // rows a-2, a-1
                 auto rowp = [&](int r) -> const float* { return r < 0 ? ring + (r + 2) * UW : cur + r * UW; };
+                // both output rows of a 4-pixel column group in one pass: the four L rows a-2 .. a+1 are read
+                // once and their horizontal minima/maxima are shared by the two 3x3 windows
 #pragma unroll 1
-                for (int ch = 0; ch < 4; ch++) {
-                    const int w = ch >> 1, h = ch & 1;
-                    const int y = a - 1 + w;
-                    if (i >= 0 && y >= y0 && y < y1) {                     // uniform over the half
-                        const int rN = (y == 0) ? 0 : w - 2;              // tap rows relative to a; row -1 clamps to row 0
-                        const float* rows[3] = {rowp(rN), rowp(w - 1), rowp(w)};
-                        const bool have_Sn = (w == 0);                    // row y+2 present only for y = a-1
-                        const float* nxt[3] = {(y == 0) ? rowp(rN + 1) : rows[1], rows[2], rowp(have_Sn ? w + 1 : w)};
+                for (int h = 0; h < 2; h++) {
+                    const bool out0 = i >= 0 && (a - 1) >= y0 && (a - 1) < y1;      // row y = a-1
+                    const bool out1 = i >= 0 && a >= y0 && a < y1;                  // row y = a
+                    if (out0 || out1) {
                         const int x0 = 4 * (lt + T * h);
-                        float t[3][6];
+                        // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
+                        const float* rows[4] = {rowp(-2), (a == 0) ? rowp(0) : rowp(-1), rowp(0), rowp(1)};
+                        float t[4][6];
 #pragma unroll
-                        for (int r = 0; r < 3; r++) {
+                        for (int r = 0; r < 4; r++) {
+                            if (r == 0 && !out0) continue;
                             float4 q = *(const float4*)(rows[r] + x0);
                             t[r][1] = q.x; t[r][2] = q.y; t[r][3] = q.z; t[r][4] = q.w;
                             float el = q.x, er = 0.f;
                             if ((lt & 63) == 0 && x0 != 0) el = rows[r][x0 - 1];
-                            if ((lt & 63) == 63) er = (x0 + 4 == UW) ? nxt[r][0] : rows[r][x0 + 4];
+                            if ((lt & 63) == 63) {
+                                // x = UW wraps to x = 0 of the next row (rows past a+1: see below)
+                                const float* nx = (r < 3) ? ((a == 0 && r == 1) ? rowp(1) : rows[r + 1]) : rows[3];
+                                er = (x0 + 4 == UW) ? nx[0] : rows[r][x0 + 4];
+                            }
                             t[r][0] = lane_from_below(q.w, el);
                             t[r][5] = lane_from_above(q.x, er);
                         }
                         const bool last_chunk = (x0 + 4 == UW);
-                        bool defer = false;
-                        if (last_chunk && !have_Sn) {
-                            const int r2 = min(y + 2, uH - 1) - a;
-                            if (r2 <= 1) t[2][5] = rowp(r2)[0];
-                            else if (i != npairs - 1) defer = true;
-                            else {
+                        if (last_chunk) {
+                            // SE tap of pixel (a, UW-1) is L(a+2, 0): past the plane it clamps to row uH-1; in the
+                            // last step it is the corner sample; otherwise the pixel is finished next step
+                            const int r2 = min(a + 2, uH - 1) - a;
+                            if (r2 <= 1) t[3][5] = rowp(r2)[0];
+                            else if (i == npairs - 1) {
                                 float sum = 0.f;
                                 for (int w2 = 0; w2 < T / 64; w2++) sum += red[w2];
-                                t[2][5] = to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq);
+                                t[3][5] = to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq);
                             }
                         }
-                        float o[4];
-                        sharpen_quad<HALF>(t, p.coef, o);
-                        const long of = c * plane + (long)y * UW + x0;
-                        // one 16-byte (8-byte for half) store per lane, always: a deferred last pixel gets a
-                        // placeholder now and is overwritten by the owning thread of the other half next step
-                        (void)defer;
-                        // non-temporal: the output is written once and never re-read on the device; keeping it
-                        // out of L2 leaves the spectra there (-3 us/frame measured)
-                        if constexpr (HALF) {
-                            __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
-                            typedef float f2v __attribute__((ext_vector_type(2)));
-                            f2v val = {*(float*)&h0, *(float*)&h1};
-                            __builtin_nontemporal_store(val, (f2v*)((__half*)p.out + of));
-                        } else {
-                            typedef float f4v __attribute__((ext_vector_type(4)));
-                            f4v val = {o[0], o[1], o[2], o[3]};
-                            __builtin_nontemporal_store(val, (f4v*)((float*)p.out + of));
+                        float hmn[4][4], hmx[4][4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                hmn[r][k] = fminf(fminf(t[r][k], t[r][k + 1]), t[r][k + 2]);
+                                hmx[r][k] = fmaxf(fmaxf(t[r][k], t[r][k + 1]), t[r][k + 2]);
+                            }
+#pragma unroll
+                        for (int w = 0; w < 2; w++) {
+                            if (w == 0 ? !out0 : !out1) continue;
+                            float o[4];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const float N = t[w][k + 1], S = t[w + 2][k + 1], Wv = t[w + 1][k], C = t[w + 1][k + 1], E = t[w + 1][k + 2];
+                                const float mn0 = fminf(fminf(N, S), hmn[w + 1][k]);
+                                const float mx0 = fmaxf(fmaxf(N, S), hmx[w + 1][k]);
+                                const float mn1 = fminf(fminf(hmn[w][k], hmn[w + 2][k]), mn0);
+                                const float mx1 = fmaxf(fmaxf(hmx[w][k], hmx[w + 2][k]), mx0);
+                                if constexpr (HALF) o[k] = sharpen_eval_half_fast(N, S, Wv, E, C, mn0, mn1, mx0, mx1, p.coef);
+                                else o[k] = sharpen_eval_fast(((N + Wv) + E) + S, C, mn0, mn1, mx0, mx1, p.coef);
+                            }
+                            const long of = c * plane + (long)(a - 1 + w) * UW + x0;
+                            if constexpr (HALF) {
+                                __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
+                                typedef float f2v __attribute__((ext_vector_type(2)));
+                                f2v val = {*(float*)&h0, *(float*)&h1};
+                                __builtin_nontemporal_store(val, (f2v*)((__half*)p.out + of));
+                            } else {
+                                typedef float f4v __attribute__((ext_vector_type(4)));
+                                f4v val = {o[0], o[1], o[2], o[3]};
+                                __builtin_nontemporal_store(val, (f4v*)((float*)p.out + of));
+                            }
                         }
                     }
                     __syncthreads();
-                    if (ch < 2) __syncthreads();                                               // 6 in total
+                    __syncthreads();
+                    __syncthreads();                                                           // 6 in total
                 }
                 if (i >= 0 && lt == T - 1) {
                     // finish the pixel deferred by the previous pair: (a-2, UW-1); L(a,0) is known now
