@@ -301,3 +301,46 @@ def test_mixed_radix_plans_equal_generic():
     (pre2, out2, u82), _ = _run(1920, 1080, 2.0, 0, "N", seed=5, flags=FLAG_GENERIC_KERNELS)
     assert np.abs(pre - pre2).max() * 4 <= 2e-6
     assert np.abs(out - out2).max() <= 1e-4
+
+
+def test_timed_ring_and_profile_api():
+    """measurement entry points: kernel durations are positive, ordered like the launches, and the timed batch
+    produces the same pixels as the plain one"""
+    from vkresample_amd import synth
+    W, H = 512, 256
+    with _up(W, H, 2.0, 0, ring=2) as up:
+        for s in range(2):
+            up.upload_rgb8(synth.frame(40 + s, W, H), slot=s)
+        up.execute_ring(4, 0)
+        ref = [up.download_planar(s) for s in range(2)]
+        ms, km = up.execute_ring_timed(8, 0, 2)
+        got = [up.download_planar(s) for s in range(2)]
+        iso = up.profile_kernels(3)
+        assert up.kernel_names[:3] == ["row_r2c", "col_fwd_pad_inv", "row_c2r_sharpen"]
+    assert ms > 0 and all(k > 0 for k in km[:3]) and all(k > 0 for k in iso[:3])
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+
+
+def test_u8_wrap_flag():
+    """FFTUP_FLAG_U8_WRAP reproduces the x86 behaviour of the reference's C cast (VR:1715) where the sharpened value
+    leaves [0,1]; the default saturates.  Both agree with the oracle's two store modes."""
+    from vkresample_amd import FLAG_U8_WRAP, synth
+    rgb = synth.frame(8, 128, 64, "U")                      # uniform noise: plenty of overshoot after sharpening
+    outs = {}
+    for flags in (0, FLAG_U8_WRAP):
+        with _up(128, 64, 2.0, 0, 0.2, 0, flags) as up:
+            up.upload_rgb8(rgb)
+            up.execute(1)
+            outs[flags] = (up.download_rgb8(), up.download_planar().astype(np.float64))
+    sat, planes = outs[0]
+    wrap, _ = outs[FLAG_U8_WRAP]
+    x = planes.transpose(1, 2, 0) * 255.0
+    inside = (x >= 0) & (x < 255)
+    assert np.array_equal(sat[inside], wrap[inside])
+    lo, hi = x < 0, x >= 256
+    assert lo.any() or hi.any()
+    assert (sat[lo] == 0).all() and (sat[x >= 255] == 255).all()
+    assert np.array_equal(wrap[lo], (np.trunc(x[lo]).astype(np.int64) & 0xFF).astype(np.uint8))
+    if hi.any():
+        assert np.array_equal(wrap[hi], (np.trunc(x[hi]).astype(np.int64) & 0xFF).astype(np.uint8))
