@@ -26,7 +26,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-step", type=int, default=64)
-    ap.add_argument("--ring", type=int, default=4, help="distinct resident input/output frame slots per GPU")
+    ap.add_argument("--ring", type=int, default=8,
+                    help="distinct resident input/output frame slots per GPU (8 x 131 MB > the 256 MB Infinity Cache)")
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--upscale", type=float, default=2.0)
