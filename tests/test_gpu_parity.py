@@ -344,3 +344,33 @@ def test_u8_wrap_flag():
     assert np.array_equal(wrap[lo], (np.trunc(x[lo]).astype(np.int64) & 0xFF).astype(np.uint8))
     if hi.any():
         assert np.array_equal(wrap[hi], (np.trunc(x[hi]).astype(np.int64) & 0xFF).astype(np.uint8))
+
+
+def test_largest_r2c_size_vs_oracle():
+    """uW = 8192 is the largest width the reference's R2C path accepts (VkResample.cpp:1424); one size further
+    is rejected with FFTUP_E_UNSUPPORTED_SIZE."""
+    import vkresample_amd as v
+    (pre, out, u8), (opre, oout, ou8) = _run(4096, 64, 2.0, 0, "N", seed=9)
+    assert _rel_l2(pre, opre) <= 1e-5 and np.abs(pre - opre).max() * 4 <= 1e-4
+    assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-4
+    with pytest.raises(v.FftupError) as e:
+        v.Upscaler(4608, 64, 2.0)               # 9216 = 2^10 * 9: smooth but beyond the R2C limit
+    assert e.value.code == 2
+
+
+def test_4k_to_8k_properties():
+    """4096x2048 -> 8192x4096 (size-generic kernels, 0.4 GB of output): DC preservation and determinism."""
+    from vkresample_amd import synth
+    W, H = 4096, 2048
+    rgb = synth.frame(12, W, H, "N")
+    with _up(W, H, 2.0, 0) as up:
+        up.upload_rgb8(rgb)
+        up.execute(1)
+        pre = up.download_presharpen().astype(np.float64) * 4
+        out1 = up.download_planar()
+        up.execute(2)
+        out2 = up.download_planar()
+    want = (rgb.astype(np.float32) / np.float32(255)).astype(np.float64).mean(axis=(0, 1))
+    assert np.abs(pre.mean(axis=(1, 2)) - want).max() <= 1e-6
+    assert np.array_equal(out1, out2)
+    assert out1.min() > -0.05 and out1.max() < 1.05
