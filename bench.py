@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--event-stride", type=int, default=8, help="kernel-timing events on every n-th frame of the timed region")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams (lanes) consecutive frames alternate on; 1 = strictly sequential kernels")
+    ap.add_argument("--host-streamed", action="store_true",
+                    help="NOT the headline: frames start and end in pinned host memory (fftup_submit_rgb8 queue, "
+                         "uint8 RGB over PCIe both ways); the line is marked pcie_inclusive")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
                     help="per-launch HBM bytes of the dominant kernel from a committed rocprofv3 --pmc run")
     return ap.parse_args()
@@ -96,8 +99,23 @@ def main():
         if torch.cuda.is_available():
             torch.cuda.synchronize()
 
+    pins = None
+    if args.host_streamed:
+        pins = (v.PinnedArray((args.ring, args.height, args.width, 3)),
+                v.PinnedArray((args.ring, up.out_height, up.out_width, 3)))
+        for s in range(args.ring):
+            pins[0].array[s] = synth.frame(rank * args.ring + s, args.width, args.height, "U")
+
+    def streamed_step():
+        for k in range(args.frames_per_step):
+            up.submit_rgb8(pins[0].array[k % args.ring], pins[1].array[k % args.ring])
+        up.drain()
+
     slot = 0
     for _ in range(args.warmup):
+        if args.host_streamed:
+            streamed_step()
+            continue
         up.execute_ring(args.frames_per_step, slot)
         slot = (slot + args.frames_per_step) % args.ring
     barrier()
@@ -105,6 +123,11 @@ def main():
     dev_ms = 0.0
     kms = [0.0] * len(up.kernel_names)
     for _ in range(args.steps):
+        if args.host_streamed:
+            t1 = time.perf_counter()
+            streamed_step()
+            dev_ms += (time.perf_counter() - t1) * 1e3
+            continue
         # HIP events before/after every kernel launch of every --event-stride-th frame, on the stream that runs
         # it, inside the timed region
         ms, km = up.execute_ring_timed(args.frames_per_step, slot, args.event_stride)   # blocks until the batch is done
@@ -132,6 +155,8 @@ def main():
         # with --streams 2 the timed region runs two frames at once and a kernel's wall duration there
         # (kernel_ms, roofline.achieved_overlapped) includes the other lane's co-resident kernels
         achieved = up.kernel_alg_bytes[dom] / (iso[dom] * 1e-3) / 1e9
+        if args.host_streamed:
+            kms = list(iso)                   # no per-kernel events in the streamed loop
         achieved_ovl = up.kernel_alg_bytes[dom] / (kms[dom] * 1e-3) / 1e9
         traffic = None
         if os.path.exists(args.traffic_json):
@@ -164,9 +189,18 @@ def main():
                          "frame_achieved": up.alg_bytes_per_frame / (frame_ms * 1e-3) / 1e9,
                          "frame_frac": up.alg_bytes_per_frame / (frame_ms * 1e-3) / 8e12},
         }
+        if args.host_streamed:
+            pcie = 3.0 * (args.width * args.height + up.out_width * up.out_height)
+            line["pcie_inclusive"] = True
+            line["config"]["workload"] += ", HOST-STREAMED: uint8 RGB frames from/to pinned host memory"
+            line["pcie_bytes_per_frame"] = pcie
+            line["pcie_GBps"] = pcie / (frame_ms * 1e-3) / 1e9
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args)
     up.close()
+    if pins:
+        pins[0].close()
+        pins[1].close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

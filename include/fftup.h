@@ -127,6 +127,21 @@ FFTUP_API int fftup_download_planar(fftup_plan* plan, uint32_t slot, void* plane
 FFTUP_API int fftup_download_presharpen(fftup_plan* plan, void* planes);
 FFTUP_API int fftup_download_input_planar(fftup_plan* plan, uint32_t slot, void* planes);
 
+/* Host-streamed batches (replaces the blocking transferDataFromCPU / transferDataToCPU + the two CPU
+ * conversion loops of VR:1636-1748 for the batched mode, VR:1621-1760).  fftup_submit_rgb8 enqueues one whole
+ * frame -- H2D copy, uint8 -> float conversion, the frame's kernels, float -> uint8 conversion, D2H copy -- and
+ * returns at once with a ticket; up to `ring` frames are in flight, copies of one frame overlap the kernels of
+ * its neighbours (each frame runs start to end on one of the plan's streams, consecutive frames on different ones).  A submit that finds its ring slot
+ * still busy first waits for that slot's frame.  fftup_wait(ticket) returns when rgb_out of that submission is
+ * complete; fftup_drain waits for everything submitted.  For the copies to be asynchronous both host buffers
+ * must be page-locked: allocate them with fftup_host_alloc (pageable memory works, the copies then block). */
+FFTUP_API void* fftup_host_alloc(size_t bytes);      /* NULL on failure (fftup_last_error) */
+FFTUP_API void fftup_host_free(void* ptr);
+FFTUP_API int fftup_submit_rgb8(fftup_plan* plan, const uint8_t* rgb_in, size_t in_stride_bytes, uint8_t* rgb_out,
+                                size_t out_stride_bytes, uint64_t* ticket);
+FFTUP_API int fftup_wait(fftup_plan* plan, uint64_t ticket);
+FFTUP_API int fftup_drain(fftup_plan* plan);
+
 FFTUP_API const char* fftup_strerror(int code);
 FFTUP_API const char* fftup_last_error(void);   /* thread-local detail of the last failure */
 FFTUP_API const char* fftup_version(void);

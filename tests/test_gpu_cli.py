@@ -57,6 +57,33 @@ def test_cli_batched_two_threads(tmp_path):
         assert d.max() <= 2 and (d > 1).mean() <= 1e-3          # fp16 storage: a one-ulp flip can move a code by 2
 
 
+def test_cli_batched_queue_one_thread_and_missing_file(tmp_path):
+    """one thread, 7 files: the double-buffered queue (fftup_submit_rgb8) writes every frame; -n 3 takes the
+    blocking path with identical files; a missing file ends the thread like the reference (VR:1631-1634)."""
+    from vkresample_amd import synth
+    for d in ("inp", "o1", "o3", "o4"):
+        os.makedirs(tmp_path / d)
+    frames = [synth.frame(40 + k, 128, 64, "U" if k % 2 else "N") for k in range(7)]
+    for k, f in enumerate(frames):
+        _png_write(tmp_path / "inp" / ("%06d.png" % (k + 1)), f)
+    base = [CLI, "-ifolder", "inp", "-numfiles", "7", "-numthreads", "1", "-u", "2", "-p", "0"]
+    r = subprocess.run(base + ["-ofolder", "o1"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and r.stdout.count("finished.") == 1, r.stdout + r.stderr
+    r = subprocess.run(base + ["-ofolder", "o3", "-n", "3"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for k, f in enumerate(frames):
+        a = _png_read(tmp_path / "o1" / ("%06d.png" % (k + 1)))
+        b = _png_read(tmp_path / "o3" / ("%06d.png" % (k + 1)))
+        assert np.array_equal(a, b), k
+        _, _, ou8 = O.upscale_rgb8(f, 2.0, 0, 0.2)
+        d = np.abs(a[:-1].astype(int) - ou8[:-1].astype(int))
+        assert d.max() <= 1 and (d != 0).mean() <= 5e-3
+    os.remove(tmp_path / "inp" / "000005.png")
+    r = subprocess.run(base + ["-ofolder", "o4"], capture_output=True, text=True, cwd=tmp_path)
+    assert "Image not found" in r.stdout and r.returncode != 0
+    assert sorted(os.listdir(tmp_path / "o4")) == ["%06d.png" % k for k in (1, 2, 3, 4)]
+
+
 def test_cli_devices_and_errors(tmp_path):
     r = subprocess.run([CLI, "-devices"], capture_output=True, text=True)
     assert r.returncode == 0 and "Device id: 0 name:" in r.stdout

@@ -374,3 +374,46 @@ def test_4k_to_8k_properties():
     assert np.abs(pre.mean(axis=(1, 2)) - want).max() <= 1e-6
     assert np.array_equal(out1, out2)
     assert out1.min() > -0.05 and out1.max() < 1.05
+
+
+@pytest.mark.parametrize("W,H,precision,flags,ring,pinned", [(128, 64, 0, 0, 3, True), (512, 256, 0, 0, 2, False),
+                                                             (512, 256, 2, 2, 4, True), (60, 36, 0, 0, 1, True)])
+def test_host_streamed_queue_equals_blocking_calls(W, H, precision, flags, ring, pinned):
+    """fftup_submit_rgb8 / fftup_wait: every frame of a queue deeper than the ring comes back
+    byte-identical to upload_rgb8 -> execute -> download_rgb8 of the same frame."""
+    import vkresample_amd as v
+    from vkresample_amd import synth
+    n = 3 * ring + 1
+    frames = [synth.frame(100 + k, W, H, "N" if k % 2 else "U") for k in range(n)]
+    with _up(W, H, 2.0, precision, flags=flags, ring=ring) as up:
+        want = []
+        for f in frames:
+            up.upload_rgb8(f)
+            up.execute(1)
+            want.append(up.download_rgb8())
+        if pinned:
+            pin_in, pin_out = v.PinnedArray((n, H, W, 3)), v.PinnedArray((n, 2 * H, 2 * W, 3))
+            ins, outs = pin_in.array, pin_out.array
+        else:
+            ins, outs = np.empty((n, H, W, 3), np.uint8), np.empty((n, 2 * H, 2 * W, 3), np.uint8)
+        outs[:] = 7
+        for k, f in enumerate(frames):
+            ins[k] = f
+        tickets = [up.submit_rgb8(ins[k], outs[k]) for k in range(n)]
+        assert tickets == list(range(n))
+        up.wait(tickets[0])                        # long since retired (slot reused)
+        up.wait(tickets[-1])
+        up.drain()
+        for k in range(n):
+            assert np.array_equal(outs[k], want[k]), k
+        # the queue keeps working after a drain, tickets keep counting
+        t = up.submit_rgb8(ins[1], outs[0])
+        assert t == n
+        up.wait(t)
+        assert np.array_equal(outs[0], want[1])
+        with pytest.raises(v.FftupError) as e:
+            up.wait(t + 1)
+        assert e.value.code == 1
+        if pinned:
+            pin_in.close()
+            pin_out.close()

@@ -84,6 +84,9 @@ def test_error_paths_without_device():
             v.Upscaler(64, 32)
         assert e.value.code == 4                                   # FFTUP_E_NO_DEVICE: no CPU fallback
     assert lib.fftup_execute(None, 1, None) == 1
+    assert lib.fftup_submit_rgb8(None, None, 0, None, 0, None) == 1
+    assert lib.fftup_wait(None, 0) == 1 and lib.fftup_drain(None) == 1
+    lib.fftup_host_free(None)                                      # no-op
     lib.fftup_plan_destroy(None)                                   # no-op
 
 

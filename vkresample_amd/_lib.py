@@ -18,7 +18,8 @@ EXPORTS = [
     "fftup_device_count", "fftup_device_name", "fftup_plan_create", "fftup_plan_destroy", "fftup_plan_info",
     "fftup_upload_rgb8", "fftup_upload_rgb8_slot", "fftup_upload_planar", "fftup_execute", "fftup_execute_ring", "fftup_execute_ring_timed",
     "fftup_profile_kernels", "fftup_download_rgb8", "fftup_download_planar", "fftup_download_presharpen",
-    "fftup_download_input_planar", "fftup_strerror", "fftup_last_error", "fftup_version",
+    "fftup_download_input_planar", "fftup_host_alloc", "fftup_host_free", "fftup_submit_rgb8", "fftup_wait",
+    "fftup_drain", "fftup_strerror", "fftup_last_error", "fftup_version",
 ]
 
 
@@ -65,6 +66,13 @@ def load():
     lib.fftup_download_planar.argtypes = [vp, u32, vp]
     lib.fftup_download_presharpen.argtypes = [vp, vp]
     lib.fftup_download_input_planar.argtypes = [vp, u32, vp]
+    lib.fftup_host_alloc.argtypes = [sz]
+    lib.fftup_host_alloc.restype = vp
+    lib.fftup_host_free.argtypes = [vp]
+    lib.fftup_host_free.restype = None
+    lib.fftup_submit_rgb8.argtypes = [vp, vp, sz, vp, sz, C.POINTER(C.c_uint64)]
+    lib.fftup_wait.argtypes = [vp, C.c_uint64]
+    lib.fftup_drain.argtypes = [vp]
     lib.fftup_strerror.argtypes = [C.c_int]
     lib.fftup_strerror.restype = C.c_char_p
     lib.fftup_last_error.restype = C.c_char_p

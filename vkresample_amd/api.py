@@ -127,10 +127,46 @@ class Upscaler:
         _check(self._lib.fftup_download_input_planar(self._h, slot, out.ctypes.data), "fftup_download_input_planar")
         return out
 
+    def submit_rgb8(self, rgb_in, rgb_out):
+        """Enqueue one host frame end to end (H2D, convert, kernels, convert, D2H) and return its ticket; up to
+        `ring` frames are in flight.  rgb_in [H][W][3] / rgb_out [uH][uW][3] uint8, C-contiguous, and they must
+        stay alive and untouched until wait(ticket) returns (pinned memory: PinnedArray)."""
+        assert rgb_in.dtype == np.uint8 and rgb_in.shape == (self.height, self.width, 3) and rgb_in.flags.c_contiguous
+        assert rgb_out.dtype == np.uint8 and rgb_out.shape == (self.out_height, self.out_width, 3) and rgb_out.flags.c_contiguous
+        t = C.c_uint64()
+        _check(self._lib.fftup_submit_rgb8(self._h, rgb_in.ctypes.data, 3 * self.width, rgb_out.ctypes.data,
+                                           3 * self.out_width, C.byref(t)), "fftup_submit_rgb8")
+        return t.value
+
+    def wait(self, ticket):
+        _check(self._lib.fftup_wait(self._h, ticket), "fftup_wait")
+
+    def drain(self):
+        _check(self._lib.fftup_drain(self._h), "fftup_drain")
+
     def download_rgb8(self, slot=0):
         out = np.empty((self.out_height, self.out_width, 3), dtype=np.uint8)
         _check(self._lib.fftup_download_rgb8(self._h, slot, out.ctypes.data, out.strides[0]), "fftup_download_rgb8")
         return out
+
+
+class PinnedArray:
+    """uint8 numpy view of page-locked host memory from fftup_host_alloc (needed for truly asynchronous copies
+    in Upscaler.submit_rgb8); free with .close() after the frames using it have been waited for."""
+
+    def __init__(self, shape):
+        self._lib = _lib.load()
+        n = int(np.prod(shape))
+        self._p = self._lib.fftup_host_alloc(n)
+        if not self._p:
+            raise FftupError(5, "fftup_host_alloc")
+        self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_uint8)), shape=(n,)).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            self._lib.fftup_host_free(self._p)
+            self._p = None
 
 
 def upscale_image(rgb, upscale=2.0, precision=0, sharpen=0.2, num_iter=1, device=0, flags=0):

@@ -85,7 +85,7 @@ static int launchResample(ResampleConfiguration config)                      // 
     fftup_config cfg{};
     cfg.width = (uint32_t)width; cfg.height = (uint32_t)height; cfg.channels = 3;
     cfg.upscale = config.upscale; cfg.precision = config.precision; cfg.sharpen = config.sharpenConst;
-    cfg.device = device; cfg.flags = config.flags; cfg.ring = 1;
+    cfg.device = device; cfg.flags = config.flags; cfg.ring = config.fileUpload ? 2 : 1;
     fftup_plan* plan = nullptr;
     int res = fftup_plan_create(&plan, &cfg);
     if (res != FFTUP_OK) {
@@ -104,6 +104,59 @@ static int launchResample(ResampleConfiguration config)                      // 
     if (config.fileUpload) {                                                   // VR:1622-1625
         numLocalFiles = (int)std::ceil(config.numFiles / (float)config.numThreads);
         if ((numLocalFiles - 1) * config.numThreads + config.threadId > config.numFiles - 1) numLocalFiles--;
+    }
+    if (config.fileUpload && config.numIter == 1 && numLocalFiles > 1) {
+        // batched mode, double-buffered: frame f is on the device (fftup_submit_rgb8: H2D, kernels,
+        // D2H asynchronously from/to page-locked memory) while this thread encodes frame f-1 and decodes frame f+1
+        const size_t inBytes = (size_t)width * height * 3, outBytes = (size_t)uW * uH * 3;
+        uint8_t* pin[2] = {(uint8_t*)fftup_host_alloc(inBytes), (uint8_t*)fftup_host_alloc(inBytes)};
+        uint8_t* pout[2] = {(uint8_t*)fftup_host_alloc(outBytes), (uint8_t*)fftup_host_alloc(outBytes)};
+        auto release = [&]() {
+            fftup_drain(plan);
+            for (int i = 0; i < 2; i++) { fftup_host_free(pin[i]); fftup_host_free(pout[i]); }
+            fftup_plan_destroy(plan);
+        };
+        if (!pin[0] || !pin[1] || !pout[0] || !pout[1]) {
+            printf("Upscale failed: %s (%s)\n", fftup_strerror(FFTUP_E_OUT_OF_MEMORY), fftup_last_error());
+            release();
+            return FFTUP_E_OUT_OF_MEMORY;
+        }
+        auto fileIndex = [&](int f) { return f * config.numThreads + config.threadId + 1; };
+        auto writeFrame = [&](int f, uint64_t ticket) -> int {
+            int r = fftup_wait(plan, ticket);
+            if (r != FFTUP_OK) { printf("Download failed: %s (%s)\n", fftup_strerror(r), fftup_last_error()); return r; }
+            char outName[1024];
+            snprintf(outName, sizeof outName, "%s/%06d.png", config.ofolder_prefix, fileIndex(f));
+            if (!pngio::write_rgb8(outName, pout[f & 1], (int)uW, (int)uH, (size_t)uW * 3, err))
+                printf("Could not write %s: %s\n", outName, err.c_str());
+            return FFTUP_OK;
+        };
+        uint64_t tickets[2] = {0, 0};
+        for (int f = 0; f < numLocalFiles; f++) {
+            if (f > 0) {
+                snprintf(fileName, sizeof fileName, "%s/%06d.png", config.ifolder_prefix, fileIndex(f));
+                int w2 = 0, h2 = 0;
+                if (!pngio::load_rgb8(fileName, png_input, w2, h2, channels, err) || w2 != width || h2 != height) {
+                    writeFrame(f - 1, tickets[(f - 1) & 1]);                   // the reference finished file f-1 before opening f
+                    printf("Image not found\n");                               // VR:1631-1634
+                    release();
+                    return FFTUP_E_INCOMPLETE;
+                }
+            }
+            memcpy(pin[f & 1], png_input.data(), inBytes);          // frame f-2 (same buffers) was waited for below
+            res = fftup_submit_rgb8(plan, pin[f & 1], (size_t)width * 3, pout[f & 1], (size_t)uW * 3, &tickets[f & 1]);
+            if (res != FFTUP_OK) {
+                printf("Upscale failed: %s (%s)\n", fftup_strerror(res), fftup_last_error());
+                release();
+                return res;
+            }
+            if (f > 0 && (res = writeFrame(f - 1, tickets[(f - 1) & 1])) != FFTUP_OK) { release(); return res; }
+        }
+        res = writeFrame(numLocalFiles - 1, tickets[(numLocalFiles - 1) & 1]);
+        release();
+        if (res != FFTUP_OK) return res;
+        printf("Thread %d finished. Device name: %s API:HIP\n", config.threadId, info.device_name);   // VR:1773
+        return FFTUP_OK;
     }
     for (int f = 0; f < numLocalFiles; f++) {
         if (f > 0) {

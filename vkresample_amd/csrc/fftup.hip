@@ -72,6 +72,10 @@ struct fftup_plan {
     int nlanes = 1, cur = 0, last_lane = 0;
     std::vector<void*> out;           // per slot: dense [3][uH][uW]
     uint8_t* out_u8 = nullptr;        // staging for download_rgb8
+    // host-streamed queue (fftup_submit_rgb8): created on first use
+    struct QSlot { uint8_t* out_u8 = nullptr; hipEvent_t done = nullptr; };
+    std::vector<QSlot> q;
+    uint64_t q_next = 0;
     float2 *twW = nullptr, *twH = nullptr, *twUW = nullptr, *twUH = nullptr;
     uint64_t device_bytes = 0;
     size_t in_plane_stride = 0;
@@ -175,6 +179,8 @@ void fftup_plan_destroy(fftup_plan* P)
         if (P->lanes[l].stream) { (void)hipStreamSynchronize(P->lanes[l].stream); (void)hipStreamDestroy(P->lanes[l].stream); }
         if (P->lanes[l].done) (void)hipEventDestroy(P->lanes[l].done);
     }
+    for (auto& qs : P->q)
+        if (qs.done) (void)hipEventDestroy(qs.done);
     for (void* p : P->allocs) (void)hipFree(p);
     if (P->ev0) (void)hipEventDestroy(P->ev0);
     if (P->ev1) (void)hipEventDestroy(P->ev1);
@@ -824,6 +830,113 @@ int fftup_download_rgb8(fftup_plan* P, uint32_t slot, uint8_t* rgb, size_t row_s
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy2DAsync(rgb, row_stride_bytes, P->out_u8, (size_t)3 * P->uW, (size_t)3 * P->uW, P->uH, hipMemcpyDeviceToHost, P->stream));
     HIP_TRY(hipStreamSynchronize(P->stream));
+    return FFTUP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-streamed frames: H2D | convert + frame kernels + convert | D2H on three kinds of streams,
+// `ring` frames in flight
+void* fftup_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        fail(FFTUP_E_OUT_OF_MEMORY, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+void fftup_host_free(void* ptr)
+{
+    if (ptr) (void)hipHostFree(ptr);
+}
+
+static int queue_init(fftup_plan* P)
+{
+    if (!P->q.empty()) return FFTUP_OK;
+    P->q.resize(P->ring);
+    for (uint32_t s = 0; s < P->ring; s++) {
+        if (s == 0) P->q[s].out_u8 = P->out_u8;
+        else {
+            int rc = dev_alloc(P, (void**)&P->q[s].out_u8, (size_t)3 * P->uW * P->uH);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipEventCreateWithFlags(&P->q[s].done, hipEventDisableTiming));
+    }
+    return FFTUP_OK;
+}
+
+int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, uint8_t* rgb_out, size_t out_stride,
+                      uint64_t* ticket)
+{
+    if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
+    if (!rgb_in || in_stride < (size_t)3 * P->W) return fail(FFTUP_E_INVALID_ARG, "bad input pointer/stride");
+    if (!rgb_out || out_stride < (size_t)3 * P->uW) return fail(FFTUP_E_INVALID_ARG, "bad output pointer/stride");
+    HIP_TRY(hipSetDevice(P->device));
+    int rc = queue_init(P);
+    if (rc) return rc;
+    const uint64_t t = P->q_next;
+    const uint32_t s = (uint32_t)(t % P->ring);
+    fftup_plan::QSlot& Q = P->q[s];
+    if (t >= P->ring) HIP_TRY(hipEventSynchronize(Q.done));          // the slot's previous frame has left the device
+    // The whole frame -- H2D, conversion, kernels, conversion, D2H -- goes to ONE stream (lane t % nlanes), so no
+    // cross-stream dependency exists and nothing can stall behind a neighbour's wait when streams share a hardware
+    // queue; the copies of one lane overlap the kernels and the opposite-direction copies of the other lanes.
+    const int lane = (int)(t % (uint64_t)P->nlanes);
+    hipStream_t cs = P->lanes[lane].stream;
+    const size_t in_row = (size_t)3 * P->W, out_row = (size_t)3 * P->uW;
+    if (in_stride == in_row) HIP_TRY(hipMemcpyAsync(P->in_u8[s], rgb_in, in_row * P->H, hipMemcpyHostToDevice, cs));
+    else HIP_TRY(hipMemcpy2DAsync(P->in_u8[s], in_row, rgb_in, in_stride, in_row, P->H, hipMemcpyHostToDevice, cs));
+    if (P->cfg.flags & FFTUP_FLAG_FUSE_U8_LOAD) {
+        P->in_kind[s] = 2;
+    } else {
+        dim3 grid((P->W + 255) / 256, P->H);
+        if (P->half)
+            hipLaunchKernelGGL(k_unpack_u8<true>, grid, dim3(256), 0, cs, P->in_u8[s], (long)3 * P->W, P->in_planar[s],
+                               (int)P->W, (int)P->H, (long)P->in_plane_stride);
+        else
+            hipLaunchKernelGGL(k_unpack_u8<false>, grid, dim3(256), 0, cs, P->in_u8[s], (long)3 * P->W, P->in_planar[s],
+                               (int)P->W, (int)P->H, (long)P->in_plane_stride);
+        P->in_kind[s] = 1;
+    }
+    P->cur = lane;
+    rc = launch_frame(P, s, s, -1);
+    P->last_lane = lane;
+    P->cur = 0;
+    if (rc) return rc;
+    {
+        dim3 grid((P->uW + 255) / 256, P->uH);
+        const int wrap = (P->cfg.flags & FFTUP_FLAG_U8_WRAP) ? 1 : 0;
+        if (P->half) hipLaunchKernelGGL(k_pack_u8<true>, grid, dim3(256), 0, cs, P->out[s], Q.out_u8, (int)P->uW, (int)P->uH, wrap);
+        else hipLaunchKernelGGL(k_pack_u8<false>, grid, dim3(256), 0, cs, P->out[s], Q.out_u8, (int)P->uW, (int)P->uH, wrap);
+        HIP_TRY(hipGetLastError());
+    }
+    if (out_stride == out_row) HIP_TRY(hipMemcpyAsync(rgb_out, Q.out_u8, out_row * P->uH, hipMemcpyDeviceToHost, cs));
+    else HIP_TRY(hipMemcpy2DAsync(rgb_out, out_stride, Q.out_u8, out_row, out_row, P->uH, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipEventRecord(Q.done, cs));
+    P->q_next = t + 1;
+    P->executed = 1;
+    if (ticket) *ticket = t;
+    return FFTUP_OK;
+}
+
+int fftup_wait(fftup_plan* P, uint64_t ticket)
+{
+    if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
+    if (ticket >= P->q_next) return fail(FFTUP_E_INVALID_ARG, "ticket was never issued");
+    if (ticket + P->ring < P->q_next) return FFTUP_OK;        // its slot has been reused: submit already waited for it
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipEventSynchronize(P->q[ticket % P->ring].done));
+    return FFTUP_OK;
+}
+
+int fftup_drain(fftup_plan* P)
+{
+    if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
+    if (P->q.empty()) return FFTUP_OK;
+    HIP_TRY(hipSetDevice(P->device));
+    for (int l = 0; l < P->nlanes; l++) HIP_TRY(hipStreamSynchronize(P->lanes[l].stream));
     return FFTUP_OK;
 }
 
