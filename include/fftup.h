@@ -33,7 +33,7 @@ enum {
     FFTUP_E_INVALID_ARG = 1,    /* null pointer, bad slot, odd size, channels != 3 (VR:1368)            */
     FFTUP_E_UNSUPPORTED_SIZE = 2, /* a dimension is not 2,3,5,7-smooth: VF:4719-4726
                                      (VK_ERROR_FORMAT_NOT_SUPPORTED), or exceeds the R2C limit VR:1424  */
-    FFTUP_E_UNSUPPORTED_PRECISION = 3, /* -p 1 (double) is not implemented; 0 and 2 are              */
+    FFTUP_E_UNSUPPORTED_PRECISION = 3, /* -p must be 0, 1 or 2                                         */
     FFTUP_E_NO_DEVICE = 4,      /* no HIP device / bad device id (VR:1292-1296)                         */
     FFTUP_E_HIP = 5,            /* a HIP runtime call failed (message in fftup_last_error)              */
     FFTUP_E_OUT_OF_MEMORY = 6,  /* device allocation failed (allocateFFTBuffer VR:361-384)              */
@@ -58,7 +58,7 @@ typedef struct fftup_config {
     uint32_t width, height;   /* input image size; both even                                         */
     uint32_t channels;        /* must be 3 (stbi_load(...,3) VR:1362, channels = 3 VR:1368)           */
     float    upscale;         /* -u; output = (uint32_t)(upscale*size) (VR:1417-1418)                */
-    uint32_t precision;       /* -p: 0 single, 2 half-memory/fp32-math (VR:1420-1421); 1 unsupported */
+    uint32_t precision;       /* -p: 0 single, 1 double (VR:1422), 2 half-memory/fp32-math (VR:1420-1421) */
     float    sharpen;         /* -s sharpening constant (VR:1616)                                    */
     int32_t  device;          /* -d HIP device ordinal                                               */
     uint32_t flags;           /* FFTUP_FLAG_*                                                        */
@@ -96,8 +96,8 @@ FFTUP_API int fftup_plan_info(const fftup_plan* plan, fftup_info* info);
  * row_stride_bytes (>= 3*W).  Blocking, like the reference. */
 FFTUP_API int fftup_upload_rgb8(fftup_plan* plan, const uint8_t* rgb, size_t row_stride_bytes);
 FFTUP_API int fftup_upload_rgb8_slot(fftup_plan* plan, uint32_t slot, const uint8_t* rgb, size_t row_stride_bytes);
-/* transferDataFromCPU of an already packed planar buffer: float (precision 0) or IEEE half
- * (precision 2) planes, 3 planes of H rows; strides in elements (the reference's inputBuffer uses
+/* transferDataFromCPU of an already packed planar buffer: float (precision 0), double (precision 1) or IEEE
+ * half (precision 2) planes, 3 planes of H rows; strides in elements (the reference's inputBuffer uses
  * row stride W and plane stride (W+2)*H, VR:1644). */
 FFTUP_API int fftup_upload_planar(fftup_plan* plan, uint32_t slot, const void* planes,
                                   size_t row_stride_elems, size_t plane_stride_elems);
@@ -119,7 +119,7 @@ FFTUP_API int fftup_execute_ring_timed(fftup_plan* plan, uint32_t n_frames, uint
 FFTUP_API int fftup_profile_kernels(fftup_plan* plan, uint32_t n_iter, double* ms_per_kernel);
 
 /* transferDataToCPU + unpack loop (VR:1697-1748).  rgb8: u8 = trunc(255*x), saturating unless
- * FFTUP_FLAG_U8_WRAP.  planar: dense [3][uH][uW] float (precision 0) or half (precision 2). */
+ * FFTUP_FLAG_U8_WRAP.  planar: dense [3][uH][uW] float (precision 0), double (1) or half (2). */
 FFTUP_API int fftup_download_rgb8(fftup_plan* plan, uint32_t slot, uint8_t* rgb, size_t row_stride_bytes);
 FFTUP_API int fftup_download_planar(fftup_plan* plan, uint32_t slot, void* planes);
 /* parity-test taps: the C2R output before sharpening (the reference's tempBuffer contents,

@@ -27,6 +27,8 @@
  * Arithmetic: IEEE double everywhere ("ideal" semantics of the reference's fp32 math); storage
  * roundings of `-p 2` (fp16 memory: input, C2R output, and the sharpen shader evaluated in
  * float16_t) are emulated exactly with round-to-nearest-even half rounding after every operation.
+ * `-p 1` (double buffers and shaders) differs from the fp32 semantics only in the load (no float rounding,
+ * VR:1650-1668); its shader literals stay float constants promoted to double (VR:893-920 prints no suffix).
  */
 #define _GNU_SOURCE
 #include <math.h>
@@ -45,7 +47,7 @@ typedef struct { double re, im; } cpx;
 typedef struct {
     uint32_t width, height;   /* input size                                          */
     float    upscale;         /* -u (float, VR:1886)                                 */
-    uint32_t precision;       /* 0 = fp32 semantics, 2 = fp16 memory (VR:1420-1421)  */
+    uint32_t precision;       /* 0 = fp32 semantics, 1 = double (VR:1422), 2 = fp16 memory (VR:1420-1421)  */
     float    sharpen;         /* -s (VR:1875)                                        */
     uint32_t u8_wrap;         /* 0 = saturating u8 store, 1 = x86 wrap of VR:1715    */
 } orc_config;
@@ -95,7 +97,7 @@ ORC_API int orc_check(const orc_config* c)
     if (c->width < 2 || c->height < 2 || (c->width & 1) || (c->height & 1)) return 1;
     if (uW < c->width || uH < c->height || (uW & 1) || (uH & 1)) return 1;
     if (!is_smooth(c->width) || !is_smooth(c->height) || !is_smooth(uW) || !is_smooth(uH)) return 2;
-    if (c->precision != 0 && c->precision != 2) return 3;
+    if (c->precision > 2) return 3;
     return 0;
 }
 
@@ -191,6 +193,7 @@ ORC_API double orc_load_u8(uint32_t precision, uint8_t v)
         float f = (float)h;                        /* half.hpp arithmetic promotes to float */
         return round_half((double)f / 255.0);      /* double quotient, RN to half (half.hpp:373-374) */
     }
+    if (precision == 1) return (double)v / 255.0;  /* VR:1657 (double)png / 255.0, stored as double */
     return (double)(float)((double)(float)v / 255.0);
 }
 

@@ -417,3 +417,53 @@ def test_host_streamed_queue_equals_blocking_calls(W, H, precision, flags, ring,
         if pinned:
             pin_in.close()
             pin_out.close()
+
+
+@pytest.mark.parametrize("W,H,u", [(16, 8, 2.0), (60, 42, 2.0), (24, 16, 3.0), (16, 8, 1.5), (256, 128, 2.0),
+                                   (240, 270, 2.0), (1024, 512, 2.0), (2048, 64, 2.0)])
+@pytest.mark.parametrize("dist", ["U", "N"])
+def test_fp64_parity(W, H, u, dist):
+    """-p 1: double buffers and double arithmetic end to end; the oracle is fp64 too, so the two
+    agree to rounding: 1e-12 before the sharpen, 1e-9 after it (sqrt(min) amplifies near 0, see the fp32 test)."""
+    (pre, out, u8), (opre, oout, ou8) = _run(W, H, u, 1, dist)
+    assert pre.dtype == np.float64
+    assert np.abs(pre - opre).max() <= 1e-12
+    assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1e-9
+    d = u8[:-1].astype(int) - ou8[:-1].astype(int)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() <= 1e-4      # trunc(255*x) flips where 255*x is an integer +- 1 ulp
+
+
+def test_fp64_planar_input_and_limits():
+    import vkresample_amd as v
+    rng = np.random.default_rng(5)
+    planes = rng.random((3, 36, 60))
+    with _up(60, 36, 2.0, 1) as up:
+        up.upload_planar(planes)
+        assert np.array_equal(up.download_input_planar(), planes)
+        up.execute(2)
+        pre, out = up.download_presharpen(), up.download_planar()
+    opre, oout = O.upscale_planes(planes, 2.0, 1)[:2]
+    assert np.abs(pre - opre).max() <= 1e-12 and np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1e-9
+    with pytest.raises(v.FftupError) as e:            # complexSizeCalc = 16 halves the R2C limit (VR:1424)
+        v.Upscaler(4096, 64, 2.0, 1)
+    assert e.value.code == 2
+    # double vs single on the same frame: they differ by fp32 rounding only
+    (pre64, _, _), _ = _run(256, 128, 2.0, 1, "N", seed=3)
+    (pre32, _, _), _ = _run(256, 128, 2.0, 0, "N", seed=3)
+    assert 1e-9 < np.abs(pre64 - pre32).max() < 1e-5
+
+
+def test_fp64_host_streamed_queue():
+    from vkresample_amd import synth
+    W, H = 128, 64
+    frames = [synth.frame(300 + k, W, H) for k in range(5)]
+    with _up(W, H, 2.0, 1, ring=2) as up:
+        outs = np.zeros((5, 2 * H, 2 * W, 3), np.uint8)
+        ins = np.stack(frames)
+        for k in range(5):
+            up.submit_rgb8(ins[k], outs[k])
+        up.drain()
+    for k in range(5):
+        _, _, ou8 = O.upscale_rgb8(frames[k], 2.0, 1)
+        d = outs[k][:-1].astype(int) - ou8[:-1].astype(int)
+        assert np.abs(d).max() <= 1 and (d != 0).mean() <= 1e-4

@@ -70,7 +70,7 @@ def test_error_paths_without_device():
     assert b"unsupported size" in lib.fftup_strerror(2)
     assert lib.fftup_version().startswith(b"fftup")
     for kwargs, code in ((dict(width=2 * 11 * 64, height=64), 2), (dict(width=63, height=64), 1),
-                         (dict(width=64, height=64, precision=1), 3), (dict(width=64, height=64, upscale=0.5), 1),
+                         (dict(width=64, height=64, precision=3), 3), (dict(width=4096, height=64, precision=1), 2), (dict(width=64, height=64, upscale=0.5), 1),
                          (dict(width=8192, height=64), 2)):
         with pytest.raises(v.FftupError) as e:
             v.Upscaler(**kwargs)

@@ -39,7 +39,7 @@ def test_out_dims_and_checks():
     assert O.check(2048, 1024) == 0
     assert O.check(2 * 11 * 64, 64) == 2          # KAT8: not 2,3,5,7-smooth (vkFFT.h:4719-4726)
     assert O.check(63, 64) == 1
-    assert O.check(64, 64, precision=1) == 3
+    assert O.check(64, 64, precision=1) == 0 and O.check(64, 64, precision=3) == 3
 
 
 def test_load_conversion_table():
@@ -49,6 +49,7 @@ def test_load_conversion_table():
     assert np.array_equal(O.load_lut(0), f32)
     f16 = (v.astype(np.float16).astype(np.float32).astype(np.float64) / 255.0).astype(np.float32).astype(np.float16)
     assert np.array_equal(O.load_lut(2), f16.astype(np.float64))
+    assert np.array_equal(O.load_lut(1), v / 255.0)              # -p 1: (double)v / 255.0 (VkResample.cpp:1657)
     # fused device conversion = fp32 division (checked on the GPU side too)
     assert np.array_equal(O.load_lut(0), (v.astype(np.float32) / np.float32(255)).astype(np.float64))
 
@@ -162,6 +163,25 @@ def test_sharpen_constants_via_percent_f():
     a = O.sharpen(R, 2.0, 0, 0.123456789)
     b = O.sharpen(R, 2.0, 0, 0.123457)
     assert np.array_equal(a, b)
+
+
+def test_double_mode_differs_from_single_only_in_the_load():
+    """-p 1: same restatement, un-rounded load; its shader literals are float constants promoted to double
+    (VkResample.cpp:893-920 prints them without a suffix), e.g. s = 0.2 acts as float(0.2) in both modes."""
+    rgb = np.random.default_rng(4).integers(0, 256, (12, 20, 3), dtype=np.uint8)
+    pre1, out1, _ = O.upscale_rgb8(rgb, 2.0, 1)
+    planes = (rgb.astype(np.float64) / 255.0).transpose(2, 0, 1)
+    pre0, out0, _ = O.upscale_planes(planes, 2.0, 0)
+    assert np.array_equal(pre1, pre0) and np.array_equal(out1, out0)
+    pre32, _, _ = O.upscale_rgb8(rgb, 2.0, 0)
+    assert 0 < np.abs(pre32 - pre1).max() < 1e-6
+    R = np.random.default_rng(1).random((3, 8, 8)) * 0.25
+    assert np.array_equal(O.sharpen(R, 2.0, 1, 0.2), O.sharpen(R, 2.0, 0, 0.2))
+    x = 0.05                                   # constant neighbourhood: closed form with the FLOAT constant
+    got = O.sharpen(np.full((3, 4, 4), x), 2.0, 1, 0.2)[0, 1, 1]
+    l = 4.0 * x
+    sc = -float(np.float32(0.2)) * np.sqrt(min(l / (1 - l), (1 - l) / l))
+    assert got == (l + sc * (l + l + l + l)) / (1.0 + sc * 4.0)
 
 
 def test_fp16_mode_values_are_halves():

@@ -56,7 +56,7 @@ class Upscaler:
         self.device_name = info.device_name.decode()
         self.device_bytes = info.device_bytes
         self.tuned = bool(info.tuned)
-        self._dtype = np.float16 if precision == 2 else np.float32
+        self._dtype = {0: np.float32, 1: np.float64, 2: np.float16}[precision]
 
     def close(self):
         if self._h:

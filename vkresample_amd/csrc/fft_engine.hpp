@@ -1,7 +1,7 @@
 // fft_engine.hpp -- LDS-staged Stockham FFT building blocks for gfx950 (wave64).
 //
 // Radix-2/3/4/5/7/8 butterflies and one Stockham autosort stage that works on TK interleaved
-// sequences held in LDS as float2 [n][TK].  Sign convention follows the reference: DIR=+1 is
+// sequences held in LDS as complex [n][TK].  Sign convention follows the reference: DIR=+1 is
 // exp(+2 pi i nk/N) (VkFFT "forward", vkFFT.h:4545/751), DIR=-1 the inverse kernel; the 1/N
 // of the inverse (vkFFT.h:2921-2923) is applied by the caller when it stores the result.
 // Twiddles come from a per-length table tw[k] = exp(+2 pi i k/N) computed on the host in double
@@ -18,106 +18,121 @@ struct StagePlan {           // radix sequence of one 1-D transform (product = N
     uint8_t radix[16];
 };
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+// complex arithmetic on float2 (fp32 plans) or double2 (-p 1 plans); C is deduced at every call site
+template <typename C> using scalar_t = decltype(C::x);
+template <typename C> __device__ __forceinline__ C mk(scalar_t<C> x, scalar_t<C> y)
 {
-    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+    C r;
+    r.x = x;
+    r.y = y;
+    return r;
 }
-__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+__device__ __forceinline__ float ffma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double ffma(double a, double b, double c) { return fma(a, b, c); }
+template <typename C> __device__ __forceinline__ C cadd(C a, C b) { return mk<C>(a.x + b.x, a.y + b.y); }
+template <typename C> __device__ __forceinline__ C csub(C a, C b) { return mk<C>(a.x - b.x, a.y - b.y); }
+template <typename C> __device__ __forceinline__ C cmul(C a, C b)
+{
+    return mk<C>(ffma(a.x, b.x, -a.y * b.y), ffma(a.x, b.y, a.y * b.x));
+}
+template <typename C> __device__ __forceinline__ C cscale(C a, scalar_t<C> s) { return mk<C>(a.x * s, a.y * s); }
 // multiply by DIR*i
-template <int DIR> __device__ __forceinline__ float2 mul_i(float2 a)
+template <int DIR, typename C> __device__ __forceinline__ C mul_i(C a)
 {
-    return DIR > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+    return DIR > 0 ? mk<C>(-a.y, a.x) : mk<C>(a.y, -a.x);
 }
-template <int DIR> __device__ __forceinline__ float2 twid(float2 w)   // table holds exp(+i..)
+template <int DIR, typename C> __device__ __forceinline__ C twid(C w)   // table holds exp(+i..)
 {
-    return DIR > 0 ? w : make_float2(w.x, -w.y);
+    return DIR > 0 ? w : mk<C>(w.x, -w.y);
 }
 
-// LDS index padding: one float2 of padding per 16 (keeps stride-R*TK scatter writes of the
+// LDS index padding: one element of padding per 16 (keeps stride-R*TK scatter writes of the
 // first Stockham stages off a single pair of banks; ds_write_b64 banks = (addr/4) % 32).
 __device__ __forceinline__ int lpad(int i) { return i + (i >> 4); }
 __host__ __device__ constexpr int lpad_size(int n) { return n + (n >> 4) + 1; }
 
 // ---------------------------------------------------------------- butterflies (in place on v[])
-template <int DIR> __device__ __forceinline__ void bfly2(float2* v)
+template <int DIR, typename C> __device__ __forceinline__ void bfly2(C* v)
 {
-    float2 a = v[0], b = v[1];
+    C a = v[0], b = v[1];
     v[0] = cadd(a, b);
     v[1] = csub(a, b);
 }
-template <int DIR> __device__ __forceinline__ void bfly4(float2* v)
+template <int DIR, typename C> __device__ __forceinline__ void bfly4(C* v)
 {
-    float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
-    float2 t2 = cadd(v[1], v[3]), t3 = mul_i<DIR>(csub(v[1], v[3]));
+    C t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+    C t2 = cadd(v[1], v[3]), t3 = mul_i<DIR>(csub(v[1], v[3]));
     v[0] = cadd(t0, t2);
     v[2] = csub(t0, t2);
     v[1] = cadd(t1, t3);
     v[3] = csub(t1, t3);
 }
-template <int DIR> __device__ __forceinline__ void bfly8(float2* v)
+template <int DIR, typename C> __device__ __forceinline__ void bfly8(C* v)
 {
-    const float h = 0.70710678118654752440f;
-    float2 e[4] = {v[0], v[2], v[4], v[6]};
-    float2 o[4] = {v[1], v[3], v[5], v[7]};
+    using S = scalar_t<C>;
+    const S h = S(0.70710678118654752440);
+    C e[4] = {v[0], v[2], v[4], v[6]};
+    C o[4] = {v[1], v[3], v[5], v[7]};
     bfly4<DIR>(e);
     bfly4<DIR>(o);
     // w^q, w = exp(DIR*2 pi i/8)
-    float2 o1 = cscale(cadd(o[1], mul_i<DIR>(o[1])), h);            // (1 + DIR*i)/sqrt2
-    float2 o2 = mul_i<DIR>(o[2]);
-    float2 o3 = cscale(csub(mul_i<DIR>(o[3]), o[3]), h);            // (-1 + DIR*i)/sqrt2
+    C o1 = cscale(cadd(o[1], mul_i<DIR>(o[1])), h);            // (1 + DIR*i)/sqrt2
+    C o2 = mul_i<DIR>(o[2]);
+    C o3 = cscale(csub(mul_i<DIR>(o[3]), o[3]), h);            // (-1 + DIR*i)/sqrt2
     v[0] = cadd(e[0], o[0]); v[4] = csub(e[0], o[0]);
     v[1] = cadd(e[1], o1);   v[5] = csub(e[1], o1);
     v[2] = cadd(e[2], o2);   v[6] = csub(e[2], o2);
     v[3] = cadd(e[3], o3);   v[7] = csub(e[3], o3);
 }
-template <int DIR> __device__ __forceinline__ void bfly3(float2* v)
+template <int DIR, typename C> __device__ __forceinline__ void bfly3(C* v)
 {
-    const float s3 = 0.86602540378443864676f;
-    float2 t1 = cadd(v[1], v[2]);
-    float2 t2 = make_float2(fmaf(-0.5f, t1.x, v[0].x), fmaf(-0.5f, t1.y, v[0].y));
-    float2 t3 = cscale(mul_i<DIR>(csub(v[1], v[2])), s3);
+    using S = scalar_t<C>;
+    const S s3 = S(0.86602540378443864676);
+    C t1 = cadd(v[1], v[2]);
+    C t2 = mk<C>(ffma(S(-0.5), t1.x, v[0].x), ffma(S(-0.5), t1.y, v[0].y));
+    C t3 = cscale(mul_i<DIR>(csub(v[1], v[2])), s3);
     v[0] = cadd(v[0], t1);
     v[1] = cadd(t2, t3);
     v[2] = csub(t2, t3);
 }
-template <int DIR> __device__ __forceinline__ void bfly5(float2* v)
+template <int DIR, typename C> __device__ __forceinline__ void bfly5(C* v)
 {
-    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
-    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
-    float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
-    float2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
-    float2 a = v[0];
-    float2 p1 = make_float2(a.x + c1 * t1.x + c2 * t2.x, a.y + c1 * t1.y + c2 * t2.y);
-    float2 p2 = make_float2(a.x + c2 * t1.x + c1 * t2.x, a.y + c2 * t1.y + c1 * t2.y);
-    float2 q1 = mul_i<DIR>(make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
-    float2 q2 = mul_i<DIR>(make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+    using S = scalar_t<C>;
+    const S c1 = S(0.30901699437494742410), c2 = S(-0.80901699437494742410);
+    const S s1 = S(0.95105651629515357212), s2 = S(0.58778525229247312917);
+    C t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
+    C t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    C a = v[0];
+    C p1 = mk<C>(a.x + c1 * t1.x + c2 * t2.x, a.y + c1 * t1.y + c2 * t2.y);
+    C p2 = mk<C>(a.x + c2 * t1.x + c1 * t2.x, a.y + c2 * t1.y + c1 * t2.y);
+    C q1 = mul_i<DIR>(mk<C>(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
+    C q2 = mul_i<DIR>(mk<C>(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
     v[0] = cadd(a, cadd(t1, t2));
     v[1] = cadd(p1, q1);
     v[4] = csub(p1, q1);
     v[2] = cadd(p2, q2);
     v[3] = csub(p2, q2);
 }
-template <int DIR> __device__ __forceinline__ void bfly7(float2* v)
+template <int DIR, typename C> __device__ __forceinline__ void bfly7(C* v)
 {
-    const float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
-    const float s1 = 0.78183148246802980871f, s2 = 0.97492791218182360702f, s3 = 0.43388373911755812048f;
-    float2 t1 = cadd(v[1], v[6]), t2 = cadd(v[2], v[5]), t3 = cadd(v[3], v[4]);
-    float2 u1 = csub(v[1], v[6]), u2 = csub(v[2], v[5]), u3 = csub(v[3], v[4]);
-    float2 a = v[0];
-    float2 p1 = make_float2(a.x + c1 * t1.x + c2 * t2.x + c3 * t3.x, a.y + c1 * t1.y + c2 * t2.y + c3 * t3.y);
-    float2 p2 = make_float2(a.x + c2 * t1.x + c3 * t2.x + c1 * t3.x, a.y + c2 * t1.y + c3 * t2.y + c1 * t3.y);
-    float2 p3 = make_float2(a.x + c3 * t1.x + c1 * t2.x + c2 * t3.x, a.y + c3 * t1.y + c1 * t2.y + c2 * t3.y);
-    float2 q1 = mul_i<DIR>(make_float2(s1 * u1.x + s2 * u2.x + s3 * u3.x, s1 * u1.y + s2 * u2.y + s3 * u3.y));
-    float2 q2 = mul_i<DIR>(make_float2(s2 * u1.x - s3 * u2.x - s1 * u3.x, s2 * u1.y - s3 * u2.y - s1 * u3.y));
-    float2 q3 = mul_i<DIR>(make_float2(s3 * u1.x - s1 * u2.x + s2 * u3.x, s3 * u1.y - s1 * u2.y + s2 * u3.y));
+    using S = scalar_t<C>;
+    const S c1 = S(0.62348980185873353053), c2 = S(-0.22252093395631440429), c3 = S(-0.90096886790241912624);
+    const S s1 = S(0.78183148246802980871), s2 = S(0.97492791218182360702), s3 = S(0.43388373911755812048);
+    C t1 = cadd(v[1], v[6]), t2 = cadd(v[2], v[5]), t3 = cadd(v[3], v[4]);
+    C u1 = csub(v[1], v[6]), u2 = csub(v[2], v[5]), u3 = csub(v[3], v[4]);
+    C a = v[0];
+    C p1 = mk<C>(a.x + c1 * t1.x + c2 * t2.x + c3 * t3.x, a.y + c1 * t1.y + c2 * t2.y + c3 * t3.y);
+    C p2 = mk<C>(a.x + c2 * t1.x + c3 * t2.x + c1 * t3.x, a.y + c2 * t1.y + c3 * t2.y + c1 * t3.y);
+    C p3 = mk<C>(a.x + c3 * t1.x + c1 * t2.x + c2 * t3.x, a.y + c3 * t1.y + c1 * t2.y + c2 * t3.y);
+    C q1 = mul_i<DIR>(mk<C>(s1 * u1.x + s2 * u2.x + s3 * u3.x, s1 * u1.y + s2 * u2.y + s3 * u3.y));
+    C q2 = mul_i<DIR>(mk<C>(s2 * u1.x - s3 * u2.x - s1 * u3.x, s2 * u1.y - s3 * u2.y - s1 * u3.y));
+    C q3 = mul_i<DIR>(mk<C>(s3 * u1.x - s1 * u2.x + s2 * u3.x, s3 * u1.y - s1 * u2.y + s2 * u3.y));
     v[0] = cadd(a, cadd(t1, cadd(t2, t3)));
     v[1] = cadd(p1, q1); v[6] = csub(p1, q1);
     v[2] = cadd(p2, q2); v[5] = csub(p2, q2);
     v[3] = cadd(p3, q3); v[4] = csub(p3, q3);
 }
-template <int R, int DIR> __device__ __forceinline__ void bfly(float2* v)
+template <int R, int DIR, typename C> __device__ __forceinline__ void bfly(C* v)
 {
     if constexpr (R == 2) bfly2<DIR>(v);
     else if constexpr (R == 3) bfly3<DIR>(v);
@@ -130,42 +145,42 @@ template <int R, int DIR> __device__ __forceinline__ void bfly(float2* v)
 // twiddle the R inputs of one butterfly: v[m] *= exp(DIR * 2 pi i * m * tidx / N), tidx = k*tstep.
 // One table fetch for m=1; powers 2 and 4 are fetched too (cheap, L1/L2 resident), the rest are
 // products -- two roundings instead of one, ~1e-7 relative.
-template <int R, int DIR>
-__device__ __forceinline__ void apply_twiddles(float2* v, const float2* __restrict__ tw, int tidx)
+template <int R, int DIR, typename C>
+__device__ __forceinline__ void apply_twiddles(C* v, const C* __restrict__ tw, int tidx)
 {
     if constexpr (R == 2) {
         v[1] = cmul(v[1], twid<DIR>(tw[tidx]));
     } else if constexpr (R == 3) {
-        float2 w1 = twid<DIR>(tw[tidx]), w2 = twid<DIR>(tw[2 * tidx]);
+        C w1 = twid<DIR>(tw[tidx]), w2 = twid<DIR>(tw[2 * tidx]);
         v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2);
     } else if constexpr (R == 4) {
-        float2 w1 = twid<DIR>(tw[tidx]), w2 = twid<DIR>(tw[2 * tidx]);
-        float2 w3 = cmul(w1, w2);
+        C w1 = twid<DIR>(tw[tidx]), w2 = twid<DIR>(tw[2 * tidx]);
+        C w3 = cmul(w1, w2);
         v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3);
     } else if constexpr (R == 5) {
-        float2 w1 = twid<DIR>(tw[tidx]), w2 = twid<DIR>(tw[2 * tidx]), w4 = twid<DIR>(tw[4 * tidx]);
-        float2 w3 = cmul(w1, w2);
+        C w1 = twid<DIR>(tw[tidx]), w2 = twid<DIR>(tw[2 * tidx]), w4 = twid<DIR>(tw[4 * tidx]);
+        C w3 = cmul(w1, w2);
         v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
     } else if constexpr (R == 7) {
-        float2 w1 = twid<DIR>(tw[tidx]), w2 = twid<DIR>(tw[2 * tidx]), w4 = twid<DIR>(tw[4 * tidx]);
-        float2 w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4);
+        C w1 = twid<DIR>(tw[tidx]), w2 = twid<DIR>(tw[2 * tidx]), w4 = twid<DIR>(tw[4 * tidx]);
+        C w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4);
         v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3);
         v[4] = cmul(v[4], w4); v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6);
     } else if constexpr (R == 8) {
-        float2 w1 = twid<DIR>(tw[tidx]), w2 = twid<DIR>(tw[2 * tidx]), w4 = twid<DIR>(tw[4 * tidx]);
-        float2 w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
+        C w1 = twid<DIR>(tw[tidx]), w2 = twid<DIR>(tw[2 * tidx]), w4 = twid<DIR>(tw[4 * tidx]);
+        C w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
         v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
         v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7);
     }
 }
 
 // ---------------------------------------------------------------- one generic Stockham stage
-// in/out: LDS, float2 [n][TK] with lpad() applied to the flattened element index.
+// in/out: LDS, C [n][TK] with lpad() applied to the flattened element index.
 // Butterfly j (0 <= j < N/R) of sequence col reads in[j + m*N/R], writes
 // out[(j - k)*R + k + m*Ns], k = j % Ns (Stockham autosort, decimation in time).
-template <int R, int DIR, int TK>
-__device__ __forceinline__ void stage_lds(const float2* __restrict__ in, float2* __restrict__ out,
-                                          int N, int Ns, const float2* __restrict__ tw, int tid, int T)
+template <int R, int DIR, int TK, typename C>
+__device__ __forceinline__ void stage_lds(const C* __restrict__ in, C* __restrict__ out,
+                                          int N, int Ns, const C* __restrict__ tw, int tid, int T)
 {
     const int nb = N / R;
     const int tstep = nb / Ns;                 // N / (Ns*R)
@@ -174,7 +189,7 @@ __device__ __forceinline__ void stage_lds(const float2* __restrict__ in, float2*
         const int col = g % TK;                // TK is a compile-time power of two
         const int j = g / TK;
         const int k = ns_pow2 ? (j & (Ns - 1)) : (j % Ns);
-        float2 v[R];
+        C v[R];
 #pragma unroll
         for (int m = 0; m < R; m++) v[m] = in[lpad((j + m * nb) * TK + col)];
         if (Ns > 1) apply_twiddles<R, DIR>(v, tw, k * tstep);
@@ -187,9 +202,9 @@ __device__ __forceinline__ void stage_lds(const float2* __restrict__ in, float2*
 
 // Full transform of TK interleaved sequences.  Data in `a` (valid after a barrier executed by the
 // caller); ping-pongs between a and b; returns the buffer holding the result (already synced).
-template <int DIR, int TK>
-__device__ __forceinline__ float2* fft_lds(float2* a, float2* b, const StagePlan& P,
-                                           const float2* __restrict__ tw, int tid, int T)
+template <int DIR, int TK, typename C>
+__device__ __forceinline__ C* fft_lds(C* a, C* b, const StagePlan& P,
+                                      const C* __restrict__ tw, int tid, int T)
 {
     const int N = P.n;
     int Ns = 1;
@@ -205,7 +220,7 @@ __device__ __forceinline__ float2* fft_lds(float2* a, float2* b, const StagePlan
         }
         Ns *= R;
         __syncthreads();
-        float2* t = a; a = b; b = t;
+        C* t = a; a = b; b = t;
     }
     return a;
 }

@@ -39,7 +39,9 @@ struct fftup_plan {
     fftup_config cfg{};
     uint32_t W = 0, H = 0, uW = 0, uH = 0;
     uint32_t ring = 1;
-    bool half = false;
+    bool half = false;                // -p 2: binary16 storage
+    bool dbl = false;                 // -p 1: double storage and arithmetic (size-generic kernels, double2 spectra)
+    size_t esz = 4, csz = 8;          // bytes per real / complex element in HBM
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -126,6 +128,17 @@ static int dev_alloc(fftup_plan* P, void** ptr, size_t bytes)
 
 static int make_twiddles(fftup_plan* P, float2** dptr, uint32_t n)
 {
+    if (P->dbl) {                     // double2 table behind the same pointer member
+        std::vector<double2> h(n);
+        for (uint32_t k = 0; k < n; k++) {
+            double a = 2.0 * M_PI * (double)k / (double)n;
+            h[k] = make_double2(std::cos(a), std::sin(a));
+        }
+        int rc = dev_alloc(P, (void**)dptr, sizeof(double2) * n);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(*dptr, h.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
+        return FFTUP_OK;
+    }
     std::vector<float2> h(n);
     for (uint32_t k = 0; k < n; k++) {
         // exact octant reduction is unnecessary in double; rounded once to fp32
@@ -147,6 +160,9 @@ static float const_via_percent_f(double v, bool half)
     if (half) f = __half2float(__float2half_rn(f));
     return f;
 }
+
+// the row kernel reads uint8 RGB directly (fp32 / fp16 plans only)
+static bool fuse_u8(const fftup_plan* P) { return (P->cfg.flags & FFTUP_FLAG_FUSE_U8_LOAD) && !P->dbl; }
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -193,8 +209,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
     if (!out || !cfg) return fail(FFTUP_E_INVALID_ARG, "null argument");
     *out = nullptr;
     if (cfg->channels != 3) return fail(FFTUP_E_INVALID_ARG, "channels must be 3 (VkResample.cpp:1368)");
-    if (cfg->precision == 1) return fail(FFTUP_E_UNSUPPORTED_PRECISION, "double precision (-p 1) is not implemented");
-    if (cfg->precision != 0 && cfg->precision != 2) return fail(FFTUP_E_UNSUPPORTED_PRECISION, "precision must be 0 or 2");
+    if (cfg->precision > 2) return fail(FFTUP_E_UNSUPPORTED_PRECISION, "precision must be 0 (single), 1 (double) or 2 (half)");
     const uint32_t W = cfg->width, H = cfg->height;
     const uint32_t uW = (uint32_t)(cfg->upscale * (float)W);     // VkResample.cpp:1417-1418
     const uint32_t uH = (uint32_t)(cfg->upscale * (float)H);
@@ -204,7 +219,9 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         return fail(FFTUP_E_UNSUPPORTED_SIZE, "sizes must factor into 2,3,5,7 (vkFFT.h:4719-4726)");
     // R2C rule of the reference: uW <= maxComputeSharedMemorySize/8 with 64 KB (VkResample.cpp:1424);
     // beyond it the reference switches to its complex path, which is out of scope here.
-    if (uW > 8192) return fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width > 8192: non-R2C path not implemented (VkResample.cpp:1424)");
+    // (complexSizeCalc = 16 for -p 1, VkResample.cpp:1334-1336, halves the limit)
+    if (uW > (cfg->precision == 1 ? 4096u : 8192u))
+        return fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width beyond the R2C limit (8192, 4096 for -p 1): non-R2C path not implemented (VkResample.cpp:1424)");
 
     int ndev = fftup_device_count();
     if (ndev <= 0) return fail(FFTUP_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
@@ -215,6 +232,9 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
     P->W = W; P->H = H; P->uW = uW; P->uH = uH;
     P->ring = cfg->ring ? cfg->ring : 1;
     P->half = cfg->precision == 2;
+    P->dbl = cfg->precision == 1;
+    P->esz = P->dbl ? 8 : P->esz;
+    P->csz = P->dbl ? 16 : 8;
     P->device = cfg->device;
     int rc = FFTUP_OK;
 #define PLAN_TRY(expr)                                                                             \
@@ -252,7 +272,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
 
         const size_t lds_max = P->prop.sharedMemPerBlock ? P->prop.sharedMemPerBlock : 65536;
         // size-specialised kernels: u == 2 and power-of-two sizes with instantiated plans
-        P->tuned = !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && uW == 2 * W && uH == 2 * H &&
+        P->tuned = !P->dbl && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && uW == 2 * W && uH == 2 * H &&
                    (W == 512 || W == 1024 || W == 2048) && (H == 256 || H == 512 || H == 1024);
         P->TK = 0;
         if (P->tuned) {
@@ -261,12 +281,12 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         } else {
             // column tile width: widest of 8,4,2,1 whose ping-pong buffers fit in LDS
             for (int tk : {8, 4, 2, 1}) {
-                size_t need = 2 * sizeof(float2) * (size_t)lpad_size((int)uH * tk);
+                size_t need = 2 * P->csz * (size_t)lpad_size((int)uH * tk);
                 if (need <= lds_max) { P->TK = tk; P->ldsCol = need; break; }
             }
         }
         if (!P->TK) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled height too large for LDS"); goto bad; }
-        P->mixed1080 = !P->tuned && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && W == 1920 && H == 1080 && uW == 3840 &&
+        P->mixed1080 = !P->dbl && !P->tuned && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && W == 1920 && H == 1080 && uW == 3840 &&
                        uH == 2160 && P->TK == 4;
         P->fused = P->tuned && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
         {
@@ -277,8 +297,8 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         if (const char* e = getenv("FFTUP_PAIRS_PER_STRIP")) P->pairs_per_strip = std::max(1, atoi(e));
         P->ldsFused2 = uW == 1024 ? Fused2Lds<1024>::TOTAL : uW == 2048 ? Fused2Lds<2048>::TOTAL : Fused2Lds<4096>::TOTAL;
         P->NT = ((int)(W / 2 + 1) + P->TK - 1) / P->TK;
-        P->ldsRowF = 2 * sizeof(float2) * (size_t)lpad_size((int)W);
-        P->ldsRowI = 2 * sizeof(float2) * (size_t)lpad_size((int)uW);
+        P->ldsRowF = 2 * P->csz * (size_t)lpad_size((int)W);
+        P->ldsRowI = 2 * P->csz * (size_t)lpad_size((int)uW);
         if (P->ldsRowI > lds_max) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width too large for LDS"); goto bad; }
         P->thrW = std::min(1024, std::max(64, round_up((int)W / 8, 64)));
         P->thrUW = std::min(1024, std::max(64, round_up((int)uW / 8, 64)));
@@ -292,7 +312,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         PLAN_RC(make_twiddles(P, &P->twUW, uW));
         PLAN_RC(make_twiddles(P, &P->twUH, uH));
 
-        const size_t esz = P->half ? 2 : 4;
+        const size_t esz = P->esz;
         P->in_plane_stride = (size_t)(W + 2) * H;                    // VkResample.cpp:1644
         P->in_planar.assign(P->ring, nullptr);
         P->in_u8.assign(P->ring, nullptr);
@@ -303,8 +323,8 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             PLAN_RC(dev_alloc(P, (void**)&P->in_u8[s], (size_t)3 * W * H));
             PLAN_RC(dev_alloc(P, &P->out[s], (size_t)3 * uW * uH * esz));
         }
-        PLAN_RC(dev_alloc(P, (void**)&P->S1, sizeof(float2) * 3 * (size_t)P->NT * H * P->TK));
-        PLAN_RC(dev_alloc(P, (void**)&P->S2, sizeof(float2) * 3 * (size_t)P->NT * uH * P->TK));
+        PLAN_RC(dev_alloc(P, (void**)&P->S1, P->csz * 3 * (size_t)P->NT * H * P->TK));
+        PLAN_RC(dev_alloc(P, (void**)&P->S2, P->csz * 3 * (size_t)P->NT * uH * P->TK));
         PLAN_RC(dev_alloc(P, &P->R, (size_t)3 * uW * uH * esz));
         PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH));
         {
@@ -316,8 +336,8 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             for (int l = 1; l < P->nlanes; l++) {
                 PLAN_TRY(hipStreamCreateWithFlags(&P->lanes[l].stream, hipStreamNonBlocking));
                 PLAN_TRY(hipEventCreateWithFlags(&P->lanes[l].done, hipEventDisableTiming));
-                PLAN_RC(dev_alloc(P, (void**)&P->lanes[l].S1, sizeof(float2) * 3 * (size_t)P->NT * H * P->TK));
-                PLAN_RC(dev_alloc(P, (void**)&P->lanes[l].S2, sizeof(float2) * 3 * (size_t)P->NT * uH * P->TK));
+                PLAN_RC(dev_alloc(P, (void**)&P->lanes[l].S1, P->csz * 3 * (size_t)P->NT * H * P->TK));
+                PLAN_RC(dev_alloc(P, (void**)&P->lanes[l].S2, P->csz * 3 * (size_t)P->NT * uH * P->TK));
                 PLAN_RC(dev_alloc(P, &P->lanes[l].R, (size_t)3 * uW * uH * esz));
             }
         }
@@ -334,6 +354,14 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         SET_LDS(k_col<1>, P->ldsCol);
         SET_LDS(k_row_c2r<false>, P->ldsRowI);
         SET_LDS(k_row_c2r<true>, P->ldsRowI);
+        if (P->dbl) {
+            SET_LDS((k_row_r2c<IN_F64, double2>), P->ldsRowF);
+            SET_LDS((k_col<8, double2>), P->ldsCol);
+            SET_LDS((k_col<4, double2>), P->ldsCol);
+            SET_LDS((k_col<2, double2>), P->ldsCol);
+            SET_LDS((k_col<1, double2>), P->ldsCol);
+            SET_LDS((k_row_c2r<false, double2>), P->ldsRowI);
+        }
         if (P->mixed1080) {
             SET_LDS((k_row_r2c_ct<Plan1920, IN_F32>), P->ldsRowF);
             SET_LDS((k_row_r2c_ct<Plan1920, IN_F16>), P->ldsRowF);
@@ -376,12 +404,12 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
     info->tuned = (P->tuned || P->mixed1080) ? 1 : 0;
     // B_alg = in + 2*S1 + 2*S2 + 2*R + out
     const double C = 3.0, W = P->W, H = P->H, uW = P->uW, uH = P->uH;
-    const bool fused_u8 = (P->cfg.flags & FFTUP_FLAG_FUSE_U8_LOAD) != 0;
-    const double b_in = fused_u8 ? 1.0 : (P->half ? 2.0 : 4.0);
-    const double b_r = P->half ? 2.0 : 4.0, b_out = b_r;
+    const bool fused_u8 = fuse_u8(P);
+    const double b_in = fused_u8 ? 1.0 : (double)P->esz;
+    const double b_r = (double)P->esz, b_out = b_r, b_c = (double)P->csz;
     const double in = C * W * H * b_in;
-    const double S1 = C * (W / 2 + 1) * H * 8.0;
-    const double S2 = C * (W / 2 + 1) * uH * 8.0;
+    const double S1 = C * (W / 2 + 1) * H * b_c;
+    const double S2 = C * (W / 2 + 1) * uH * b_c;
     const double R = C * uW * uH * b_r;
     const double o = C * uW * uH * b_out;
     info->alg_bytes_per_frame = in + 2 * S1 + 2 * S2 + 2 * R + o;
@@ -401,6 +429,30 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
 }
 
 // ------------------------------------------------------------------------------------------------
+// the two host loops of the reference as kernels (VR:1636-1685, VR:1708-1748)
+static void launch_unpack(fftup_plan* P, uint32_t slot, hipStream_t st)
+{
+    dim3 grid((P->W + 255) / 256, P->H);
+    if (P->dbl)
+        hipLaunchKernelGGL(k_unpack_u8_f64, grid, dim3(256), 0, st, P->in_u8[slot], (long)3 * P->W, (double*)P->in_planar[slot],
+                           (int)P->W, (int)P->H, (long)P->in_plane_stride);
+    else if (P->half)
+        hipLaunchKernelGGL(k_unpack_u8<true>, grid, dim3(256), 0, st, P->in_u8[slot], (long)3 * P->W, P->in_planar[slot],
+                           (int)P->W, (int)P->H, (long)P->in_plane_stride);
+    else
+        hipLaunchKernelGGL(k_unpack_u8<false>, grid, dim3(256), 0, st, P->in_u8[slot], (long)3 * P->W, P->in_planar[slot],
+                           (int)P->W, (int)P->H, (long)P->in_plane_stride);
+}
+
+static void launch_pack(fftup_plan* P, uint32_t slot, uint8_t* dst, hipStream_t st)
+{
+    dim3 grid((P->uW + 255) / 256, P->uH);
+    const int wrap = (P->cfg.flags & FFTUP_FLAG_U8_WRAP) ? 1 : 0;
+    if (P->dbl) hipLaunchKernelGGL(k_pack_u8_f64, grid, dim3(256), 0, st, (const double*)P->out[slot], dst, (int)P->uW, (int)P->uH, wrap);
+    else if (P->half) hipLaunchKernelGGL(k_pack_u8<true>, grid, dim3(256), 0, st, P->out[slot], dst, (int)P->uW, (int)P->uH, wrap);
+    else hipLaunchKernelGGL(k_pack_u8<false>, grid, dim3(256), 0, st, P->out[slot], dst, (int)P->uW, (int)P->uH, wrap);
+}
+
 static int check_slot(fftup_plan* P, uint32_t slot)
 {
     if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
@@ -416,16 +468,10 @@ int fftup_upload_rgb8_slot(fftup_plan* P, uint32_t slot, const uint8_t* rgb, siz
     HIP_TRY(hipSetDevice(P->device));
     HIP_TRY(hipMemcpy2DAsync(P->in_u8[slot], (size_t)3 * P->W, rgb, row_stride_bytes, (size_t)3 * P->W, P->H,
                              hipMemcpyHostToDevice, P->stream));
-    if (P->cfg.flags & FFTUP_FLAG_FUSE_U8_LOAD) {
+    if (fuse_u8(P)) {
         P->in_kind[slot] = 2;
     } else {
-        dim3 grid((P->W + 255) / 256, P->H);
-        if (P->half)
-            hipLaunchKernelGGL(k_unpack_u8<true>, grid, dim3(256), 0, P->stream, P->in_u8[slot], (long)3 * P->W,
-                               P->in_planar[slot], (int)P->W, (int)P->H, (long)P->in_plane_stride);
-        else
-            hipLaunchKernelGGL(k_unpack_u8<false>, grid, dim3(256), 0, P->stream, P->in_u8[slot], (long)3 * P->W,
-                               P->in_planar[slot], (int)P->W, (int)P->H, (long)P->in_plane_stride);
+        launch_unpack(P, slot, P->stream);
         HIP_TRY(hipGetLastError());
         P->in_kind[slot] = 1;
     }
@@ -445,7 +491,7 @@ int fftup_upload_planar(fftup_plan* P, uint32_t slot, const void* planes, size_t
     if (!planes || row_stride < P->W || plane_stride < row_stride * (P->H - 1) + P->W)
         return fail(FFTUP_E_INVALID_ARG, "bad planes pointer/strides");
     HIP_TRY(hipSetDevice(P->device));
-    const size_t esz = P->half ? 2 : 4;
+    const size_t esz = P->esz;
     for (int c = 0; c < 3; c++)
         HIP_TRY(hipMemcpy2DAsync((char*)P->in_planar[slot] + c * P->in_plane_stride * esz, P->W * esz,
                                  (const char*)planes + c * plane_stride * esz, row_stride * esz, P->W * esz, P->H,
@@ -490,7 +536,7 @@ template <int UW> static void launch_fused_t(fftup_plan* P, const FusedParams& p
     else hipLaunchKernelGGL((k_c2r_sharpen_t<UW, false, TUNED_TK>), grid, block, P->ldsFused2, P->lanes[P->cur].stream, p);
 }
 
-static bool fast_sharpen_ok(const fftup_plan* P) { return P->uW % 256 == 0 && P->uH % 16 == 0; }
+static bool fast_sharpen_ok(const fftup_plan* P) { return !P->dbl && P->uW % 256 == 0 && P->uH % 16 == 0; }
 
 static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
 {
@@ -548,10 +594,53 @@ static void launch_sharpen_fast(fftup_plan* P, uint32_t out_slot)
     else hipLaunchKernelGGL((k_sharpen_t<false, 4>), grid, block, 0, P->lanes[P->cur].stream, p);
 }
 
+// -p 1: the size-generic kernels instantiated on double2 + the double sharpen
+static int launch_frame_f64(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
+{
+    hipStream_t st = P->lanes[P->cur].stream;
+    if (which < 0 || which == 0) {
+        RowR2CParamsT<double2> p{};
+        p.S1 = (double2*)P->lanes[P->cur].S1; p.tw = (const double2*)P->twW; p.plan = P->planW; p.W = (int)P->W; p.H = (int)P->H;
+        p.TK = P->TK; p.NT = P->NT;
+        p.in = P->in_planar[in_slot]; p.in_row_stride = P->W; p.in_plane_stride = (long)P->in_plane_stride;
+        hipLaunchKernelGGL((k_row_r2c<IN_F64, double2>), dim3(P->H / 2, 3), dim3(P->thrW), P->ldsRowF, st, p);
+    }
+    if (which < 0 || which == 1) {
+        ColParamsT<double2> p{};
+        p.S1 = (const double2*)P->lanes[P->cur].S1; p.S2 = (double2*)P->lanes[P->cur].S2;
+        p.twH = (const double2*)P->twH; p.twUH = (const double2*)P->twUH; p.planH = P->planH; p.planUH = P->planUH;
+        p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.zly = P->zly; p.zry = P->zry;
+        p.inv_norm = 1.0 / (double)P->uH;
+        dim3 grid(P->NT, 3), block(P->thrCol);
+        switch (P->TK) {
+        case 8: hipLaunchKernelGGL((k_col<8, double2>), grid, block, P->ldsCol, st, p); break;
+        case 4: hipLaunchKernelGGL((k_col<4, double2>), grid, block, P->ldsCol, st, p); break;
+        case 2: hipLaunchKernelGGL((k_col<2, double2>), grid, block, P->ldsCol, st, p); break;
+        default: hipLaunchKernelGGL((k_col<1, double2>), grid, block, P->ldsCol, st, p); break;
+        }
+    }
+    if (which < 0 || which == 2) {
+        RowC2RParamsT<double2> p{};
+        p.S2 = (const double2*)P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = (const double2*)P->twUW; p.plan = P->planUW;
+        p.W = (int)P->W; p.uW = (int)P->uW; p.uH = (int)P->uH; p.TK = P->TK; p.NT = P->NT; p.zlx = P->zlx; p.zrx = P->zrx;
+        p.inv_norm = 1.0 / (double)P->uW;
+        hipLaunchKernelGGL((k_row_c2r<false, double2>), dim3(P->uH / 2, 3), dim3(P->thrUW), P->ldsRowI, st, p);
+    }
+    if (which < 0 || which == 3) {
+        SharpenParams p{};
+        p.R = P->lanes[P->cur].R; p.out = P->out[out_slot]; p.uW = (int)P->uW; p.uH = (int)P->uH; p.upsq = P->upsq; p.coef = P->coef;
+        hipLaunchKernelGGL(k_sharpen_f64, dim3((P->uW + 255) / 256, P->uH, 3), dim3(256), 0, st, p);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FFTUP_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return FFTUP_OK;
+}
+
 static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
 {
     const int kind = P->in_kind[in_slot];
     if (kind == 0) return fail(FFTUP_E_NO_INPUT, "no input uploaded for this slot");
+    if (P->dbl) return launch_frame_f64(P, in_slot, out_slot, which);
     if (P->tuned) {
         launch_frame_tuned(P, in_slot, out_slot, which);
         if ((which < 0 || which == 3) && !P->fused) launch_sharpen_fast(P, out_slot);
@@ -777,7 +866,7 @@ int fftup_download_planar(fftup_plan* P, uint32_t slot, void* planes)
     if (!planes) return fail(FFTUP_E_INVALID_ARG, "null destination");
     if (!P->executed) return fail(FFTUP_E_NO_INPUT, "nothing executed yet");
     HIP_TRY(hipSetDevice(P->device));
-    HIP_TRY(hipMemcpyAsync(planes, P->out[slot], (size_t)3 * P->uW * P->uH * (P->half ? 2 : 4), hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipMemcpyAsync(planes, P->out[slot], (size_t)3 * P->uW * P->uH * P->esz, hipMemcpyDeviceToHost, P->stream));
     HIP_TRY(hipStreamSynchronize(P->stream));
     return FFTUP_OK;
 }
@@ -796,7 +885,7 @@ int fftup_download_presharpen(fftup_plan* P, void* planes)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(P->lanes[P->last_lane].stream));
     }
-    HIP_TRY(hipMemcpyAsync(planes, P->lanes[P->last_lane].R, (size_t)3 * P->uW * P->uH * (P->half ? 2 : 4), hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipMemcpyAsync(planes, P->lanes[P->last_lane].R, (size_t)3 * P->uW * P->uH * P->esz, hipMemcpyDeviceToHost, P->stream));
     HIP_TRY(hipStreamSynchronize(P->stream));
     return FFTUP_OK;
 }
@@ -808,7 +897,7 @@ int fftup_download_input_planar(fftup_plan* P, uint32_t slot, void* planes)
     if (!planes) return fail(FFTUP_E_INVALID_ARG, "null destination");
     if (P->in_kind[slot] != 1) return fail(FFTUP_E_NO_INPUT, "slot holds no planar input");
     HIP_TRY(hipSetDevice(P->device));
-    const size_t esz = P->half ? 2 : 4;
+    const size_t esz = P->esz;
     for (int c = 0; c < 3; c++)
         HIP_TRY(hipMemcpyAsync((char*)planes + (size_t)c * P->W * P->H * esz, (char*)P->in_planar[slot] + c * P->in_plane_stride * esz,
                                (size_t)P->W * P->H * esz, hipMemcpyDeviceToHost, P->stream));
@@ -823,10 +912,7 @@ int fftup_download_rgb8(fftup_plan* P, uint32_t slot, uint8_t* rgb, size_t row_s
     if (!rgb || row_stride_bytes < (size_t)3 * P->uW) return fail(FFTUP_E_INVALID_ARG, "bad rgb pointer/stride");
     if (!P->executed) return fail(FFTUP_E_NO_INPUT, "nothing executed yet");
     HIP_TRY(hipSetDevice(P->device));
-    dim3 grid((P->uW + 255) / 256, P->uH);
-    const int wrap = (P->cfg.flags & FFTUP_FLAG_U8_WRAP) ? 1 : 0;
-    if (P->half) hipLaunchKernelGGL(k_pack_u8<true>, grid, dim3(256), 0, P->stream, P->out[slot], P->out_u8, (int)P->uW, (int)P->uH, wrap);
-    else hipLaunchKernelGGL(k_pack_u8<false>, grid, dim3(256), 0, P->stream, P->out[slot], P->out_u8, (int)P->uW, (int)P->uH, wrap);
+    launch_pack(P, slot, P->out_u8, P->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy2DAsync(rgb, row_stride_bytes, P->out_u8, (size_t)3 * P->uW, (size_t)3 * P->uW, P->uH, hipMemcpyDeviceToHost, P->stream));
     HIP_TRY(hipStreamSynchronize(P->stream));
@@ -888,16 +974,10 @@ int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, ui
     const size_t in_row = (size_t)3 * P->W, out_row = (size_t)3 * P->uW;
     if (in_stride == in_row) HIP_TRY(hipMemcpyAsync(P->in_u8[s], rgb_in, in_row * P->H, hipMemcpyHostToDevice, cs));
     else HIP_TRY(hipMemcpy2DAsync(P->in_u8[s], in_row, rgb_in, in_stride, in_row, P->H, hipMemcpyHostToDevice, cs));
-    if (P->cfg.flags & FFTUP_FLAG_FUSE_U8_LOAD) {
+    if (fuse_u8(P)) {
         P->in_kind[s] = 2;
     } else {
-        dim3 grid((P->W + 255) / 256, P->H);
-        if (P->half)
-            hipLaunchKernelGGL(k_unpack_u8<true>, grid, dim3(256), 0, cs, P->in_u8[s], (long)3 * P->W, P->in_planar[s],
-                               (int)P->W, (int)P->H, (long)P->in_plane_stride);
-        else
-            hipLaunchKernelGGL(k_unpack_u8<false>, grid, dim3(256), 0, cs, P->in_u8[s], (long)3 * P->W, P->in_planar[s],
-                               (int)P->W, (int)P->H, (long)P->in_plane_stride);
+        launch_unpack(P, s, cs);
         P->in_kind[s] = 1;
     }
     P->cur = lane;
@@ -905,13 +985,8 @@ int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, ui
     P->last_lane = lane;
     P->cur = 0;
     if (rc) return rc;
-    {
-        dim3 grid((P->uW + 255) / 256, P->uH);
-        const int wrap = (P->cfg.flags & FFTUP_FLAG_U8_WRAP) ? 1 : 0;
-        if (P->half) hipLaunchKernelGGL(k_pack_u8<true>, grid, dim3(256), 0, cs, P->out[s], Q.out_u8, (int)P->uW, (int)P->uH, wrap);
-        else hipLaunchKernelGGL(k_pack_u8<false>, grid, dim3(256), 0, cs, P->out[s], Q.out_u8, (int)P->uW, (int)P->uH, wrap);
-        HIP_TRY(hipGetLastError());
-    }
+    launch_pack(P, s, Q.out_u8, cs);
+    HIP_TRY(hipGetLastError());
     if (out_stride == out_row) HIP_TRY(hipMemcpyAsync(rgb_out, Q.out_u8, out_row * P->uH, hipMemcpyDeviceToHost, cs));
     else HIP_TRY(hipMemcpy2DAsync(rgb_out, out_stride, Q.out_u8, out_row, out_row, P->uH, hipMemcpyDeviceToHost, cs));
     HIP_TRY(hipEventRecord(Q.done, cs));

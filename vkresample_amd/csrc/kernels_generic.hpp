@@ -16,7 +16,7 @@
 
 namespace fftup {
 
-enum InMode { IN_F32 = 0, IN_F16 = 1, IN_U8_F32 = 2, IN_U8_F16 = 3 };
+enum InMode { IN_F32 = 0, IN_F16 = 1, IN_U8_F32 = 2, IN_U8_F16 = 3, IN_F64 = 4 };   // IN_F64: -p 1 plans (C = double2)
 
 // VkResample.cpp:1644  x = float(double(v)/255.0)   -- fp32 division is correctly rounded here
 // and agrees with the double-rounded reference expression for all 256 inputs (tests check it).
@@ -24,19 +24,22 @@ __device__ __forceinline__ float cvt_u8_f32(uint8_t v) { return __fdiv_rn((float
 // VkResample.cpp:1676  x = half((float)half(v)/255.0)  (round to nearest even)
 __device__ __forceinline__ float cvt_u8_f16(uint8_t v) { return __half2float(__float2half_rn(__fdiv_rn((float)v, 255.0f))); }
 
-struct RowR2CParams {
-    const void* in;          // planar float/half (row stride, plane stride in elements) or u8 RGB (row stride bytes)
-    float2* S1;              // blocked half spectrum, H rows
-    const float2* tw;        // W-th roots
+template <typename C> struct RowR2CParamsT {
+    const void* in;          // planar float/half/double (row stride, plane stride in elements) or u8 RGB (row stride bytes)
+    C* S1;                   // blocked half spectrum, H rows
+    const C* tw;             // W-th roots
     StagePlan plan;          // n = W
     int W, H;
     long in_row_stride, in_plane_stride;
     int TK, NT;              // tile width (complex), number of tiles = ceil((W/2+1)/TK)
 };
+using RowR2CParams = RowR2CParamsT<float2>;
 
-template <int MODE> __device__ __forceinline__ float load_px(const RowR2CParams& p, int c, int y, int x)
+template <int MODE, typename P> __device__ __forceinline__ auto load_px(const P& p, int c, int y, int x)
 {
-    if constexpr (MODE == IN_F32) {
+    if constexpr (MODE == IN_F64) {
+        return ((const double*)p.in)[c * p.in_plane_stride + y * p.in_row_stride + x];
+    } else if constexpr (MODE == IN_F32) {
         return ((const float*)p.in)[c * p.in_plane_stride + y * p.in_row_stride + x];
     } else if constexpr (MODE == IN_F16) {
         return __half2float(((const __half*)p.in)[c * p.in_plane_stride + y * p.in_row_stride + x]);
@@ -47,70 +50,73 @@ template <int MODE> __device__ __forceinline__ float load_px(const RowR2CParams&
     }
 }
 
-// grid (H/2, 3); dynamic LDS = 2 * lpad_size(W) float2
-template <int MODE>
-__global__ void __launch_bounds__(1024) k_row_r2c(RowR2CParams p)
+// grid (H/2, 3); dynamic LDS = 2 * lpad_size(W) complex
+template <int MODE, typename C = float2>
+__global__ void __launch_bounds__(1024) k_row_r2c(RowR2CParamsT<C> p)
 {
+    using S = scalar_t<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* a = (float2*)smem;
-    float2* b = a + lpad_size(p.W);
+    C* a = (C*)smem;
+    C* b = a + lpad_size(p.W);
     const int tid = threadIdx.x, T = blockDim.x;
     const int j = blockIdx.x, c = blockIdx.y;
     const int W = p.W;
     for (int n = tid; n < W; n += T)
-        a[lpad(n)] = make_float2(load_px<MODE>(p, c, 2 * j, n), load_px<MODE>(p, c, 2 * j + 1, n));
+        a[lpad(n)] = mk<C>(load_px<MODE>(p, c, 2 * j, n), load_px<MODE>(p, c, 2 * j + 1, n));
     __syncthreads();
-    const float2* Z = fft_lds<+1, 1>(a, b, p.plan, p.tw, tid, T);
+    const C* Z = fft_lds<+1, 1>(a, b, p.plan, p.tw, tid, T);
     // unpack two real rows (vkFFT.h:4292-4323): A = (Z[k]+conj Z[W-k])/2, B = (Z[k]-conj Z[W-k])/(2i)
     const long tile_stride = (long)p.H * p.TK;
-    float2* base = p.S1 + (long)c * p.NT * tile_stride;
+    C* base = p.S1 + (long)c * p.NT * tile_stride;
     for (int k = tid; k <= W / 2; k += T) {
-        float2 zk = Z[lpad(k)];
-        float2 zn = Z[lpad(k == 0 ? 0 : W - k)];
-        float2 A = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-        float2 B = make_float2(0.5f * (zk.y + zn.y), 0.5f * (-zk.x + zn.x));
-        float2* dst = base + (long)(k / p.TK) * tile_stride + (long)(2 * j) * p.TK + (k % p.TK);
+        C zk = Z[lpad(k)];
+        C zn = Z[lpad(k == 0 ? 0 : W - k)];
+        C A = mk<C>(S(0.5) * (zk.x + zn.x), S(0.5) * (zk.y - zn.y));
+        C B = mk<C>(S(0.5) * (zk.y + zn.y), S(0.5) * (-zk.x + zn.x));
+        C* dst = base + (long)(k / p.TK) * tile_stride + (long)(2 * j) * p.TK + (k % p.TK);
         dst[0] = A;
         dst[p.TK] = B;
     }
 }
 
-struct ColParams {
-    const float2* S1;
-    float2* S2;
-    const float2 *twH, *twUH;
+template <typename C> struct ColParamsT {
+    const C* S1;
+    C* S2;
+    const C *twH, *twUH;
     StagePlan planH, planUH;
     int W, H, uH;
     int NT;
     int zly, zry;            // inverse read guard: rows [zly,zry) read as zero (VkResample.cpp:1494-1495)
-    float inv_norm;          // 1/uH
+    scalar_t<C> inv_norm;    // 1/uH
 };
+using ColParams = ColParamsT<float2>;
 
-// grid (NT, 3); dynamic LDS = 2 * lpad_size(uH*TK) float2
-template <int TK>
-__global__ void __launch_bounds__(1024) k_col(ColParams p)
+// grid (NT, 3); dynamic LDS = 2 * lpad_size(uH*TK) complex
+template <int TK, typename C = float2>
+__global__ void __launch_bounds__(1024) k_col(ColParamsT<C> p)
 {
+    using S = scalar_t<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* a = (float2*)smem;
-    float2* b = a + lpad_size(p.uH * TK);
+    C* a = (C*)smem;
+    C* b = a + lpad_size(p.uH * TK);
     const int tid = threadIdx.x, T = blockDim.x;
     const int tile = blockIdx.x, c = blockIdx.y;
     const int H = p.H, uH = p.uH;
     const int ncol_valid = min(TK, p.W / 2 + 1 - tile * TK);
-    const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
+    const C* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
     for (int e = tid; e < H * TK; e += T) {
-        float2 v = make_float2(0.f, 0.f);
+        C v = mk<C>(S(0), S(0));
         if ((e % TK) < ncol_valid) v = src[e];
         a[lpad(e)] = v;
     }
     __syncthreads();
-    float2* F = fft_lds<+1, TK>(a, b, p.planH, p.twH, tid, T);
-    float2* G = (F == a) ? b : a;
+    C* F = fft_lds<+1, TK>(a, b, p.planH, p.twH, tid, T);
+    C* G = (F == a) ? b : a;
     // shift (VkResample.cpp:514-526): buffer row ky' holds F[ky'-(uH-H)] for ky' >= uH-H/2, else the
     // un-shifted F[ky'] while ky' < H; then the zero-padding read guard of the inverse plan.
     for (int e = tid; e < uH * TK; e += T) {
         const int ky = e / TK, col = e % TK;
-        float2 v = make_float2(0.f, 0.f);
+        C v = mk<C>(S(0), S(0));
         if (!(ky >= p.zly && ky < p.zry)) {
             if (ky >= uH - H / 2) v = F[lpad((ky - (uH - H)) * TK + col)];
             else if (ky < H) v = F[lpad(e)];
@@ -118,62 +124,64 @@ __global__ void __launch_bounds__(1024) k_col(ColParams p)
         G[lpad(e)] = v;
     }
     __syncthreads();
-    const float2* D = fft_lds<-1, TK>(G, F, p.planUH, p.twUH, tid, T);
-    float2* dst = p.S2 + ((long)c * p.NT + tile) * uH * TK;
+    const C* D = fft_lds<-1, TK>(G, F, p.planUH, p.twUH, tid, T);
+    C* dst = p.S2 + ((long)c * p.NT + tile) * uH * TK;
     for (int e = tid; e < uH * TK; e += T)
         if ((e % TK) < ncol_valid) dst[e] = cscale(D[lpad(e)], p.inv_norm);
 }
 
-struct RowC2RParams {
-    const float2* S2;
-    void* R;                 // dense [3][uH][uW] float or half
-    const float2* tw;        // uW-th roots
+template <typename C> struct RowC2RParamsT {
+    const C* S2;
+    void* R;                 // dense [3][uH][uW] float, half or double
+    const C* tw;             // uW-th roots
     StagePlan plan;          // n = uW
     int W, uW, uH;
     int TK, NT;
     int zlx, zrx;            // column-index read guard [zlx,zrx) (VkResample.cpp:1492-1493)
-    float inv_norm;          // 1/uW
+    scalar_t<C> inv_norm;    // 1/uW
 };
+using RowC2RParams = RowC2RParamsT<float2>;
 
-// grid (uH/2, 3); dynamic LDS = 2 * lpad_size(uW) float2
-template <bool HALF_OUT>
-__global__ void __launch_bounds__(1024) k_row_c2r(RowC2RParams p)
+// grid (uH/2, 3); dynamic LDS = 2 * lpad_size(uW) complex
+template <bool HALF_OUT, typename C = float2>
+__global__ void __launch_bounds__(1024) k_row_c2r(RowC2RParamsT<C> p)
 {
+    using S = scalar_t<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* a = (float2*)smem;
-    float2* b = a + lpad_size(p.uW);
+    C* a = (C*)smem;
+    C* b = a + lpad_size(p.uW);
     const int tid = threadIdx.x, T = blockDim.x;
     const int j = blockIdx.x, c = blockIdx.y;
     const int uW = p.uW;
     const long tile_stride = (long)p.uH * p.TK;
-    const float2* base = p.S2 + (long)c * p.NT * tile_stride + (long)(2 * j) * p.TK;
+    const C* base = p.S2 + (long)c * p.NT * tile_stride + (long)(2 * j) * p.TK;
     // vkFFT.h:2059-2131: Z[k] = A + iB, Z[uW-k] = conj(A) + i conj(B); column index cidx = k-1
     for (int cidx = tid; cidx < uW / 2; cidx += T) {
         const int k = cidx + 1;
-        float2 A = make_float2(0.f, 0.f), B = A;
+        C A = mk<C>(S(0), S(0)), B = A;
         if ((cidx < p.zlx || cidx >= p.zrx) && k <= p.W / 2) {
-            const float2* s = base + (long)(k / p.TK) * tile_stride + (k % p.TK);
+            const C* s = base + (long)(k / p.TK) * tile_stride + (k % p.TK);
             A = s[0];
             B = s[p.TK];
         }
-        a[lpad(k)] = make_float2(A.x - B.y, A.y + B.x);
-        a[lpad(uW - k)] = make_float2(A.x + B.y, -A.y + B.x);
+        a[lpad(k)] = mk<C>(A.x - B.y, A.y + B.x);
+        a[lpad(uW - k)] = mk<C>(A.x + B.y, -A.y + B.x);
     }
     if (tid == 0) {
-        float2 A = base[0], B = base[p.TK];
-        a[lpad(0)] = make_float2(A.x - B.y, A.y + B.x);
+        C A = base[0], B = base[p.TK];
+        a[lpad(0)] = mk<C>(A.x - B.y, A.y + B.x);
     }
     __syncthreads();
-    const float2* z = fft_lds<-1, 1>(a, b, p.plan, p.tw, tid, T);
+    const C* z = fft_lds<-1, 1>(a, b, p.plan, p.tw, tid, T);
     const long plane = (long)uW * p.uH;
     for (int n = tid; n < uW; n += T) {
-        float2 v = cscale(z[lpad(n)], p.inv_norm);
+        C v = cscale(z[lpad(n)], p.inv_norm);
         if constexpr (HALF_OUT) {
             __half* R = (__half*)p.R + c * plane + (long)(2 * j) * uW;
             R[n] = __float2half_rn(v.x);
             R[uW + n] = __float2half_rn(v.y);
         } else {
-            float* R = (float*)p.R + c * plane + (long)(2 * j) * uW;
+            S* R = (S*)p.R + c * plane + (long)(2 * j) * uW;
             R[n] = v.x;
             R[uW + n] = v.y;
         }
@@ -299,6 +307,77 @@ __global__ void __launch_bounds__(256) k_pack_u8(const void* planes, uint8_t* rg
         } else {
             o = !(d > 0.0) ? 0 : (d >= 255.0 ? 255 : (uint8_t)d);
         }
+        rgb[((long)y * uW + x) * 3 + c] = o;
+    }
+}
+
+// ---------------------------------------------------------------- -p 1 (double) variants
+// The GLSL the reference generates for -p 1 declares double/dvec2 buffers but keeps its literals unsuffixed, i.e.
+// float constants promoted to double (VkResample.cpp:893-920): upsq and coef arrive here as such floats.
+__device__ __forceinline__ double sharpen_px_f64(const double* len, double coef)
+{
+    double mn0 = fmin(len[1], fmin(len[3], fmin(len[4], fmin(len[5], len[7]))));
+    double mn1 = fmin(mn0, fmin(len[0], fmin(len[2], fmin(len[6], len[8]))));
+    double mx0 = fmax(len[1], fmax(len[3], fmax(len[4], fmax(len[5], len[7]))));
+    double mx1 = fmax(mx0, fmax(len[0], fmax(len[2], fmax(len[6], len[8]))));
+    double minlen = 0.5 * (mn0 + mn1);
+    double maxlen = 0.5 * (mx0 + mx1);
+    minlen = minlen / (1.0 - minlen);
+    maxlen = (1.0 - maxlen) / maxlen;
+    double scale = (minlen < maxlen) ? minlen : maxlen;
+    scale = -coef * sqrt(scale);
+    return (len[4] + scale * (((len[1] + len[3]) + len[5]) + len[7])) / (1.0 + scale * 4.0);
+}
+
+// one thread = one pixel; grid (ceil(uW/256), uH, 3)
+__global__ void __launch_bounds__(256) k_sharpen_f64(SharpenParams p)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, c = blockIdx.z;
+    const int uW = p.uW, uH = p.uH;
+    if (x >= uW) return;
+    const long plane = (long)uW * uH;
+    const double* R = (const double*)p.R + c * plane;
+    const int xs[3] = {x > 0 ? x - 1 : x, x, x + 1};
+    const int ys[3] = {y > 0 ? y - 1 : y, y, y + 1};
+    double len[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            long f = (long)ys[a] * uW + xs[b];
+            while (f >= plane) f -= uW;
+            double t = fabs((double)p.upsq * R[f]);
+            len[a * 3 + b] = fmin(fmax(t, 0.0), 1.0);
+        }
+    ((double*)p.out)[c * plane + (long)y * uW + x] = sharpen_px_f64(len, (double)p.coef);
+}
+
+// VkResample.cpp:1650-1668: x = (double)v / 255.0
+__global__ void __launch_bounds__(256) k_unpack_u8_f64(const uint8_t* rgb, long row_stride_bytes, double* planes, int W, int H,
+                                                        long plane_stride)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t* s = rgb + (long)y * row_stride_bytes + 3l * x;
+#pragma unroll
+    for (int c = 0; c < 3; c++) planes[c * plane_stride + (long)y * W + x] = __ddiv_rn((double)s[c], 255.0);
+}
+
+// VkResample.cpp:1722-1734: u8 = (unsigned char)(255.0 * x)
+__global__ void __launch_bounds__(256) k_pack_u8_f64(const double* planes, uint8_t* rgb, int uW, int uH, int wrap)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= uW) return;
+    const long plane = (long)uW * uH;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double d = 255.0 * planes[c * plane + (long)y * uW + x];
+        uint8_t o;
+        if (wrap) o = (d > -2147483648.0 && d < 2147483648.0) ? (uint8_t)(((int)d) & 0xFF) : 0;
+        else o = !(d > 0.0) ? 0 : (d >= 255.0 ? 255 : (uint8_t)d);
         rgb[((long)y * uW + x) * 3 + c] = o;
     }
 }
