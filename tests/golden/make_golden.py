@@ -22,8 +22,8 @@ from vkresample_amd import synth  # noqa: E402
 
 def save(name, rgb, u, precision, sharpen=0.2):
     pre, out, u8 = O.upscale_rgb8(rgb, u, precision, sharpen)
-    if precision == 0:
-        lut = O.load_lut(0)
+    if precision in (0, 1):
+        lut = O.load_lut(precision)
         R, _ = E.emulate(np.stack([lut[rgb[..., c]] for c in range(3)]), u)
         assert np.abs(R - pre).max() < 1e-14
     np.savez_compressed(os.path.join(HERE, name + ".npz"), rgb=rgb, upscale=u, precision=precision, sharpen=sharpen,
@@ -44,6 +44,7 @@ def sample_crop():
 if __name__ == "__main__":
     save("g16x8_u2_p0", synth.frame(100, 16, 8, "U"), 2.0, 0)
     save("g20x12_u2_p0", synth.frame(101, 20, 12, "U"), 2.0, 0)
+    save("g20x12_u2_p1", synth.frame(101, 20, 12, "U"), 2.0, 1)
     save("g64x32_u2_p0", synth.frame(102, 64, 32, "N"), 2.0, 0)
     save("g64x32_u2_p2", synth.frame(102, 64, 32, "N"), 2.0, 2)
     save("gsample64_u2_p0", sample_crop(), 2.0, 0)

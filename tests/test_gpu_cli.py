@@ -84,6 +84,19 @@ def test_cli_batched_queue_one_thread_and_missing_file(tmp_path):
     assert sorted(os.listdir(tmp_path / "o4")) == ["%06d.png" % k for k in (1, 2, 3, 4)]
 
 
+def test_cli_double_precision(tmp_path):
+    """-p 1 end to end (the reference's double path, VkResample.cpp:1422)"""
+    from vkresample_amd import synth
+    rgb = synth.frame(12, 240, 126, "N")
+    _png_write(tmp_path / "in.png", rgb)
+    r = subprocess.run([CLI, "-i", "in.png", "-o", "out.png", "-u", "2", "-p", "1"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = _png_read(tmp_path / "out.png")
+    _, _, ou8 = O.upscale_rgb8(rgb, 2.0, 1, 0.2)
+    d = np.abs(out[:-1].astype(int) - ou8[:-1].astype(int))
+    assert out.shape == (252, 480, 3) and d.max() <= 1 and (d != 0).mean() <= 1e-4
+
+
 def test_cli_devices_and_errors(tmp_path):
     r = subprocess.run([CLI, "-devices"], capture_output=True, text=True)
     assert r.returncode == 0 and "Device id: 0 name:" in r.stdout

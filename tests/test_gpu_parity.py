@@ -189,7 +189,7 @@ def test_error_codes():
         v.Upscaler(2 * 11 * 64, 64)          # KAT8: non-smooth size
     assert e.value.code == 2
     with pytest.raises(v.FftupError) as e:
-        v.Upscaler(64, 64, precision=1)
+        v.Upscaler(64, 64, precision=3)
     assert e.value.code == 3
     with pytest.raises(v.FftupError) as e:
         v.Upscaler(63, 64)
@@ -277,14 +277,17 @@ def test_fused_sharpen_equals_unfused(precision, pps, monkeypatch):
         assert (out != out2).mean() <= 0.02
 
 
-@pytest.mark.parametrize("name", ["g16x8_u2_p0", "g20x12_u2_p0", "g64x32_u2_p0", "g64x32_u2_p2", "gsample64_u2_p0"])
+@pytest.mark.parametrize("name", ["g16x8_u2_p0", "g20x12_u2_p0", "g20x12_u2_p1", "g64x32_u2_p0", "g64x32_u2_p2", "gsample64_u2_p0"])
 def test_golden_vectors_gpu(name):
     """HIP path against the committed golden fixtures (tests/golden/make_golden.py)."""
     import os
     d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
     precision = int(d["precision"])
     (pre, out, u8), _ = _run_rgb(d["rgb"], float(d["upscale"]), precision, float(d["sharpen"]))
-    if precision == 0:
+    if precision == 1:
+        assert np.abs(pre - d["pre"]).max() <= 1e-12 and np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 1e-9
+        assert np.abs(u8[:-1].astype(int) - d["u8"][:-1].astype(int)).max() <= 1
+    elif precision == 0:
         assert np.abs(pre - d["pre"]).max() * 4 <= 1e-4 and _rel_l2(pre, d["pre"]) <= 1e-5
         assert np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 1e-3 and _rel_l2(out[:, :-1], d["out"][:, :-1]) <= 1e-4
         assert np.abs(u8[:-1].astype(int) - d["u8"][:-1].astype(int)).max() <= 1

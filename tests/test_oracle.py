@@ -195,7 +195,7 @@ def test_fp16_mode_values_are_halves():
 
 
 # ------------------------------------------------------------------ golden vectors (tests/golden/make_golden.py)
-@pytest.mark.parametrize("name", ["g16x8_u2_p0", "g20x12_u2_p0", "g64x32_u2_p0", "g64x32_u2_p2", "gsample64_u2_p0"])
+@pytest.mark.parametrize("name", ["g16x8_u2_p0", "g20x12_u2_p0", "g20x12_u2_p1", "g64x32_u2_p0", "g64x32_u2_p2", "gsample64_u2_p0"])
 def test_golden_vectors(name):
     d = np.load(os.path.join(GOLDEN, name + ".npz"))
     pre, out, u8 = O.upscale_rgb8(d["rgb"], float(d["upscale"]), int(d["precision"]), float(d["sharpen"]))

@@ -233,7 +233,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
     P->ring = cfg->ring ? cfg->ring : 1;
     P->half = cfg->precision == 2;
     P->dbl = cfg->precision == 1;
-    P->esz = P->dbl ? 8 : P->esz;
+    P->esz = P->dbl ? 8 : (P->half ? 2 : 4);
     P->csz = P->dbl ? 16 : 8;
     P->device = cfg->device;
     int rc = FFTUP_OK;
