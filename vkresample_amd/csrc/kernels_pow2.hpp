@@ -22,7 +22,9 @@
 namespace fftup {
 
 constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n / 2); }
-constexpr int stage_radix(int N, int Ns) { return (N / Ns >= 8) ? 8 : (N / Ns); }
+// radix of the stage that starts at sub-transform length Ns: the largest allowed one (RMAX = 8, or 16 for
+// threads that own 16 points) the remaining length still holds
+constexpr int stage_radix(int N, int Ns, int RMAX = 8) { return (N / Ns >= RMAX) ? RMAX : (N / Ns); }
 
 // LDS element index of point idx of sequence col (TK interleaved sequences)
 template <int TK> __device__ __forceinline__ int lidx(int idx, int col) { return lpad(idx * TK + col); }
@@ -32,17 +34,17 @@ template <int TK> __device__ __forceinline__ int lidx(int idx, int col) { return
 // (TwSet::load, issued next to the first-stage input loads so that no stage waits on memory), and
 // forms the powers by multiplication (<= 3 roundings, ~2e-7).  A thread's butterflies b > 0 of one
 // stage differ from b = 0 by a compile-time rotation (only in the last stage, where Ns > Tc).
-constexpr int num_stages(int N, int Ns = 1) { return Ns >= N ? 0 : 1 + num_stages(N, Ns * stage_radix(N, Ns)); }
-constexpr int stage_ns(int N, int s) { return s == 0 ? 1 : stage_ns(N, s - 1) * stage_radix(N, stage_ns(N, s - 1)); }
+constexpr int num_stages(int N, int RMAX = 8, int Ns = 1) { return Ns >= N ? 0 : 1 + num_stages(N, RMAX, Ns * stage_radix(N, Ns, RMAX)); }
+constexpr int stage_ns(int N, int s, int RMAX = 8) { return s == 0 ? 1 : stage_ns(N, s - 1, RMAX) * stage_radix(N, stage_ns(N, s - 1, RMAX), RMAX); }
 
-template <int N, int E> struct TwSet {
-    static constexpr int S = num_stages(N);
+template <int N, int E, int RMAX = 8> struct TwSet {
+    static constexpr int S = num_stages(N, RMAX);
     float2 w[S > 1 ? S - 1 : 1];                 // base twiddle of stages 1..S-1 (table sign: exp(+i..))
     template <int s> __device__ __forceinline__ void load_stage(const float2* __restrict__ tw, int p)
     {
         if constexpr (s < S) {
-            constexpr int Ns = stage_ns(N, s);
-            constexpr int R = stage_radix(N, Ns);
+            constexpr int Ns = stage_ns(N, s, RMAX);
+            constexpr int R = stage_radix(N, Ns, RMAX);
             constexpr int tstep = N / (Ns * R);
             w[s - 1] = tw[(p & (Ns - 1)) * tstep];
             load_stage<s + 1>(tw, p);
@@ -74,6 +76,32 @@ template <int R> __device__ __forceinline__ void twiddle_powers(float2* v, float
         float2 w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
         v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
         v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7);
+        if constexpr (R == 16) {
+            float2 w8 = cmul(w4, w4);
+            v[8] = cmul(v[8], w8); v[9] = cmul(v[9], cmul(w8, w1)); v[10] = cmul(v[10], cmul(w5, w5));
+            v[11] = cmul(v[11], cmul(w8, w3)); v[12] = cmul(v[12], cmul(w6, w6)); v[13] = cmul(v[13], cmul(w8, w5));
+            v[14] = cmul(v[14], cmul(w7, w7)); v[15] = cmul(v[15], cmul(w8, w7));
+        }
+    }
+}
+
+// radix-16 butterfly as 4 x 4 (n = 4 n1 + n2, k = k1 + 4 k2) with the internal twiddles exp(DIR 2 pi i n2 k1/16)
+template <int DIR> __device__ __forceinline__ void bfly16(float2* v)
+{
+    float2 y[4][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) {
+        y[n2][0] = v[n2]; y[n2][1] = v[4 + n2]; y[n2][2] = v[8 + n2]; y[n2][3] = v[12 + n2];
+        bfly4<DIR>(y[n2]);
+    }
+    y[1][1] = cmul(y[1][1], twid<DIR>(rot16<1>())); y[1][2] = cmul(y[1][2], twid<DIR>(rot16<2>())); y[1][3] = cmul(y[1][3], twid<DIR>(rot16<3>()));
+    y[2][1] = cmul(y[2][1], twid<DIR>(rot16<2>())); y[2][2] = mul_i<DIR>(y[2][2]);                  y[2][3] = cmul(y[2][3], twid<DIR>(rot16<6>()));
+    y[3][1] = cmul(y[3][1], twid<DIR>(rot16<3>())); y[3][2] = cmul(y[3][2], twid<DIR>(rot16<6>())); y[3][3] = cmul(y[3][3], twid<DIR>(rot16<9>()));
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) {
+        float2 z[4] = {y[0][k1], y[1][k1], y[2][k1], y[3][k1]};
+        bfly4<DIR>(z);
+        v[k1] = z[0]; v[k1 + 4] = z[1]; v[k1 + 8] = z[2]; v[k1 + 12] = z[3];
     }
 }
 
@@ -93,7 +121,8 @@ __device__ __forceinline__ void butterfly_b(float2 (&v)[E], float2 wbase)
             if constexpr (Ns > Tc && B > 0) w1 = cmul(w1, twid<DIR>(rot16<B * (16 / E)>()));
             twiddle_powers<R>(w, w1);
         }
-        bfly<R, DIR>(w);
+        if constexpr (R == 16) bfly16<DIR>(w);
+        else bfly<R, DIR>(w);
 #pragma unroll
         for (int m = 0; m < R; m++) v[B + m * NB] = w[m];
         butterfly_b<N, E, R, Ns, DIR, B + 1>(v, wbase);
@@ -135,12 +164,12 @@ __device__ __forceinline__ void reg_gather(float2 (&v)[E], const float2* __restr
 // ---- all stages.  On entry v[i] = x[p + Tc*i].  If FINAL_TO_LDS the result X is left in LDS in
 // natural order (valid after the trailing barrier); otherwise v[i] = X[p + Tc*i] on return.
 // `buf` must not be in use by anyone on entry (callers barrier before re-using it).
-template <int N, int E, int DIR, int TK, bool FINAL_TO_LDS, int S = 0>
+template <int N, int E, int DIR, int TK, bool FINAL_TO_LDS, int S = 0, int RMAX = 8>
 __device__ __forceinline__ void reg_fft(float2 (&v)[E], float2* __restrict__ buf, int p, int col,
-                                        const TwSet<N, E>& tws)
+                                        const TwSet<N, E, RMAX>& tws)
 {
-    constexpr int Ns = stage_ns(N, S);
-    constexpr int R = stage_radix(N, Ns);
+    constexpr int Ns = stage_ns(N, S, RMAX);
+    constexpr int R = stage_radix(N, Ns, RMAX);
     static_assert(E % R == 0, "radix must divide the per-thread point count");
     reg_butterflies<N, E, R, Ns, DIR>(v, tws.w[S > 0 ? S - 1 : 0]);
     constexpr bool last = (Ns * R == N);
@@ -151,7 +180,7 @@ __device__ __forceinline__ void reg_fft(float2 (&v)[E], float2* __restrict__ buf
     if constexpr (!last) {
         reg_gather<N, E, TK>(v, buf, p, col);
         __syncthreads();
-        reg_fft<N, E, DIR, TK, FINAL_TO_LDS, S + 1>(v, buf, p, col, tws);
+        reg_fft<N, E, DIR, TK, FINAL_TO_LDS, S + 1, RMAX>(v, buf, p, col, tws);
     }
 }
 
@@ -240,7 +269,7 @@ __global__ void __launch_bounds__(TK* H / 8) k_col_t(ColTParams p)
     const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
     float2 v[8];
     TwSet<H, 8> twsF;
-    TwSet<UH, 16> twsI;
+    TwSet<UH, 16, 16> twsI;                          // inverse: radix-16 stages (2H = 16*16*8 for H = 1024)
     twsF.load(p.twH, pp);
     twsI.load(p.twUH, pp);
 #pragma unroll
@@ -257,7 +286,7 @@ __global__ void __launch_bounds__(TK* H / 8) k_col_t(ColTParams p)
         else g[i] = make_float2(0.f, 0.f);
     }
     __syncthreads();
-    reg_fft<UH, 16, -1, TK, false>(g, buf, pp, col, twsI);
+    reg_fft<UH, 16, -1, TK, false, 0, 16>(g, buf, pp, col, twsI);
     float2* dst = p.S2 + ((long)c * p.NT + tile) * UH * TK;
     constexpr float inv = 1.0f / (float)UH;
     if (valid) {
@@ -645,7 +674,13 @@ __global__ void __launch_bounds__(UW / 4) k_c2r_sharpen_t(FusedParams p)
         const int a0 = top ? 0 : y0 - 1;
         const int npairs = (j1 - j0) + 1;
         const float2* base = p.S2 + (long)c * p.NT * tile_stride;
-        auto S2at = [&](int k, int row) -> float2 { return base[(long)(k / TK) * tile_stride + (long)row * TK + (k % TK)]; };
+        // 32-bit element offsets from the (wave-uniform) plane base: one plane of S2 is < 2^31 elements
+        const unsigned tile_stride32 = (unsigned)uH * TK;
+        auto S2at = [&](int k, int row) -> float2 {
+            // byte offset kept in 32 bits so that the load takes the "SGPR base + VGPR offset" form
+            const unsigned off = ((unsigned)(k / TK) * tile_stride32 + (unsigned)row * TK + (unsigned)(k % TK)) * (unsigned)sizeof(float2);
+            return *(const float2*)((const char*)base + off);
+        };
         const bool need_corner = !top && (y1 + 1 < uH);
         const int rs = y1 + 1;
 
@@ -748,80 +783,159 @@ __global__ void __launch_bounds__(UW / 4) k_c2r_sharpen_t(FusedParams p)
                 auto rowp = [&](int r) -> const float* { return r < 0 ? ring + (r + 2) * UW : cur + r * UW; };
                 // both output rows of a 4-pixel column group in one pass: the four L rows a-2 .. a+1 are read
                 // once and their horizontal minima/maxima are shared by the two 3x3 windows
-#pragma unroll 1
-                for (int h = 0; h < 2; h++) {
-                    const bool out0 = i >= 0 && (a - 1) >= y0 && (a - 1) < y1;      // row y = a-1
-                    const bool out1 = i >= 0 && a >= y0 && a < y1;                  // row y = a
-                    if (out0 || out1) {
+                if constexpr (HALF) {
+                    // -p 2: one undivided pass per column half (the binary16 evaluation needs the registers), its three
+                    // barriers after it
+    #pragma unroll 1
+                    for (int h = 0; h < 2; h++) {
+                        const bool out0 = i >= 0 && (a - 1) >= y0 && (a - 1) < y1;      // row y = a-1
+                        const bool out1 = i >= 0 && a >= y0 && a < y1;                  // row y = a
+                        if (out0 || out1) {
+                            const int x0 = 4 * (lt + T * h);
+                            // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
+                            const float* rows[4] = {rowp(-2), (a == 0) ? rowp(0) : rowp(-1), rowp(0), rowp(1)};
+                            float t[4][6];
+    #pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                if (r == 0 && !out0) continue;
+                                float4 q = *(const float4*)(rows[r] + x0);
+                                t[r][1] = q.x; t[r][2] = q.y; t[r][3] = q.z; t[r][4] = q.w;
+                                float el = q.x, er = 0.f;
+                                if ((lt & 63) == 0 && x0 != 0) el = rows[r][x0 - 1];
+                                if ((lt & 63) == 63) {
+                                    // x = UW wraps to x = 0 of the next row (rows past a+1: see below)
+                                    const float* nx = (r < 3) ? ((a == 0 && r == 1) ? rowp(1) : rows[r + 1]) : rows[3];
+                                    er = (x0 + 4 == UW) ? nx[0] : rows[r][x0 + 4];
+                                }
+                                t[r][0] = lane_from_below(q.w, el);
+                                t[r][5] = lane_from_above(q.x, er);
+                            }
+                            const bool last_chunk = (x0 + 4 == UW);
+                            if (last_chunk) {
+                                // SE tap of pixel (a, UW-1) is L(a+2, 0): past the plane it clamps to row uH-1; in the
+                                // last step it is the corner sample; otherwise the pixel is finished next step
+                                const int r2 = min(a + 2, uH - 1) - a;
+                                if (r2 <= 1) t[3][5] = rowp(r2)[0];
+                                else if (i == npairs - 1) {
+                                    float sum = 0.f;
+                                    for (int w2 = 0; w2 < T / 64; w2++) sum += red[w2];
+                                    t[3][5] = to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq);
+                                }
+                            }
+                            float hmn[4][4], hmx[4][4];
+    #pragma unroll
+                            for (int r = 0; r < 4; r++)
+    #pragma unroll
+                                for (int k = 0; k < 4; k++) {
+                                    hmn[r][k] = fminf(fminf(t[r][k], t[r][k + 1]), t[r][k + 2]);
+                                    hmx[r][k] = fmaxf(fmaxf(t[r][k], t[r][k + 1]), t[r][k + 2]);
+                                }
+    #pragma unroll
+                            for (int w = 0; w < 2; w++) {
+                                if (w == 0 ? !out0 : !out1) continue;
+                                float o[4];
+    #pragma unroll
+                                for (int k = 0; k < 4; k++) {
+                                    const float N = t[w][k + 1], S = t[w + 2][k + 1], Wv = t[w + 1][k], C = t[w + 1][k + 1], E = t[w + 1][k + 2];
+                                    const float mn0 = fminf(fminf(N, S), hmn[w + 1][k]);
+                                    const float mx0 = fmaxf(fmaxf(N, S), hmx[w + 1][k]);
+                                    const float mn1 = fminf(fminf(hmn[w][k], hmn[w + 2][k]), mn0);
+                                    const float mx1 = fmaxf(fmaxf(hmx[w][k], hmx[w + 2][k]), mx0);
+                                    if constexpr (HALF) o[k] = sharpen_eval_half_fast(N, S, Wv, E, C, mn0, mn1, mx0, mx1, p.coef);
+                                    else o[k] = sharpen_eval_fast(((N + Wv) + E) + S, C, mn0, mn1, mx0, mx1, p.coef);
+                                }
+                                const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
+                                if constexpr (HALF) {
+                                    __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
+                                    typedef float f2v __attribute__((ext_vector_type(2)));
+                                    f2v val = {*(float*)&h0, *(float*)&h1};
+                                    __builtin_nontemporal_store(val, (f2v*)((char*)((__half*)p.out + row_of) + (unsigned)x0 * 2u));
+                                } else {
+                                    typedef float f4v __attribute__((ext_vector_type(4)));
+                                    f4v val = {o[0], o[1], o[2], o[3]};
+                                    __builtin_nontemporal_store(val, (f4v*)((char*)((float*)p.out + row_of) + (unsigned)x0 * 4u));
+                                }
+                            }
+                        }
+                        __syncthreads();
+                        __syncthreads();
+                        __syncthreads();                                                           // 6 in total
+                    }
+                } else {
+    #pragma unroll 1
+                    for (int h = 0; h < 2; h++) {
+                        const bool out0 = i >= 0 && (a - 1) >= y0 && (a - 1) < y1;      // row y = a-1
+                        const bool out1 = i >= 0 && a >= y0 && a < y1;                  // row y = a
+                        const bool act = out0 || out1;
                         const int x0 = 4 * (lt + T * h);
-                        // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
-                        const float* rows[4] = {rowp(-2), (a == 0) ? rowp(0) : rowp(-1), rowp(0), rowp(1)};
                         float t[4][6];
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            if (r == 0 && !out0) continue;
-                            float4 q = *(const float4*)(rows[r] + x0);
-                            t[r][1] = q.x; t[r][2] = q.y; t[r][3] = q.z; t[r][4] = q.w;
-                            float el = q.x, er = 0.f;
-                            if ((lt & 63) == 0 && x0 != 0) el = rows[r][x0 - 1];
-                            if ((lt & 63) == 63) {
-                                // x = UW wraps to x = 0 of the next row (rows past a+1: see below)
-                                const float* nx = (r < 3) ? ((a == 0 && r == 1) ? rowp(1) : rows[r + 1]) : rows[3];
-                                er = (x0 + 4 == UW) ? nx[0] : rows[r][x0 + 4];
+                        // the pass is cut in three by the barriers it has to take part in anyway, so that its arithmetic
+                        // is spread over the other half's transform stages instead of running beside only one of them
+                        if (act) {
+                            // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
+                            const float* rows[4] = {rowp(-2), (a == 0) ? rowp(0) : rowp(-1), rowp(0), rowp(1)};
+    #pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                if (r == 0 && !out0) {
+    #pragma unroll
+                                    for (int k = 0; k < 6; k++) t[0][k] = 0.f;
+                                    continue;
+                                }
+                                float4 q = *(const float4*)(rows[r] + x0);
+                                t[r][1] = q.x; t[r][2] = q.y; t[r][3] = q.z; t[r][4] = q.w;
+                                float el = q.x, er = 0.f;
+                                if ((lt & 63) == 0 && x0 != 0) el = rows[r][x0 - 1];
+                                if ((lt & 63) == 63) {
+                                    // x = UW wraps to x = 0 of the next row (rows past a+1: see below)
+                                    const float* nx = (r < 3) ? ((a == 0 && r == 1) ? rowp(1) : rows[r + 1]) : rows[3];
+                                    er = (x0 + 4 == UW) ? nx[0] : rows[r][x0 + 4];
+                                }
+                                t[r][0] = lane_from_below(q.w, el);
+                                t[r][5] = lane_from_above(q.x, er);
                             }
-                            t[r][0] = lane_from_below(q.w, el);
-                            t[r][5] = lane_from_above(q.x, er);
+                            const bool last_chunk = (x0 + 4 == UW);
+                            if (last_chunk) {
+                                // SE tap of pixel (a, UW-1) is L(a+2, 0): past the plane it clamps to row uH-1; in the
+                                // last step it is the corner sample; otherwise the pixel is finished next step
+                                const int r2 = min(a + 2, uH - 1) - a;
+                                if (r2 <= 1) t[3][5] = rowp(r2)[0];
+                                else if (i == npairs - 1) {
+                                    float sum = 0.f;
+                                    for (int w2 = 0; w2 < T / 64; w2++) sum += red[w2];
+                                    t[3][5] = to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq);
+                                }
+                            }
                         }
-                        const bool last_chunk = (x0 + 4 == UW);
-                        if (last_chunk) {
-                            // SE tap of pixel (a, UW-1) is L(a+2, 0): past the plane it clamps to row uH-1; in the
-                            // last step it is the corner sample; otherwise the pixel is finished next step
-                            const int r2 = min(a + 2, uH - 1) - a;
-                            if (r2 <= 1) t[3][5] = rowp(r2)[0];
-                            else if (i == npairs - 1) {
-                                float sum = 0.f;
-                                for (int w2 = 0; w2 < T / 64; w2++) sum += red[w2];
-                                t[3][5] = to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq);
-                            }
-                        }
-                        float hmn[4][4], hmx[4][4];
-#pragma unroll
-                        for (int r = 0; r < 4; r++)
-#pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                hmn[r][k] = fminf(fminf(t[r][k], t[r][k + 1]), t[r][k + 2]);
-                                hmx[r][k] = fmaxf(fmaxf(t[r][k], t[r][k + 1]), t[r][k + 2]);
-                            }
-#pragma unroll
+    #pragma unroll
                         for (int w = 0; w < 2; w++) {
-                            if (w == 0 ? !out0 : !out1) continue;
+                            __syncthreads();
+                            if (!act || (w == 0 ? !out0 : !out1)) continue;
                             float o[4];
-#pragma unroll
+    #pragma unroll
                             for (int k = 0; k < 4; k++) {
                                 const float N = t[w][k + 1], S = t[w + 2][k + 1], Wv = t[w + 1][k], C = t[w + 1][k + 1], E = t[w + 1][k + 2];
-                                const float mn0 = fminf(fminf(N, S), hmn[w + 1][k]);
-                                const float mx0 = fmaxf(fmaxf(N, S), hmx[w + 1][k]);
-                                const float mn1 = fminf(fminf(hmn[w][k], hmn[w + 2][k]), mn0);
-                                const float mx1 = fmaxf(fmaxf(hmx[w][k], hmx[w + 2][k]), mx0);
+                                // only t[][] lives across the barriers; min/max are exact in any order
+                                const float mn0 = fminf(fminf(N, S), fminf(fminf(Wv, C), E));
+                                const float mx0 = fmaxf(fmaxf(N, S), fmaxf(fmaxf(Wv, C), E));
+                                const float mn1 = fminf(fminf(fminf(fminf(t[w][k], N), t[w][k + 2]), fminf(fminf(t[w + 2][k], S), t[w + 2][k + 2])), mn0);
+                                const float mx1 = fmaxf(fmaxf(fmaxf(fmaxf(t[w][k], N), t[w][k + 2]), fmaxf(fmaxf(t[w + 2][k], S), t[w + 2][k + 2])), mx0);
                                 if constexpr (HALF) o[k] = sharpen_eval_half_fast(N, S, Wv, E, C, mn0, mn1, mx0, mx1, p.coef);
                                 else o[k] = sharpen_eval_fast(((N + Wv) + E) + S, C, mn0, mn1, mx0, mx1, p.coef);
                             }
-                            const long of = c * plane + (long)(a - 1 + w) * UW + x0;
+                            const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
                             if constexpr (HALF) {
                                 __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
                                 typedef float f2v __attribute__((ext_vector_type(2)));
                                 f2v val = {*(float*)&h0, *(float*)&h1};
-                                __builtin_nontemporal_store(val, (f2v*)((__half*)p.out + of));
+                                __builtin_nontemporal_store(val, (f2v*)((char*)((__half*)p.out + row_of) + (unsigned)x0 * 2u));
                             } else {
                                 typedef float f4v __attribute__((ext_vector_type(4)));
                                 f4v val = {o[0], o[1], o[2], o[3]};
-                                __builtin_nontemporal_store(val, (f4v*)((float*)p.out + of));
+                                __builtin_nontemporal_store(val, (f4v*)((char*)((float*)p.out + row_of) + (unsigned)x0 * 4u));
                             }
                         }
+                        __syncthreads();                                                           // 3 per pass, 6 in total
                     }
-                    __syncthreads();
-                    __syncthreads();
-                    __syncthreads();                                                           // 6 in total
                 }
                 if (i >= 0 && lt == T - 1) {
                     // finish the pixel deferred by the previous pair: (a-2, UW-1); L(a,0) is known now
