@@ -31,7 +31,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--upscale", type=float, default=2.0)
-    ap.add_argument("--precision", type=int, default=0, help="0 = fp32 (headline), 2 = fp16 memory")
+    ap.add_argument("--precision", type=int, default=0, help="0 = fp32 (headline), 1 = fp64, 2 = fp16 memory")
     ap.add_argument("--fuse-u8", action="store_true", help="row kernel reads uint8 RGB directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8)
@@ -167,15 +167,16 @@ def main():
                 traffic = None
         frame_ms = dev_ms / (args.steps * args.frames_per_step)
         line = {
-            "metric": "frames/s, 2048x1024->4096x2048 fp32 FFT upscale (R2C+zero-pad+C2R+sharpen)",
+            "metric": "frames/s, %dx%d->%dx%d %s FFT upscale (R2C+zero-pad+C2R+sharpen)"
+                      % (args.width, args.height, up.out_width, up.out_height, {0: "fp32", 1: "fp64", 2: "fp16-memory"}[args.precision]),
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision == 0 else "f16-memory/f32-math",
+            "vs_baseline": None, "dtype": {0: "f32", 1: "f64", 2: "f16-memory/f32-math"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "%dx%d->%dx%d -u %g -p %d, %d frames/step/GPU, ring of %d resident %s frames/GPU"
                                    % (args.width, args.height, up.out_width, up.out_height, args.upscale,
                                       args.precision, args.frames_per_step, args.ring,
-                                      "uint8 RGB (fused load)" if args.fuse_u8 else "planar fp%d" % (16 if args.precision == 2 else 32)),
+                                      "uint8 RGB (fused load)" if args.fuse_u8 and args.precision != 1 else "planar fp%d" % {0: 32, 1: 64, 2: 16}[args.precision]),
                        "frames_per_step": args.frames_per_step, "sharding": "independent frames, no collective",
                        "kernels": "tuned" if up.tuned else "generic", "streams": args.streams, "device": up.device_name},
             "ms_per_frame": frame_ms,
