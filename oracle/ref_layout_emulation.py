@@ -1,6 +1,6 @@
 """Index-faithful numpy emulation of the reference's device buffers.  TEST INFRASTRUCTURE ONLY.
 
-*** PARITY UNPINNED *** (see oracle/fftup_oracle.c): the reference cannot be built or run here and
+Parity pin and its limits: see oracle/fftup_oracle.c (border quirks remain "PARITY UNPINNED"): the reference cannot be built or run here and
 ships no golden data.  This module re-creates the three device buffers of VkResample
 (`inputBuffer`, `buffer`, `tempBuffer`) as flat arrays and replays, dispatch by dispatch, what
 each of the reference's eight kernels reads and writes -- with the reference's strides, the

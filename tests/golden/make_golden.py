@@ -2,7 +2,8 @@
 """Generates tests/golden/*.npz: inputs + expected outputs of the CPU oracle (oracle/fftup_oracle.c), which at
 generation time was cross-checked against oracle/ref_layout_emulation.py (index-faithful replay of the
 reference's buffers) and numpy's rfft2/irfft2 closed form.  The reference itself ships no golden data and
-cannot run here (no Vulkan): these vectors pin the ORACLE, not the Vulkan binary ("parity unpinned").
+cannot run here (no Vulkan): these vectors pin the ORACLE, not the Vulkan binary (the vectors that come from the
+reference's own output are made by make_readme_crops.py).
 The 64x64 crop comes from the reference's samples/no_upscaling.png decoded by the reference's own
 stb_image (oracle/_ref/libref_host.so), forced to 3 channels like VkResample.cpp:1362."""
 import ctypes as C

@@ -470,3 +470,21 @@ def test_fp64_host_streamed_queue():
         _, _, ou8 = O.upscale_rgb8(frames[k], 2.0, 1)
         d = outs[k][:-1].astype(int) - ou8[:-1].astype(int)
         assert np.abs(d).max() <= 1 and (d != 0).mean() <= 1e-4
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+@pytest.mark.parametrize("name", ["car", "close_people", "distant_people", "skyscraper", "trees"])
+def test_hip_path_reproduces_reference_output_crops(name, flags):
+    """The product against the reference's OWN pixels (tests/golden/make_readme_crops.py): crops of the images
+    VkResample produced for its README, with the exact input of the crop window.  flags 0: size-specialised + fused
+    kernels (512x512), 4: size-generic kernels."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "readme_%s.npz" % name))
+    with _up(512, 512, 2.0, 0, 0.2, 0, flags) as up:
+        up.upload_rgb8(d["rgb"])
+        up.execute(1)
+        u8 = up.download_rgb8()
+    r0, r1, c0, c1 = [int(v) for v in d["inner"]]
+    Yo, Xo = int(d["Yo"]), int(d["Xo"])
+    diff = np.abs(u8[Yo:Yo + 300, Xo:Xo + 300].astype(np.int64) - d["fft_panel"].astype(np.int64))[r0:r1, c0:c1]
+    assert diff.mean() <= 0.35 and np.percentile(diff, 99) <= 1 and diff.max() <= 3

@@ -1,6 +1,7 @@
 """CPU suite: the oracle against numpy.fft, the index-faithful layout emulation, analytic known-answer
 tests and the committed golden vectors.  No GPU."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -202,3 +203,40 @@ def test_golden_vectors(name):
     assert np.abs(pre - d["pre"]).max() <= 1e-13
     assert np.abs(out - d["out"]).max() <= 1e-12
     assert np.array_equal(u8, d["u8"])
+
+
+# ------------------------------------------------------------------ the reference's own output (README strips)
+README_STRIPS = ["car", "close_people", "distant_people", "skyscraper", "trees"]
+
+
+def _panel_diff(u8, d):
+    r0, r1, c0, c1 = [int(v) for v in d["inner"]]
+    Yo, Xo = int(d["Yo"]), int(d["Xo"])
+    diff = np.abs(u8[Yo:Yo + 300, Xo:Xo + 300].astype(np.int64) - d["fft_panel"].astype(np.int64))[r0:r1, c0:c1]
+    return float(diff.mean()), float(np.percentile(diff, 99)), int(diff.max())
+
+
+@pytest.mark.parametrize("name", README_STRIPS)
+def test_oracle_reproduces_reference_output_crops(name):
+    """tests/golden/make_readme_crops.py: the FFT panels of the README's comparison strips are crops of images the
+    reference itself produced; their NN panels give the exact input pixels of the same window.  The oracle run on
+    that input reproduces the reference's pixels to the 8-bit grid (the residue comes from the input outside the
+    window, known only to ~2 grey levels), and only with the reference's default sharpen strength."""
+    d = np.load(os.path.join(GOLDEN, "readme_%s.npz" % name))
+    _, _, u8 = O.upscale_rgb8(d["rgb"], float(d["upscale"]), int(d["precision"]), float(d["sharpen"]))
+    mean, p99, mx = _panel_diff(u8, d)
+    assert mean <= 0.35 and p99 <= 1 and mx <= 3, (mean, p99, mx)
+    _, _, weak = O.upscale_rgb8(d["rgb"], 2.0, 0, 0.1)          # discriminating power: -s 0.1 is visibly off
+    assert _panel_diff(weak, d)[0] > 2 * mean and _panel_diff(weak, d)[2] >= 10
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/samples/car.png"), reason="needs the reference's samples")
+def test_oracle_reproduces_reference_output_whole_frame():
+    """the same with the whole 2048x1152 frame instead of the committed 512x512 windows (here only)"""
+    sys.path.insert(0, GOLDEN)
+    import make_readme_crops as M
+    b = M.build("car")
+    assert b["dup"] > 0.99 and b["rms"] < 1.5
+    _, _, u8 = O.upscale_rgb8(b["rgb"], 2.0, 0, 0.2)
+    mean, p99, mx = M.compare(u8, b["fft"], 2 * b["yA"] + b["py"], 2 * b["xA"] + b["px"])
+    assert mean <= 0.2 and p99 <= 1 and mx <= 2, (mean, p99, mx)
