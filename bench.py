@@ -63,6 +63,30 @@ def cpu_baseline(args):
                       % (len(frames), args.width, args.height, dt)}
 
 
+def reference_vulkan_baseline(args):
+    """the reference itself on this GPU through Vulkan -- only possible when the box has a Vulkan loader
+    and a prebuilt VkResample binary is supplied out of band (VKRESAMPLE_REF_BIN); never fabricated."""
+    import ctypes.util
+    import re
+    import subprocess
+    import tempfile
+    ref_bin = os.environ.get("VKRESAMPLE_REF_BIN")
+    if not ref_bin or not os.path.exists(ref_bin) or not ctypes.util.find_library("vulkan"):
+        return {"available": False,
+                "note": "reference Vulkan baseline unavailable (no libvulkan / VKRESAMPLE_REF_BIN on this box); the reference "
+                        "publishes < 2 ms per 2048x1024->4096x2048 frame on a GTX 1660 Ti (README.md:12)"}
+    from PIL import Image
+    from vkresample_amd import synth
+    with tempfile.TemporaryDirectory() as tmp:
+        Image.fromarray(synth.frame(0, args.width, args.height, "U")).save(os.path.join(tmp, "in.png"))
+        r = subprocess.run([ref_bin, "-i", "in.png", "-o", "out.png", "-u", str(args.upscale), "-p", str(args.precision), "-n", "1000"],
+                           cwd=tmp, capture_output=True, text=True, timeout=300)
+        m = re.search(r"Time: ([0-9.]+) ms", r.stdout)
+        if not m:
+            return {"available": False, "note": "reference binary ran but printed no time: " + r.stdout[-200:]}
+        return {"available": True, "ms_per_frame": float(m.group(1)), "frames_per_s": 1e3 / float(m.group(1)), "command": "-u 2 -n 1000"}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -198,6 +222,7 @@ def main():
             line["pcie_GBps"] = pcie / (frame_ms * 1e-3) / 1e9
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args)
+            line["reference_vulkan_baseline"] = reference_vulkan_baseline(args)
     up.close()
     if pins:
         pins[0].close()
