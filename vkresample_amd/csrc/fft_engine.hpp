@@ -132,6 +132,83 @@ template <int DIR, typename C> __device__ __forceinline__ void bfly7(C* v)
     v[2] = cadd(p2, q2); v[5] = csub(p2, q2);
     v[3] = cadd(p3, q3); v[4] = csub(p3, q3);
 }
+// cos/sin of 2 pi q / 16 and 2 pi q / 9 (q as used by bfly16 / bfly9)
+template <int DIR, int Q, typename C> __device__ __forceinline__ C rot16c(C a)
+{
+    using S = scalar_t<C>;
+    constexpr double c[10] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173, 0.0,
+                              -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613, -1.0,
+                              -0.92387953251128675613};
+    constexpr double sn[10] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613, 1.0,
+                               0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173, 0.0,
+                               -0.38268343236508977173};
+    return cmul(a, mk<C>(S(c[Q]), S(DIR > 0 ? sn[Q] : -sn[Q])));
+}
+template <int DIR, int Q, typename C> __device__ __forceinline__ C rot9c(C a)
+{
+    using S = scalar_t<C>;
+    constexpr double c[5] = {1.0, 0.76604444311897803520, 0.17364817766693034885, -0.5, -0.93969262078590838405};
+    constexpr double sn[5] = {0.0, 0.64278760968653932632, 0.98480775301220805937, 0.86602540378443864676, 0.34202014332566873304};
+    return cmul(a, mk<C>(S(c[Q]), S(DIR > 0 ? sn[Q] : -sn[Q])));
+}
+
+// radix 16 = 4 x 4 (n = 4 n1 + n2, k = k1 + 4 k2), internal twiddles exp(DIR 2 pi i n2 k1 / 16)
+template <int DIR, typename C> __device__ __forceinline__ void bfly16(C* v)
+{
+    C y[4][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) {
+        y[n2][0] = v[n2]; y[n2][1] = v[4 + n2]; y[n2][2] = v[8 + n2]; y[n2][3] = v[12 + n2];
+        bfly4<DIR>(y[n2]);
+    }
+    y[1][1] = rot16c<DIR, 1>(y[1][1]); y[1][2] = rot16c<DIR, 2>(y[1][2]); y[1][3] = rot16c<DIR, 3>(y[1][3]);
+    y[2][1] = rot16c<DIR, 2>(y[2][1]); y[2][2] = mul_i<DIR>(y[2][2]);      y[2][3] = rot16c<DIR, 6>(y[2][3]);
+    y[3][1] = rot16c<DIR, 3>(y[3][1]); y[3][2] = rot16c<DIR, 6>(y[3][2]); y[3][3] = rot16c<DIR, 9>(y[3][3]);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) {
+        C z[4] = {y[0][k1], y[1][k1], y[2][k1], y[3][k1]};
+        bfly4<DIR>(z);
+        v[k1] = z[0]; v[k1 + 4] = z[1]; v[k1 + 8] = z[2]; v[k1 + 12] = z[3];
+    }
+}
+// radix 9 = 3 x 3 (n = 3 n1 + n2, k = k1 + 3 k2), internal twiddles exp(DIR 2 pi i n2 k1 / 9)
+template <int DIR, typename C> __device__ __forceinline__ void bfly9(C* v)
+{
+    C y[3][3];
+#pragma unroll
+    for (int n2 = 0; n2 < 3; n2++) {
+        y[n2][0] = v[n2]; y[n2][1] = v[3 + n2]; y[n2][2] = v[6 + n2];
+        bfly3<DIR>(y[n2]);
+    }
+    y[1][1] = rot9c<DIR, 1>(y[1][1]); y[1][2] = rot9c<DIR, 2>(y[1][2]);
+    y[2][1] = rot9c<DIR, 2>(y[2][1]); y[2][2] = rot9c<DIR, 4>(y[2][2]);
+#pragma unroll
+    for (int k1 = 0; k1 < 3; k1++) {
+        C z[3] = {y[0][k1], y[1][k1], y[2][k1]};
+        bfly3<DIR>(z);
+        v[k1] = z[0]; v[k1 + 3] = z[1]; v[k1 + 6] = z[2];
+    }
+}
+// radix 15 = 3 x 5 by the prime-factor mapping (no internal twiddles): n = (5 n1 + 3 n2) mod 15,
+// k = (10 k1 + 6 k2) mod 15, so that w15^(nk) = w3^(n1 k1) w5^(n2 k2)
+template <int DIR, typename C> __device__ __forceinline__ void bfly15(C* v)
+{
+    C y[5][3];
+#pragma unroll
+    for (int n2 = 0; n2 < 5; n2++) {
+#pragma unroll
+        for (int n1 = 0; n1 < 3; n1++) y[n2][n1] = v[(5 * n1 + 3 * n2) % 15];
+        bfly3<DIR>(y[n2]);                          // -> y[n2][k1]
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 3; k1++) {
+        C z[5] = {y[0][k1], y[1][k1], y[2][k1], y[3][k1], y[4][k1]};
+        bfly5<DIR>(z);                              // -> z[k2]
+#pragma unroll
+        for (int k2 = 0; k2 < 5; k2++) v[(10 * k1 + 6 * k2) % 15] = z[k2];
+    }
+}
+
 template <int R, int DIR, typename C> __device__ __forceinline__ void bfly(C* v)
 {
     if constexpr (R == 2) bfly2<DIR>(v);
@@ -140,6 +217,9 @@ template <int R, int DIR, typename C> __device__ __forceinline__ void bfly(C* v)
     else if constexpr (R == 5) bfly5<DIR>(v);
     else if constexpr (R == 7) bfly7<DIR>(v);
     else if constexpr (R == 8) bfly8<DIR>(v);
+    else if constexpr (R == 9) bfly9<DIR>(v);
+    else if constexpr (R == 15) bfly15<DIR>(v);
+    else if constexpr (R == 16) bfly16<DIR>(v);
 }
 
 // twiddle the R inputs of one butterfly: v[m] *= exp(DIR * 2 pi i * m * tidx / N), tidx = k*tstep.
@@ -171,6 +251,18 @@ __device__ __forceinline__ void apply_twiddles(C* v, const C* __restrict__ tw, i
         C w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
         v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
         v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7);
+    } else {
+        // R = 9, 15, 16: powers 1, 2, 4, 8 from the table, the others as products of two of them
+        static_assert(R == 9 || R == 15 || R == 16, "radix");
+        C w1 = twid<DIR>(tw[tidx]), w2 = twid<DIR>(tw[2 * tidx]), w4 = twid<DIR>(tw[4 * tidx]), w8 = twid<DIR>(tw[8 * tidx]);
+        C w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
+        v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
+        v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7); v[8] = cmul(v[8], w8);
+        if constexpr (R >= 15) {
+            v[9] = cmul(v[9], cmul(w8, w1)); v[10] = cmul(v[10], cmul(w8, w2)); v[11] = cmul(v[11], cmul(w8, w3));
+            v[12] = cmul(v[12], cmul(w8, w4)); v[13] = cmul(v[13], cmul(w8, w5)); v[14] = cmul(v[14], cmul(w8, w6));
+        }
+        if constexpr (R == 16) v[15] = cmul(v[15], cmul(w8, w7));
     }
 }
 

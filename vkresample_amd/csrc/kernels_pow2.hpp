@@ -85,26 +85,6 @@ template <int R> __device__ __forceinline__ void twiddle_powers(float2* v, float
     }
 }
 
-// radix-16 butterfly as 4 x 4 (n = 4 n1 + n2, k = k1 + 4 k2) with the internal twiddles exp(DIR 2 pi i n2 k1/16)
-template <int DIR> __device__ __forceinline__ void bfly16(float2* v)
-{
-    float2 y[4][4];
-#pragma unroll
-    for (int n2 = 0; n2 < 4; n2++) {
-        y[n2][0] = v[n2]; y[n2][1] = v[4 + n2]; y[n2][2] = v[8 + n2]; y[n2][3] = v[12 + n2];
-        bfly4<DIR>(y[n2]);
-    }
-    y[1][1] = cmul(y[1][1], twid<DIR>(rot16<1>())); y[1][2] = cmul(y[1][2], twid<DIR>(rot16<2>())); y[1][3] = cmul(y[1][3], twid<DIR>(rot16<3>()));
-    y[2][1] = cmul(y[2][1], twid<DIR>(rot16<2>())); y[2][2] = mul_i<DIR>(y[2][2]);                  y[2][3] = cmul(y[2][3], twid<DIR>(rot16<6>()));
-    y[3][1] = cmul(y[3][1], twid<DIR>(rot16<3>())); y[3][2] = cmul(y[3][2], twid<DIR>(rot16<6>())); y[3][3] = cmul(y[3][3], twid<DIR>(rot16<9>()));
-#pragma unroll
-    for (int k1 = 0; k1 < 4; k1++) {
-        float2 z[4] = {y[0][k1], y[1][k1], y[2][k1], y[3][k1]};
-        bfly4<DIR>(z);
-        v[k1] = z[0]; v[k1 + 4] = z[1]; v[k1 + 8] = z[2]; v[k1 + 12] = z[3];
-    }
-}
-
 // ---- one stage on registers: E/R butterflies of radix R (compile-time recursion over b)
 template <int N, int E, int R, int Ns, int DIR, int B>
 __device__ __forceinline__ void butterfly_b(float2 (&v)[E], float2 wbase)
@@ -121,8 +101,7 @@ __device__ __forceinline__ void butterfly_b(float2 (&v)[E], float2 wbase)
             if constexpr (Ns > Tc && B > 0) w1 = cmul(w1, twid<DIR>(rot16<B * (16 / E)>()));
             twiddle_powers<R>(w, w1);
         }
-        if constexpr (R == 16) bfly16<DIR>(w);
-        else bfly<R, DIR>(w);
+        bfly<R, DIR>(w);
 #pragma unroll
         for (int m = 0; m < R; m++) v[B + m * NB] = w[m];
         butterfly_b<N, E, R, Ns, DIR, B + 1>(v, wbase);
