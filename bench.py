@@ -34,7 +34,7 @@ def parse_args():
     ap.add_argument("--precision", type=int, default=0, help="0 = fp32 (headline), 1 = fp64, 2 = fp16 memory")
     ap.add_argument("--fuse-u8", action="store_true", help="row kernel reads uint8 RGB directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the bounded CPU-baseline sample (~15 s on 128 threads)")
     ap.add_argument("--profile-iters", type=int, default=50)
     ap.add_argument("--event-stride", type=int, default=8, help="kernel-timing events on every n-th frame of the timed region")
     ap.add_argument("--streams", type=int, default=2,
