@@ -65,6 +65,10 @@ typedef struct fftup_config {
     uint32_t ring;            /* resident input/output frame slots (0 or 1 = one, like the reference) */
 } fftup_config;
 
+/* Environment read once by fftup_plan_create (tuning and test knobs, not part of the reference's surface):
+ *   FFTUP_STREAMS=n          HIP streams consecutive frames / iterations alternate on (default 2, 1..4)
+ *   FFTUP_PAIRS_PER_STRIP=n  row pairs per workgroup of the fused C2R+sharpen kernel (default: pairs / compute units) */
+
 typedef struct fftup_plan fftup_plan;   /* opaque; replaces VkGPU + 2x VkFFTApplication +
                                            2x VkShiftApplication + the three device buffers      */
 
