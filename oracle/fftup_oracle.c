@@ -460,6 +460,16 @@ ORC_API int orc_upscale_rgb8(const orc_config* c, const uint8_t* rgb, double* pr
     return rc;
 }
 
+/* threads used by the following calls (small images: a team of 100+ threads costs more than the work) */
+ORC_API void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORC_API int orc_num_threads(void)
 {
 #ifdef _OPENMP

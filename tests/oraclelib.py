@@ -66,6 +66,7 @@ def upscale_planes(planes, upscale=2.0, precision=0, sharpen=0.2):
     _, H, W = planes.shape
     cfg = _cfg(W, H, upscale, precision, sharpen)
     uW, uH = out_dims(W, H, upscale)
+    _fit_threads(uW * uH)
     pre = np.empty((3, uH, uW))
     out = np.empty((3, uH, uW))
     poison = C.c_uint64(0)
@@ -83,6 +84,7 @@ def upscale_rgb8(rgb, upscale=2.0, precision=0, sharpen=0.2, u8_wrap=0):
     H, W, _ = rgb.shape
     cfg = _cfg(W, H, upscale, precision, sharpen, u8_wrap)
     uW, uH = out_dims(W, H, upscale)
+    _fit_threads(uW * uH)
     pre = np.empty((3, uH, uW))
     out = np.empty((3, uH, uW))
     rgb_out = np.empty((uH, uW, 3), dtype=np.uint8)
@@ -102,6 +104,18 @@ def sharpen(R, upscale=2.0, precision=0, sharpen=0.2):
     lib().orc_sharpen(C.byref(cfg), R.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
                       C.c_uint32(uW), C.c_uint32(uH))
     return out
+
+
+_MAX_THREADS = None
+
+
+def _fit_threads(pixels):
+    """a thread team sized to the image: one thread per ~64k output pixels, at most what the host offers"""
+    global _MAX_THREADS
+    L = lib()
+    if _MAX_THREADS is None:
+        _MAX_THREADS = L.orc_num_threads()
+    L.orc_set_num_threads(int(min(_MAX_THREADS, max(1, pixels // 65536))))
 
 
 def num_threads():

@@ -1,0 +1,60 @@
+"""GPU: seeded sweep over sizes / upscale factors / precisions / flags on the size-generic path (every
+2,3,5,7-smooth size the reference's scheduler accepts, vkFFT.h:4719-4726), each case against the oracle."""
+import numpy as np
+import pytest
+
+import oraclelib as O
+
+pytestmark = pytest.mark.gpu
+
+SMOOTH = sorted({2 ** a * 3 ** b * 5 ** c * 7 ** d for a in range(1, 10) for b in range(4) for c in range(3) for d in range(3)
+                 if 4 <= 2 ** a * 3 ** b * 5 ** c * 7 ** d <= 640})
+
+
+def _smooth(n):
+    for q in (2, 3, 5, 7):
+        while n % q == 0:
+            n //= q
+    return n == 1
+
+
+def _cases():
+    rng = np.random.default_rng(20260930)
+    out = []
+    while len(out) < 72:
+        W, H = int(rng.choice(SMOOTH)), int(rng.choice(SMOOTH))
+        u = float(rng.choice([1.0, 1.25, 1.5, 2.0, 2.0, 2.0, 2.5, 3.0, 4.0]))
+        uW, uH = int(np.float32(u) * np.float32(W)), int(np.float32(u) * np.float32(H))
+        if uW % 2 or uH % 2 or not _smooth(uW) or not _smooth(uH) or uW * uH > 1 << 20 or uW > 4096:
+            continue
+        p = int(rng.choice([0, 0, 1, 2]))
+        flags = int(rng.choice([0, 2])) if p != 1 else 0
+        out.append((W, H, u, p, flags, float(rng.choice([0.2, 0.2, 0.05, 0.0])), len(out)))
+    return out
+
+
+@pytest.mark.parametrize("W,H,u,p,flags,sharpen,seed", _cases())
+def test_sweep_against_oracle(W, H, u, p, flags, sharpen, seed):
+    import vkresample_amd as v
+    from vkresample_amd import synth
+    rgb = synth.frame(1000 + seed, W, H, "N" if seed % 3 else "U")
+    if O.check(W, H, u, p) != 0:
+        pytest.skip("not a configuration of the reference")
+    with v.Upscaler(W, H, u, p, sharpen, 0, flags) as up:
+        up.upload_rgb8(rgb)
+        up.execute(1)
+        pre = up.download_presharpen().astype(np.float64)
+        out = up.download_planar().astype(np.float64)
+    opre, oout, _ = O.upscale_rgb8(rgb, u, p, sharpen)
+    scale = 1.0 / (np.float32(u) * np.float32(u))                      # the pre-sharpen image is g / u^2
+    if p == 1:
+        assert np.abs(pre - opre).max() <= 1e-12
+        assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1e-7      # sqrt(min) has unbounded slope at 0 (see the fp32 test)
+    elif p == 0:
+        assert np.abs(pre - opre).max() <= 1e-4 * scale * 4 and np.linalg.norm(pre - opre) <= 1e-5 * np.linalg.norm(opre)
+        assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 2e-3
+        assert np.linalg.norm(out[:, :-1] - oout[:, :-1]) <= 2e-4 * np.linalg.norm(oout[:, :-1])
+    else:
+        ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
+        assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
+        assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1.6e-2 and np.linalg.norm(out[:, :-1] - oout[:, :-1]) <= 2e-3 * np.linalg.norm(oout[:, :-1])
