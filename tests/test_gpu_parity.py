@@ -488,3 +488,44 @@ def test_hip_path_reproduces_reference_output_crops(name, flags):
     Yo, Xo = int(d["Yo"]), int(d["Xo"])
     diff = np.abs(u8[Yo:Yo + 300, Xo:Xo + 300].astype(np.int64) - d["fft_panel"].astype(np.int64))[r0:r1, c0:c1]
     assert diff.mean() <= 0.35 and np.percentile(diff, 99) <= 1 and diff.max() <= 3
+
+
+def test_plans_in_concurrent_host_threads():
+    """one plan per host thread, no shared mutable state (the reference's -numthreads model, VR:1282-1320, 1959-1969):
+    four threads with different configurations run interleaved on one device and reproduce their single-threaded
+    results bit for bit; errors stay thread-local."""
+    import threading
+    import vkresample_amd as v
+    from vkresample_amd import synth
+    cfgs = [(512, 256, 0, 0), (240, 126, 0, 0), (512, 256, 2, 2), (128, 64, 1, 0)]
+    frames = [[synth.frame(700 + 10 * t + k, W, H) for k in range(6)] for t, (W, H, _, _) in enumerate(cfgs)]
+
+    def run(t, out):
+        W, H, p, flags = cfgs[t]
+        res = []
+        with v.Upscaler(W, H, 2.0, p, 0.2, 0, flags, ring=2) as up:
+            for rep in range(3):
+                for k, f in enumerate(frames[t]):
+                    up.upload_rgb8(f, slot=k % 2)
+                    up.execute_ring(1, k % 2)
+                    if rep == 2:
+                        res.append(up.download_rgb8(k % 2))
+            try:
+                v.Upscaler(2 * 11 * 64, 64)                 # a failing call in this thread ...
+            except v.FftupError as e:
+                res.append(e.code)
+        out[t] = res
+
+    want = [None] * 4
+    for t in range(4):
+        run(t, want)
+    got = [None] * 4
+    th = [threading.Thread(target=run, args=(t, got)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for t in range(4):
+        assert got[t][-1] == 2 and want[t][-1] == 2
+        for a, b in zip(got[t][:-1], want[t][:-1]):
+            assert np.array_equal(a, b)
