@@ -19,9 +19,10 @@ def _smooth(n):
 
 
 def _cases():
-    rng = np.random.default_rng(20260930)
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FFTUP_SWEEP_SEED", "20260930")))
     out = []
-    while len(out) < 72:
+    while len(out) < int(os.environ.get("FFTUP_SWEEP_N", "72")):      # (a one-off 1500-case run is logged in profiles/)
         W, H = int(rng.choice(SMOOTH)), int(rng.choice(SMOOTH))
         u = float(rng.choice([1.0, 1.25, 1.5, 2.0, 2.0, 2.0, 2.5, 3.0, 4.0]))
         uW, uH = int(np.float32(u) * np.float32(W)), int(np.float32(u) * np.float32(H))
