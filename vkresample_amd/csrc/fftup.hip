@@ -925,7 +925,7 @@ int fftup_download_rgb8(fftup_plan* P, uint32_t slot, uint8_t* rgb, size_t row_s
 void* fftup_host_alloc(size_t bytes)
 {
     void* p = nullptr;
-    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);   // page-locked for every device (-alldevices)
     if (e != hipSuccess) {
         fail(FFTUP_E_OUT_OF_MEMORY, std::string("hipHostMalloc: ") + hipGetErrorString(e));
         return nullptr;
