@@ -62,11 +62,12 @@ typedef struct fftup_config {
     float    sharpen;         /* -s sharpening constant (VR:1616)                                    */
     int32_t  device;          /* -d HIP device ordinal                                               */
     uint32_t flags;           /* FFTUP_FLAG_*                                                        */
-    uint32_t ring;            /* resident input/output frame slots (0 or 1 = one, like the reference) */
+    uint32_t ring;            /* resident input/output frame slots (0 or 1 = one, like the reference; <= 64) */
 } fftup_config;
 
 /* Environment read once by fftup_plan_create (tuning and test knobs, not part of the reference's surface):
- *   FFTUP_STREAMS=n          HIP streams consecutive frames / iterations alternate on (default 2, 1..4)
+ *   FFTUP_STREAMS=n          HIP streams consecutive frames of fftup_execute_ring / fftup_submit_rgb8 alternate on
+ *                            (default 2, 1..4); fftup_execute always uses one
  *   FFTUP_PAIRS_PER_STRIP=n  row pairs per workgroup of the fused C2R+sharpen kernel (default: pairs / compute units) */
 
 typedef struct fftup_plan fftup_plan;   /* opaque; replaces VkGPU + 2x VkFFTApplication +
@@ -106,8 +107,11 @@ FFTUP_API int fftup_upload_rgb8_slot(fftup_plan* plan, uint32_t slot, const uint
 FFTUP_API int fftup_upload_planar(fftup_plan* plan, uint32_t slot, const void* planes,
                                   size_t row_stride_elems, size_t plane_stride_elems);
 
-/* performVulkanUpscale (VR:1249-1279): enqueue n_iter full pipelines back to back on the plan's
- * stream, one synchronisation, returns device-timed milliseconds per iteration. */
+/* performVulkanUpscale (VR:1249-1279): enqueue n_iter full pipelines back to back on the plan's ONE
+ * stream (the reference records them into one command buffer on one queue), one synchronisation.
+ * *ms_per_iter = device time from before the first to after the last launch, divided by n_iter -- the
+ * reference's "Time: X ms" (VR:1270-1278): single-queue frame latency, no overlap between iterations.
+ * Every iteration reads input slot 0 and writes output slot 0. */
 FFTUP_API int fftup_execute(fftup_plan* plan, uint32_t n_iter, double* ms_per_iter);
 /* batched mode: n_frames pipelines, frame i reads input slot (first_slot+i) % ring and writes
  * output slot (first_slot+i) % ring; returns total device milliseconds. */

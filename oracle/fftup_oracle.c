@@ -193,6 +193,9 @@ ORC_API int orc_fft1d(double* data, uint32_t n, int sign)
 
 /* VR:1644  buffer_input[...] = (float)png_input[...] / 255.0;   (double division, float store)
  * VR:1676  buffer_input[...] = (half)png_input[...] / 255.0;     (half -> float -> double / -> half) */
+/* exported for tests/test_oracle.py: pinned against the reference's half.hpp (oracle/_ref) */
+ORC_API double orc_round_half(double x) { return round_half(x); }
+
 ORC_API double orc_load_u8(uint32_t precision, uint8_t v)
 {
     if (precision == 2) {

@@ -32,14 +32,31 @@ def save(name, rgb, u, precision, sharpen=0.2):
     print(name, rgb.shape, "->", u8.shape)
 
 
-def sample_crop():
+def sample_full():
+    """stb_image decode (forced to 3 channels, VkResample.cpp:1362) of the reference's samples/no_upscaling.png"""
     ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_host.so"))
     ref.ref_png_load_rgb.restype = C.POINTER(C.c_ubyte)
     w, h, ch = C.c_int(), C.c_int(), C.c_int()
     p = ref.ref_png_load_rgb(b"/root/reference/samples/no_upscaling.png", C.byref(w), C.byref(h), C.byref(ch))
     img = np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
     ref.ref_free(p)
-    return img[500:564, 900:964].copy()
+    return img
+
+
+def sample_crop():
+    return sample_full()[500:564, 900:964].copy()
+
+
+def save_config1():
+    """BASELINE config 1: the decoded pixels of samples/no_upscaling.png (data, not source) + digests of the oracle's
+    -u 2 -p 0 output so that a GPU-box run can tell a broken oracle build from a broken HIP path."""
+    rgb = sample_full()
+    assert rgb.shape == (1080, 1920, 3)
+    pre, out, u8 = O.upscale_rgb8(rgb, 2.0, 0, 0.2)
+    np.savez_compressed(os.path.join(HERE, "no_upscaling_rgb.npz"), rgb=rgb, upscale=2.0, precision=0, sharpen=0.2,
+                        out_plane_means=out.mean(axis=(1, 2)), out_crop=out[:, 1000:1064, 1800:1864],
+                        u8_crop=u8[1000:1064, 1800:1864], u8_sum=np.int64(u8.astype(np.int64).sum()))
+    print("no_upscaling_rgb", rgb.shape, "->", u8.shape)
 
 
 if __name__ == "__main__":
@@ -49,3 +66,4 @@ if __name__ == "__main__":
     save("g64x32_u2_p0", synth.frame(102, 64, 32, "N"), 2.0, 0)
     save("g64x32_u2_p2", synth.frame(102, 64, 32, "N"), 2.0, 2)
     save("gsample64_u2_p0", sample_crop(), 2.0, 0)
+    save_config1()

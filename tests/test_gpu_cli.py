@@ -39,6 +39,22 @@ def test_cli_single_image_1080p(tmp_path):
     assert out.shape == (2160, 3840, 3) and d.max() <= 1 and (d != 0).mean() <= 5e-3
 
 
+def test_cli_config1_literal_image(tmp_path):
+    """BASELINE config 1 end to end: the pixels of the reference's samples/no_upscaling.png (committed as data,
+    tests/golden/no_upscaling_rgb.npz; the reference decodes RGBA to 3 channels, VR:1362) -u 2 -p 0 -n 1."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", "no_upscaling_rgb.npz"))
+    _png_write(tmp_path / "no_upscaling.png", d["rgb"])
+    r = subprocess.run([CLI, "-i", "no_upscaling.png", "-o", "up.png", "-u", "2", "-p", "0", "-n", "1"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert re.search(r"VkResample 2\.0x upscale: 1920x1080 to 3840x2160 Time: [0-9.]+ ms", r.stdout)
+    out = _png_read(tmp_path / "up.png")
+    _, _, ou8 = O.upscale_rgb8(d["rgb"], 2.0, 0, 0.2)
+    assert np.array_equal(ou8[1000:1064, 1800:1864], d["u8_crop"])
+    dd = np.abs(out[:-1].astype(int) - ou8[:-1].astype(int))
+    assert out.shape == (2160, 3840, 3) and dd.max() <= 1 and (dd != 0).mean() <= 5e-3
+
+
 def test_cli_batched_two_threads(tmp_path):
     from vkresample_amd import synth
     os.makedirs(tmp_path / "inp")

@@ -136,9 +136,9 @@ def test_sharpen_fp16_bit_exact_given_same_R():
     assert np.array_equal(out, oout)
 
 
-def _run_rgb(rgb, u, precision, sharpen=0.2):
+def _run_rgb(rgb, u, precision, sharpen=0.2, flags=0):
     H, W, _ = rgb.shape
-    with _up(W, H, u, precision, sharpen) as up:
+    with _up(W, H, u, precision, sharpen, 0, flags) as up:
         up.upload_rgb8(rgb)
         up.execute(1)
         pre = up.download_presharpen().astype(np.float64)
@@ -219,20 +219,66 @@ def test_repeat_is_deterministic_and_ring():
         assert np.abs(outs[s][:, :-1] - oout[:, :-1]).max() <= 1e-3
 
 
-@pytest.mark.parametrize("W,H,precision", [(2048, 1024, 0), (1920, 1080, 0), (2048, 1024, 2)])
-def test_full_size_vs_oracle(W, H, precision):
-    """BASELINE configs 2-4 at full size against the (multi-threaded) oracle."""
-    (pre, out, u8), (opre, oout, ou8) = _run(W, H, 2.0, precision, "N")
+def _report(tag, err, thr):
+    """error distribution of a full-size comparison: printed (pytest -s / the committed profiles/*_parity.txt) and
+    returned, so that the tail is a number and not a story"""
+    a = np.abs(err).ravel()
+    stats = {"p50": float(np.percentile(a, 50)), "p99": float(np.percentile(a, 99)), "p99.99": float(np.percentile(a, 99.99)),
+             "max": float(a.max()), "count_above": int((a > thr).sum()), "n": int(a.size), "thr": thr}
+    print("PARITY %s: p50 %.3g  p99 %.3g  p99.99 %.3g  max %.3g  count(>%g) %d of %d (%.2e)"
+          % (tag, stats["p50"], stats["p99"], stats["p99.99"], stats["max"], thr, stats["count_above"], stats["n"],
+             stats["count_above"] / stats["n"]))
+    return stats
+
+
+FULL_SIZE = [(2048, 1024, 0, 0), (2048, 1024, 0, 2), (1920, 1080, 0, 0), (1920, 1080, 0, 2), (2048, 1024, 2, 0), (2048, 1024, 2, 2)]
+
+
+@pytest.mark.parametrize("W,H,precision,flags", FULL_SIZE)
+@pytest.mark.parametrize("dist", ["N", "U"])
+def test_full_size_vs_oracle(W, H, precision, flags, dist):
+    """BASELINE configs 2-4 at full size against the (multi-threaded) oracle; flags = 2 is FFTUP_FLAG_FUSE_U8_LOAD,
+    i.e. config 3 exactly as BASELINE states it (-p 2, uint8 load fused) and the same for fp32.
+    fp32: sharpened output p99.99 <= 1e-4 (north_star's tolerance), max <= 1e-3 (the filter's sqrt has unbounded
+    slope at 0: a handful of pixels whose 3x3 minimum is exactly 0 in fp64 amplify fp32 noise)."""
+    (pre, out, u8), (opre, oout, ou8) = _run(W, H, 2.0, precision, dist, flags=flags)
+    tag = "%dx%d p%d flags%d %s" % (W, H, precision, flags, dist)
     if precision == 0:
+        sp = _report(tag + " pre*u^2", (pre - opre) * 4, 1e-5)
+        so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 1e-4)
         assert _rel_l2(pre, opre) <= 1e-5
-        assert np.abs(pre - opre).max() * 4 <= 1e-4
+        assert sp["max"] <= 1e-4 and sp["p99.99"] <= 1e-5
         assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-4
-        assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1e-3
+        assert so["p99.99"] <= 1e-4 and so["max"] <= 1e-3 and so["count_above"] <= 1e-4 * so["n"]
+        d = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
+        assert d.max() <= 1 and (d != 0).mean() <= 5e-3
     else:
         ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
         assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
+        # in binary16 ulps of the output (ulp at 0.5..1 = 4.9e-4): the sharpen amplifies one-ulp input flips
+        so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 2.0 ** -10)
         assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-3
-        assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 8e-3
+        assert so["max"] <= 8e-3 and so["p99"] <= 2.0 ** -10 and so["p99.99"] <= 4e-3
+
+
+def _config1_rgb():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "no_upscaling_rgb.npz"))
+
+
+@pytest.mark.parametrize("flags", [0, 2])
+def test_config1_literal_image_api(flags):
+    """BASELINE config 1: the decoded pixels of the reference's samples/no_upscaling.png (stb_image, 3 channels,
+    VR:1362) -u 2 -p 0 -n 1 through the C ABI, float planes and u8 against the oracle."""
+    d = _config1_rgb()
+    (pre, out, u8), (opre, oout, ou8) = _run_rgb(d["rgb"], 2.0, 0, flags=flags)
+    assert np.abs(oout[:, 1000:1064, 1800:1864] - d["out_crop"]).max() <= 1e-12       # the oracle build is sane
+    so = _report("config1 no_upscaling.png flags%d out" % flags, out[:, :-1] - oout[:, :-1], 1e-4)
+    assert np.abs(pre - opre).max() * 4 <= 1e-4 and _rel_l2(pre, opre) <= 1e-5
+    assert so["p99.99"] <= 1e-4 and so["max"] <= 1e-3
+    dd = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
+    print("PARITY config1 u8: differing codes %.2e, max %d" % ((dd != 0).mean(), dd.max()))
+    assert dd.max() <= 1 and (dd != 0).mean() <= 5e-3
 
 
 def test_full_size_properties():

@@ -55,6 +55,47 @@ def test_load_conversion_table():
     assert np.array_equal(O.load_lut(0), (v.astype(np.float32) / np.float32(255)).astype(np.float64))
 
 
+REFSO = os.path.join(os.path.dirname(GOLDEN.rstrip("/")), "..", "oracle", "_ref", "libref_host.so")
+
+
+@pytest.mark.skipif(not os.path.exists(REFSO), reason="oracle/_ref is built only where /root/reference exists")
+def test_oracle_load_matches_reference_half_hpp():
+    """The oracle's load/store conversions against the REFERENCE's own host code compiled where it lies
+    (oracle/ref_host_shim.cpp -> oracle/_ref/libref_host.so): VkResample.cpp:1644 (float), :1676 (half.hpp
+    arithmetic, -p 2), :1715 (unsigned char cast of 255.0*x) and half.hpp's float->half rounding."""
+    import ctypes as C
+    ref = C.CDLL(REFSO)
+    ref.ref_pack_half.restype = C.c_double
+    ref.ref_pack_half.argtypes = [C.c_ubyte]
+    ref.ref_pack_float.restype = C.c_double
+    ref.ref_pack_float.argtypes = [C.c_ubyte]
+    ref.ref_unpack_float.restype = C.c_ubyte
+    ref.ref_unpack_float.argtypes = [C.c_float]
+    ref.ref_half_round.restype = C.c_double
+    ref.ref_half_round.argtypes = [C.c_double]
+    lut0, lut2 = O.load_lut(0), O.load_lut(2)
+    assert np.array_equal(lut0, np.array([ref.ref_pack_float(v) for v in range(256)]))
+    assert np.array_equal(lut2, np.array([ref.ref_pack_half(v) for v in range(256)]))
+    # every value the -p 2 path can hold round-trips through half.hpp unchanged, and the oracle's
+    # round-to-binary16 equals half.hpp's on a dense sweep incl. ties, subnormals and the overflow edge
+    L = O.lib()
+    L.orc_round_half.restype = C.c_double
+    L.orc_round_half.argtypes = [C.c_double]
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.uniform(-2, 2, 20000), rng.uniform(-1e-4, 1e-4, 5000),
+                         (np.arange(0, 4096) + 0.5) * 2.0 ** -11, [0.0, 6.0e-8, 2.0 ** -25, 65504.0, 65519.0]])
+    xs = xs.astype(np.float32).astype(np.float64)              # half.hpp converts from float
+    for x in xs:
+        assert L.orc_round_half(float(x)) == ref.ref_half_round(float(x)), x
+    # store: in range the reference's cast truncates exactly like the oracle (both modes agree there)
+    for x in np.concatenate([np.arange(256) / 255.0, rng.uniform(0, 1, 4000)]).astype(np.float32):
+        want = ref.ref_unpack_float(float(x))
+        assert L.orc_store_u8(float(x), 0) == want and L.orc_store_u8(float(x), 1) == want, x
+    # out of range the reference is UB; the wrap mode reproduces what x86-64 gcc does with it
+    for x in (-1.6 / 255, -0.3, 256.3 / 255, 1.5):
+        assert L.orc_store_u8(float(np.float32(x)), 1) == ref.ref_unpack_float(float(np.float32(x)))
+
+
 def test_store_u8():
     L = O.lib()
     assert L.orc_store_u8(0.5, 0) == 127 and L.orc_store_u8(1.0, 0) == 255 and L.orc_store_u8(0.999, 0) == 254
@@ -203,6 +244,17 @@ def test_golden_vectors(name):
     assert np.abs(pre - d["pre"]).max() <= 1e-13
     assert np.abs(out - d["out"]).max() <= 1e-12
     assert np.array_equal(u8, d["u8"])
+
+
+def test_config1_fixture_digests():
+    """BASELINE config 1 (samples/no_upscaling.png, stb_image-decoded, -u 2 -p 0): the oracle on the committed
+    pixels reproduces the digests stored with them (bounded: one 1080p frame, ~2 s)."""
+    d = np.load(os.path.join(GOLDEN, "no_upscaling_rgb.npz"))
+    assert d["rgb"].shape == (1080, 1920, 3)
+    _, out, u8 = O.upscale_rgb8(d["rgb"], 2.0, 0, 0.2)
+    assert np.abs(out.mean(axis=(1, 2)) - d["out_plane_means"]).max() <= 1e-12
+    assert np.abs(out[:, 1000:1064, 1800:1864] - d["out_crop"]).max() <= 1e-12
+    assert np.array_equal(u8[1000:1064, 1800:1864], d["u8_crop"]) and int(u8.astype(np.int64).sum()) == int(d["u8_sum"])
 
 
 # ------------------------------------------------------------------ the reference's own output (README strips)

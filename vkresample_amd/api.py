@@ -168,6 +168,18 @@ class PinnedArray:
             self._lib.fftup_host_free(self._p)
             self._p = None
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 def upscale_image(rgb, upscale=2.0, precision=0, sharpen=0.2, num_iter=1, device=0, flags=0):
     """Single-image path of launchResample(): returns (rgb_out uint8 [uH][uW][3], ms_per_iter)."""

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 
 namespace pngio {
 namespace {
@@ -101,17 +102,34 @@ bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& width, i
         const char* type = (const char*)&file[pos + 4];
         if (pos + 12 + (size_t)len > file.size()) { err = "truncated PNG"; return false; }
         const uint8_t* d = &file[pos + 8];
-        if (!memcmp(type, "IHDR", 4) && len >= 13) {
-            hd.w = (int)be32(d); hd.h = (int)be32(d + 4); hd.depth = d[8]; hd.ctype = d[9]; hd.interlace = d[12];
+        if (!memcmp(type, "IHDR", 4)) {
+            if (have_hdr || len != 13) { err = "bad IHDR"; return false; }
+            const uint32_t w32 = be32(d), h32 = be32(d + 4);
+            // stb_image's own limits: 2^24 per dimension; the decoded RGB must also fit comfortably in memory
+            if (w32 == 0 || h32 == 0 || w32 > (1u << 24) || h32 > (1u << 24) || (uint64_t)w32 * h32 > (1ull << 28)) { err = "bad IHDR (size)"; return false; }
+            hd.w = (int)w32; hd.h = (int)h32; hd.depth = d[8]; hd.ctype = d[9]; hd.interlace = d[12];
+            if (d[10] != 0 || d[11] != 0 || d[12] > 1) { err = "bad IHDR (compression/filter/interlace method)"; return false; }
             have_hdr = true;
-        } else if (!memcmp(type, "PLTE", 4)) pal.assign(d, d + len);
+        } else if (!have_hdr) { err = "first chunk is not IHDR"; return false; }
+        else if (!memcmp(type, "PLTE", 4)) {
+            if (len == 0 || len % 3 != 0 || len > 768) { err = "bad PLTE"; return false; }
+            pal.assign(d, d + len);
+        }
         else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), d, d + len);
         else if (!memcmp(type, "IEND", 4)) break;
         pos += 12 + (size_t)len;
     }
     if (!have_hdr || hd.w <= 0 || hd.h <= 0) { err = "bad IHDR"; return false; }
     if (!(hd.ctype == 0 || hd.ctype == 2 || hd.ctype == 3 || hd.ctype == 4 || hd.ctype == 6)) { err = "bad colour type"; return false; }
-    if (hd.ctype == 3 && pal.empty()) { err = "palette missing"; return false; }
+    {
+        // legal depth per colour type (PNG spec table 11.1): grey 1/2/4/8/16, palette 1/2/4/8, the others 8/16
+        const int dp = hd.depth;
+        const bool pow2 = dp == 1 || dp == 2 || dp == 4 || dp == 8 || dp == 16;
+        const bool ok = pow2 && (hd.ctype == 0 || (hd.ctype == 3 ? dp <= 8 : dp >= 8));
+        if (!ok) { err = "bad bit depth for colour type"; return false; }
+    }
+    if (hd.ctype == 3 && pal.size() < 3) { err = "palette missing"; return false; }
+    if (idat.empty()) { err = "no image data"; return false; }
     const int nch = channels_of(hd.ctype);
     const int bits = nch * hd.depth;
     const int bpp = bits >= 8 ? bits / 8 : 1;
@@ -126,14 +144,17 @@ bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& width, i
         const int ph = hd.interlace ? (hd.h - ys[p] + dy[p] - 1) / dy[p] : hd.h;
         if (pw > 0 && ph > 0) raw_size += (size_t)ph * (rowbytes(pw) + 1);
     }
-    std::vector<uint8_t> raw(raw_size);
+    std::vector<uint8_t> raw;
+    try {
+        raw.resize(raw_size);
+        rgb.assign((size_t)hd.w * hd.h * 3, 0);
+    } catch (const std::bad_alloc&) { err = "image too large"; return false; }
     uLongf dl = (uLongf)raw_size;
     int zr = uncompress(raw.data(), &dl, idat.data(), (uLong)idat.size());
     if (zr != Z_OK || dl != raw_size) { err = "zlib inflate failed"; return false; }
 
     width = hd.w; height = hd.h;
     channels_in_file = hd.ctype == 3 ? 3 : nch;
-    rgb.assign((size_t)hd.w * hd.h * 3, 0);
     size_t off = 0;
     std::vector<uint8_t> img;
     for (int p = 0; p < npass; p++) {

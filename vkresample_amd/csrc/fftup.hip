@@ -35,6 +35,22 @@ static int fail(int code, const std::string& msg)
                         std::string(#expr) + ": " + hipGetErrorString(_e));                        \
     } while (0)
 
+// events that are destroyed on every exit path
+struct EventList {
+    std::vector<hipEvent_t> ev;
+    ~EventList() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+    int create(size_t n)
+    {
+        ev.assign(n, nullptr);
+        for (auto& e : ev) {
+            hipError_t r = hipEventCreate(&e);
+            if (r != hipSuccess) { e = nullptr; return fail(FFTUP_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(r)); }
+        }
+        return FFTUP_OK;
+    }
+    hipEvent_t& operator[](size_t i) { return ev[i]; }
+};
+
 struct fftup_plan {
     fftup_config cfg{};
     uint32_t W = 0, H = 0, uW = 0, uH = 0;
@@ -211,6 +227,11 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
     if (cfg->channels != 3) return fail(FFTUP_E_INVALID_ARG, "channels must be 3 (VkResample.cpp:1368)");
     if (cfg->precision > 2) return fail(FFTUP_E_UNSUPPORTED_PRECISION, "precision must be 0 (single), 1 (double) or 2 (half)");
     const uint32_t W = cfg->width, H = cfg->height;
+    // the float -> uint32 casts below are undefined for NaN / out-of-range products: bound the inputs first
+    if (!(cfg->upscale >= 1.0f && cfg->upscale <= 64.0f)) return fail(FFTUP_E_INVALID_ARG, "upscale must be a finite number in [1, 64]");
+    if (W > (1u << 16) || H > (1u << 16)) return fail(FFTUP_E_INVALID_ARG, "width/height above 65536");
+    if (cfg->ring > 64) return fail(FFTUP_E_INVALID_ARG, "ring must be <= 64");
+    if (!(cfg->sharpen == cfg->sharpen)) return fail(FFTUP_E_INVALID_ARG, "sharpen is NaN");
     const uint32_t uW = (uint32_t)(cfg->upscale * (float)W);     // VkResample.cpp:1417-1418
     const uint32_t uH = (uint32_t)(cfg->upscale * (float)H);
     if (W < 2 || H < 2 || (W & 1) || (H & 1) || (uW & 1) || (uH & 1) || uW < W || uH < H)
@@ -729,10 +750,10 @@ static int execute_ring_impl(fftup_plan* P, uint32_t n_frames, uint32_t first_sl
     // every `stride`-th frame is bracketed with events (an event record costs ~1 us of queue time each)
     if (stride == 0) stride = 1;
     const uint32_t n_timed = kernel_ms ? (n_frames + stride - 1) / stride : 0;
-    std::vector<hipEvent_t> ev;
+    EventList ev;
     if (kernel_ms) {
-        ev.resize((size_t)n_timed * (nk + 1));
-        for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+        int erc = ev.create((size_t)n_timed * (nk + 1));
+        if (erc) return erc;
     }
     HIP_TRY(hipEventRecord(P->ev0, P->stream));
     // consecutive frames go to distinct lanes; they must then also write distinct output slots
@@ -778,7 +799,6 @@ static int execute_ring_impl(fftup_plan* P, uint32_t n_frames, uint32_t first_sl
         }
         P->executed = 1;
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
 }
 
@@ -799,20 +819,16 @@ int fftup_execute(fftup_plan* P, uint32_t n_iter, double* ms_per_iter)
     if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
     if (n_iter == 0) return fail(FFTUP_E_INVALID_ARG, "n_iter must be > 0");
     HIP_TRY(hipSetDevice(P->device));
-    // The reference records n_iter identical pipelines on one queue (VR:1260-1265).  They are independent
-    // (same input, bit-identical output), so they are spread over the plan's lanes like batched frames.
+    // The reference records n_iter identical pipelines in ONE command buffer on ONE queue (VR:1260-1265) and
+    // reports wall time / n_iter (VR:1270-1278): back-to-back frames on the plan's own stream, no overlap between
+    // iterations, every iteration writes output slot 0.  (Overlapped throughput is what fftup_execute_ring and
+    // fftup_submit_rgb8 are for.)
     HIP_TRY(hipEventRecord(P->ev0, P->stream));
-    for (int l = 1; l < P->nlanes; l++) HIP_TRY(hipStreamWaitEvent(P->lanes[l].stream, P->ev0, 0));
     for (uint32_t i = 0; i < n_iter; i++) {
-        P->cur = (int)(i % (uint32_t)P->nlanes);
-        int rc = launch_frame(P, 0, 0, -1);
-        P->last_lane = P->cur;
         P->cur = 0;
+        int rc = launch_frame(P, 0, 0, -1);
+        P->last_lane = 0;
         if (rc) return rc;
-    }
-    for (int l = 1; l < P->nlanes; l++) {
-        HIP_TRY(hipEventRecord(P->lanes[l].done, P->lanes[l].stream));
-        HIP_TRY(hipStreamWaitEvent(P->stream, P->lanes[l].done, 0));
     }
     HIP_TRY(hipEventRecord(P->ev1, P->stream));
     HIP_TRY(hipEventSynchronize(P->ev1));
@@ -828,9 +844,9 @@ int fftup_profile_kernels(fftup_plan* P, uint32_t n_iter, double* ms_per_kernel)
     if (!P || !ms_per_kernel) return fail(FFTUP_E_INVALID_ARG, "null argument");
     if (n_iter == 0) return fail(FFTUP_E_INVALID_ARG, "n_iter must be > 0");
     HIP_TRY(hipSetDevice(P->device));
-    std::vector<hipEvent_t> ev((size_t)n_iter * (FFTUP_NUM_KERNELS + 1));
-    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
-    int rc = FFTUP_OK;
+    EventList ev;
+    int rc = ev.create((size_t)n_iter * (FFTUP_NUM_KERNELS + 1));
+    if (rc) return rc;
     for (uint32_t i = 0; i < n_iter && !rc; i++) {
         hipEvent_t* e = &ev[(size_t)i * (FFTUP_NUM_KERNELS + 1)];
         (void)hipEventRecord(e[0], P->stream);
@@ -854,7 +870,6 @@ int fftup_profile_kernels(fftup_plan* P, uint32_t n_iter, double* ms_per_kernel)
         for (int k = 0; k < FFTUP_NUM_KERNELS; k++) ms_per_kernel[k] /= n_iter;
         P->executed = 1;
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
 }
 
@@ -941,15 +956,23 @@ void fftup_host_free(void* ptr)
 static int queue_init(fftup_plan* P)
 {
     if (!P->q.empty()) return FFTUP_OK;
-    P->q.resize(P->ring);
-    for (uint32_t s = 0; s < P->ring; s++) {
-        if (s == 0) P->q[s].out_u8 = P->out_u8;
-        else {
-            int rc = dev_alloc(P, (void**)&P->q[s].out_u8, (size_t)3 * P->uW * P->uH);
-            if (rc) return rc;
+    // built aside and published only when complete: a failure half way leaves the plan without a queue
+    std::vector<fftup_plan::QSlot> q(P->ring);
+    int rc = FFTUP_OK;
+    for (uint32_t s = 0; s < P->ring && !rc; s++) {
+        if (s == 0) q[s].out_u8 = P->out_u8;
+        else rc = dev_alloc(P, (void**)&q[s].out_u8, (size_t)3 * P->uW * P->uH);     // owned by P->allocs either way
+        if (!rc) {
+            hipError_t e = hipEventCreateWithFlags(&q[s].done, hipEventDisableTiming);
+            if (e != hipSuccess) { q[s].done = nullptr; rc = fail(FFTUP_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
         }
-        HIP_TRY(hipEventCreateWithFlags(&P->q[s].done, hipEventDisableTiming));
     }
+    if (rc) {
+        for (auto& qs : q)
+            if (qs.done) (void)hipEventDestroy(qs.done);
+        return rc;
+    }
+    P->q.swap(q);
     return FFTUP_OK;
 }
 
