@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the bounded CPU-baseline sample (~15 s on 128 threads)")
     ap.add_argument("--profile-iters", type=int, default=50)
     ap.add_argument("--event-stride", type=int, default=8, help="kernel-timing events on every n-th frame of the timed region")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams (lanes) consecutive frames alternate on; 1 = strictly sequential kernels")
     ap.add_argument("--host-streamed", action="store_true",
                     help="NOT the headline: frames start and end in pinned host memory (fftup_submit_rgb8 queue, "

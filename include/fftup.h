@@ -67,7 +67,8 @@ typedef struct fftup_config {
 
 /* Environment read once by fftup_plan_create (tuning and test knobs, not part of the reference's surface):
  *   FFTUP_STREAMS=n          HIP streams consecutive frames of fftup_execute_ring / fftup_submit_rgb8 alternate on
- *                            (default 2, 1..4); fftup_execute always uses one
+ *                            (default 3, 1..4); fftup_execute always uses one
+ *   FFTUP_G_PER_CU=n         strips (workgroups) of the fused C2R+sharpen kernel per compute unit (default 1)
  *   FFTUP_PAIRS_PER_STRIP=n  row pairs per workgroup of the fused C2R+sharpen kernel (default: pairs / compute units) */
 
 typedef struct fftup_plan fftup_plan;   /* opaque; replaces VkGPU + 2x VkFFTApplication +

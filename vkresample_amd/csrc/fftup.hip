@@ -74,7 +74,6 @@ struct fftup_plan {
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
     bool mixed1080 = false;           // compile-time mixed-radix plans (1920x1080 -> 3840x2160)
     int pairs_per_strip = 6;
-    size_t ldsFused2 = 0;
     bool R_valid = false;             // pre-sharpen buffer holds the last frame (unfused path only)
 
     // device memory
@@ -298,7 +297,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         P->TK = 0;
         if (P->tuned) {
             P->TK = TUNED_TK;
-            P->ldsCol = sizeof(float2) * (size_t)lpad_size((int)uH * TUNED_TK);
+            P->ldsCol = sizeof(float2) * (size_t)lswz_size((int)H * TUNED_TK);     // both transforms of k_col_t have length H
         } else {
             // column tile width: widest of 8,4,2,1 whose ping-pong buffers fit in LDS
             for (int tk : {8, 4, 2, 1}) {
@@ -311,12 +310,15 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
                        uH == 2160 && P->TK == 4;
         P->fused = P->tuned && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
         {
-            // one strip (workgroup) per compute unit
-            const int total_pairs = 3 * (int)uH / 2, cus = std::max(1, P->prop.multiProcessorCount);
-            P->pairs_per_strip = std::max(2, (total_pairs + cus - 1) / cus);
+            // One strip (workgroup of uW/8 threads) per compute unit by default.  Two fit (FFTUP_G_PER_CU=2: the kernel
+            // alone is 8 % faster), but one leaves half of every compute unit to the row and column kernels of the
+            // frames on the other streams, and the frame time is what counts (measured: 82 vs 86 us).
+            int per_cu = 1;
+            if (const char* e = getenv("FFTUP_G_PER_CU")) per_cu = std::max(1, std::min(4, atoi(e)));
+            const int total_pairs = 3 * (int)uH / 2, slots = std::max(1, P->prop.multiProcessorCount) * per_cu;
+            P->pairs_per_strip = std::max(2, (total_pairs + slots - 1) / slots);
         }
         if (const char* e = getenv("FFTUP_PAIRS_PER_STRIP")) P->pairs_per_strip = std::max(1, atoi(e));
-        P->ldsFused2 = uW == 1024 ? Fused2Lds<1024>::TOTAL : uW == 2048 ? Fused2Lds<2048>::TOTAL : Fused2Lds<4096>::TOTAL;
         P->NT = ((int)(W / 2 + 1) + P->TK - 1) / P->TK;
         P->ldsRowF = 2 * P->csz * (size_t)lpad_size((int)W);
         P->ldsRowI = 2 * P->csz * (size_t)lpad_size((int)uW);
@@ -344,12 +346,23 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             PLAN_RC(dev_alloc(P, (void**)&P->in_u8[s], (size_t)3 * W * H));
             PLAN_RC(dev_alloc(P, &P->out[s], (size_t)3 * uW * uH * esz));
         }
-        PLAN_RC(dev_alloc(P, (void**)&P->S1, P->csz * 3 * (size_t)P->NT * H * P->TK));
-        PLAN_RC(dev_alloc(P, (void**)&P->S2, P->csz * 3 * (size_t)P->NT * uH * P->TK));
+        // tuned plans (k_col_t): S2 holds the odd rows only and sits right behind S1 in ONE allocation (the fused
+        // kernel addresses both with 32-bit offsets from one base)
+        const size_t s1_elems = (size_t)3 * P->NT * H * P->TK;
+        auto alloc_spectra = [&](float2** s1, float2** s2) -> int {
+            if (P->tuned) {
+                int r = dev_alloc(P, (void**)s1, P->csz * 2 * s1_elems);
+                *s2 = r ? nullptr : *s1 + s1_elems;
+                return r;
+            }
+            int r = dev_alloc(P, (void**)s1, P->csz * s1_elems);
+            return r ? r : dev_alloc(P, (void**)s2, P->csz * 3 * (size_t)P->NT * uH * P->TK);
+        };
+        PLAN_RC(alloc_spectra(&P->S1, &P->S2));
         PLAN_RC(dev_alloc(P, &P->R, (size_t)3 * uW * uH * esz));
         PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH));
         {
-            int nl = 2;
+            int nl = 3;
             if (const char* e = getenv("FFTUP_STREAMS")) nl = atoi(e);
             P->nlanes = std::max(1, std::min(nl, 4));
             P->lanes.resize(P->nlanes);
@@ -357,8 +370,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             for (int l = 1; l < P->nlanes; l++) {
                 PLAN_TRY(hipStreamCreateWithFlags(&P->lanes[l].stream, hipStreamNonBlocking));
                 PLAN_TRY(hipEventCreateWithFlags(&P->lanes[l].done, hipEventDisableTiming));
-                PLAN_RC(dev_alloc(P, (void**)&P->lanes[l].S1, P->csz * 3 * (size_t)P->NT * H * P->TK));
-                PLAN_RC(dev_alloc(P, (void**)&P->lanes[l].S2, P->csz * 3 * (size_t)P->NT * uH * P->TK));
+                PLAN_RC(alloc_spectra(&P->lanes[l].S1, &P->lanes[l].S2));
                 PLAN_RC(dev_alloc(P, &P->lanes[l].R, (size_t)3 * uW * uH * esz));
             }
         }
@@ -394,9 +406,9 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         }
         if (P->tuned) {
             switch (uW) {
-            case 1024: SET_LDS((k_c2r_sharpen_t<1024, false, TUNED_TK>), P->ldsFused2); SET_LDS((k_c2r_sharpen_t<1024, true, TUNED_TK>), P->ldsFused2); break;
-            case 2048: SET_LDS((k_c2r_sharpen_t<2048, false, TUNED_TK>), P->ldsFused2); SET_LDS((k_c2r_sharpen_t<2048, true, TUNED_TK>), P->ldsFused2); break;
-            default: SET_LDS((k_c2r_sharpen_t<4096, false, TUNED_TK>), P->ldsFused2); SET_LDS((k_c2r_sharpen_t<4096, true, TUNED_TK>), P->ldsFused2); break;
+            case 1024: SET_LDS((k_c2r_sharpen_g<1024, false, TUNED_TK>), FusedGLds<1024>::TOTAL); SET_LDS((k_c2r_sharpen_g<1024, true, TUNED_TK>), FusedGLds<1024>::TOTAL); break;
+            case 2048: SET_LDS((k_c2r_sharpen_g<2048, false, TUNED_TK>), FusedGLds<2048>::TOTAL); SET_LDS((k_c2r_sharpen_g<2048, true, TUNED_TK>), FusedGLds<2048>::TOTAL); break;
+            default: SET_LDS((k_c2r_sharpen_g<4096, false, TUNED_TK>), FusedGLds<4096>::TOTAL); SET_LDS((k_c2r_sharpen_g<4096, true, TUNED_TK>), FusedGLds<4096>::TOTAL); break;
             }
             switch (H) {
             case 256: SET_LDS((k_col_t<256, TUNED_TK>), P->ldsCol); break;
@@ -551,10 +563,9 @@ template <int UW> static void launch_c2r_t(fftup_plan* P, const RowC2RTParams& p
 template <int UW> static void launch_fused_t(fftup_plan* P, const FusedParams& p)
 {
     const int total_pairs = 3 * (int)P->uH / 2;
-    dim3 grid((total_pairs + p.pairs_per_strip - 1) / p.pairs_per_strip);
-    dim3 block(UW / 4);
-    if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_t<UW, true, TUNED_TK>), grid, block, P->ldsFused2, P->lanes[P->cur].stream, p);
-    else hipLaunchKernelGGL((k_c2r_sharpen_t<UW, false, TUNED_TK>), grid, block, P->ldsFused2, P->lanes[P->cur].stream, p);
+    dim3 grid((total_pairs + p.pairs_per_strip - 1) / p.pairs_per_strip), block(UW / 8);
+    if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_g<UW, true, TUNED_TK>), grid, block, FusedGLds<UW>::TOTAL, P->lanes[P->cur].stream, p);
+    else hipLaunchKernelGGL((k_c2r_sharpen_g<UW, false, TUNED_TK>), grid, block, FusedGLds<UW>::TOTAL, P->lanes[P->cur].stream, p);
 }
 
 static bool fast_sharpen_ok(const fftup_plan* P) { return !P->dbl && P->uW % 256 == 0 && P->uH % 16 == 0; }
@@ -585,7 +596,8 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
     }
     if ((which < 0 || which == 2) && P->fused) {
         FusedParams p{};
-        p.S2 = P->lanes[P->cur].S2; p.out = P->out[out_slot]; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
+        p.S1 = P->lanes[P->cur].S1; p.odd_delta = (unsigned)(P->lanes[P->cur].S2 - P->lanes[P->cur].S1);
+        p.out = P->out[out_slot]; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
         p.pairs_per_strip = P->pairs_per_strip; p.upsq = P->upsq; p.coef = P->coef;
         switch (P->uW) {
         case 1024: launch_fused_t<1024>(P, p); break;
@@ -595,7 +607,7 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
         P->R_valid = false;
     } else if (which < 0 || which == 2 || which == 22) {   // 22: pre-sharpen tap requested for a fused plan
         RowC2RTParams p{};
-        p.S2 = P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
+        p.S1 = P->lanes[P->cur].S1; p.S2 = P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
         switch (P->uW) {
         case 1024: launch_c2r_t<1024>(P, p); break;
         case 2048: launch_c2r_t<2048>(P, p); break;

@@ -19,6 +19,13 @@
 
 
 
+#ifndef FFTUP_OPQ
+#define FFTUP_OPQ 1
+#endif
+#ifndef FFTUP_KO
+#define FFTUP_KO 0          // timing experiments only (results invalid): 1 no sharpen arithmetic, 2 no transform, 4 no output stores, 8 no tap loads
+#endif
+
 namespace fftup {
 
 constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n / 2); }
@@ -26,8 +33,16 @@ constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n / 2); }
 // threads that own 16 points) the remaining length still holds
 constexpr int stage_radix(int N, int Ns, int RMAX = 8) { return (N / Ns >= RMAX) ? RMAX : (N / Ns); }
 
+// LDS index map of the register-resident kernels.  A stage's scatter writes (ds_write_b64: groups of 16 lanes, 16
+// eight-byte slots) hit elements 8 or more apart, its gather reads (ds_read_b64: groups of 32 lanes, 32 slots) hit
+// consecutive elements.  XOR-ing index bits 3..6 into bits 0..3 keeps every aligned block of 16 elements in place (so
+// consecutive reads stay conflict-free and no padding is needed) and spreads the strided writes over all slots:
+// tools/lds_conflicts.py finds 4 / 2 LDS cycles per write / read (the conflict-free minimum) for every plan used here,
+// against 5.3 / 4 with one padding element per 16 (the gathers paid double for the padding).
+__device__ __forceinline__ int lswz(int i) { return i ^ ((i >> 3) & 15); }
+__host__ __device__ constexpr int lswz_size(int n) { return (n + 15) & ~15; }
 // LDS element index of point idx of sequence col (TK interleaved sequences)
-template <int TK> __device__ __forceinline__ int lidx(int idx, int col) { return lpad(idx * TK + col); }
+template <int TK> __device__ __forceinline__ int lidx(int idx, int col) { return lswz(idx * TK + col); }
 
 // ---- twiddles.  Stage with Ns > 1 of butterfly j needs exp(DIR*2 pi i*m*k/(Ns*R)), k = j % Ns,
 // m < R.  Every thread fetches ONE base twiddle per stage from the table, all of them up front
@@ -64,6 +79,35 @@ template <int Q> __device__ __forceinline__ float2 rot16()
     return make_float2(cr, ci);
 }
 
+// exp(2 pi i q/32), q = 0..31
+constexpr float kCos32[32] = {1.f, 0.98078528040323045f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+                              0.55557023301960223f, 0.38268343236508977f, 0.19509032201612827f, 0.f,
+                              -0.19509032201612827f, -0.38268343236508977f, -0.55557023301960223f, -0.70710678118654752f,
+                              -0.83146961230254524f, -0.92387953251128674f, -0.98078528040323045f, -1.f,
+                              -0.98078528040323045f, -0.92387953251128674f, -0.83146961230254524f, -0.70710678118654752f,
+                              -0.55557023301960223f, -0.38268343236508977f, -0.19509032201612827f, 0.f,
+                              0.19509032201612827f, 0.38268343236508977f, 0.55557023301960223f, 0.70710678118654752f,
+                              0.83146961230254524f, 0.92387953251128674f, 0.98078528040323045f};
+template <int Q> __device__ __forceinline__ float2 rot32()
+{
+    constexpr float cr = kCos32[Q & 31], ci = kCos32[(Q + 24) & 31];
+    return make_float2(cr, ci);
+}
+
+// LDS exchange synchronisation: the whole workgroup (s_barrier), or -- when every wave transforms its own sequences
+// in its own LDS region -- nothing but program order: a wave's LDS instructions execute in issue order, so the
+// fences only keep the compiler from moving the reads above the writes.
+template <bool WAVE> __device__ __forceinline__ void lds_sync()
+{
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 template <int R> __device__ __forceinline__ void twiddle_powers(float2* v, float2 w1)
 {
     if constexpr (R == 2) {
@@ -98,7 +142,7 @@ __device__ __forceinline__ void butterfly_b(float2 (&v)[E], float2 wbase)
         if constexpr (Ns > 1) {
             float2 w1 = twid<DIR>(wbase);
             // last stage (Ns > Tc): k_b = p + b*Tc, i.e. an extra b/E of a revolution
-            if constexpr (Ns > Tc && B > 0) w1 = cmul(w1, twid<DIR>(rot16<B * (16 / E)>()));
+            if constexpr (Ns > Tc && B > 0) w1 = cmul(w1, twid<DIR>(rot32<B * (32 / E)>()));
             twiddle_powers<R>(w, w1);
         }
         bfly<R, DIR>(w);
@@ -143,7 +187,7 @@ __device__ __forceinline__ void reg_gather(float2 (&v)[E], const float2* __restr
 // ---- all stages.  On entry v[i] = x[p + Tc*i].  If FINAL_TO_LDS the result X is left in LDS in
 // natural order (valid after the trailing barrier); otherwise v[i] = X[p + Tc*i] on return.
 // `buf` must not be in use by anyone on entry (callers barrier before re-using it).
-template <int N, int E, int DIR, int TK, bool FINAL_TO_LDS, int S = 0, int RMAX = 8>
+template <int N, int E, int DIR, int TK, bool FINAL_TO_LDS, int S = 0, int RMAX = 8, bool WAVE = false>
 __device__ __forceinline__ void reg_fft(float2 (&v)[E], float2* __restrict__ buf, int p, int col,
                                         const TwSet<N, E, RMAX>& tws)
 {
@@ -154,12 +198,12 @@ __device__ __forceinline__ void reg_fft(float2 (&v)[E], float2* __restrict__ buf
     constexpr bool last = (Ns * R == N);
     if constexpr (!last || FINAL_TO_LDS) {
         reg_scatter<N, E, R, Ns, TK>(v, buf, p, col);
-        __syncthreads();
+        lds_sync<WAVE>();
     }
     if constexpr (!last) {
         reg_gather<N, E, TK>(v, buf, p, col);
-        __syncthreads();
-        reg_fft<N, E, DIR, TK, FINAL_TO_LDS, S + 1, RMAX>(v, buf, p, col, tws);
+        lds_sync<WAVE>();
+        reg_fft<N, E, DIR, TK, FINAL_TO_LDS, S + 1, RMAX, WAVE>(v, buf, p, col, tws);
     }
 }
 
@@ -180,12 +224,12 @@ template <int MODE> __device__ __forceinline__ float load_px_t(const RowR2CTPara
     else return cvt_u8_f16(((const uint8_t*)p.in)[y * p.in_row_stride + 3l * x + c]);
 }
 
-// grid (H/2, 3), block W/8.  LDS: lpad_size(W) float2.
+// grid (H/2, 3), block W/8.  LDS: lswz_size(W) float2.
 template <int W, int MODE, int TK>
 __global__ void __launch_bounds__(W / 8) k_row_r2c_t(RowR2CTParams p)
 {
     constexpr int E = 8, T = W / E;
-    __shared__ float2 buf[lpad_size(W)];
+    __shared__ float2 buf[lswz_size(W)];
     const int tid = threadIdx.x, c = blockIdx.y;
     const int j = blockIdx.x;      // (an XCD-aware pair order -- pairs 2i, 2i+1 on one XCD -- measured no gain)
     float2 v[E];
@@ -212,8 +256,8 @@ __global__ void __launch_bounds__(W / 8) k_row_r2c_t(RowR2CTParams p)
             const int k = tile * TK + kk + e;
             float2 r = make_float2(0.f, 0.f);
             if (k <= W / 2) {
-                float2 zk = buf[lpad(k)];
-                float2 zn = buf[lpad((W - k) & (W - 1))];
+                float2 zk = buf[lswz(k)];
+                float2 zn = buf[lswz((W - k) & (W - 1))];
                 r = isB ? make_float2(0.5f * (zk.y + zn.y), 0.5f * (-zk.x + zn.x))
                         : make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
             }
@@ -232,12 +276,33 @@ struct ColTParams {
     int W, NT;
 };
 
-// grid (NT, 3), block TK*H/8.  Forward length H (E=8), inverse length 2H (E=16), both with H/8
-// threads per column.  LDS: lpad_size(2H*TK) float2.
+// v[i] = F[pp + Tc*i] * w * exp(-2 pi i * q/16), q = i (i < 4) or i + 8 (i >= 4: the extra half turn is the -1)
+template <int TK, int Tc, int I>
+__device__ __forceinline__ void col_phase(float2 (&v)[8], const float2* __restrict__ buf, int pp, int col, float2 w)
+{
+    if constexpr (I < 8) {
+        constexpr int q = (I < 4) ? I : I + 8;
+        const float2 f = buf[lidx<TK>(pp + Tc * I, col)];
+        const float2 t = (q == 0) ? w : cmul(w, twid<-1>(rot16<q>()));
+        v[I] = cmul(f, t);
+        col_phase<TK, Tc, I + 1>(v, buf, pp, col, w);
+    }
+}
+
+// grid (NT, 3), block TK*H/8, H/8 threads per column.  LDS: lswz_size(H*TK) float2.
+//
+// The reference transforms a column forward (length H), places it in a zero-padded buffer of 2H rows
+// (G[ky'] = F[ky'] for ky' < H/2, F[ky'-H] for ky' >= 3H/2, zero between: shift VkResample.cpp:514-526, read guard
+// vkFFT.h:1670-1695) and transforms back (length 2H).  With n = 2m / 2m+1 in D[n] = sum G[ky'] exp(-2 pi i n ky'/2H):
+//   D[2m]   = sum_k F[k] exp(-2 pi i m k/H)            = H * (the column itself)  -> S2[2m] = S1[m] / 2, no arithmetic;
+//   D[2m+1] = sum_k F[k] t[k] exp(-2 pi i m k/H),  t[k] = exp(-2 pi i k/2H) * (k < H/2 ? 1 : -1)
+// (the second half sits H rows higher: exp(-i pi (2m+1)) = -1).  So the inverse is a transform of length H of the
+// phase-shifted spectrum and yields the ODD rows only; the even rows are never written -- the row kernels read them
+// from S1.  Both halves are kept at TWICE the reference's normalisation (S1 as it is, odd rows D/H instead of D/2H);
+// the consumers fold the 1/2 into their final scale.  Exact for every column vector, Nyquist row included.
 template <int H, int TK>
 __global__ void __launch_bounds__(TK* H / 8) k_col_t(ColTParams p)
 {
-    constexpr int UH = 2 * H;
     constexpr int Tc = H / 8;                        // threads per column
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* buf = (float2*)smem;
@@ -247,54 +312,46 @@ __global__ void __launch_bounds__(TK* H / 8) k_col_t(ColTParams p)
     const bool valid = tile * TK + col <= p.W / 2;
     const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
     float2 v[8];
-    TwSet<H, 8> twsF;
-    TwSet<UH, 16, 16> twsI;                          // inverse: radix-16 stages (2H = 16*16*8 for H = 1024)
-    twsF.load(p.twH, pp);
-    twsI.load(p.twUH, pp);
+    TwSet<H, 8> tws;                                 // same base twiddles for both directions (conjugated inside)
+    tws.load(p.twH, pp);
+    const float2 ph = p.twUH[pp];                    // exp(+2 pi i pp/2H)
 #pragma unroll
     for (int i = 0; i < 8; i++) v[i] = valid ? src[(pp + Tc * i) * TK + col] : make_float2(0.f, 0.f);
-    reg_fft<H, 8, +1, TK, true>(v, buf, pp, col, twsF);           // F[ky] natural order in LDS
-    // inverse input (shift VkResample.cpp:514-526 + zero-pad guard vkFFT.h:1670-1695, u = 2):
-    //   G[ky'] = F[ky'] (ky' < H/2), F[ky' - H] (ky' >= 3H/2), 0 otherwise.
-    // Thread owns G[pp + Tc*i], i < 16 (UH/16 = Tc): i<4 -> F[pp+Tc*i]; i>=12 -> F[pp+Tc*(i-8)].
-    float2 g[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if (i < 4) g[i] = buf[lidx<TK>(pp + Tc * i, col)];
-        else if (i >= 12) g[i] = buf[lidx<TK>(pp + Tc * (i - 8), col)];
-        else g[i] = make_float2(0.f, 0.f);
-    }
+    reg_fft<H, 8, +1, TK, true>(v, buf, pp, col, tws);            // F[k] natural order in LDS
+    // thread owns F[pp + Tc*i]: t = conj(ph) * exp(-2 pi i * i/16) * (i < 4 ? 1 : -1)      (Tc/2H = 1/16)
+    col_phase<TK, Tc, 0>(v, buf, pp, col, twid<-1>(ph));
     __syncthreads();
-    reg_fft<UH, 16, -1, TK, false, 0, 16>(g, buf, pp, col, twsI);
-    float2* dst = p.S2 + ((long)c * p.NT + tile) * UH * TK;
-    constexpr float inv = 1.0f / (float)UH;
+    reg_fft<H, 8, -1, TK, false>(v, buf, pp, col, tws);
+    float2* dst = p.S2 + ((long)c * p.NT + tile) * H * TK;
+    constexpr float inv = 1.0f / (float)H;
     if (valid) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) dst[(pp + Tc * i) * TK + col] = cscale(g[i], inv);
+        for (int i = 0; i < 8; i++) dst[(pp + Tc * i) * TK + col] = cscale(v[i], inv);
     }
 }
 
 // =================================================================================== row C2R
 struct RowC2RTParams {
-    const float2* S2;
+    const float2* S1;        // even spectrum rows (the forward spectrum itself), see k_col_t
+    const float2* S2;        // odd spectrum rows; both at twice the reference's normalisation
     void* R;
     const float2* tw;
     int uH, NT;
 };
 
-// grid (uH/2, 3), block UW/8.  u = 2: kx = 0..UW/4 non-zero.  LDS: lpad_size(UW) float2.
+// grid (uH/2, 3), block UW/8.  u = 2: kx = 0..UW/4 non-zero.  LDS: lswz_size(UW) float2.
 template <int UW, bool HALF_OUT, int TK, bool WIDE>
 __global__ void __launch_bounds__(UW / 8) k_row_c2r_t(RowC2RTParams p)
 {
     constexpr int E = 8, T = UW / E;                 // T = UW/8; W/2 = UW/4 = 2T
-    __shared__ float2 buf[lpad_size(UW)];
+    __shared__ float2 buf[lswz_size(UW)];
     const int tid = threadIdx.x, j = blockIdx.x, c = blockIdx.y;
-    const long tile_stride = (long)p.uH * TK;
-    const float2* base = p.S2 + (long)c * p.NT * tile_stride + (long)(2 * j) * TK;
+    const long tile_stride = (long)(p.uH / 2) * TK;
+    const long roff = (long)c * p.NT * tile_stride + (long)j * TK;
     auto ldAB = [&](int k, float2& A, float2& B) {
-        const float2* s = base + (long)(k / TK) * tile_stride + (k % TK);
-        A = s[0];
-        B = s[TK];
+        const long o = roff + (long)(k / TK) * tile_stride + (k % TK);
+        A = p.S1[o];                                 // row 2j
+        B = p.S2[o];                                 // row 2j+1
     };
     // thread owns Z[tid + T*i]: i=0,1 direct (k = tid, tid+T); i=2: k = 2T = W/2 only for tid 0;
     // i=3..5 zero; i=6: mirror of k' = 2T - tid; i=7: mirror of k' = T - tid  (vkFFT.h:2096-2106)
@@ -313,7 +370,7 @@ __global__ void __launch_bounds__(UW / 8) k_row_c2r_t(RowC2RTParams p)
     v[7] = make_float2(A.x + B.y, -A.y + B.x);
     v[3] = v[4] = v[5] = make_float2(0.f, 0.f);
     const long plane = (long)UW * p.uH;
-    constexpr float inv = 1.0f / (float)UW;
+    constexpr float inv = 0.5f / (float)UW;          // 1/2: the spectrum rows carry twice the reference's scale
     if constexpr (!WIDE) {
         reg_fft<UW, E, -1, 1, false>(v, buf, tid, 0, tws);
 #pragma unroll
@@ -337,7 +394,7 @@ __global__ void __launch_bounds__(UW / 8) k_row_c2r_t(RowC2RTParams p)
             const int n0 = (tid + T * h) * 4;
             float2 z[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) z[e] = buf[lpad(n0 + e)];
+            for (int e = 0; e < 4; e++) z[e] = buf[lswz(n0 + e)];
             if constexpr (HALF_OUT) {
                 __half* R = (__half*)p.R + c * plane + (long)(2 * j) * UW + n0;
                 __half2 r0 = __floats2half2_rn(z[0].x * inv, z[1].x * inv), r1 = __floats2half2_rn(z[2].x * inv, z[3].x * inv);
@@ -454,6 +511,61 @@ __device__ __forceinline__ float sharpen_eval_fast(float s4, float C, float mn0,
     return fmaf(scale, s4, C) * __builtin_amdgcn_rcpf(fmaf(scale, 4.0f, 1.0f));
 }
 
+// ---- two pixels per operation.  The vector ALUs of gfx950 issue one instruction per wave every four cycles whatever it
+// does; v_pk_add/mul/fma_f32 retire two lanes' worth of fp32 work in that slot, so the filter is written on pairs of
+// pixels: 13 packed + 8 scalar (min, max, v_rsq, v_rcp have no packed form) operations per pair instead of 2 x 22.
+// Same formula as sharpen_eval_fast with the two exact halvings dropped (everything is carried doubled:
+// smn = 2 mn, smx = 2 mx) and the a < b selection written as n = min(mn, 1 - mx), d = max(1 - mn, mx)
+// (a < b <=> mn + mx < 1 <=> mn < 1 - mx <=> 1 - mn > mx).
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v mk2(float a, float b) { f2v r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f2v sharpen_eval_pair(f2v N, f2v S, f2v Wv, f2v E, f2v C, f2v mn0, f2v mn1, f2v mx0, f2v mx1, float coef)
+{
+    const f2v two = mk2(2.0f, 2.0f);
+    const f2v smn = mn0 + mn1, smx = mx0 + mx1;
+    const f2v u = two - smx, v = two - smn;
+    const f2v n2 = mk2(fminf(smn.x, u.x), fminf(smn.y, u.y));
+    const f2v d2 = mk2(fmaxf(v.x, smx.x), fmaxf(v.y, smx.y));                           // in [1, 2]
+    const f2v pr = __builtin_elementwise_fma(n2, d2, mk2(1e-30f, 1e-30f));               // n2 = 0 -> r = 0, no NaN
+    const f2v r = n2 * mk2(__builtin_amdgcn_rsqf(pr.x), __builtin_amdgcn_rsqf(pr.y));   // sqrt(n/d)
+    const f2v s4 = ((N + Wv) + E) + S;
+    const f2v num = __builtin_elementwise_fma(mk2(-coef, -coef), r * s4, C);
+    const f2v den = __builtin_elementwise_fma(mk2(-4.0f * coef, -4.0f * coef), r, mk2(1.0f, 1.0f));
+    return num * mk2(__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y));
+}
+
+// vertical 3-row minima / maxima of 6 columns (4 pixels + halo) for the window whose top row is t[w]
+__device__ __forceinline__ void sharpen_vminmax(const float (&t)[4][6], int w, float (&vmn)[6], float (&vmx)[6])
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        vmn[i] = fminf(fminf(t[w][i], t[w + 1][i]), t[w + 2][i]);
+        vmx[i] = fmaxf(fmaxf(t[w][i], t[w + 1][i]), t[w + 2][i]);
+    }
+}
+// 4 output pixels of the window rows t[w..w+2] (7 three-input min/max per pixel: min/max are exact in any order)
+__device__ __forceinline__ void sharpen_quad_packed(const float (&t)[4][6], int w, const float (&vmn)[6], const float (&vmx)[6],
+                                                    float coef, float (&o)[4])
+{
+    float mn0[4], mn1[4], mx0[4], mx1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        mn1[k] = fminf(fminf(vmn[k], vmn[k + 1]), vmn[k + 2]);                          // full 3x3
+        mx1[k] = fmaxf(fmaxf(vmx[k], vmx[k + 1]), vmx[k + 2]);
+        mn0[k] = fminf(fminf(vmn[k + 1], t[w + 1][k]), t[w + 1][k + 2]);               // cross: N, C, S, W, E
+        mx0[k] = fmaxf(fmaxf(vmx[k + 1], t[w + 1][k]), t[w + 1][k + 2]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {
+        const f2v r = sharpen_eval_pair(mk2(t[w][k + 1], t[w][k + 2]), mk2(t[w + 2][k + 1], t[w + 2][k + 2]),
+                                        mk2(t[w + 1][k], t[w + 1][k + 1]), mk2(t[w + 1][k + 2], t[w + 1][k + 3]),
+                                        mk2(t[w + 1][k + 1], t[w + 1][k + 2]), mk2(mn0[k], mn0[k + 1]), mk2(mn1[k], mn1[k + 1]),
+                                        mk2(mx0[k], mx0[k + 1]), mk2(mx1[k], mx1[k + 1]), coef);
+        o[k] = r.x;
+        o[k + 1] = r.y;
+    }
+}
+
 struct SharpenTParams {
     const void* R;
     void* out;
@@ -526,7 +638,8 @@ __global__ void __launch_bounds__(256) k_sharpen_t(SharpenTParams p)
 // for the last row of a strip the one
 // missing sample g[y1+1][0] = (sum over k of Z[k])/uW is evaluated directly from the spectrum row.
 struct FusedParams {
-    const float2* S2;
+    const float2* S1;        // even spectrum rows = the forward spectrum; odd rows at S1 + odd_delta (one allocation)
+    unsigned odd_delta;      // in float2 elements
     void* out;               // dense [3][uH][uW] float / half
     const float2* tw;
     int uH, NT;
@@ -534,7 +647,7 @@ struct FusedParams {
     float upsq, coef;
 };
 
-__host__ __device__ constexpr size_t fused_buf_bytes(int uw) { return (sizeof(float2) * lpad_size(uw) + 15) & ~(size_t)15; }
+__host__ __device__ constexpr size_t fused_buf_bytes(int uw) { return (sizeof(float2) * lswz_size(uw) + 15) & ~(size_t)15; }
 
 template <bool HALF> __device__ __forceinline__ float to_L(float g, float upsq)
 {
@@ -607,39 +720,35 @@ __device__ __forceinline__ void sharpen_quad(const float (&t)[3][6], float coef,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The kernel: ONE workgroup of 2*T threads per compute unit in which the two halves swap roles every step: while one half transforms row pair s (LDS exchange buffer X[s%3]), the
-// other half sharpens the rows of pair s-1 (X[(s-1)%3] and X[(s-2)%3]) and stages the spectrum rows of
-// pair s+1 into LDS.  Both halves pass the same 8 workgroup barriers per step, so in every barrier interval
-// each SIMD holds latency-bound FFT waves next to arithmetic-bound sharpen waves.  One strip per CU keeps
-// the halo overhead at one pair in thirteen for the headline size.
-template <int UW> struct Fused2Lds {
-    static constexpr int KH = UW / 4;                                        // highest non-zero kx (= W/2)
-    static constexpr size_t XB = fused_buf_bytes(UW);                        // exchange buffer / two L rows
-    static constexpr size_t SB = (sizeof(float2) * (2 * (KH + 1) + 2) + 15) & ~(size_t)15;   // A row, B row, leak terms
-    static constexpr size_t RED = 3 * XB + 2 * SB;
+// Fused C2R + sharpen: a workgroup of T = UW/8 threads owns a strip and alternates, all
+// threads together, between transforming row pair s and sharpening the two output rows that pair completes.  Two such
+// workgroups live on a compute unit (70 KB of LDS, <= 128 VGPRs each); they are not synchronised with each other, so
+// one's barrier-free sharpen phase (a long run of arithmetic) fills the gaps the other's transform leaves at its
+// exchange barriers.  No role split, no barrier counting: every thread reaches the same __syncthreads().
+//   LDS: two exchange buffers X[0], X[1]; pair s is transformed in X[s&1], which then holds its two L rows; the rows of
+//   pair s-1 (X[(s-1)&1]) are the "ring".  The spectrum rows of pair s+1 are prefetched into REGISTERS while pair s is
+//   processed (every thread loads the 8 values its first butterfly needs, mirrored ones included), so no LDS staging
+//   and -- loads being older than the output stores of the same step -- no wait on a store, ever (vmcnt is in order).
+template <int UW> struct FusedGLds {
+    static constexpr size_t XB = fused_buf_bytes(UW);
+    static constexpr size_t RED = 2 * XB;
     static constexpr size_t TOTAL = RED + 32 * sizeof(float);
 };
 
 template <int UW, bool HALF, int TK>
-__global__ void __launch_bounds__(UW / 4) k_c2r_sharpen_t(FusedParams p)
+__global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 / 256 : 1) k_c2r_sharpen_g(FusedParams p)
 {
     constexpr int E = 8, T = UW / E;
-    constexpr int KH = UW / 4;
-    constexpr float inv = 1.0f / (float)UW;
-    using L = Fused2Lds<UW>;
+    constexpr float inv = 0.5f / (float)UW;         // 1/2: the spectrum rows carry twice the reference's scale (k_col_t)
+    using L = FusedGLds<UW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)(smem + L::RED);      // [0..15] corner partial sums, [16] corner DC term, [20..21] deferred-pixel taps
-    const int tid = threadIdx.x;
-    const int grp = __builtin_amdgcn_readfirstlane(tid / T);      // 0 / 1, wave-uniform
-    const int lt = tid - grp * T;
+    int lt = threadIdx.x;                       // (made opaque at the phase entries, see FFTUP_OPQ)
     const int uH = p.uH;
     const int pairs_per_plane = uH / 2;
-    const long tile_stride = (long)uH * TK;
     const long plane = (long)UW * uH;
-    // Loads and stores retire through ONE in-order counter (vmcnt): a wave that waits for a load also waits
-    // for every output store it issued before it.  Hence all loads belong to the FFT role (which stores
-    // nothing, and whose previous stores are a whole step old): twiddles first (L1/L2 hits, needed at stage
-    // 1), then the staging loads (a whole step to land); the sharpen role never waits on memory at all.
+    TwSet<UW, E> tws;
+    tws.load(p.tw, lt);                         // once: inside the loop a load would queue behind the output stores
 
     int f0 = blockIdx.x * p.pairs_per_strip;
     const int f1 = min(f0 + p.pairs_per_strip, 3 * pairs_per_plane);
@@ -652,52 +761,34 @@ __global__ void __launch_bounds__(UW / 4) k_c2r_sharpen_t(FusedParams p)
         const bool top = (y0 == 0);
         const int a0 = top ? 0 : y0 - 1;
         const int npairs = (j1 - j0) + 1;
-        const float2* base = p.S2 + (long)c * p.NT * tile_stride;
-        // 32-bit element offsets from the (wave-uniform) plane base: one plane of S2 is < 2^31 elements
-        const unsigned tile_stride32 = (unsigned)uH * TK;
+        const unsigned tile_stride32 = (unsigned)(uH / 2) * TK;
+        const float2* base = p.S1 + (long)c * p.NT * (long)tile_stride32;
+        // spectrum row `row` of the 2H-row buffer: even rows are rows of S1, odd rows live odd_delta elements further on
         auto S2at = [&](int k, int row) -> float2 {
-            // byte offset kept in 32 bits so that the load takes the "SGPR base + VGPR offset" form
-            const unsigned off = ((unsigned)(k / TK) * tile_stride32 + (unsigned)row * TK + (unsigned)(k % TK)) * (unsigned)sizeof(float2);
+            const unsigned off = ((unsigned)(k / TK) * tile_stride32 + (unsigned)(row >> 1) * TK + (unsigned)(k % TK) +
+                                  (unsigned)(row & 1) * p.odd_delta) * (unsigned)sizeof(float2);
             return *(const float2*)((const char*)base + off);
         };
         const bool need_corner = !top && (y1 + 1 < uH);
         const int rs = y1 + 1;
 
-        // ---- staging of the spectrum rows of pair i: issue (registers) and commit (LDS slot i&1)
-        struct Stage { float2 a0, a1, b0, b1, x0, x1; };
-        auto stage_issue = [&](int i) -> Stage {
-            Stage st;
+        // inputs of the transform of pair i: A (first row) and B (second row) at k = lt, lt+T and at the mirror partners
+        // 2T-lt, T-lt (vkFFT.h:2096-2106); thread 0 also needs Im of the DC column of the two reference partners (leak)
+        struct In { float2 a0, a1, am0, am1, b0, b1, bm0, bm1; float lka, lkb; };
+        auto load_pair = [&](int i) -> In {
+            In in;
             const int a = a0 + 2 * i;
             const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);       // rows past the plane: duplicate of the last row
-            st.a0 = S2at(lt, ya); st.a1 = S2at(lt + T, ya);
-            st.b0 = S2at(lt, yb); st.b1 = S2at(lt + T, yb);
-            // lane 0: k = W/2; lane 1: DC column of the reference partners (leak); others: a harmless re-read
-            const int kx = (lt == 0) ? KH : 0;
-            st.x0 = S2at(kx, (lt == 1) ? (ya ^ 1) : ya);
-            st.x1 = S2at(kx, (lt == 1) ? (yb ^ 1) : yb);
-            return st;
-        };
-        auto stage_commit = [&](int i, const Stage& st) {
-            float2* SA = (float2*)(smem + 3 * L::XB + (i & 1) * L::SB);
-            float2* SBp = SA + (KH + 1);
-            SA[lt] = st.a0; SA[lt + T] = st.a1;
-            SBp[lt] = st.b0; SBp[lt + T] = st.b1;
-            if (lt == 0) { SA[KH] = st.x0; SBp[KH] = st.x1; }
-            if (lt == 1) {
-                const int a = a0 + 2 * i;
-                const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);
-                // leak: row y gets -Im D[y+1] (y even) / +Im D[y-1] (y odd)
-                SBp[KH + 1] = make_float2((ya & 1) ? st.x0.y : -st.x0.y, (yb & 1) ? st.x1.y : -st.x1.y);
-            }
+            in.a0 = S2at(lt, ya); in.a1 = S2at(lt + T, ya); in.am0 = S2at(2 * T - lt, ya); in.am1 = S2at(T - lt, ya);
+            in.b0 = S2at(lt, yb); in.b1 = S2at(lt + T, yb); in.bm0 = S2at(2 * T - lt, yb); in.bm1 = S2at(T - lt, yb);
+            // Im of the DC column of the reference partners (used by thread 0 only; loaded by every lane, raw, so that no
+            // lane-dependent branch and no arithmetic -- hence no wait -- follows the loads)
+            in.lka = S2at(0, ya ^ 1).y;
+            in.lkb = S2at(0, yb ^ 1).y;
+            return in;
         };
 
-        // ---- prologue: each half stages the first pair it will transform (pair 0 by half 0, pair 1 by
-        // half 1); half 1 also evaluates the corner sums; one barrier publishes everything
-        if (grp < npairs) {
-            const Stage st = stage_issue(grp);
-            stage_commit(grp, st);
-        }
-        if (grp == 1 && need_corner) {
+        if (need_corner) {
             float part = S2at(lt + 1, rs).x + S2at(lt + 1 + T, rs).x;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
@@ -707,239 +798,181 @@ __global__ void __launch_bounds__(UW / 4) k_c2r_sharpen_t(FusedParams p)
                 red[16] = (rs & 1) ? d.x + dp.y : d.x - dp.y;
             }
         }
-        __syncthreads();
+        In in = load_pair(0);
+#define FFTUP_SETTLE_IN()                                                                                                       \
+    do {                                                                                                                       \
+        __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0), nothing else */                                                       \
+        asm volatile("" : "+v"(in.a0.x), "+v"(in.a0.y), "+v"(in.a1.x), "+v"(in.a1.y), "+v"(in.am0.x), "+v"(in.am0.y),         \
+                          "+v"(in.am1.x), "+v"(in.am1.y), "+v"(in.b0.x), "+v"(in.b0.y), "+v"(in.b1.x), "+v"(in.b1.y),          \
+                          "+v"(in.bm0.x), "+v"(in.bm0.y), "+v"(in.bm1.x), "+v"(in.bm1.y), "+v"(in.lka), "+v"(in.lkb));         \
+    } while (0)
+        FFTUP_SETTLE_IN();
+        __syncthreads();            // red[] published; the previous segment's last reads of X[] are over
 
-        for (int s = 0; s <= npairs; s++) {
-            if (grp == (s & 1)) {
-                // ================= FFT role: pair s
-                if (s < npairs) {
-                    const float2* SA = (const float2*)(smem + 3 * L::XB + (s & 1) * L::SB);
-                    const float2* SBp = SA + (KH + 1);
-                    float2* buf = (float2*)(smem + (s % 3) * L::XB);
-                    float* cur = (float*)buf;
-                    TwSet<UW, E> tws;
-                    tws.load(p.tw, lt);
-                    float2 v[E];
-                    {
-                        float2 A = SA[lt], B = SBp[lt];
-                        v[0] = make_float2(A.x - B.y, A.y + B.x);
-                        A = SA[lt + T]; B = SBp[lt + T];
-                        v[1] = make_float2(A.x - B.y, A.y + B.x);
-                        A = SA[2 * T - lt]; B = SBp[2 * T - lt];
-                        v[6] = make_float2(A.x + B.y, -A.y + B.x);
-                        v[2] = make_float2(0.f, 0.f);
-                        if (lt == 0) {
-                            v[2] = make_float2(A.x - B.y, A.y + B.x);                       // k = 2T = W/2
-                            const float2 lk = SBp[KH + 1];
-                            v[0] = make_float2(SA[0].x + lk.x, SBp[0].x + lk.y);              // DC terms incl. the pair leak
-                        }
-                        A = SA[T - lt]; B = SBp[T - lt];
-                        v[7] = make_float2(A.x + B.y, -A.y + B.x);
-                        v[3] = v[4] = v[5] = make_float2(0.f, 0.f);
-                    }
-                    // this half's next transform is pair s+2 (clamped re-read when there is none)
-                    const bool do_stage = (s + 2 < npairs);
-                    const Stage st = stage_issue(do_stage ? s + 2 : s);
-                    reg_fft<UW, E, -1, 1, false>(v, buf, lt, 0, tws);                           // 6 barriers
-#pragma unroll
-                    for (int i = 0; i < E; i++) {
-                        cur[lt + T * i] = to_L<HALF>(v[i].x * inv, p.upsq);
-                        cur[UW + lt + T * i] = to_L<HALF>(v[i].y * inv, p.upsq);
-                    }
-                    if (do_stage) stage_commit(s + 2, st);        // same slot (s&1) that was consumed above
-                    __syncthreads();                                                            // 7
-                    __syncthreads();                                                            // 8
-                } else {
-#pragma unroll
-                    for (int b = 0; b < 8; b++) __syncthreads();
-                }
-            } else {
-                // ================= sharpen role: rows of pair i = s-1; stage pair s+1
-                const int i = s - 1;
-                const int a = a0 + 2 * i;
-                const float* cur = (const float*)(smem + ((i + 3) % 3) * L::XB);               // rows a, a+1
-                const float* ring = (const float*)(smem + ((i + 2) % 3) * L::XB);              // rows a-2, a-1
-                auto rowp = [&](int r) -> const float* { return r < 0 ? ring + (r + 2) * UW : cur + r * UW; };
-                // both output rows of a 4-pixel column group in one pass: the four L rows a-2 .. a+1 are read
-                // once and their horizontal minima/maxima are shared by the two 3x3 windows
-                if constexpr (HALF) {
-                    // -p 2: one undivided pass per column half (the binary16 evaluation needs the registers), its three
-                    // barriers after it
-    #pragma unroll 1
-                    for (int h = 0; h < 2; h++) {
-                        const bool out0 = i >= 0 && (a - 1) >= y0 && (a - 1) < y1;      // row y = a-1
-                        const bool out1 = i >= 0 && a >= y0 && a < y1;                  // row y = a
-                        if (out0 || out1) {
-                            const int x0 = 4 * (lt + T * h);
-                            // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
-                            const float* rows[4] = {rowp(-2), (a == 0) ? rowp(0) : rowp(-1), rowp(0), rowp(1)};
-                            float t[4][6];
-    #pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                if (r == 0 && !out0) continue;
-                                float4 q = *(const float4*)(rows[r] + x0);
-                                t[r][1] = q.x; t[r][2] = q.y; t[r][3] = q.z; t[r][4] = q.w;
-                                float el = q.x, er = 0.f;
-                                if ((lt & 63) == 0 && x0 != 0) el = rows[r][x0 - 1];
-                                if ((lt & 63) == 63) {
-                                    // x = UW wraps to x = 0 of the next row (rows past a+1: see below)
-                                    const float* nx = (r < 3) ? ((a == 0 && r == 1) ? rowp(1) : rows[r + 1]) : rows[3];
-                                    er = (x0 + 4 == UW) ? nx[0] : rows[r][x0 + 4];
-                                }
-                                t[r][0] = lane_from_below(q.w, el);
-                                t[r][5] = lane_from_above(q.x, er);
-                            }
-                            const bool last_chunk = (x0 + 4 == UW);
-                            if (last_chunk) {
-                                // SE tap of pixel (a, UW-1) is L(a+2, 0): past the plane it clamps to row uH-1; in the
-                                // last step it is the corner sample; otherwise the pixel is finished next step
-                                const int r2 = min(a + 2, uH - 1) - a;
-                                if (r2 <= 1) t[3][5] = rowp(r2)[0];
-                                else if (i == npairs - 1) {
-                                    float sum = 0.f;
-                                    for (int w2 = 0; w2 < T / 64; w2++) sum += red[w2];
-                                    t[3][5] = to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq);
-                                }
-                            }
-                            float hmn[4][4], hmx[4][4];
-    #pragma unroll
-                            for (int r = 0; r < 4; r++)
-    #pragma unroll
-                                for (int k = 0; k < 4; k++) {
-                                    hmn[r][k] = fminf(fminf(t[r][k], t[r][k + 1]), t[r][k + 2]);
-                                    hmx[r][k] = fmaxf(fmaxf(t[r][k], t[r][k + 1]), t[r][k + 2]);
-                                }
-    #pragma unroll
-                            for (int w = 0; w < 2; w++) {
-                                if (w == 0 ? !out0 : !out1) continue;
-                                float o[4];
-    #pragma unroll
-                                for (int k = 0; k < 4; k++) {
-                                    const float N = t[w][k + 1], S = t[w + 2][k + 1], Wv = t[w + 1][k], C = t[w + 1][k + 1], E = t[w + 1][k + 2];
-                                    const float mn0 = fminf(fminf(N, S), hmn[w + 1][k]);
-                                    const float mx0 = fmaxf(fmaxf(N, S), hmx[w + 1][k]);
-                                    const float mn1 = fminf(fminf(hmn[w][k], hmn[w + 2][k]), mn0);
-                                    const float mx1 = fmaxf(fmaxf(hmx[w][k], hmx[w + 2][k]), mx0);
-                                    if constexpr (HALF) o[k] = sharpen_eval_half_fast(N, S, Wv, E, C, mn0, mn1, mx0, mx1, p.coef);
-                                    else o[k] = sharpen_eval_fast(((N + Wv) + E) + S, C, mn0, mn1, mx0, mx1, p.coef);
-                                }
-                                const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
-                                if constexpr (HALF) {
-                                    __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
-                                    typedef float f2v __attribute__((ext_vector_type(2)));
-                                    f2v val = {*(float*)&h0, *(float*)&h1};
-                                    __builtin_nontemporal_store(val, (f2v*)((char*)((__half*)p.out + row_of) + (unsigned)x0 * 2u));
-                                } else {
-                                    typedef float f4v __attribute__((ext_vector_type(4)));
-                                    f4v val = {o[0], o[1], o[2], o[3]};
-                                    __builtin_nontemporal_store(val, (f4v*)((char*)((float*)p.out + row_of) + (unsigned)x0 * 4u));
-                                }
-                            }
-                        }
-                        __syncthreads();
-                        __syncthreads();
-                        __syncthreads();                                                           // 6 in total
-                    }
-                } else {
-    #pragma unroll 1
-                    for (int h = 0; h < 2; h++) {
-                        const bool out0 = i >= 0 && (a - 1) >= y0 && (a - 1) < y1;      // row y = a-1
-                        const bool out1 = i >= 0 && a >= y0 && a < y1;                  // row y = a
-                        const bool act = out0 || out1;
-                        const int x0 = 4 * (lt + T * h);
-                        float t[4][6];
-                        // the pass is cut in three by the barriers it has to take part in anyway, so that its arithmetic
-                        // is spread over the other half's transform stages instead of running beside only one of them
-                        if (act) {
-                            // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
-                            const float* rows[4] = {rowp(-2), (a == 0) ? rowp(0) : rowp(-1), rowp(0), rowp(1)};
-    #pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                if (r == 0 && !out0) {
-    #pragma unroll
-                                    for (int k = 0; k < 6; k++) t[0][k] = 0.f;
-                                    continue;
-                                }
-                                float4 q = *(const float4*)(rows[r] + x0);
-                                t[r][1] = q.x; t[r][2] = q.y; t[r][3] = q.z; t[r][4] = q.w;
-                                float el = q.x, er = 0.f;
-                                if ((lt & 63) == 0 && x0 != 0) el = rows[r][x0 - 1];
-                                if ((lt & 63) == 63) {
-                                    // x = UW wraps to x = 0 of the next row (rows past a+1: see below)
-                                    const float* nx = (r < 3) ? ((a == 0 && r == 1) ? rowp(1) : rows[r + 1]) : rows[3];
-                                    er = (x0 + 4 == UW) ? nx[0] : rows[r][x0 + 4];
-                                }
-                                t[r][0] = lane_from_below(q.w, el);
-                                t[r][5] = lane_from_above(q.x, er);
-                            }
-                            const bool last_chunk = (x0 + 4 == UW);
-                            if (last_chunk) {
-                                // SE tap of pixel (a, UW-1) is L(a+2, 0): past the plane it clamps to row uH-1; in the
-                                // last step it is the corner sample; otherwise the pixel is finished next step
-                                const int r2 = min(a + 2, uH - 1) - a;
-                                if (r2 <= 1) t[3][5] = rowp(r2)[0];
-                                else if (i == npairs - 1) {
-                                    float sum = 0.f;
-                                    for (int w2 = 0; w2 < T / 64; w2++) sum += red[w2];
-                                    t[3][5] = to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq);
-                                }
-                            }
-                        }
-    #pragma unroll
-                        for (int w = 0; w < 2; w++) {
-                            __syncthreads();
-                            if (!act || (w == 0 ? !out0 : !out1)) continue;
-                            float o[4];
-    #pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                const float N = t[w][k + 1], S = t[w + 2][k + 1], Wv = t[w + 1][k], C = t[w + 1][k + 1], E = t[w + 1][k + 2];
-                                // only t[][] lives across the barriers; min/max are exact in any order
-                                const float mn0 = fminf(fminf(N, S), fminf(fminf(Wv, C), E));
-                                const float mx0 = fmaxf(fmaxf(N, S), fmaxf(fmaxf(Wv, C), E));
-                                const float mn1 = fminf(fminf(fminf(fminf(t[w][k], N), t[w][k + 2]), fminf(fminf(t[w + 2][k], S), t[w + 2][k + 2])), mn0);
-                                const float mx1 = fmaxf(fmaxf(fmaxf(fmaxf(t[w][k], N), t[w][k + 2]), fmaxf(fmaxf(t[w + 2][k], S), t[w + 2][k + 2])), mx0);
-                                if constexpr (HALF) o[k] = sharpen_eval_half_fast(N, S, Wv, E, C, mn0, mn1, mx0, mx1, p.coef);
-                                else o[k] = sharpen_eval_fast(((N + Wv) + E) + S, C, mn0, mn1, mx0, mx1, p.coef);
-                            }
-                            const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
-                            if constexpr (HALF) {
-                                __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
-                                typedef float f2v __attribute__((ext_vector_type(2)));
-                                f2v val = {*(float*)&h0, *(float*)&h1};
-                                __builtin_nontemporal_store(val, (f2v*)((char*)((__half*)p.out + row_of) + (unsigned)x0 * 2u));
-                            } else {
-                                typedef float f4v __attribute__((ext_vector_type(4)));
-                                f4v val = {o[0], o[1], o[2], o[3]};
-                                __builtin_nontemporal_store(val, (f4v*)((char*)((float*)p.out + row_of) + (unsigned)x0 * 4u));
-                            }
-                        }
-                        __syncthreads();                                                           // 3 per pass, 6 in total
-                    }
-                }
-                if (i >= 0 && lt == T - 1) {
-                    // finish the pixel deferred by the previous pair: (a-2, UW-1); L(a,0) is known now
-                    if (i > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1) {
-                        const float* r2 = rowp(-2);
-                        const float* r1 = rowp(-1);
-                        const float* r0 = rowp(0);
-                        const float ne = (a - 2 == 0) ? r1[0] : r2[0];
-                        const float pn0 = red[20], pn1 = red[21];
-                        const float t[3][6] = {{pn0, pn0, pn1, ne, ne, ne},
-                                               {r2[UW - 2], r2[UW - 2], r2[UW - 1], r1[0], r1[0], r1[0]},
-                                               {r1[UW - 2], r1[UW - 2], r1[UW - 1], r0[0], r0[0], r0[0]}};
-                        float o[4];
-                        sharpen_quad<HALF>(t, p.coef, o);
-                        const long of = c * plane + (long)(a - 2) * UW + (UW - 1);
-                        if constexpr (HALF) ((__half*)p.out)[of] = __float2half_rn(o[1]);
-                        else ((float*)p.out)[of] = o[1];
-                    }
-                    const float* rn = (a == 0) ? rowp(0) : rowp(-1);
-                    red[20] = rn[UW - 2];
-                    red[21] = rn[UW - 1];
-                }
-                __syncthreads();                                                               // 7
-                __syncthreads();                                                               // 8
+        for (int s = 0; s < npairs; s++) {
+            const int a = a0 + 2 * s;
+            float2* buf = (float2*)(smem + (s & 1) * L::XB);
+            float* cur = (float*)buf;                                               // rows a, a+1 after the transform
+            const float* ring = (const float*)(smem + ((s + 1) & 1) * L::XB);       // rows a-2, a-1
+            // ================= transform of pair s
+            if constexpr ((FFTUP_OPQ & 1) != 0) asm volatile("" : "+v"(lt));
+            float2 v[E];
+            v[0] = make_float2(in.a0.x - in.b0.y, in.a0.y + in.b0.x);
+            v[1] = make_float2(in.a1.x - in.b1.y, in.a1.y + in.b1.x);
+            v[6] = make_float2(in.am0.x + in.bm0.y, -in.am0.y + in.bm0.x);
+            v[7] = make_float2(in.am1.x + in.bm1.y, -in.am1.y + in.bm1.x);
+            v[2] = v[3] = v[4] = v[5] = make_float2(0.f, 0.f);
+            if (lt == 0) {
+                v[2] = make_float2(in.am0.x - in.bm0.y, in.am0.y + in.bm0.x);       // k = 2T = W/2
+                // DC terms incl. the pair leak: row y gets -Im D[y+1] (y even) / +Im D[y-1] (y odd)
+                const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);
+                v[0] = make_float2(in.a0.x + ((ya & 1) ? in.lka : -in.lka), in.b0.x + ((yb & 1) ? in.lkb : -in.lkb));
             }
+            if constexpr ((FFTUP_KO & 32) == 0)
+            in = load_pair(min(s + 1, npairs - 1));                                 // lands during this step (last step: a harmless re-read)
+            if constexpr ((FFTUP_KO & 2) == 0) reg_fft<UW, E, -1, 1, false>(v, buf, lt, 0, tws);   // its last barrier follows the last gather
+            // Loads and stores retire through ONE in-order counter (vmcnt).  Waiting HERE -- the prefetch was issued a whole
+            // transform ago, the previous step's stores even earlier -- costs nothing and leaves the registers of `in`
+            // settled, so that the next step's first instructions do not have to wait for the stores issued below.
+            // (re-defining the values keeps the compiler from copying the just-issued loads' registers -- and thus waiting
+            // for them -- right behind the loads; any loop-carried copy now happens after the data has landed)
+            FFTUP_SETTLE_IN();
+            if constexpr (HALF) {
+#pragma unroll
+                for (int i = 0; i < E; i++) {
+                    cur[lt + T * i] = to_L<HALF>(v[i].x * inv, p.upsq);
+                    cur[UW + lt + T * i] = to_L<HALF>(v[i].y * inv, p.upsq);
+                }
+            } else if constexpr ((FFTUP_KO & 16) != 0) {
+                if (v[0].x + v[1].y + v[6].x + v[7].y + v[2].x == 12345.f) cur[lt] = v[0].x;
+            } else {
+                // 1/UW is a power of two, so (v / UW) * u^2 == v * (u^2 / UW) bit for bit: one packed multiply
+                const float ks = inv * p.upsq;
+#pragma unroll
+                for (int i = 0; i < E; i++) {
+                    const f2v sv = mk2(v[i].x, v[i].y) * mk2(ks, ks);
+                    cur[lt + T * i] = fminf(fabsf(sv.x), 1.0f);
+                    cur[UW + lt + T * i] = fminf(fabsf(sv.y), 1.0f);
+                }
+            }
+            __syncthreads();                                                        // L rows a, a+1 visible
+            // ================= sharpen rows a-1 and a
+            if constexpr ((FFTUP_OPQ & 2) != 0) asm volatile("" : "+v"(lt));
+            auto rowp = [&](int r) -> const float* { return r < 0 ? ring + (r + 2) * UW : cur + r * UW; };
+            const bool out0 = (a - 1) >= y0 && (a - 1) < y1;                        // row y = a-1
+            const bool out1 = a >= y0 && a < y1;                                    // row y = a
+            if (out0 || out1) {
+#pragma unroll 1
+                for (int h = 0; h < 2; h++) {
+                    const int x0 = 4 * (lt + T * h);
+                    // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
+                    const float* rows[4] = {rowp(-2), (a == 0) ? rowp(0) : rowp(-1), rowp(0), rowp(1)};
+                    float t[4][6];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        if (r == 0 && !out0) {
+#pragma unroll
+                            for (int k = 0; k < 6; k++) t[0][k] = 0.f;
+                            continue;
+                        }
+                        // own four pixels and the quads of both neighbours: three conflict-free 16-byte reads, no cross-lane
+                        // moves, no wave-edge branches.  The two rows of a pair are contiguous in LDS, so x = UW of the first
+                        // one IS x = 0 of the second (quirk B5); x0 == 0 reads 16 bytes in front of the row (at worst out of
+                        // range: LDS returns 0) and is replaced below.
+                        const float* rp = rows[r] + x0;
+                        if constexpr ((FFTUP_KO & 8) != 0) {
+                            for (int k = 0; k < 6; k++) t[r][k] = p.coef * (float)(x0 + k + r);
+                        } else {
+                        const float4 q = *(const float4*)rp;
+                        t[r][1] = q.x; t[r][2] = q.y; t[r][3] = q.z; t[r][4] = q.w;
+                        t[r][0] = (*(const float4*)(rp - 4)).w;
+                        t[r][5] = (*(const float4*)(rp + 4)).x;
+                        }
+                    }
+                    if (x0 == 0) {                             // id_x_m clamp (VkResample.cpp:889)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) t[r][0] = t[r][1];
+                    }
+                    if (x0 + 4 == UW) {
+                        // row a-1 wraps into row a, which lives in the other buffer
+                        if (a != 0) t[1][5] = rowp(0)[0];
+                        // SE tap of pixel (a, UW-1) is L(a+2, 0): past the plane it clamps to row uH-1; in the last step
+                        // it is the corner sample; otherwise the pixel is finished next step (placeholder now)
+                        t[3][5] = rowp(1)[0];
+                        const int r2 = min(a + 2, uH - 1) - a;
+                        if (r2 <= 1) t[3][5] = rowp(r2)[0];
+                        else if (s == npairs - 1) {
+                            float sum = 0.f;
+                            for (int w2 = 0; w2 < (T + 63) / 64; w2++) sum += red[w2];
+                            t[3][5] = to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq);
+                        }
+                    }
+#pragma unroll
+                    for (int w = 0; w < 2; w++) {
+                        if (w == 0 ? !out0 : !out1) continue;
+                        float o[4];
+                        if constexpr (HALF) {
+                            float hmn[3][4], hmx[3][4];
+#pragma unroll
+                            for (int r = 0; r < 3; r++)
+#pragma unroll
+                                for (int k = 0; k < 4; k++) {
+                                    hmn[r][k] = fminf(fminf(t[w + r][k], t[w + r][k + 1]), t[w + r][k + 2]);
+                                    hmx[r][k] = fmaxf(fmaxf(t[w + r][k], t[w + r][k + 1]), t[w + r][k + 2]);
+                                }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const float N = t[w][k + 1], S = t[w + 2][k + 1], Wv = t[w + 1][k], C = t[w + 1][k + 1], Ev = t[w + 1][k + 2];
+                                const float mn0 = fminf(fminf(N, S), hmn[1][k]);
+                                const float mx0 = fmaxf(fmaxf(N, S), hmx[1][k]);
+                                const float mn1 = fminf(fminf(hmn[0][k], hmn[2][k]), mn0);
+                                const float mx1 = fmaxf(fmaxf(hmx[0][k], hmx[2][k]), mx0);
+                                o[k] = sharpen_eval_half_fast(N, S, Wv, Ev, C, mn0, mn1, mx0, mx1, p.coef);
+                            }
+                        } else if constexpr ((FFTUP_KO & 1) != 0) {
+                            for (int k = 0; k < 4; k++) o[k] = t[w][k + 1] + t[w + 1][k] + t[w + 1][k + 2] + t[w + 2][k + 1] + t[w+1][k+1];
+                        } else {
+                            float vmn[6], vmx[6];
+                            sharpen_vminmax(t, w, vmn, vmx);
+                            sharpen_quad_packed(t, w, vmn, vmx, p.coef, o);
+                        }
+                        const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
+                        if constexpr ((FFTUP_KO & 4) != 0) {
+                            if (o[0] + o[1] + o[2] + o[3] == 12345.f) ((float*)p.out)[row_of + x0] = o[0];
+                        } else if constexpr (HALF) {
+                            __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
+                            f2v val = {*(float*)&h0, *(float*)&h1};
+                            __builtin_nontemporal_store(val, (f2v*)((char*)((__half*)p.out + row_of) + (unsigned)x0 * 2u));
+                        } else {
+                            typedef float f4v __attribute__((ext_vector_type(4)));
+                            f4v val = {o[0], o[1], o[2], o[3]};
+                            __builtin_nontemporal_store(val, (f4v*)((char*)((float*)p.out + row_of) + (unsigned)x0 * 4u));
+                        }
+                    }
+                }
+            }
+            if (lt == T - 1) {
+                // finish the pixel deferred by the previous pair: (a-2, UW-1); L(a,0) is known now
+                if (s > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1) {
+                    const float* r2 = rowp(-2);
+                    const float* r1 = rowp(-1);
+                    const float* r0 = rowp(0);
+                    const float ne = (a - 2 == 0) ? r1[0] : r2[0];
+                    const float pn0 = red[20], pn1 = red[21];
+                    const float tt[3][6] = {{pn0, pn0, pn1, ne, ne, ne},
+                                            {r2[UW - 2], r2[UW - 2], r2[UW - 1], r1[0], r1[0], r1[0]},
+                                            {r1[UW - 2], r1[UW - 2], r1[UW - 1], r0[0], r0[0], r0[0]}};
+                    float o[4];
+                    sharpen_quad<HALF>(tt, p.coef, o);
+                    const long of = c * plane + (long)(a - 2) * UW + (UW - 1);
+                    if constexpr (HALF) ((__half*)p.out)[of] = __float2half_rn(o[1]);
+                    else ((float*)p.out)[of] = o[1];
+                }
+                const float* rn = (a == 0) ? rowp(0) : rowp(-1);
+                red[20] = rn[UW - 2];
+                red[21] = rn[UW - 1];
+            }
+            __syncthreads();        // the ring rows are dead: the next transform exchanges through their buffer
         }
     }
 }
