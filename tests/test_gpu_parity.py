@@ -319,8 +319,10 @@ def test_fused_sharpen_equals_unfused(precision, pps, monkeypatch):
         # the quirk column x = uW-1 and the strip-boundary rows are where the bookkeeping lives
         assert np.abs(out[:, :, -1] - out2[:, :, -1]).max() <= 1e-4
     else:
+        # the fused kernel's packed-binary16 sharpen (native reciprocal + one residual step, native square root) against
+        # the exactly rounded per-operation sequence of k_sharpen_t: measured 1e-4 .. 8e-4 of the pixels differ, by one ulp
         assert np.abs(out - out2).max() <= 8e-3
-        assert (out != out2).mean() <= 0.02
+        assert (out != out2).mean() <= 5e-3
 
 
 @pytest.mark.parametrize("name", ["g16x8_u2_p0", "g20x12_u2_p0", "g20x12_u2_p1", "g64x32_u2_p0", "g64x32_u2_p2", "gsample64_u2_p0"])

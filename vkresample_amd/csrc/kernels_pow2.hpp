@@ -13,6 +13,8 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "fft_engine.hpp"
 #include "kernels_generic.hpp"
 
@@ -719,6 +721,61 @@ __device__ __forceinline__ void sharpen_quad(const float (&t)[3][6], float coef,
     }
 }
 
+// ---- -p 2 sharpen on PAIRS of pixels in packed binary16.  The reference evaluates this shader in float16_t
+// (VkResample.cpp:823-826): every addition and multiplication below is one v_pk_*_f16 instruction, i.e. rounded to
+// binary16 per operation like the reference's (contraction is off: C + scale*s4 rounds twice, as there).  Same
+// algebra as sharpen_eval_pair: values carried doubled (2 - smx = 2 (1 - mx) exactly), n = min(mn, 1 - mx),
+// d = max(1 - mn, mx).  The inner quotient is the native binary16 reciprocal plus one residual step, the root the
+// native binary16 square root (1 ulp; the Vulkan spec allows the reference's own fp16 division 2.5 ulp), the final
+// quotient is formed in fp32 and rounded once.  k_sharpen_t keeps the exactly rounded sequence, bit for bit against the oracle.
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2v h2_bits(unsigned u) { return __builtin_bit_cast(h2v, u); }
+__device__ __forceinline__ unsigned bits_h2(h2v h) { return __builtin_bit_cast(unsigned, h); }
+__device__ __forceinline__ h2v h2_splat(float f) { const _Float16 x = (_Float16)f; h2v r = {x, x}; return r; }
+__device__ __forceinline__ h2v sharpen_eval_pair_half(h2v N, h2v S, h2v Wv, h2v E, h2v C, h2v mn0, h2v mn1, h2v mx0, h2v mx1, h2v ncoef)
+{
+#pragma clang fp contract(off)
+    const h2v one = {(_Float16)1.0f, (_Float16)1.0f}, two = {(_Float16)2.0f, (_Float16)2.0f}, four = {(_Float16)4.0f, (_Float16)4.0f};
+    const h2v smn = mn0 + mn1, smx = mx0 + mx1;
+    const h2v u = two - smx, v = two - smn;
+    const h2v n2 = __builtin_elementwise_min(smn, u), d2 = __builtin_elementwise_max(v, smx);     // d2 in [1, 2]
+    const h2v rc = {(_Float16)__builtin_amdgcn_rcph(d2.x), (_Float16)__builtin_amdgcn_rcph(d2.y)};
+    const h2v qa = n2 * rc;
+    const h2v q = __builtin_elementwise_fma(__builtin_elementwise_fma(-qa, d2, n2), rc, qa);     // residual step: RN(n2/d2) but for rare ties
+    const h2v r = {(_Float16)__builtin_amdgcn_sqrth(q.x), (_Float16)__builtin_amdgcn_sqrth(q.y)};
+    const h2v scale = ncoef * r;
+    const h2v s4 = ((N + Wv) + E) + S;
+    const h2v prod = scale * s4;
+    const h2v num = C + prod;
+    const h2v den = one + scale * four;                // 4 * scale is exact: one rounding either way
+    const float q0 = (float)num.x * __builtin_amdgcn_rcpf((float)den.x), q1 = (float)num.y * __builtin_amdgcn_rcpf((float)den.y);
+    h2v o = {(_Float16)q0, (_Float16)q1};
+    return o;
+}
+// one window (three rows) of four pixels: P[r] = the five column pairs (-1,0) (0,1) (1,2) (2,3) (3,4) of row r
+struct H2Row { h2v sa, h01, sb, h23, sc; };
+__device__ __forceinline__ void sharpen_quad_half(const H2Row& r0, const H2Row& r1, const H2Row& r2, h2v ncoef, h2v& o01, h2v& o23)
+{
+#define V3MIN(f) __builtin_elementwise_min(__builtin_elementwise_min(r0.f, r1.f), r2.f)
+#define V3MAX(f) __builtin_elementwise_max(__builtin_elementwise_max(r0.f, r1.f), r2.f)
+    const h2v na = V3MIN(sa), nb = V3MIN(h01), nc = V3MIN(sb), nd = V3MIN(h23), ne = V3MIN(sc);
+    const h2v xa = V3MAX(sa), xb = V3MAX(h01), xc = V3MAX(sb), xd = V3MAX(h23), xe = V3MAX(sc);
+#undef V3MIN
+#undef V3MAX
+    // pixels 0,1: columns (-1,0) (0,1) (1,2); cross = N, C, S (the vertical triple of the centre pair) and W, E
+    const h2v mn1a = __builtin_elementwise_min(__builtin_elementwise_min(na, nb), nc);
+    const h2v mx1a = __builtin_elementwise_max(__builtin_elementwise_max(xa, xb), xc);
+    const h2v mn0a = __builtin_elementwise_min(__builtin_elementwise_min(nb, r1.sa), r1.sb);
+    const h2v mx0a = __builtin_elementwise_max(__builtin_elementwise_max(xb, r1.sa), r1.sb);
+    o01 = sharpen_eval_pair_half(r0.h01, r2.h01, r1.sa, r1.sb, r1.h01, mn0a, mn1a, mx0a, mx1a, ncoef);
+    // pixels 2,3: columns (1,2) (2,3) (3,4)
+    const h2v mn1b = __builtin_elementwise_min(__builtin_elementwise_min(nc, nd), ne);
+    const h2v mx1b = __builtin_elementwise_max(__builtin_elementwise_max(xc, xd), xe);
+    const h2v mn0b = __builtin_elementwise_min(__builtin_elementwise_min(nd, r1.sb), r1.sc);
+    const h2v mx0b = __builtin_elementwise_max(__builtin_elementwise_max(xd, r1.sb), r1.sc);
+    o23 = sharpen_eval_pair_half(r0.h23, r2.h23, r1.sb, r1.sc, r1.h23, mn0b, mn1b, mx0b, mx1b, ncoef);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Fused C2R + sharpen: a workgroup of T = UW/8 threads owns a strip and alternates, all
 // threads together, between transforming row pair s and sharpening the two output rows that pair completes.  Two such
@@ -741,6 +798,7 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
     constexpr int E = 8, T = UW / E;
     constexpr float inv = 0.5f / (float)UW;         // 1/2: the spectrum rows carry twice the reference's scale (k_col_t)
     using L = FusedGLds<UW>;
+    using LT = typename std::conditional<HALF, _Float16, float>::type;      // L rows in LDS: binary16 for -p 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)(smem + L::RED);      // [0..15] corner partial sums, [16] corner DC term, [20..21] deferred-pixel taps
     int lt = threadIdx.x;                       // (made opaque at the phase entries, see FFTUP_OPQ)
@@ -812,8 +870,8 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
         for (int s = 0; s < npairs; s++) {
             const int a = a0 + 2 * s;
             float2* buf = (float2*)(smem + (s & 1) * L::XB);
-            float* cur = (float*)buf;                                               // rows a, a+1 after the transform
-            const float* ring = (const float*)(smem + ((s + 1) & 1) * L::XB);       // rows a-2, a-1
+            LT* cur = (LT*)buf;                                                     // rows a, a+1 after the transform
+            const LT* ring = (const LT*)(smem + ((s + 1) & 1) * L::XB);             // rows a-2, a-1
             // ================= transform of pair s
             if constexpr ((FFTUP_OPQ & 1) != 0) asm volatile("" : "+v"(lt));
             float2 v[E];
@@ -838,10 +896,15 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
             // for them -- right behind the loads; any loop-carried copy now happens after the data has landed)
             FFTUP_SETTLE_IN();
             if constexpr (HALF) {
+                // C2R output stored as binary16 (vkFFT.h:7289-7290), then |u^2 g| clamped, each step rounded like the shader's
+                const h2v up2 = h2_splat(p.upsq), one2 = h2_splat(1.0f);
 #pragma unroll
                 for (int i = 0; i < E; i++) {
-                    cur[lt + T * i] = to_L<HALF>(v[i].x * inv, p.upsq);
-                    cur[UW + lt + T * i] = to_L<HALF>(v[i].y * inv, p.upsq);
+                    const f2v sv = mk2(v[i].x, v[i].y) * mk2(inv, inv);
+                    const h2v g = {(_Float16)sv.x, (_Float16)sv.y};
+                    const h2v Lv = __builtin_elementwise_min(h2_bits(bits_h2(up2 * g) & 0x7fff7fffu), one2);
+                    cur[lt + T * i] = Lv.x;
+                    cur[UW + lt + T * i] = Lv.y;
                 }
             } else if constexpr ((FFTUP_KO & 16) != 0) {
                 if (v[0].x + v[1].y + v[6].x + v[7].y + v[2].x == 12345.f) cur[lt] = v[0].x;
@@ -858,9 +921,63 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
             __syncthreads();                                                        // L rows a, a+1 visible
             // ================= sharpen rows a-1 and a
             if constexpr ((FFTUP_OPQ & 2) != 0) asm volatile("" : "+v"(lt));
-            auto rowp = [&](int r) -> const float* { return r < 0 ? ring + (r + 2) * UW : cur + r * UW; };
+            auto rowp = [&](int r) -> const LT* { return r < 0 ? ring + (r + 2) * UW : cur + r * UW; };
             const bool out0 = (a - 1) >= y0 && (a - 1) < y1;                        // row y = a-1
             const bool out1 = a >= y0 && a < y1;                                    // row y = a
+            if constexpr (HALF) {
+                if (out0 || out1) {
+                    const h2v ncoef = h2_splat(-p.coef);
+#pragma unroll 1
+                    for (int h = 0; h < 2; h++) {
+                        const int x0 = 4 * (lt + T * h);
+                        // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
+                        const LT* rows[4] = {rowp(-2), (a == 0) ? rowp(0) : rowp(-1), rowp(0), rowp(1)};
+                        H2Row R[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            if (r == 0 && !out0) {
+                                R[0].sa = R[0].h01 = R[0].sb = R[0].h23 = R[0].sc = h2_splat(0.f);
+                                continue;
+                            }
+                            // own four pixels (8 bytes) and the quads of both neighbours; the shifted pairs by v_alignbit
+                            const LT* rp = rows[r] + x0;
+                            const uint2 q = *(const uint2*)rp, ql = *(const uint2*)(rp - 4), qr = *(const uint2*)(rp + 4);
+                            R[r].h01 = h2_bits(q.x);
+                            R[r].h23 = h2_bits(q.y);
+                            R[r].sa = h2_bits(__builtin_amdgcn_alignbit(q.x, ql.y, 16));        // (x0-1, x0)
+                            R[r].sb = h2_bits(__builtin_amdgcn_alignbit(q.y, q.x, 16));         // (x0+1, x0+2)
+                            R[r].sc = h2_bits(__builtin_amdgcn_alignbit(qr.x, q.y, 16));        // (x0+3, x0+4)
+                        }
+                        if (x0 == 0) {                         // id_x_m clamp (VkResample.cpp:889)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) R[r].sa = h2_bits((bits_h2(R[r].h01) & 0xffffu) * 0x10001u);
+                        }
+                        if (x0 + 4 == UW) {
+                            auto set_hi = [](h2v& d, LT v) { d.y = v; };
+                            // row a-1 wraps into row a, which lives in the other buffer
+                            if (a != 0) set_hi(R[1].sc, rowp(0)[0]);
+                            // SE tap of pixel (a, UW-1) is L(a+2, 0): see the fp32 pass
+                            set_hi(R[3].sc, rowp(1)[0]);
+                            const int r2 = min(a + 2, uH - 1) - a;
+                            if (r2 <= 1) set_hi(R[3].sc, rowp(r2)[0]);
+                            else if (s == npairs - 1) {
+                                float sum = 0.f;
+                                for (int w2 = 0; w2 < (T + 63) / 64; w2++) sum += red[w2];
+                                set_hi(R[3].sc, (LT)to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq));
+                            }
+                        }
+#pragma unroll
+                        for (int w = 0; w < 2; w++) {
+                            if (w == 0 ? !out0 : !out1) continue;
+                            h2v o01, o23;
+                            sharpen_quad_half(R[w], R[w + 1], R[w + 2], ncoef, o01, o23);
+                            const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
+                            f2v val = {__builtin_bit_cast(float, o01), __builtin_bit_cast(float, o23)};
+                            __builtin_nontemporal_store(val, (f2v*)((char*)((__half*)p.out + row_of) + (unsigned)x0 * 2u));
+                        }
+                    }
+                }
+            } else {
             if (out0 || out1) {
 #pragma unroll 1
                 for (int h = 0; h < 2; h++) {
@@ -911,24 +1028,7 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
                     for (int w = 0; w < 2; w++) {
                         if (w == 0 ? !out0 : !out1) continue;
                         float o[4];
-                        if constexpr (HALF) {
-                            float hmn[3][4], hmx[3][4];
-#pragma unroll
-                            for (int r = 0; r < 3; r++)
-#pragma unroll
-                                for (int k = 0; k < 4; k++) {
-                                    hmn[r][k] = fminf(fminf(t[w + r][k], t[w + r][k + 1]), t[w + r][k + 2]);
-                                    hmx[r][k] = fmaxf(fmaxf(t[w + r][k], t[w + r][k + 1]), t[w + r][k + 2]);
-                                }
-#pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                const float N = t[w][k + 1], S = t[w + 2][k + 1], Wv = t[w + 1][k], C = t[w + 1][k + 1], Ev = t[w + 1][k + 2];
-                                const float mn0 = fminf(fminf(N, S), hmn[1][k]);
-                                const float mx0 = fmaxf(fmaxf(N, S), hmx[1][k]);
-                                const float mn1 = fminf(fminf(hmn[0][k], hmn[2][k]), mn0);
-                                const float mx1 = fmaxf(fmaxf(hmx[0][k], hmx[2][k]), mx0);
-                                o[k] = sharpen_eval_half_fast(N, S, Wv, Ev, C, mn0, mn1, mx0, mx1, p.coef);
-                            }
+                        if constexpr (false) {
                         } else if constexpr ((FFTUP_KO & 1) != 0) {
                             for (int k = 0; k < 4; k++) o[k] = t[w][k + 1] + t[w + 1][k] + t[w + 1][k + 2] + t[w + 2][k + 1] + t[w+1][k+1];
                         } else {
@@ -939,10 +1039,6 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
                         const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
                         if constexpr ((FFTUP_KO & 4) != 0) {
                             if (o[0] + o[1] + o[2] + o[3] == 12345.f) ((float*)p.out)[row_of + x0] = o[0];
-                        } else if constexpr (HALF) {
-                            __half2 h0 = __floats2half2_rn(o[0], o[1]), h1 = __floats2half2_rn(o[2], o[3]);
-                            f2v val = {*(float*)&h0, *(float*)&h1};
-                            __builtin_nontemporal_store(val, (f2v*)((char*)((__half*)p.out + row_of) + (unsigned)x0 * 2u));
                         } else {
                             typedef float f4v __attribute__((ext_vector_type(4)));
                             f4v val = {o[0], o[1], o[2], o[3]};
@@ -951,26 +1047,28 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
                     }
                 }
             }
+            }
             if (lt == T - 1) {
                 // finish the pixel deferred by the previous pair: (a-2, UW-1); L(a,0) is known now
                 if (s > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1) {
-                    const float* r2 = rowp(-2);
-                    const float* r1 = rowp(-1);
-                    const float* r0 = rowp(0);
-                    const float ne = (a - 2 == 0) ? r1[0] : r2[0];
+                    const LT* r2 = rowp(-2);
+                    const LT* r1 = rowp(-1);
+                    const LT* r0 = rowp(0);
+                    const float r10 = (float)r1[0], r00 = (float)r0[0];
+                    const float ne = (a - 2 == 0) ? r10 : (float)r2[0];
                     const float pn0 = red[20], pn1 = red[21];
                     const float tt[3][6] = {{pn0, pn0, pn1, ne, ne, ne},
-                                            {r2[UW - 2], r2[UW - 2], r2[UW - 1], r1[0], r1[0], r1[0]},
-                                            {r1[UW - 2], r1[UW - 2], r1[UW - 1], r0[0], r0[0], r0[0]}};
+                                            {(float)r2[UW - 2], (float)r2[UW - 2], (float)r2[UW - 1], r10, r10, r10},
+                                            {(float)r1[UW - 2], (float)r1[UW - 2], (float)r1[UW - 1], r00, r00, r00}};
                     float o[4];
                     sharpen_quad<HALF>(tt, p.coef, o);
                     const long of = c * plane + (long)(a - 2) * UW + (UW - 1);
                     if constexpr (HALF) ((__half*)p.out)[of] = __float2half_rn(o[1]);
                     else ((float*)p.out)[of] = o[1];
                 }
-                const float* rn = (a == 0) ? rowp(0) : rowp(-1);
-                red[20] = rn[UW - 2];
-                red[21] = rn[UW - 1];
+                const LT* rn = (a == 0) ? rowp(0) : rowp(-1);
+                red[20] = (float)rn[UW - 2];
+                red[21] = (float)rn[UW - 1];
             }
             __syncthreads();        // the ring rows are dead: the next transform exchanges through their buffer
         }
