@@ -308,12 +308,13 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         if (!P->TK) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled height too large for LDS"); goto bad; }
         P->mixed1080 = !P->dbl && !P->tuned && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && W == 1920 && H == 1080 && uW == 3840 &&
                        uH == 2160 && P->TK == 4;
-        P->fused = P->tuned && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
+        if (P->mixed1080) P->ldsCol = sizeof(float2) * (size_t)H * 4;                        // k_col_m1080: one in-place buffer
+        P->fused = (P->tuned || P->mixed1080) && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
         {
             // One strip (workgroup of uW/8 threads) per compute unit by default.  Two fit (FFTUP_G_PER_CU=2: the kernel
             // alone is 8 % faster), but one leaves half of every compute unit to the row and column kernels of the
             // frames on the other streams, and the frame time is what counts (measured: 82 vs 86 us).
-            int per_cu = 1;
+            int per_cu = P->mixed1080 ? 2 : 1;          // (the 3840 plan runs 256-thread workgroups: two = the same 8 waves)
             if (const char* e = getenv("FFTUP_G_PER_CU")) per_cu = std::max(1, std::min(4, atoi(e)));
             const int total_pairs = 3 * (int)uH / 2, slots = std::max(1, P->prop.multiProcessorCount) * per_cu;
             P->pairs_per_strip = std::max(2, (total_pairs + slots - 1) / slots);
@@ -350,7 +351,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         // kernel addresses both with 32-bit offsets from one base)
         const size_t s1_elems = (size_t)3 * P->NT * H * P->TK;
         auto alloc_spectra = [&](float2** s1, float2** s2) -> int {
-            if (P->tuned) {
+            if (P->tuned || P->mixed1080) {
                 int r = dev_alloc(P, (void**)s1, P->csz * 2 * s1_elems);
                 *s2 = r ? nullptr : *s1 + s1_elems;
                 return r;
@@ -396,19 +397,18 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             SET_LDS((k_row_c2r<false, double2>), P->ldsRowI);
         }
         if (P->mixed1080) {
-            SET_LDS((k_row_r2c_ct<Plan1920, IN_F32>), P->ldsRowF);
-            SET_LDS((k_row_r2c_ct<Plan1920, IN_F16>), P->ldsRowF);
-            SET_LDS((k_row_r2c_ct<Plan1920, IN_U8_F32>), P->ldsRowF);
-            SET_LDS((k_row_r2c_ct<Plan1920, IN_U8_F16>), P->ldsRowF);
-            SET_LDS((k_col_ct<Plan1080, Plan2160, 4>), P->ldsCol);
+            SET_LDS(k_col_m1080, P->ldsCol);
             SET_LDS((k_row_c2r_ct<Plan3840, false>), P->ldsRowI);
             SET_LDS((k_row_c2r_ct<Plan3840, true>), P->ldsRowI);
+            SET_LDS((k_c2r_sharpen_g<FusedPlan3840, false, 4>), FusedGLds<FusedPlan3840>::TOTAL);
+            SET_LDS((k_c2r_sharpen_g<FusedPlan3840, true, 4>), FusedGLds<FusedPlan3840>::TOTAL);
         }
         if (P->tuned) {
             switch (uW) {
-            case 1024: SET_LDS((k_c2r_sharpen_g<1024, false, TUNED_TK>), FusedGLds<1024>::TOTAL); SET_LDS((k_c2r_sharpen_g<1024, true, TUNED_TK>), FusedGLds<1024>::TOTAL); break;
-            case 2048: SET_LDS((k_c2r_sharpen_g<2048, false, TUNED_TK>), FusedGLds<2048>::TOTAL); SET_LDS((k_c2r_sharpen_g<2048, true, TUNED_TK>), FusedGLds<2048>::TOTAL); break;
-            default: SET_LDS((k_c2r_sharpen_g<4096, false, TUNED_TK>), FusedGLds<4096>::TOTAL); SET_LDS((k_c2r_sharpen_g<4096, true, TUNED_TK>), FusedGLds<4096>::TOTAL); break;
+#define SET_FUSED(PL) SET_LDS((k_c2r_sharpen_g<PL, false, TUNED_TK>), FusedGLds<PL>::TOTAL); SET_LDS((k_c2r_sharpen_g<PL, true, TUNED_TK>), FusedGLds<PL>::TOTAL)
+            case 1024: SET_FUSED(FusedPlanPow2<1024>); break;
+            case 2048: SET_FUSED(FusedPlanPow2<2048>); break;
+            default: SET_FUSED(FusedPlanPow2<4096>); break;
             }
             switch (H) {
             case 256: SET_LDS((k_col_t<256, TUNED_TK>), P->ldsCol); break;
@@ -560,12 +560,20 @@ template <int UW> static void launch_c2r_t(fftup_plan* P, const RowC2RTParams& p
     else hipLaunchKernelGGL((k_row_c2r_t<UW, false, TUNED_TK, true>), grid, block, 0, P->lanes[P->cur].stream, p);
 }
 
-template <int UW> static void launch_fused_t(fftup_plan* P, const FusedParams& p)
+template <class PL> static void launch_fused_t(fftup_plan* P, const FusedParams& p)
 {
     const int total_pairs = 3 * (int)P->uH / 2;
-    dim3 grid((total_pairs + p.pairs_per_strip - 1) / p.pairs_per_strip), block(UW / 8);
-    if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_g<UW, true, TUNED_TK>), grid, block, FusedGLds<UW>::TOTAL, P->lanes[P->cur].stream, p);
-    else hipLaunchKernelGGL((k_c2r_sharpen_g<UW, false, TUNED_TK>), grid, block, FusedGLds<UW>::TOTAL, P->lanes[P->cur].stream, p);
+    dim3 grid((total_pairs + p.pairs_per_strip - 1) / p.pairs_per_strip), block(PL::T);
+    if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_g<PL, true, TUNED_TK>), grid, block, FusedGLds<PL>::TOTAL, P->lanes[P->cur].stream, p);
+    else hipLaunchKernelGGL((k_c2r_sharpen_g<PL, false, TUNED_TK>), grid, block, FusedGLds<PL>::TOTAL, P->lanes[P->cur].stream, p);
+}
+static FusedParams fused_params(fftup_plan* P, uint32_t out_slot)
+{
+    FusedParams p{};
+    p.S1 = P->lanes[P->cur].S1; p.odd_delta = (unsigned)(P->lanes[P->cur].S2 - P->lanes[P->cur].S1);
+    p.out = P->out[out_slot]; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
+    p.pairs_per_strip = P->pairs_per_strip; p.upsq = P->upsq; p.coef = P->coef;
+    return p;
 }
 
 static bool fast_sharpen_ok(const fftup_plan* P) { return !P->dbl && P->uW % 256 == 0 && P->uH % 16 == 0; }
@@ -595,14 +603,11 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
         }
     }
     if ((which < 0 || which == 2) && P->fused) {
-        FusedParams p{};
-        p.S1 = P->lanes[P->cur].S1; p.odd_delta = (unsigned)(P->lanes[P->cur].S2 - P->lanes[P->cur].S1);
-        p.out = P->out[out_slot]; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
-        p.pairs_per_strip = P->pairs_per_strip; p.upsq = P->upsq; p.coef = P->coef;
+        const FusedParams p = fused_params(P, out_slot);
         switch (P->uW) {
-        case 1024: launch_fused_t<1024>(P, p); break;
-        case 2048: launch_fused_t<2048>(P, p); break;
-        default: launch_fused_t<4096>(P, p); break;
+        case 1024: launch_fused_t<FusedPlanPow2<1024>>(P, p); break;
+        case 2048: launch_fused_t<FusedPlanPow2<2048>>(P, p); break;
+        default: launch_fused_t<FusedPlanPow2<4096>>(P, p); break;
         }
         P->R_valid = false;
     } else if (which < 0 || which == 2 || which == 22) {   // 22: pre-sharpen tap requested for a fused plan
@@ -687,15 +692,17 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         p.TK = P->TK; p.NT = P->NT;
         dim3 grid(P->H / 2, 3), block(P->thrW);
         if (P->mixed1080) {
-            dim3 blk(Plan1920::T);
-            if (kind == 2) {
-                p.in = P->in_u8[in_slot]; p.in_row_stride = 3l * P->W; p.in_plane_stride = 0;
-                if (P->half) hipLaunchKernelGGL((k_row_r2c_ct<Plan1920, IN_U8_F16>), grid, blk, P->ldsRowF, P->lanes[P->cur].stream, p);
-                else hipLaunchKernelGGL((k_row_r2c_ct<Plan1920, IN_U8_F32>), grid, blk, P->ldsRowF, P->lanes[P->cur].stream, p);
-            } else {
-                p.in = P->in_planar[in_slot]; p.in_row_stride = P->W; p.in_plane_stride = (long)P->in_plane_stride;
-                if (P->half) hipLaunchKernelGGL((k_row_r2c_ct<Plan1920, IN_F16>), grid, blk, P->ldsRowF, P->lanes[P->cur].stream, p);
-                else hipLaunchKernelGGL((k_row_r2c_ct<Plan1920, IN_F32>), grid, blk, P->ldsRowF, P->lanes[P->cur].stream, p);
+            RowR2CTParams q{};
+            q.S1 = P->lanes[P->cur].S1; q.tw = P->twW; q.H = (int)P->H; q.NT = P->NT;
+            int mode;
+            if (kind == 2) { q.in = P->in_u8[in_slot]; q.in_row_stride = 3l * P->W; q.in_plane_stride = 0; mode = P->half ? IN_U8_F16 : IN_U8_F32; }
+            else { q.in = P->in_planar[in_slot]; q.in_row_stride = P->W; q.in_plane_stride = (long)P->in_plane_stride; mode = P->half ? IN_F16 : IN_F32; }
+            hipStream_t st = P->lanes[P->cur].stream;
+            switch (mode) {
+            case IN_F32: hipLaunchKernelGGL((k_row_r2c_m1920<IN_F32>), grid, dim3(256), 0, st, q); break;
+            case IN_F16: hipLaunchKernelGGL((k_row_r2c_m1920<IN_F16>), grid, dim3(256), 0, st, q); break;
+            case IN_U8_F32: hipLaunchKernelGGL((k_row_r2c_m1920<IN_U8_F32>), grid, dim3(256), 0, st, q); break;
+            default: hipLaunchKernelGGL((k_row_r2c_m1920<IN_U8_F16>), grid, dim3(256), 0, st, q); break;
             }
         } else if (kind == 2) {
             p.in = P->in_u8[in_slot]; p.in_row_stride = 3l * P->W; p.in_plane_stride = 0;
@@ -713,17 +720,23 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.zly = P->zly; p.zry = P->zry;
         p.inv_norm = 1.0f / (float)P->uH;
         dim3 grid(P->NT, 3), block(P->thrCol);
-        if (P->mixed1080) hipLaunchKernelGGL((k_col_ct<Plan1080, Plan2160, 4>), grid, dim3(Plan2160::T), P->ldsCol, P->lanes[P->cur].stream, p);
-        else switch (P->TK) {
+        if (P->mixed1080) {
+            ColTParams q{};
+            q.S1 = P->lanes[P->cur].S1; q.S2 = P->lanes[P->cur].S2; q.twH = P->twH; q.twUH = P->twUH; q.W = (int)P->W; q.NT = P->NT;
+            hipLaunchKernelGGL(k_col_m1080, grid, dim3(576), P->ldsCol, P->lanes[P->cur].stream, q);
+        } else switch (P->TK) {
         case 8: hipLaunchKernelGGL(k_col<8>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
         case 4: hipLaunchKernelGGL(k_col<4>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
         case 2: hipLaunchKernelGGL(k_col<2>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
         default: hipLaunchKernelGGL(k_col<1>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
         }
     }
-    if (which < 0 || which == 2) {
+    if ((which < 0 || which == 2) && P->fused) {
+        launch_fused_t<FusedPlan3840>(P, fused_params(P, out_slot));     // (only the 3840 plan is fused on this path)
+        P->R_valid = false;
+    } else if (which < 0 || which == 2 || which == 22) {                 // 22: pre-sharpen tap requested for a fused plan
         RowC2RParams p{};
-        p.S2 = P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = P->twUW; p.plan = P->planUW; p.W = (int)P->W; p.uW = (int)P->uW;
+        p.S1 = P->lanes[P->cur].S1; p.S2 = P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = P->twUW; p.plan = P->planUW; p.W = (int)P->W; p.uW = (int)P->uW;
         p.uH = (int)P->uH; p.TK = P->TK; p.NT = P->NT; p.zlx = P->zlx; p.zrx = P->zrx;
         p.inv_norm = 1.0f / (float)P->uW;
         dim3 grid(P->uH / 2, 3), block(P->thrUW);
@@ -732,8 +745,11 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
             else hipLaunchKernelGGL((k_row_c2r_ct<Plan3840, false>), grid, dim3(Plan3840::T), P->ldsRowI, P->lanes[P->cur].stream, p);
         } else if (P->half) hipLaunchKernelGGL(k_row_c2r<true>, grid, block, P->ldsRowI, P->lanes[P->cur].stream, p);
         else hipLaunchKernelGGL(k_row_c2r<false>, grid, block, P->ldsRowI, P->lanes[P->cur].stream, p);
+        P->R_valid = true;
     }
-    if ((which < 0 || which == 3) && fast_sharpen_ok(P)) {
+    if (P->fused) {
+        // sharpen is part of launch 2
+    } else if ((which < 0 || which == 3) && fast_sharpen_ok(P)) {
         launch_sharpen_fast(P, out_slot);
     } else if (which < 0 || which == 3) {
         SharpenParams p{};
@@ -907,7 +923,8 @@ int fftup_download_presharpen(fftup_plan* P, void* planes)
         // the fused kernel never writes the pre-sharpen image; rebuild it from the spectrum of the last
         // frame (still in S2) with the stand-alone C2R kernel
         P->cur = P->last_lane;
-        launch_frame_tuned(P, 0, 0, 22);
+        if (P->tuned) launch_frame_tuned(P, 0, 0, 22);
+        else launch_frame(P, 0, 0, 22);
         P->cur = 0;
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(P->lanes[P->last_lane].stream));

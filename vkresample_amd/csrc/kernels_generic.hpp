@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(1024) k_col(ColParamsT<C> p)
 }
 
 template <typename C> struct RowC2RParamsT {
+    const C* S1;             // polyphase plans only (k_row_c2r_ct): even spectrum rows; S2 then holds the odd rows
     const C* S2;
     void* R;                 // dense [3][uH][uW] float, half or double
     const C* tw;             // uW-th roots

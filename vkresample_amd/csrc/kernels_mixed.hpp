@@ -5,6 +5,7 @@
 #pragma once
 #include "fft_engine.hpp"
 #include "kernels_generic.hpp"
+#include "kernels_pow2.hpp"
 
 namespace fftup {
 
@@ -60,15 +61,17 @@ __global__ void __launch_bounds__(PW::T) k_row_r2c_ct(RowR2CParams p)
     }
 }
 
-// ---- column (see k_col), u = 2.  grid (NT, 3), block PUH::T, dynamic LDS 2*lpad_size(UH*TK) float2
-template <class PH, class PUH, int TK>
-__global__ void __launch_bounds__(PUH::T) k_col_ct(ColParams p)
+// ---- column, u = 2, polyphase form (see k_col_t in kernels_pow2.hpp for the derivation): forward FFT(H), multiplication by
+// t[k] = exp(-2 pi i k/2H) * (k < H/2 ? 1 : -1), inverse FFT(H) -> the ODD rows of the zero-padded 2H-row spectrum at
+// twice the reference's normalisation; the even rows are the rows of S1 and are never written.
+// grid (NT, 3), block PH::T, dynamic LDS 2*lpad_size(H*TK) float2
+template <class PH, int TK>
+__global__ void __launch_bounds__(PH::T) k_col_ct(ColParams p)
 {
-    constexpr int H = PH::N, UH = PUH::N, T = PUH::T;
-    static_assert(PH::T == PUH::T && UH == 2 * H, "one block size for both transforms, u = 2");
+    constexpr int H = PH::N, T = PH::T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* a = (float2*)smem;
-    float2* b = a + lpad_size(UH * TK);
+    float2* b = a + lpad_size(H * TK);
     const int tid = threadIdx.x, tile = blockIdx.x, c = blockIdx.y;
     const int ncol_valid = min(TK, p.W / 2 + 1 - tile * TK);
     const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
@@ -80,19 +83,17 @@ __global__ void __launch_bounds__(PUH::T) k_col_ct(ColParams p)
     __syncthreads();
     float2* F = run_plan<+1, TK>(PH{}, a, b, p.twH, tid);
     float2* G = (F == a) ? b : a;
-    // shift + zero-pad guard for u = 2: G[ky] = F[ky] (ky < H/2), F[ky-H] (ky >= 3H/2), else 0
-    for (int e = tid; e < UH * TK; e += T) {
-        const int ky = e / TK, col = e % TK;
-        float2 v = make_float2(0.f, 0.f);
-        if (ky < H / 2) v = F[lpad(e)];
-        else if (ky >= UH - H / 2) v = F[lpad((ky - H) * TK + col)];
-        G[lpad(e)] = v;
+    for (int e = tid; e < H * TK; e += T) {
+        const int ky = e / TK;
+        float2 t = twid<-1>(p.twUH[ky]);
+        if (ky >= H / 2) t = make_float2(-t.x, -t.y);
+        G[lpad(e)] = cmul(F[lpad(e)], t);
     }
     __syncthreads();
-    const float2* D = run_plan<-1, TK>(PUH{}, G, F, p.twUH, tid);
-    float2* dst = p.S2 + ((long)c * p.NT + tile) * UH * TK;
-    constexpr float inv = 1.0f / (float)UH;
-    for (int e = tid; e < UH * TK; e += T)
+    const float2* D = run_plan<-1, TK>(PH{}, G, F, p.twH, tid);
+    float2* dst = p.S2 + ((long)c * p.NT + tile) * H * TK;
+    constexpr float inv = 1.0f / (float)H;
+    for (int e = tid; e < H * TK; e += T)
         if ((e % TK) < ncol_valid) dst[e] = cscale(D[lpad(e)], inv);
 }
 
@@ -106,26 +107,27 @@ __global__ void __launch_bounds__(PUW::T) k_row_c2r_ct(RowC2RParams p)
     float2* b = a + lpad_size(UW);
     const int tid = threadIdx.x, j = blockIdx.x, c = blockIdx.y;
     const int TK = p.TK;
-    const long tile_stride = (long)p.uH * TK;
-    const float2* base = p.S2 + (long)c * p.NT * tile_stride + (long)(2 * j) * TK;
+    // polyphase column pass: row 2j is row j of S1, row 2j+1 is row j of the odd-row buffer (both at twice the scale)
+    const long tile_stride = (long)(p.uH / 2) * TK;
+    const long roff = (long)c * p.NT * tile_stride + (long)j * TK;
     for (int k = tid + 1; k <= UW / 2; k += T) {
         float2 A = make_float2(0.f, 0.f), B = A;
         if (k <= KH) {
-            const float2* s = base + (long)(k / TK) * tile_stride + (k % TK);
-            A = s[0];
-            B = s[TK];
+            const long o = roff + (long)(k / TK) * tile_stride + (k % TK);
+            A = p.S1[o];
+            B = p.S2[o];
         }
         a[lpad(k)] = make_float2(A.x - B.y, A.y + B.x);
         a[lpad(UW - k)] = make_float2(A.x + B.y, -A.y + B.x);
     }
     if (tid == 0) {
-        float2 A = base[0], B = base[TK];
+        float2 A = p.S1[roff], B = p.S2[roff];
         a[lpad(0)] = make_float2(A.x - B.y, A.y + B.x);
     }
     __syncthreads();
     const float2* z = run_plan<-1, 1>(PUW{}, a, b, p.tw, tid);
     const long plane = (long)UW * p.uH;
-    constexpr float inv = 1.0f / (float)UW;
+    constexpr float inv = 0.5f / (float)UW;
     // 4 consecutive points per thread: 16-byte (8-byte for half) stores
     for (int n0 = tid * 4; n0 < UW; n0 += T * 4) {
         float2 q[4];
@@ -142,6 +144,97 @@ __global__ void __launch_bounds__(PUW::T) k_row_c2r_ct(RowC2RParams p)
             *(float4*)R = make_float4(q[0].x * inv, q[1].x * inv, q[2].x * inv, q[3].x * inv);
             *(float4*)(R + UW) = make_float4(q[0].y * inv, q[1].y * inv, q[2].y * inv, q[3].y * inv);
         }
+    }
+}
+
+// =================================================================================== register-resident 1080p kernels
+// One butterfly per thread and stage, the points in registers, one in-place LDS buffer (MrFftT in kernels_pow2.hpp).
+
+// ---- row R2C, W = 1920 = 15 * 8 * 16.  grid (H/2, 3), block 256, LDS W float2.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_row_r2c_m1920(RowR2CTParams p)
+{
+    constexpr int W = 1920, TK = 4;
+    using F = MrFftT<W, +1, 1, 15, 8, 16, true>;
+    __shared__ float2 buf[W];
+    const int tid = threadIdx.x, c = blockIdx.y, j = blockIdx.x;
+    typename F::Tw tw;
+    F::load_tw(tw, p.tw, tid);
+    float2 v[F::VN];
+    if (tid < F::NB0) {
+#pragma unroll
+        for (int m = 0; m < 15; m++)
+            v[m] = make_float2(load_px_t<MODE>(p, c, 2 * j, tid + F::NB0 * m), load_px_t<MODE>(p, c, 2 * j + 1, tid + F::NB0 * m));
+    }
+    F::run(v, buf, tid, 0, tw);
+    // unpack (vkFFT.h:4292-4323), as k_row_r2c_t: 4 consecutive lanes cover one tile segment [A(4)|B(4)], 16 bytes per lane
+    const long tile_stride = (long)p.H * TK;
+    float2* base = p.S1 + (long)c * p.NT * tile_stride + (long)(2 * j) * TK;
+    constexpr int NTILE = (W / 2 + 1 + TK - 1) / TK;
+    for (int g = tid; g < NTILE * TK; g += 256) {
+        const int tile = g / TK, l = g % TK;
+        const bool isB = l >= TK / 2;
+        const int kk = (l % (TK / 2)) * 2;
+        float2 o[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int k = tile * TK + kk + e;
+            float2 r = make_float2(0.f, 0.f);
+            if (k <= W / 2) {
+                const float2 zk = buf[k], zn = buf[k == 0 ? 0 : W - k];
+                r = isB ? make_float2(0.5f * (zk.y + zn.y), 0.5f * (-zk.x + zn.x)) : make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+            }
+            o[e] = r;
+        }
+        *(float4*)(base + (long)tile * tile_stride + (isB ? TK : 0) + kk) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+    }
+}
+
+// ---- column, H = 1080 = 9 * 8 * 15, polyphase form (k_col_t): forward, phase, inverse, odd rows out.
+// grid (NT, 3), block 576 (4 columns x 144; 135 threads per column are used), LDS H*4 float2.
+__global__ void __launch_bounds__(576) k_col_m1080(ColTParams p)
+{
+    constexpr int H = 1080, TK = 4;
+    using FF = MrFftT<H, +1, TK, 9, 8, 15, true>;
+    using FI = MrFftT<H, -1, TK, 9, 8, 15, false>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* buf = (float2*)smem;
+    const int tid = threadIdx.x, col = tid % TK, j = tid / TK;
+    const int tile = blockIdx.x, c = blockIdx.y;
+    const bool valid = tile * TK + col <= p.W / 2;
+    const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
+    typename FF::Tw tw;
+    FF::load_tw(tw, p.twH, j);
+    const float2 ph = p.twUH[j < FF::NB0 ? j : 0];           // exp(+2 pi i j/2H)
+    float2 v[FF::VN];
+    if (j < FF::NB0) {
+#pragma unroll
+        for (int m = 0; m < 9; m++) v[m] = valid ? src[(j + FF::NB0 * m) * TK + col] : make_float2(0.f, 0.f);
+    }
+    FF::run(v, buf, j, col, tw);                             // F[k] in natural order in LDS
+    if (j < FI::NB0) {
+        // t[k] = exp(-2 pi i k/2H) * (k < H/2 ? 1 : -1), k = j + 120 m: exp(-2 pi i j/2H) times the 18th roots of unity
+        const float2 w = twid<-1>(ph);
+#pragma unroll
+        for (int m = 0; m < 9; m++) {
+            const float2 f = buf[(j + FI::NB0 * m) * TK + col];
+            // k >= H/2 = 540 <=> m >= 5 (j < 120) except m = 4 with j >= 60: handled by the runtime sign below
+            constexpr float c18[9] = {1.f, 0.93969262078590838f, 0.76604444311897804f, 0.5f, 0.17364817766693035f,
+                                      -0.17364817766693035f, -0.5f, -0.76604444311897804f, -0.93969262078590838f};
+            constexpr float s18[9] = {0.f, 0.34202014332566873f, 0.64278760968653933f, 0.86602540378443865f, 0.98480775301220806f,
+                                      0.98480775301220806f, 0.86602540378443865f, 0.64278760968653933f, 0.34202014332566873f};
+            float2 t = cmul(w, make_float2(c18[m], -s18[m]));
+            if (j + FI::NB0 * m >= H / 2) t = make_float2(-t.x, -t.y);
+            v[m] = cmul(f, t);
+        }
+    }
+    __syncthreads();
+    FI::run(v, buf, j, col, tw);
+    float2* dst = p.S2 + ((long)c * p.NT + tile) * H * TK;
+    constexpr float inv = 1.0f / (float)H;
+    if (j < FI::NB2 && valid) {
+#pragma unroll
+        for (int m = 0; m < 15; m++) dst[(j + FI::NB2 * m) * TK + col] = cscale(v[m], inv);
     }
 }
 

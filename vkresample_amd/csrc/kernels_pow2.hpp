@@ -776,6 +776,149 @@ __device__ __forceinline__ void sharpen_quad_half(const H2Row& r0, const H2Row& 
     o23 = sharpen_eval_pair_half(r0.h23, r2.h23, r1.sb, r1.sc, r1.h23, mn0b, mn1b, mx0b, mx1b, ncoef);
 }
 
+// =================================================================================== transform plans of the fused kernel
+// What k_c2r_sharpen_g needs from a transform of length UW run by T threads: the first stage is a radix-R0 butterfly per
+// thread j < NB0 = UW/R0 on registers (inputs Z[j + NB0*m]); on return thread lt < SOUT owns X[lt + SOUT*q], q < EOUT.
+template <int UW_> struct FusedPlanPow2 {                   // radix-8 Stockham, 8 points per thread (reg_fft)
+    static constexpr int UW = UW_, T = UW / 8, R0 = 8, NB0 = T, EOUT = 8, SOUT = T, VN = 8;
+    static constexpr size_t XB = sizeof(float2) * lswz_size(UW);
+    struct Tw { TwSet<UW, 8> t; };
+    static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { w.t.load(tw, j); }
+    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, int j, const Tw& w)
+    {
+        reg_fft<UW, 8, -1, 1, false>(v, buf, j, 0, w.t);      // its last barrier follows the last gather
+    }
+};
+
+// ---- three-stage mixed-radix transform, ONE butterfly per thread and stage (radices up to 16: 3840 = 16 * 16 * 15).
+// Stage s has NBs = N/Rs butterflies; butterfly j reads in[j + NBs*m], m < Rs, and writes out[(j - k)*Rs + k + m*Ns],
+// k = j % Ns (Stockham autosort), in place in one LDS buffer.  LDS map: one padding element per 16 (lpad).  With radices
+// 16, 16, R2 and NB1, NB2 multiples of 16 every access of a thread is ONE per-thread base plus a compile-time offset
+// (lpad(16 j + m) = 17 j + m, lpad(j + NB m) = lpad(j) + (NB + NB/16) m, lpad(16 (j-k+m) + k) = 17 (j-k) + k + 17 m),
+// i.e. an immediate of the ds instruction: no address arithmetic in the stages.  The scatters are conflict-free, the
+// gathers pay one extra LDS cycle per 32 lanes for the padding (tools/lds_conflicts.py).
+template <int R> __device__ __forceinline__ void twiddle_all(float2* v, float2 w1)      // v[m] *= w1^m, m < R <= 16
+{
+    const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+    const float2 w8 = cmul(w4, w4);
+    const float2 ws[16] = {make_float2(1.f, 0.f), w1, w2, w3, w4, w5, w6, w7, w8, cmul(w8, w1), cmul(w5, w5), cmul(w8, w3),
+                           cmul(w6, w6), cmul(w8, w5), cmul(w7, w7), cmul(w8, w7)};
+#pragma unroll
+    for (int m = 1; m < R; m++) v[m] = cmul(v[m], ws[m]);
+}
+template <int N, int DIR, int R0, int R1, int R2> struct MrFft {
+    static constexpr int NB0 = N / R0, NB1 = N / R1, NB2 = N / R2;
+    static constexpr int NS1 = R0, NS2 = R0 * R1;
+    static constexpr int VN = (R0 > R1 ? (R0 > R2 ? R0 : R2) : (R1 > R2 ? R1 : R2));
+    struct Tw { float2 w1, w2; };                           // base twiddles of stages 1 and 2 (table sign exp(+i..))
+    static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j)
+    {
+        w.w1 = tw[((j < NB1 ? j : 0) % NS1) * (N / (NS1 * R1))];
+        w.w2 = tw[(j < NB2 ? j : 0) % NS2 * (N / (NS2 * R2))];
+    }
+    static_assert(R0 == 16 && R1 == 16 && NB1 % 16 == 0 && NB2 % 16 == 0, "offsets below assume 16-aligned strides");
+    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, int j, const Tw& w)
+    {
+        float2* const g = buf + lpad(j);                     // gather base of stages 1 and 2
+        if (j < NB0) {
+            bfly<R0, DIR>(v);
+            float2* const d = buf + 17 * j;
+#pragma unroll
+            for (int m = 0; m < R0; m++) d[m] = v[m];
+        }
+        __syncthreads();
+        if (j < NB1) {
+#pragma unroll
+            for (int m = 0; m < R1; m++) v[m] = g[(NB1 + NB1 / 16) * m];
+        }
+        __syncthreads();
+        if (j < NB1) {
+            twiddle_all<R1>(v, twid<DIR>(w.w1));
+            bfly<R1, DIR>(v);
+            const int k = j % NS1;
+            float2* const d = buf + 17 * (j - k) + k;
+#pragma unroll
+            for (int m = 0; m < R1; m++) d[17 * m] = v[m];
+        }
+        __syncthreads();
+        if (j < NB2) {
+#pragma unroll
+            for (int m = 0; m < R2; m++) v[m] = g[(NB2 + NB2 / 16) * m];
+        }
+        __syncthreads();                                     // the buffer may be overwritten from here on
+        if (j < NB2) {
+            twiddle_all<R2>(v, twid<DIR>(w.w2));             // k = j (NS2 * R2 = N)
+            bfly<R2, DIR>(v);
+        }
+    }
+};
+// ---- the same with TK interleaved sequences and NO index map: when the first radix is odd the stage-0 scatter of 16
+// consecutive lanes (R0 elements apart) already covers all 16 eight-byte slots, the later scatters and all gathers hit
+// consecutive elements -- every access is a per-thread base plus an immediate.  Element (i, col) lives at i*TK + col.
+struct MrTw { float2 w1, w2; };                             // base twiddles of stages 1 and 2 (table sign exp(+i..))
+template <int N, int DIR, int TK, int R0, int R1, int R2, bool FINAL_TO_LDS> struct MrFftT {
+    static_assert(R0 % 2 == 1 && R0 * R1 * R2 == N, "first radix odd (bank spread without a map); radices multiply to N");
+    static constexpr int NB0 = N / R0, NB1 = N / R1, NB2 = N / R2;
+    static constexpr int NS1 = R0, NS2 = R0 * R1;
+    static constexpr int VN = (R0 > R1 ? (R0 > R2 ? R0 : R2) : (R1 > R2 ? R1 : R2));
+    static constexpr int TC = (NB0 > NB1 ? (NB0 > NB2 ? NB0 : NB2) : (NB1 > NB2 ? NB1 : NB2));     // threads per sequence
+    using Tw = MrTw;
+    static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j)
+    {
+        w.w1 = tw[((j < NB1 ? j : 0) % NS1) * (N / (NS1 * R1))];
+        w.w2 = tw[((j < NB2 ? j : 0) % NS2) * (N / (NS2 * R2))];
+    }
+    // on entry v[m] = x[j + NB0*m] (j < NB0); on return X[j + NB2*m] in v (j < NB2) or, FINAL_TO_LDS, in buf (synced)
+    static __device__ __forceinline__ void run(float2 (&v)[VN], float2* __restrict__ buf, int j, int col, const Tw& w)
+    {
+        float2* const g = buf + j * TK + col;
+        if (j < NB0) {
+            bfly<R0, DIR>(v);
+            float2* const d = buf + j * R0 * TK + col;
+#pragma unroll
+            for (int m = 0; m < R0; m++) d[m * TK] = v[m];
+        }
+        __syncthreads();
+        if (j < NB1) {
+#pragma unroll
+            for (int m = 0; m < R1; m++) v[m] = g[m * NB1 * TK];
+        }
+        __syncthreads();
+        if (j < NB1) {
+            twiddle_all<R1>(v, twid<DIR>(w.w1));
+            bfly<R1, DIR>(v);
+            const int k = j % NS1;
+            float2* const d = buf + ((j - k) * R1 + k) * TK + col;
+#pragma unroll
+            for (int m = 0; m < R1; m++) d[m * NS1 * TK] = v[m];
+        }
+        __syncthreads();
+        if (j < NB2) {
+#pragma unroll
+            for (int m = 0; m < R2; m++) v[m] = g[m * NB2 * TK];
+        }
+        __syncthreads();
+        if (j < NB2) {
+            twiddle_all<R2>(v, twid<DIR>(w.w2));             // k = j (NS2 * R2 = N)
+            bfly<R2, DIR>(v);
+            if constexpr (FINAL_TO_LDS) {
+#pragma unroll
+                for (int m = 0; m < R2; m++) g[m * NB2 * TK] = v[m];
+            }
+        }
+        if constexpr (FINAL_TO_LDS) __syncthreads();
+    }
+};
+
+struct FusedPlan3840 {                                      // 1920x1080 -> 3840x2160: rows of 3840 = 16 * 16 * 15, 256 threads
+    using F = MrFft<3840, -1, 16, 16, 15>;
+    static constexpr int UW = 3840, T = 256, R0 = 16, NB0 = F::NB0, EOUT = 15, SOUT = F::NB2, VN = F::VN;
+    static constexpr size_t XB = (sizeof(float2) * lpad_size(3840) + 15) & ~(size_t)15;
+    using Tw = F::Tw;
+    static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { F::load_tw(w, tw, j); }
+    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, int j, const Tw& w) { F::fft(v, buf, j, w); }
+};
+
 // ---------------------------------------------------------------------------------------------------
 // Fused C2R + sharpen: a workgroup of T = UW/8 threads owns a strip and alternates, all
 // threads together, between transforming row pair s and sharpening the two output rows that pair completes.  Two such
@@ -786,18 +929,21 @@ __device__ __forceinline__ void sharpen_quad_half(const H2Row& r0, const H2Row& 
 //   pair s-1 (X[(s-1)&1]) are the "ring".  The spectrum rows of pair s+1 are prefetched into REGISTERS while pair s is
 //   processed (every thread loads the 8 values its first butterfly needs, mirrored ones included), so no LDS staging
 //   and -- loads being older than the output stores of the same step -- no wait on a store, ever (vmcnt is in order).
-template <int UW> struct FusedGLds {
-    static constexpr size_t XB = fused_buf_bytes(UW);
+template <class PL> struct FusedGLds {
+    static constexpr size_t XB = PL::XB;
     static constexpr size_t RED = 2 * XB;
     static constexpr size_t TOTAL = RED + 32 * sizeof(float);
 };
 
-template <int UW, bool HALF, int TK>
-__global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 / 256 : 1) k_c2r_sharpen_g(FusedParams p)
+template <class PL, bool HALF, int TK>
+__global__ void __launch_bounds__(PL::T, PL::T * 2 / 256 > 0 ? PL::T * 2 / 256 : 1) k_c2r_sharpen_g(FusedParams p)
 {
-    constexpr int E = 8, T = UW / E;
+    constexpr int UW = PL::UW, T = PL::T, R0 = PL::R0, NB0 = PL::NB0, NI = R0 / 4, KH = UW / 4;
+    constexpr int EOUT = PL::EOUT, SOUT = PL::SOUT, VN = PL::VN;
+    constexpr int NPASS = (UW + 4 * T - 1) / (4 * T);           // sharpen passes of 4 pixels per thread
+    static_assert(KH == NB0 * NI, "the non-zero half spectrum must fill whole first-stage inputs");
     constexpr float inv = 0.5f / (float)UW;         // 1/2: the spectrum rows carry twice the reference's scale (k_col_t)
-    using L = FusedGLds<UW>;
+    using L = FusedGLds<PL>;
     using LT = typename std::conditional<HALF, _Float16, float>::type;      // L rows in LDS: binary16 for -p 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)(smem + L::RED);      // [0..15] corner partial sums, [16] corner DC term, [20..21] deferred-pixel taps
@@ -805,8 +951,8 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
     const int uH = p.uH;
     const int pairs_per_plane = uH / 2;
     const long plane = (long)UW * uH;
-    TwSet<UW, E> tws;
-    tws.load(p.tw, lt);                         // once: inside the loop a load would queue behind the output stores
+    typename PL::Tw tws;
+    PL::load_tw(tws, p.tw, lt);                 // once: inside the loop a load would queue behind the output stores
 
     int f0 = blockIdx.x * p.pairs_per_strip;
     const int f1 = min(f0 + p.pairs_per_strip, 3 * pairs_per_plane);
@@ -830,24 +976,40 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
         const bool need_corner = !top && (y1 + 1 < uH);
         const int rs = y1 + 1;
 
-        // inputs of the transform of pair i: A (first row) and B (second row) at k = lt, lt+T and at the mirror partners
-        // 2T-lt, T-lt (vkFFT.h:2096-2106); thread 0 also needs Im of the DC column of the two reference partners (leak)
-        struct In { float2 a0, a1, am0, am1, b0, b1, bm0, bm1; float lka, lkb; };
+        // inputs of the first-stage butterfly of thread lt for pair i: A (first row) and B (second row) at k = lt + NB0*m,
+        // m < NI, and at the mirror partners KH - lt - NB0*m (vkFFT.h:2096-2106); thread 0 also needs Im of the DC column
+        // of the two reference partners (leak).  Threads beyond the first stage (lt >= NB0) re-read valid elements.
+        struct In { float2 a[NI], am[NI], b[NI], bm[NI]; float lka, lkb; };
         auto load_pair = [&](int i) -> In {
             In in;
             const int a = a0 + 2 * i;
             const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);       // rows past the plane: duplicate of the last row
-            in.a0 = S2at(lt, ya); in.a1 = S2at(lt + T, ya); in.am0 = S2at(2 * T - lt, ya); in.am1 = S2at(T - lt, ya);
-            in.b0 = S2at(lt, yb); in.b1 = S2at(lt + T, yb); in.bm0 = S2at(2 * T - lt, yb); in.bm1 = S2at(T - lt, yb);
-            // Im of the DC column of the reference partners (used by thread 0 only; loaded by every lane, raw, so that no
-            // lane-dependent branch and no arithmetic -- hence no wait -- follows the loads)
+            const int jj = (NB0 == T) ? lt : min(lt, NB0 - 1);
+#pragma unroll
+            for (int m = 0; m < NI; m++) {
+                in.a[m] = S2at(jj + NB0 * m, ya); in.am[m] = S2at(KH - jj - NB0 * m, ya);
+                in.b[m] = S2at(jj + NB0 * m, yb); in.bm[m] = S2at(KH - jj - NB0 * m, yb);
+            }
+            // (loaded by every lane, raw, so that no lane-dependent branch and no arithmetic -- hence no wait -- follows the loads)
             in.lka = S2at(0, ya ^ 1).y;
             in.lkb = S2at(0, yb ^ 1).y;
             return in;
         };
+        // Loads and stores retire through ONE in-order counter (vmcnt).  settle() is called where the prefetch is a whole
+        // transform old and the previous step's stores even older: the wait costs nothing, and re-defining the values
+        // keeps the compiler from copying the just-issued loads' registers (and waiting for them) right behind the loads.
+        auto settle = [](In& in) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0), nothing else
+#pragma unroll
+            for (int m = 0; m < NI; m++)
+                asm volatile("" : "+v"(in.a[m].x), "+v"(in.a[m].y), "+v"(in.am[m].x), "+v"(in.am[m].y), "+v"(in.b[m].x), "+v"(in.b[m].y),
+                                  "+v"(in.bm[m].x), "+v"(in.bm[m].y));
+            asm volatile("" : "+v"(in.lka), "+v"(in.lkb));
+        };
 
         if (need_corner) {
-            float part = S2at(lt + 1, rs).x + S2at(lt + 1 + T, rs).x;
+            float part = 0.f;
+            for (int kk = lt + 1; kk <= KH; kk += T) part += S2at(kk, rs).x;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
             if ((lt & 63) == 0) red[lt >> 6] = part;
@@ -857,14 +1019,7 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
             }
         }
         In in = load_pair(0);
-#define FFTUP_SETTLE_IN()                                                                                                       \
-    do {                                                                                                                       \
-        __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0), nothing else */                                                       \
-        asm volatile("" : "+v"(in.a0.x), "+v"(in.a0.y), "+v"(in.a1.x), "+v"(in.a1.y), "+v"(in.am0.x), "+v"(in.am0.y),         \
-                          "+v"(in.am1.x), "+v"(in.am1.y), "+v"(in.b0.x), "+v"(in.b0.y), "+v"(in.b1.x), "+v"(in.b1.y),          \
-                          "+v"(in.bm0.x), "+v"(in.bm0.y), "+v"(in.bm1.x), "+v"(in.bm1.y), "+v"(in.lka), "+v"(in.lkb));         \
-    } while (0)
-        FFTUP_SETTLE_IN();
+        settle(in);
         __syncthreads();            // red[] published; the previous segment's last reads of X[] are over
 
         for (int s = 0; s < npairs; s++) {
@@ -874,48 +1029,49 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
             const LT* ring = (const LT*)(smem + ((s + 1) & 1) * L::XB);             // rows a-2, a-1
             // ================= transform of pair s
             if constexpr ((FFTUP_OPQ & 1) != 0) asm volatile("" : "+v"(lt));
-            float2 v[E];
-            v[0] = make_float2(in.a0.x - in.b0.y, in.a0.y + in.b0.x);
-            v[1] = make_float2(in.a1.x - in.b1.y, in.a1.y + in.b1.x);
-            v[6] = make_float2(in.am0.x + in.bm0.y, -in.am0.y + in.bm0.x);
-            v[7] = make_float2(in.am1.x + in.bm1.y, -in.am1.y + in.bm1.x);
-            v[2] = v[3] = v[4] = v[5] = make_float2(0.f, 0.f);
+            float2 v[VN];
+#pragma unroll
+            for (int m = 0; m < VN; m++) v[m] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int m = 0; m < NI; m++) {
+                v[m] = make_float2(in.a[m].x - in.b[m].y, in.a[m].y + in.b[m].x);
+                v[R0 - NI + m] = make_float2(in.am[m].x + in.bm[m].y, -in.am[m].y + in.bm[m].x);
+            }
             if (lt == 0) {
-                v[2] = make_float2(in.am0.x - in.bm0.y, in.am0.y + in.bm0.x);       // k = 2T = W/2
+                v[NI] = make_float2(in.am[0].x - in.bm[0].y, in.am[0].y + in.bm[0].x);       // k = KH = W/2
                 // DC terms incl. the pair leak: row y gets -Im D[y+1] (y even) / +Im D[y-1] (y odd)
                 const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);
-                v[0] = make_float2(in.a0.x + ((ya & 1) ? in.lka : -in.lka), in.b0.x + ((yb & 1) ? in.lkb : -in.lkb));
+                v[0] = make_float2(in.a[0].x + ((ya & 1) ? in.lka : -in.lka), in.b[0].x + ((yb & 1) ? in.lkb : -in.lkb));
             }
             if constexpr ((FFTUP_KO & 32) == 0)
             in = load_pair(min(s + 1, npairs - 1));                                 // lands during this step (last step: a harmless re-read)
-            if constexpr ((FFTUP_KO & 2) == 0) reg_fft<UW, E, -1, 1, false>(v, buf, lt, 0, tws);   // its last barrier follows the last gather
-            // Loads and stores retire through ONE in-order counter (vmcnt).  Waiting HERE -- the prefetch was issued a whole
-            // transform ago, the previous step's stores even earlier -- costs nothing and leaves the registers of `in`
-            // settled, so that the next step's first instructions do not have to wait for the stores issued below.
-            // (re-defining the values keeps the compiler from copying the just-issued loads' registers -- and thus waiting
-            // for them -- right behind the loads; any loop-carried copy now happens after the data has landed)
-            FFTUP_SETTLE_IN();
+            if constexpr ((FFTUP_KO & 2) == 0) PL::fft(v, buf, lt, tws);
+            settle(in);
             if constexpr (HALF) {
                 // C2R output stored as binary16 (vkFFT.h:7289-7290), then |u^2 g| clamped, each step rounded like the shader's
                 const h2v up2 = h2_splat(p.upsq), one2 = h2_splat(1.0f);
+                if (SOUT == T || lt < SOUT) {
 #pragma unroll
-                for (int i = 0; i < E; i++) {
-                    const f2v sv = mk2(v[i].x, v[i].y) * mk2(inv, inv);
-                    const h2v g = {(_Float16)sv.x, (_Float16)sv.y};
-                    const h2v Lv = __builtin_elementwise_min(h2_bits(bits_h2(up2 * g) & 0x7fff7fffu), one2);
-                    cur[lt + T * i] = Lv.x;
-                    cur[UW + lt + T * i] = Lv.y;
+                    for (int i = 0; i < EOUT; i++) {
+                        const f2v sv = mk2(v[i].x, v[i].y) * mk2(inv, inv);
+                        const h2v g = {(_Float16)sv.x, (_Float16)sv.y};
+                        const h2v Lv = __builtin_elementwise_min(h2_bits(bits_h2(up2 * g) & 0x7fff7fffu), one2);
+                        cur[lt + SOUT * i] = Lv.x;
+                        cur[UW + lt + SOUT * i] = Lv.y;
+                    }
                 }
             } else if constexpr ((FFTUP_KO & 16) != 0) {
                 if (v[0].x + v[1].y + v[6].x + v[7].y + v[2].x == 12345.f) cur[lt] = v[0].x;
             } else {
-                // 1/UW is a power of two, so (v / UW) * u^2 == v * (u^2 / UW) bit for bit: one packed multiply
+                // one packed multiply: (v / UW) * u^2 == v * (u^2 / UW), bit for bit when UW is a power of two
                 const float ks = inv * p.upsq;
+                if (SOUT == T || lt < SOUT) {
 #pragma unroll
-                for (int i = 0; i < E; i++) {
-                    const f2v sv = mk2(v[i].x, v[i].y) * mk2(ks, ks);
-                    cur[lt + T * i] = fminf(fabsf(sv.x), 1.0f);
-                    cur[UW + lt + T * i] = fminf(fabsf(sv.y), 1.0f);
+                    for (int i = 0; i < EOUT; i++) {
+                        const f2v sv = mk2(v[i].x, v[i].y) * mk2(ks, ks);
+                        cur[lt + SOUT * i] = fminf(fabsf(sv.x), 1.0f);
+                        cur[UW + lt + SOUT * i] = fminf(fabsf(sv.y), 1.0f);
+                    }
                 }
             }
             __syncthreads();                                                        // L rows a, a+1 visible
@@ -928,8 +1084,9 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
                 if (out0 || out1) {
                     const h2v ncoef = h2_splat(-p.coef);
 #pragma unroll 1
-                    for (int h = 0; h < 2; h++) {
+                    for (int h = 0; h < NPASS; h++) {
                         const int x0 = 4 * (lt + T * h);
+                        if (UW % (4 * T) != 0 && x0 >= UW) continue;      // (wave-uniform: UW/4 is a multiple of 64)
                         // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
                         const LT* rows[4] = {rowp(-2), (a == 0) ? rowp(0) : rowp(-1), rowp(0), rowp(1)};
                         H2Row R[4];
@@ -980,8 +1137,9 @@ __global__ void __launch_bounds__(UW / 8, (UW / 8) * 2 / 256 > 0 ? (UW / 8) * 2 
             } else {
             if (out0 || out1) {
 #pragma unroll 1
-                for (int h = 0; h < 2; h++) {
+                for (int h = 0; h < NPASS; h++) {
                     const int x0 = 4 * (lt + T * h);
+                    if (UW % (4 * T) != 0 && x0 >= UW) continue;          // (wave-uniform: UW/4 is a multiple of 64)
                     // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
                     const float* rows[4] = {rowp(-2), (a == 0) ? rowp(0) : rowp(-1), rowp(0), rowp(1)};
                     float t[4][6];
