@@ -5,27 +5,41 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-One "step" = one batch of --frames-per-step synthetic 2048x1024 RGB frames pushed through the whole
-path (R2C rows -> column FFT/zero-pad/iFFT -> C2R rows -> sharpen) on each GPU, inputs resident in HBM
-(a ring of --ring distinct frames per GPU).  Frames are independent, so N GPUs = N independent shards,
-no data-path collective ("weak" scaling: per-GPU work fixed).  Rank 0 prints ONE JSON line.
+One "step" = one batch of --frames-per-step synthetic 2048x1024 RGB frames pushed through the whole path (R2C rows ->
+column FFT / zero-pad / iFFT -> C2R rows -> sharpen) on each GPU, inputs resident in HBM (a ring of --ring distinct
+frames per GPU).  The default step is 1024 frames, i.e. the reference's `-n 1000` run (BASELINE config 2) per step.
+Frames are independent, so N GPUs = N independent shards, no data-path collective ("weak" scaling: per-GPU work
+fixed).  The K-step timed region (barrier + synchronize on both sides, MAX over ranks) is repeated --repeats times
+and the MEDIAN region gives `value`.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PRESETS = {
+    # BASELINE.json configs[1..4]
+    "config2": dict(width=2048, height=1024, precision=0, fuse_u8=False),
+    "config3": dict(width=2048, height=1024, precision=2, fuse_u8=True),
+    "config4": dict(width=1920, height=1080, precision=0, fuse_u8=False),
+    # 512 synthetic 2048x1024 frames, -u 2 -p 2, sharded over 8 GPUs: 64 frames per rank and step
+    "config5": dict(width=2048, height=1024, precision=2, fuse_u8=True, frames_per_step=64),
+}
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=64)
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is run this many times; the median is reported")
+    ap.add_argument("--frames-per-step", type=int, default=1024)
+    ap.add_argument("--preset", choices=sorted(PRESETS), default=None, help="a BASELINE.json configuration (default: config2 = headline)")
     ap.add_argument("--ring", type=int, default=8,
                     help="distinct resident input/output frame slots per GPU (8 x 131 MB > the 256 MB Infinity Cache)")
     ap.add_argument("--width", type=int, default=2048)
@@ -36,15 +50,24 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the bounded CPU-baseline sample (~15 s on 128 threads)")
     ap.add_argument("--profile-iters", type=int, default=50)
-    ap.add_argument("--event-stride", type=int, default=8, help="kernel-timing events on every n-th frame of the timed region")
+    ap.add_argument("--event-stride", type=int, default=32, help="kernel-timing events on every n-th frame of the first timed region")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams (lanes) consecutive frames alternate on; 1 = strictly sequential kernels")
     ap.add_argument("--host-streamed", action="store_true",
                     help="NOT the headline: frames start and end in pinned host memory (fftup_submit_rgb8 queue, "
                          "uint8 RGB over PCIe both ways); the line is marked pcie_inclusive")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
-                    help="per-launch HBM bytes of the dominant kernel from a committed rocprofv3 --pmc run")
-    return ap.parse_args()
+                    help="per-launch HBM bytes of the kernels from committed rocprofv3 --pmc runs, keyed by configuration")
+    a = ap.parse_args()
+    if a.preset:
+        for k, v in PRESETS[a.preset].items():
+            setattr(a, k, v)
+    return a
+
+
+def config_key(args):
+    """key of profiles/hbm_traffic.json: size, precision and input type"""
+    return "%dx%d_p%d_%s" % (args.width, args.height, args.precision, "u8" if (args.fuse_u8 and args.precision != 1) else "planar")
 
 
 def cpu_baseline(args):
@@ -59,8 +82,8 @@ def cpu_baseline(args):
         O.upscale_rgb8(f, args.upscale, args.precision)
     dt = time.perf_counter() - t0
     return {"value": len(frames) / dt, "unit": "frames/s", "cores": O.num_threads(), "kind": "port",
-            "sample": "%d synthetic %dx%d frames through oracle/fftup_oracle.c (fp64, OpenMP), %.1f s"
-                      % (len(frames), args.width, args.height, dt)}
+            "sample": "%d synthetic %dx%d frames through oracle/fftup_oracle.c (the fp64 restatement of the reference's algorithm, "
+                      "naive mixed-radix FFTs, OpenMP over rows/columns/planes), %.1f s" % (len(frames), args.width, args.height, dt)}
 
 
 def reference_vulkan_baseline(args):
@@ -142,54 +165,73 @@ def main():
             continue
         up.execute_ring(args.frames_per_step, slot)
         slot = (slot + args.frames_per_step) % args.ring
-    barrier()
-    t0 = time.perf_counter()
-    dev_ms = 0.0
-    kms = [0.0] * len(up.kernel_names)
-    for _ in range(args.steps):
-        if args.host_streamed:
-            t1 = time.perf_counter()
-            streamed_step()
-            dev_ms += (time.perf_counter() - t1) * 1e3
-            continue
-        # HIP events before/after every kernel launch of every --event-stride-th frame, on the stream that runs
-        # it, inside the timed region
-        ms, km = up.execute_ring_timed(args.frames_per_step, slot, args.event_stride)   # blocks until the batch is done
-        dev_ms += ms
-        kms = [a + b / args.steps for a, b in zip(kms, km)]
-        slot = (slot + args.frames_per_step) % args.ring
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
-    frames_total = world * args.steps * args.frames_per_step
-    fps = frames_total / dt
+    # ---- timed regions: EXACTLY --steps steps each, barrier + synchronize on both sides, MAX over ranks; median of --repeats
+    region_s, region_dev_ms = [], []
+    kms = [0.0] * len(up.kernel_names)
+    for rep in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        dev_ms = 0.0
+        for _ in range(args.steps):
+            if args.host_streamed:
+                t1 = time.perf_counter()
+                streamed_step()
+                dev_ms += (time.perf_counter() - t1) * 1e3
+                continue
+            if rep == 0:
+                # HIP events before/after every kernel launch of every --event-stride-th frame, on the stream that runs it
+                ms, km = up.execute_ring_timed(args.frames_per_step, slot, args.event_stride)   # blocks until the batch is done
+                kms = [a + b / args.steps for a, b in zip(kms, km)]
+            else:
+                ms = up.execute_ring(args.frames_per_step, slot)
+            dev_ms += ms
+            slot = (slot + args.frames_per_step) % args.ring
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        region_s.append(dt)
+        region_dev_ms.append(dev_ms)
+    order = sorted(range(len(region_s)), key=lambda i: region_s[i])
+    med = order[len(order) // 2]
+    dt = region_s[med]
+
+    frames_per_region = world * args.steps * args.frames_per_step
+    fps = frames_per_region / dt
     line = None
     if rank == 0:
-        # kms: average kernel durations over the timed region (consecutive frames overlap on --streams lanes, so
-        # a kernel's duration includes the time it shares the GPU with the other lane's kernels);
-        # iso: the same kernels launched strictly one after the other right after the timed region
+        # kms: average kernel durations inside the first timed region (consecutive frames overlap on --streams lanes, so a
+        # kernel's duration there includes the time it shares the GPU with the other lanes' kernels);
+        # iso: the same kernels launched strictly one after the other right after the timed regions, HIP events on the
+        # launching stream, net of the cost of an empty event pair (= what rocprofv3 --kernel-trace --stats reports)
         iso = up.profile_kernels(args.profile_iters)
         dom = max(range(len(iso)), key=lambda i: iso[i])
-        # roofline of the dominant kernel from its own launch duration (HIP events on its stream, strictly
-        # sequential launches = what `rocprofv3 --kernel-trace --stats -- python bench.py --streams 1` reports);
-        # with --streams 2 the timed region runs two frames at once and a kernel's wall duration there
-        # (kernel_ms, roofline.achieved_overlapped) includes the other lane's co-resident kernels
         achieved = up.kernel_alg_bytes[dom] / (iso[dom] * 1e-3) / 1e9
         if args.host_streamed:
             kms = list(iso)                   # no per-kernel events in the streamed loop
-        achieved_ovl = up.kernel_alg_bytes[dom] / (kms[dom] * 1e-3) / 1e9
-        traffic = None
+        achieved_ovl = up.kernel_alg_bytes[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else None
+        frame_ms = region_dev_ms[med] / (args.steps * args.frames_per_step)
+        wall_frame_ms = dt / (args.steps * args.frames_per_step) * 1e3
+        # measured HBM bytes (rocprofv3 --pmc, corrected as profiles/hbm_traffic.json documents) -- static: taken from the
+        # committed profile of THIS configuration, not re-measured by this run
+        key = config_key(args)
+        traffic, frame_hbm, tsrc = None, None, None
         if os.path.exists(args.traffic_json):
             try:
-                tj = json.load(open(args.traffic_json))
-                traffic = tj.get(up.kernel_names[dom], {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(args.traffic_json)).get(key)
+                if tj:
+                    traffic = tj.get(up.kernel_names[dom], {}).get("hbm_bytes_per_launch")
+                    parts = [tj.get(n, {}).get("hbm_bytes_per_launch") for n in up.kernel_names if n != "-"]
+                    frame_hbm = sum(parts) if all(x is not None for x in parts) else None
+                    tsrc = "static %s [%s] (%s)" % (os.path.relpath(args.traffic_json, ROOT), key, tj.get("_source", "?"))
             except Exception:
                 traffic = None
-        frame_ms = dev_ms / (args.steps * args.frames_per_step)
+        esz = {0: 4, 1: 8, 2: 2}[args.precision]
+        b_in = 1 if (args.fuse_u8 and args.precision != 1) else esz
+        b_min = 3.0 * (args.width * args.height * b_in + up.out_width * up.out_height * esz)
         line = {
             "metric": "frames/s, %dx%d->%dx%d %s FFT upscale (R2C+zero-pad+C2R+sharpen)"
                       % (args.width, args.height, up.out_width, up.out_height, {0: "fp32", 1: "fp64", 2: "fp16-memory"}[args.precision]),
@@ -201,25 +243,29 @@ def main():
                                    % (args.width, args.height, up.out_width, up.out_height, args.upscale,
                                       args.precision, args.frames_per_step, args.ring,
                                       "uint8 RGB (fused load)" if args.fuse_u8 and args.precision != 1 else "planar fp%d" % {0: 32, 1: 64, 2: 16}[args.precision]),
-                       "frames_per_step": args.frames_per_step, "sharding": "independent frames, no collective",
+                       "preset": args.preset or "config2", "frames_per_step": args.frames_per_step,
+                       "sharding": "independent frames, no collective",
                        "kernels": "tuned" if up.tuned else "generic", "streams": args.streams, "device": up.device_name},
-            "ms_per_frame": frame_ms,
-            "frame_alg_bytes": up.alg_bytes_per_frame,
-            "frame_roofline_frac": up.alg_bytes_per_frame / (frame_ms * 1e-3) / 8e12,
+            "repeats": len(region_s), "region_s": region_s, "timed_region_s_median": dt,
+            "ms_per_frame": wall_frame_ms, "ms_per_frame_device_events": frame_ms,
+            "frame_alg_bytes": up.alg_bytes_per_frame, "B_min": b_min,
+            "frame_roofline_frac": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 8e12,
+            "frame_hbm_bytes_measured": frame_hbm,
+            "real_traffic_frac": (frame_hbm / (wall_frame_ms * 1e-3) / 8e12) if frame_hbm else None,
             "kernel_ms": dict(zip(up.kernel_names, iso)),
             "kernel_ms_timed_region": dict(zip(up.kernel_names, kms)),
             "roofline": {"bound": "hbm", "kernel": up.kernel_names[dom], "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": tsrc,
                          "achieved_overlapped": achieved_ovl,
-                         "frame_achieved": up.alg_bytes_per_frame / (frame_ms * 1e-3) / 1e9,
-                         "frame_frac": up.alg_bytes_per_frame / (frame_ms * 1e-3) / 8e12},
+                         "frame_achieved": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 1e9,      # per GPU
+                         "frame_frac": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 8e12},
         }
         if args.host_streamed:
             pcie = 3.0 * (args.width * args.height + up.out_width * up.out_height)
             line["pcie_inclusive"] = True
             line["config"]["workload"] += ", HOST-STREAMED: uint8 RGB frames from/to pinned host memory"
             line["pcie_bytes_per_frame"] = pcie
-            line["pcie_GBps"] = pcie / (frame_ms * 1e-3) / 1e9
+            line["pcie_GBps"] = pcie / (wall_frame_ms * 1e-3) / 1e9
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args)
             line["reference_vulkan_baseline"] = reference_vulkan_baseline(args)

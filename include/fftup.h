@@ -124,7 +124,8 @@ FFTUP_API int fftup_execute_ring(fftup_plan* plan, uint32_t n_frames, uint32_t f
 FFTUP_API int fftup_execute_ring_timed(fftup_plan* plan, uint32_t n_frames, uint32_t first_slot, uint32_t stride,
                                        double* ms_total, double* ms_per_kernel);
 /* measurement aid: runs n_iter frames with a HIP event pair around every kernel launch on the
- * plan's stream and returns the average duration (ms) of each of the FFTUP_NUM_KERNELS kernels. */
+ * plan's stream and returns the average duration (ms) of each of the FFTUP_NUM_KERNELS kernels, net of the
+ * duration of an empty event pair measured in the same loop (unused slots read 0). */
 FFTUP_API int fftup_profile_kernels(fftup_plan* plan, uint32_t n_iter, double* ms_per_kernel);
 
 /* transferDataToCPU + unpack loop (VR:1697-1748).  rgb8: u8 = trunc(255*x), saturating unless

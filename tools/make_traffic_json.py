@@ -8,9 +8,10 @@ fully coalesced streaming reads; other patterns have to be calibrated on a known
     -> factor 2.0 (matches the guide);
   * the column kernel reads whole contiguous 64 KB tiles: known 25.19 MB, FETCH_SIZE reports 12.7 MB -> factor 2.0;
   * the C2R kernels read the blocked spectrum in 32/64-byte pieces (64-byte requests): the two-launch C2R kernel
-    reads a known 50.38 MB and FETCH_SIZE reports 49.5 MB -> factor 1.0.  For the fused kernel part of the
+    of round 1 read a known 50.38 MB and FETCH_SIZE reported 49.5 MB -> factor 1.0.  For the fused kernel part of the
     spectrum is still L2-resident from the column kernel (l2_hit_rate), so its fetch figure is below the
-    56 MB it requests.
+    54 MB it requests (50.4 MB of spectrum rows + one halo pair per strip).
+Since round 2 the column kernel writes only the odd spectrum rows (25.2 MB, the even rows are the rows of S1).
 WRITE_SIZE matched the known output bytes of every kernel within 1 % -> factor 1.0.
 """
 import json
@@ -18,11 +19,12 @@ import re
 import sys
 
 src = sys.argv[1]            # gpurun_out/<tag>/summary.txt
-out = sys.argv[2]            # profiles/hbm_traffic.json
-factor = {"k_row_r2c_t": 2.0, "k_row_r2c": 2.0, "k_col_t": 2.0}
-names = {"k_row_r2c_t": "row_r2c", "k_row_r2c": "row_r2c", "k_col_t": "col_fwd_pad_inv", "k_col": "col_fwd_pad_inv",
-         "k_c2r_sharpen_t": "row_c2r_sharpen", "k_row_c2r_t": "row_c2r", "k_row_c2r": "row_c2r",
-         "k_sharpen_t": "sharpen", "k_sharpen": "sharpen"}
+out = sys.argv[2]            # profiles/hbm_traffic.json (merged: one entry per configuration key)
+key = sys.argv[3]            # e.g. 2048x1024_p0_planar (bench.py: config_key)
+factor = {"k_row_r2c_t": 2.0, "k_row_r2c": 2.0, "k_col_t": 2.0, "k_row_r2c_m1920": 2.0, "k_col_m1080": 2.0}
+names = {"k_row_r2c_t": "row_r2c", "k_row_r2c": "row_r2c", "k_row_r2c_m1920": "row_r2c", "k_col_t": "col_fwd_pad_inv",
+         "k_col": "col_fwd_pad_inv", "k_col_m1080": "col_fwd_pad_inv", "k_c2r_sharpen_g": "row_c2r_sharpen",
+         "k_row_c2r_t": "row_c2r", "k_row_c2r": "row_c2r", "k_sharpen_t": "sharpen", "k_sharpen": "sharpen"}
 cur, data = None, {}
 for line in open(src):
     m = re.match(r"== (\w+)", line)
@@ -33,7 +35,12 @@ for line in open(src):
     m = re.match(r"\s+(\w+)\s+([0-9.]+)", line)
     if m and cur:
         data[cur][m.group(1)] = float(m.group(2))
-res = {"_source": src, "_method": __doc__}
+import os
+allres = json.load(open(out)) if os.path.exists(out) else {}
+if "_method" not in allres or "row_r2c" in allres:      # (round-1 file: not keyed)
+    allres = {}
+allres["_method"] = __doc__
+res = {"_source": src}
 for k, c in data.items():
     if k not in names or "FETCH_SIZE" not in c:
         continue
@@ -42,5 +49,6 @@ for k, c in data.items():
     wr = c["WRITE_SIZE"] * 1024
     res[names[k]] = {"kernel": k, "fetch_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
                      "fetch_correction": f, "l2_hit_rate": c.get("TCC_HIT_sum", 0) / max(1.0, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))}
-json.dump(res, open(out, "w"), indent=1)
+allres[key] = res
+json.dump(allres, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if not k.startswith("_")}, indent=1))

@@ -9,7 +9,7 @@ root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for f in sorted(glob.glob(root + "/pass*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
-        name = row["Kernel_Name"].split("(")[0].replace("void fftup::", "")
+        name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("fftup::", "")
         a = acc[name][row["Counter_Name"]]
         a[0] += float(row["Counter_Value"])
         a[1] += 1

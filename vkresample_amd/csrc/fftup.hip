@@ -872,30 +872,40 @@ int fftup_profile_kernels(fftup_plan* P, uint32_t n_iter, double* ms_per_kernel)
     if (!P || !ms_per_kernel) return fail(FFTUP_E_INVALID_ARG, "null argument");
     if (n_iter == 0) return fail(FFTUP_E_INVALID_ARG, "n_iter must be > 0");
     HIP_TRY(hipSetDevice(P->device));
+    // per iteration: e[0] .. e[NK] around the NK launch slots, then an EMPTY pair e[NK+1], e[NK+2]: what an event pair
+    // costs on this stream with nothing between (4-5 us); it is subtracted, so that the figures are kernel durations
+    // as rocprofv3 --kernel-trace reports them
+    constexpr int NE = FFTUP_NUM_KERNELS + 3;
     EventList ev;
-    int rc = ev.create((size_t)n_iter * (FFTUP_NUM_KERNELS + 1));
+    int rc = ev.create((size_t)n_iter * NE);
     if (rc) return rc;
     for (uint32_t i = 0; i < n_iter && !rc; i++) {
-        hipEvent_t* e = &ev[(size_t)i * (FFTUP_NUM_KERNELS + 1)];
+        hipEvent_t* e = &ev.ev[(size_t)i * NE];
         (void)hipEventRecord(e[0], P->stream);
         for (int k = 0; k < FFTUP_NUM_KERNELS && !rc; k++) {
             rc = launch_frame(P, i % P->ring, i % P->ring, k);
             (void)hipEventRecord(e[k + 1], P->stream);
         }
+        (void)hipEventRecord(e[FFTUP_NUM_KERNELS + 1], P->stream);
+        (void)hipEventRecord(e[FFTUP_NUM_KERNELS + 2], P->stream);
     }
     hipError_t se = hipStreamSynchronize(P->stream);
     if (!rc && se != hipSuccess) rc = fail(FFTUP_E_HIP, std::string("sync: ") + hipGetErrorString(se));
     if (!rc) {
+        double empty = 0;
         for (int k = 0; k < FFTUP_NUM_KERNELS; k++) ms_per_kernel[k] = 0;
         for (uint32_t i = 0; i < n_iter; i++) {
-            hipEvent_t* e = &ev[(size_t)i * (FFTUP_NUM_KERNELS + 1)];
+            hipEvent_t* e = &ev.ev[(size_t)i * NE];
+            float ms = 0;
             for (int k = 0; k < FFTUP_NUM_KERNELS; k++) {
-                float ms = 0;
                 (void)hipEventElapsedTime(&ms, e[k], e[k + 1]);
                 ms_per_kernel[k] += ms;
             }
+            (void)hipEventElapsedTime(&ms, e[FFTUP_NUM_KERNELS + 1], e[FFTUP_NUM_KERNELS + 2]);
+            empty += ms;
         }
-        for (int k = 0; k < FFTUP_NUM_KERNELS; k++) ms_per_kernel[k] /= n_iter;
+        empty /= n_iter;
+        for (int k = 0; k < FFTUP_NUM_KERNELS; k++) ms_per_kernel[k] = std::max(0.0, ms_per_kernel[k] / n_iter - empty);
         P->executed = 1;
     }
     return rc;
@@ -1021,7 +1031,8 @@ int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, ui
     // The whole frame -- H2D, conversion, kernels, conversion, D2H -- goes to ONE stream (lane t % nlanes), so no
     // cross-stream dependency exists and nothing can stall behind a neighbour's wait when streams share a hardware
     // queue; the copies of one lane overlap the kernels and the opposite-direction copies of the other lanes.
-    const int lane = (int)(t % (uint64_t)P->nlanes);
+    // (two lanes: with the copies in the streams a third one only adds contention, 0.56-0.75 ms/frame instead of 0.51)
+    const int lane = (int)(t % (uint64_t)std::min(P->nlanes, 2));
     hipStream_t cs = P->lanes[lane].stream;
     const size_t in_row = (size_t)3 * P->W, out_row = (size_t)3 * P->uW;
     if (in_stride == in_row) HIP_TRY(hipMemcpyAsync(P->in_u8[s], rgb_in, in_row * P->H, hipMemcpyHostToDevice, cs));
