@@ -32,7 +32,8 @@ enum {
     FFTUP_OK = 0,
     FFTUP_E_INVALID_ARG = 1,    /* null pointer, bad slot, odd size, channels != 3 (VR:1368)            */
     FFTUP_E_UNSUPPORTED_SIZE = 2, /* a dimension is not 2,3,5,7-smooth: VF:4719-4726
-                                     (VK_ERROR_FORMAT_NOT_SUPPORTED), or exceeds the R2C limit VR:1424  */
+                                     (VK_ERROR_FORMAT_NOT_SUPPORTED), or a row does not fit the LDS
+                                     (uW > ~9600 for -p 0; beyond the R2C limit VR:1424 with -p 2)      */
     FFTUP_E_UNSUPPORTED_PRECISION = 3, /* -p must be 0, 1 or 2                                         */
     FFTUP_E_NO_DEVICE = 4,      /* no HIP device / bad device id (VR:1292-1296)                         */
     FFTUP_E_HIP = 5,            /* a HIP runtime call failed (message in fftup_last_error)              */
@@ -133,7 +134,8 @@ FFTUP_API int fftup_profile_kernels(fftup_plan* plan, uint32_t n_iter, double* m
 FFTUP_API int fftup_download_rgb8(fftup_plan* plan, uint32_t slot, uint8_t* rgb, size_t row_stride_bytes);
 FFTUP_API int fftup_download_planar(fftup_plan* plan, uint32_t slot, void* planes);
 /* parity-test taps: the C2R output before sharpening (the reference's tempBuffer contents,
- * dense [3][uH][uW]) of the last executed frame, and the converted input planes [3][H][W]. */
+ * dense [3][uH][uW]) of the last executed frame -- on the non-R2C path (uW > 8192, VR:1424) the real
+ * part of the complex image -- and the converted input planes [3][H][W]. */
 FFTUP_API int fftup_download_presharpen(fftup_plan* plan, void* planes);
 FFTUP_API int fftup_download_input_planar(fftup_plan* plan, uint32_t slot, void* planes);
 

@@ -222,7 +222,8 @@ static double const_via_percent_f(double v, uint32_t precision)
 /* rounding applied after every shader operation */
 #define RQ(x) (half ? round_half(x) : (x))
 
-static void sharpen_plane(const double* R, double* out, uint32_t uW, uint32_t uH,
+/* Rim != NULL: the non-R2C path, where the shader's inputs are vec2 and length() is the complex modulus (VR:865-907) */
+static void sharpen_plane(const double* R, const double* Rim, double* out, uint32_t uW, uint32_t uH,
                           double upsq, double coef, int half)
 {
     const uint64_t plane = (uint64_t)uW * uH;
@@ -242,6 +243,7 @@ static void sharpen_plane(const double* R, double* out, uint32_t uW, uint32_t uH
                     while (f >= plane) f -= uW;
                     double t = RQ(upsq * R[f]);            /* tex = upscale * inputs[...]      */
                     double l = fabs(t);                     /* length(scalar)                   */
+                    if (Rim) { double ti = RQ(upsq * Rim[f]); l = sqrt(t * t + ti * ti); }   /* length(vec2) */
                     if (l > 1.0) l = 1.0;
                     if (l < 0.0) l = 0.0;
                     len[a * 3 + b] = l;
@@ -271,8 +273,132 @@ ORC_API int orc_sharpen(const orc_config* c, const double* R, double* out, uint3
     double upsq = const_via_percent_f((double)(c->upscale * c->upscale), c->precision); /* VR:1615 float product */
     double coef = const_via_percent_f((double)c->sharpen, c->precision);
     for (int ch = 0; ch < 3; ch++)
-        sharpen_plane(R + (uint64_t)ch * uW * uH, out + (uint64_t)ch * uW * uH, uW, uH, upsq, coef, half);
+        sharpen_plane(R + (uint64_t)ch * uW * uH, NULL, out + (uint64_t)ch * uW * uH, uW, uH, upsq, coef, half);
     return 0;
+}
+
+/* ------------------------------------------------------------------ the non-R2C path
+ * VR:1424: performR2C = bufferStride[0] <= maxComputeSharedMemorySize / complexSizeCalc, i.e. uW <= 8192 (4096 for
+ * -p 1) with the 64 KB the reference's planner assumes; wider outputs take a full complex 2-D transform:
+ *   pack: real parts only (VR:1647) -- the imaginary parts are uninitialised heap in the reference; DEFINED as 0 here;
+ *   forward C2C 2-D FFT of W x H into a buffer of strides (uW, uH);
+ *   four-quadrant shift (VR:527-546): (kx, ky) with kx >= W/2 and/or ky >= H/2 moves to (kx + uW - W) / (ky + uH - H),
+ *     in place, sources not cleared (taken from the pristine block here: race-free, quirk B6);
+ *   inverse C2C 2-D FFT of uW x uH with read guards [W/2, (2u-1) uW / 2u) in x and [uH/2u, (2u-1) uH / 2u) in y
+ *     (VR:1497-1502, float arithmetic, uint32 store); output complex;
+ *   sharpen on the complex image: len = |u^2 z| (length(vec2)), real output, plane stride uW*uH. */
+ORC_API int orc_uses_complex_path(const orc_config* c)
+{
+    uint32_t uW, uH;
+    orc_out_dims(c, &uW, &uH);
+    return uW > (c->precision == 1 ? 4096u : 8192u);
+}
+
+static int upscale_planes_complex(const orc_config* c, const double* in_planes, double* pre_re, double* pre_im, double* out,
+                                  uint64_t* poison_reads)
+{
+    const uint32_t W = c->width, H = c->height;
+    uint32_t uW, uH;
+    orc_out_dims(c, &uW, &uH);
+    const float u = c->upscale;
+    const uint32_t zlx = W / 2;
+    const uint32_t zrx = (uint32_t)((2 * u - 1) * (float)uW / (2 * u));
+    const uint32_t zly = (uint32_t)((float)uH / (2 * u));
+    const uint32_t zry = (uint32_t)((2 * u - 1) * (float)uH / (2 * u));
+    fft_plan pW, pH, puW, puH;
+    plan_init(&pW, W); plan_init(&pH, H); plan_init(&puW, uW); plan_init(&puH, uH);
+    const uint64_t plane = (uint64_t)uW * uH;
+    double* re = pre_re ? pre_re : (double*)malloc(sizeof(double) * 3 * plane);
+    double* im = pre_im ? pre_im : (double*)malloc(sizeof(double) * 3 * plane);
+    uint64_t poison_total = 0;
+    for (int ch = 0; ch < 3; ch++) {
+        const double* x = in_planes + (uint64_t)ch * W * H;
+        cpx* buf = (cpx*)malloc(sizeof(cpx) * plane);
+        for (uint64_t i = 0; i < plane; i++) { buf[i].re = NAN; buf[i].im = NAN; }
+        cpx* F = (cpx*)malloc(sizeof(cpx) * (uint64_t)W * H);          /* pristine forward spectrum */
+#pragma omp parallel
+        {
+            cpx* w = (cpx*)malloc(sizeof(cpx) * (W > H ? W : H));
+            cpx* z = (cpx*)malloc(sizeof(cpx) * (W > H ? W : H));
+#pragma omp for schedule(static)
+            for (int64_t y = 0; y < (int64_t)H; y++) {
+                for (uint32_t n = 0; n < W; n++) { z[n].re = x[(uint64_t)y * W + n]; z[n].im = 0.0; }
+                fft1d(&pW, z, w, +1);
+                memcpy(F + (uint64_t)y * W, z, sizeof(cpx) * W);
+            }
+#pragma omp for schedule(static)
+            for (int64_t kx = 0; kx < (int64_t)W; kx++) {
+                for (uint32_t ky = 0; ky < H; ky++) z[ky] = F[(uint64_t)ky * W + kx];
+                fft1d(&pH, z, w, +1);
+                for (uint32_t ky = 0; ky < H; ky++) F[(uint64_t)ky * W + kx] = z[ky];
+            }
+            free(z); free(w);
+        }
+        /* forward output as it lies in the buffer, then the four-quadrant shift from the pristine block */
+        for (uint32_t ky = 0; ky < H; ky++)
+            for (uint32_t kx = 0; kx < W; kx++) buf[(uint64_t)ky * uW + kx] = F[(uint64_t)ky * W + kx];
+        for (uint32_t ky = 0; ky < H; ky++)
+            for (uint32_t kx = 0; kx < W; kx++) {
+                if (kx < W / 2 && ky < H / 2) continue;
+                const uint32_t dx = kx >= W / 2 ? kx + uW - W : kx, dy = ky >= H / 2 ? ky + uH - H : ky;
+                buf[(uint64_t)dy * uW + dx] = F[(uint64_t)ky * W + kx];
+            }
+        free(F);
+        uint64_t poison = 0;
+#pragma omp parallel reduction(+:poison)
+        {
+            cpx* w = (cpx*)malloc(sizeof(cpx) * (uW > uH ? uW : uH));
+            cpx* z = (cpx*)malloc(sizeof(cpx) * (uW > uH ? uW : uH));
+#pragma omp for schedule(static)
+            for (int64_t kx = 0; kx < (int64_t)uW; kx++) {
+                if ((uint32_t)kx >= zlx && (uint32_t)kx < zrx) continue;        /* all-zero sequences are skipped */
+                for (uint32_t ky = 0; ky < uH; ky++) {
+                    if (ky >= zly && ky < zry) { z[ky].re = 0; z[ky].im = 0; continue; }
+                    cpx v = buf[(uint64_t)ky * uW + kx];
+                    if (v.re != v.re) { poison++; v.re = 0; v.im = 0; }
+                    z[ky] = v;
+                }
+                fft1d(&puH, z, w, -1);
+                for (uint32_t ky = 0; ky < uH; ky++) { buf[(uint64_t)ky * uW + kx].re = z[ky].re / uH; buf[(uint64_t)ky * uW + kx].im = z[ky].im / uH; }
+            }
+#pragma omp for schedule(static)
+            for (int64_t y = 0; y < (int64_t)uH; y++) {
+                for (uint32_t kx = 0; kx < uW; kx++) {
+                    if (kx >= zlx && kx < zrx) { z[kx].re = 0; z[kx].im = 0; continue; }
+                    z[kx] = buf[(uint64_t)y * uW + kx];
+                }
+                fft1d(&puW, z, w, -1);
+                for (uint32_t n = 0; n < uW; n++) {
+                    re[(uint64_t)ch * plane + (uint64_t)y * uW + n] = z[n].re / uW;
+                    im[(uint64_t)ch * plane + (uint64_t)y * uW + n] = z[n].im / uW;
+                }
+            }
+            free(z); free(w);
+        }
+        poison_total += poison;
+        free(buf);
+    }
+    if (poison_reads) *poison_reads = poison_total;
+    if (out) {
+        double upsq = const_via_percent_f((double)(c->upscale * c->upscale), c->precision);
+        double coef = const_via_percent_f((double)c->sharpen, c->precision);
+        for (int ch = 0; ch < 3; ch++)
+            sharpen_plane(re + ch * plane, im + ch * plane, out + ch * plane, uW, uH, upsq, coef, 0);
+    }
+    if (!pre_re) free(re);
+    if (!pre_im) free(im);
+    plan_free(&pW); plan_free(&pH); plan_free(&puW); plan_free(&puH);
+    return 0;
+}
+
+/* pre_re / pre_im: the complex image before the sharpen pass (either may be NULL) */
+ORC_API int orc_upscale_planes_complex(const orc_config* c, const double* in_planes, double* pre_re, double* pre_im, double* out,
+                                       uint64_t* poison_reads)
+{
+    int rc = orc_check(c);
+    if (rc) return rc;
+    if (c->precision == 2) return 3;         /* half-memory buffers of the complex path are not restated */
+    return upscale_planes_complex(c, in_planes, pre_re, pre_im, out, poison_reads);
 }
 
 /* ------------------------------------------------------------------ the pipeline */
@@ -285,6 +411,7 @@ ORC_API int orc_upscale_planes(const orc_config* c, const double* in_planes, dou
 {
     int rc = orc_check(c);
     if (rc) return rc;
+    if (orc_uses_complex_path(c)) return orc_upscale_planes_complex(c, in_planes, pre, NULL, out, poison_reads);   /* pre = real part */
     const uint32_t W = c->width, H = c->height;
     uint32_t uW, uH;
     orc_out_dims(c, &uW, &uH);

@@ -158,3 +158,80 @@ def closed_form(planes, upscale):
         g[1::2, :] += q[0::2, None]
         out[c] = g
     return out
+
+
+# ------------------------------------------------------------------ the non-R2C path (VR:1424 false), SURVEY 8 f4
+def emulate_complex(planes, upscale):
+    """The reference's buffers when performR2C is false (uW > 8192, or > 4096 for -p 1): `inputBuffer` complex with
+    strides (W, H) whose imaginary parts the host never writes (VR:1620, 1647 -- DEFINED as 0 here), `buffer` complex
+    with strides (uW, uH); forward C2C, the four-quadrant shift shader replayed invocation by invocation with its own
+    index arithmetic (VR:527-546), inverse C2C with the read guards of VR:1497-1502.  Returns the complex image the
+    sharpen shader reads, [3][uH][uW]."""
+    planes = np.asarray(planes, dtype=np.float64)
+    C, H, W = planes.shape
+    uW, uH = out_dims(W, H, upscale)
+    u = np.float32(upscale)
+    ps = uW * uH                                         # VR:1556: inputStride[2] = bufferStride[0] * bufferStride[1]
+    buffer = np.full(C * ps, np.nan + 1j * np.nan, dtype=np.complex128)
+    for c in range(C):
+        F = np.empty((H, W), dtype=np.complex128)
+        for y in range(H):
+            F[y] = _dft_plus(planes[c, y] + 0j)
+        for x in range(W):
+            F[:, x] = _dft_plus(F[:, x])
+        for y in range(H):
+            buffer[c * ps + y * uW: c * ps + y * uW + W] = F[y]
+    snapshot = buffer.copy()                             # every invocation reads "inputs" of the same buffer
+
+    def index(c, ix, iy):
+        return ix + iy * uW + c * ps
+    s0, s1 = W, H                                        # appShift.size (VR:1518-1519)
+    for c in range(C):
+        for gy in range(s1):
+            for gx in range(s0):
+                if not (gx >= s0 // 2 or gy >= s1 // 2):
+                    continue
+                if gx >= s0 // 2 and gy < s1 // 2:
+                    i_in, i_out = index(c, 3 * s0 // 2 - 1 - gx, gy), index(c, uW + s0 // 2 - 1 - gx, gy)
+                if gx >= s0 // 2 and gy >= s1 // 2:
+                    i_in = index(c, 3 * s0 // 2 - 1 - gx, 3 * s1 // 2 - 1 - gy)
+                    i_out = index(c, uW + s0 // 2 - 1 - gx, uH + s1 // 2 - 1 - gy)
+                if gx < s0 // 2 and gy >= s1 // 2:
+                    i_in, i_out = index(c, gx, 3 * s1 // 2 - 1 - gy), index(c, gx, uH + s1 // 2 - 1 - gy)
+                buffer[i_out] = snapshot[i_in]
+    zlx = W // 2
+    zrx = int(np.uint32((np.float32(2) * u - np.float32(1)) * np.float32(uW) / (np.float32(2) * u)))
+    zly = int(np.uint32(np.float32(uH) / (np.float32(2) * u)))
+    zry = int(np.uint32((np.float32(2) * u - np.float32(1)) * np.float32(uH) / (np.float32(2) * u)))
+    out = np.empty((C, uH, uW), dtype=np.complex128)
+    for c in range(C):
+        B = buffer[c * ps:(c + 1) * ps].reshape(uH, uW).copy()
+        for x in range(uW):
+            if zlx <= x < zrx:
+                continue                                 # sequences consisting of zeros only are skipped
+            col = B[:, x].copy()
+            col[zly:zry] = 0.0
+            B[:, x] = _dft_minus(col) / uH
+        for y in range(uH):
+            row = B[y].copy()
+            row[zlx:zrx] = 0.0
+            B[y] = _dft_minus(row) / uW
+        out[c] = B
+    return out
+
+
+def closed_form_complex(planes, upscale):
+    """the same as plain numpy: fft2 (numpy's sign is the reference's inverse: conjugate), quadrant placement, ifft2"""
+    planes = np.asarray(planes, dtype=np.float64)
+    C, H, W = planes.shape
+    uW, uH = out_dims(W, H, upscale)
+    out = np.empty((C, uH, uW), dtype=np.complex128)
+    for c in range(C):
+        F = np.conj(np.fft.fft2(planes[c]))              # sum x exp(+2 pi i ..) of a real image
+        G = np.zeros((uH, uW), dtype=np.complex128)
+        G[:H // 2, :W // 2] = F[:H // 2, :W // 2]
+        G[:H // 2, uW - W // 2:] = F[:H // 2, W // 2:]
+        G[uH - H // 2:, :W // 2] = F[H // 2:, :W // 2]
+        G[uH - H // 2:, uW - W // 2:] = F[H // 2:, W // 2:]
+        out[c] = np.fft.fft2(G) / (uW * uH)              # exp(-2 pi i ..), 1/N
+    return out

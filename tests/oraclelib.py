@@ -78,6 +78,28 @@ def upscale_planes(planes, upscale=2.0, precision=0, sharpen=0.2):
     return pre, out, poison.value
 
 
+def upscale_planes_complex(planes, upscale=2.0, precision=0, sharpen=0.2):
+    """the non-R2C path (the reference takes it for uW > 8192; callable at any size here):
+    planes [3][H][W] float64 -> (complex pre-sharpen image [3][uH][uW], out [3][uH][uW], poison_reads)"""
+    planes = np.ascontiguousarray(planes, dtype=np.float64)
+    _, H, W = planes.shape
+    cfg = _cfg(W, H, upscale, precision, sharpen)
+    uW, uH = out_dims(W, H, upscale)
+    _fit_threads(uW * uH)
+    re, im, out = np.empty((3, uH, uW)), np.empty((3, uH, uW)), np.empty((3, uH, uW))
+    poison = C.c_uint64(0)
+    rc = lib().orc_upscale_planes_complex(C.byref(cfg), planes.ctypes.data_as(C.c_void_p), re.ctypes.data_as(C.c_void_p),
+                                          im.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(poison))
+    if rc:
+        raise ValueError("oracle rc=%d" % rc)
+    return re + 1j * im, out, poison.value
+
+
+def uses_complex_path(W, H, upscale=2.0, precision=0):
+    cfg = _cfg(W, H, upscale, precision)
+    return bool(lib().orc_uses_complex_path(C.byref(cfg)))
+
+
 def upscale_rgb8(rgb, upscale=2.0, precision=0, sharpen=0.2, u8_wrap=0):
     """rgb: [H][W][3] uint8 -> (pre, out, rgb_out[uH][uW][3])"""
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)

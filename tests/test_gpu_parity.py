@@ -398,15 +398,41 @@ def test_u8_wrap_flag():
 
 
 def test_largest_r2c_size_vs_oracle():
-    """uW = 8192 is the largest width the reference's R2C path accepts (VkResample.cpp:1424); one size further
-    is rejected with FFTUP_E_UNSUPPORTED_SIZE."""
-    import vkresample_amd as v
+    """uW = 8192 is the largest width the reference's R2C path accepts (VkResample.cpp:1424)."""
     (pre, out, u8), (opre, oout, ou8) = _run(4096, 64, 2.0, 0, "N", seed=9)
     assert _rel_l2(pre, opre) <= 1e-5 and np.abs(pre - opre).max() * 4 <= 1e-4
     assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-4
-    with pytest.raises(v.FftupError) as e:
-        v.Upscaler(4608, 64, 2.0)               # 9216 = 2^10 * 9: smooth but beyond the R2C limit
+
+
+@pytest.mark.parametrize("W,H,u,precision,flags", [(4608, 64, 2.0, 0, 0), (4608, 64, 2.0, 0, 2), (3072, 32, 3.0, 0, 0),
+                                                   (2304, 32, 2.0, 1, 0), (6144, 16, 1.5, 0, 0)])
+def test_non_r2c_complex_path_vs_oracle(W, H, u, precision, flags):
+    """beyond the R2C limit (uW > 8192; > 4096 for -p 1) the reference runs full complex transforms with a
+    four-quadrant shift (VR:527-546) and sharpens the modulus of the complex image; the imaginary input parts, which the
+    reference leaves uninitialised, are defined as 0.  The pre-sharpen tap returns the real part."""
+    assert O.uses_complex_path(W, H, u, precision)
+    (pre, out, u8), (opre, oout, ou8) = _run(W, H, u, precision, "N", flags=flags, seed=21)
+    usq = u * u
+    if precision == 0:
+        assert _rel_l2(pre, opre) <= 1e-5 and np.abs(pre - opre).max() * usq <= 1e-4
+        so = _report("non-R2C %dx%d u%g out" % (W, H, u), out[:, :-1] - oout[:, :-1], 1e-4)
+        assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-4 and so["max"] <= 1e-3 and so["p99.99"] <= 1e-4
+    else:
+        assert np.abs(pre - opre).max() <= 1e-12 and np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1e-9
+    d = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
+    assert d.max() <= 1 and (d != 0).mean() <= 5e-3
+
+
+def test_non_r2c_limits():
+    import vkresample_amd as v
+    with pytest.raises(v.FftupError) as e:          # two LDS row buffers of 10240 complex exceed 160 KB
+        v.Upscaler(5120, 16, 2.0)
     assert e.value.code == 2
+    with pytest.raises(v.FftupError) as e:          # -p 2 beyond the R2C limit is not implemented
+        v.Upscaler(4608, 16, 2.0, 2)
+    assert e.value.code == 2
+    with _up(4608, 16, 2.0) as up:
+        assert up.kernel_names == ["row_c2c", "col_fwd_pad_inv", "row_c2c_inv", "sharpen"] and not up.tuned
 
 
 def test_4k_to_8k_properties():

@@ -236,6 +236,45 @@ def test_fp16_mode_values_are_halves():
     assert np.abs(pre - pre0).max() <= 2e-4 and np.abs(out - out0).max() <= 2e-2
 
 
+# ------------------------------------------------------------------ the non-R2C path
+@pytest.mark.parametrize("W,H,u", [(16, 8, 2.0), (20, 12, 2.0), (24, 30, 2.0), (16, 8, 3.0), (12, 8, 2.5), (16, 8, 1.5)])
+def test_complex_path_oracle_equals_layout_emulation_and_closed_form(W, H, u):
+    """VR:1424 false: full complex transform, four-quadrant shift (VR:527-546, replayed with the shader's own index
+    arithmetic), read guards VR:1497-1502; imaginary input parts defined as 0."""
+    rng = np.random.default_rng(W * 31 + H)
+    planes = rng.random((3, H, W))
+    z, out, poison = O.upscale_planes_complex(planes, u)
+    assert poison == 0
+    assert np.abs(z - E.emulate_complex(planes, u)).max() <= 1e-14
+    assert np.abs(z - E.closed_form_complex(planes, u)).max() <= 1e-14
+    # sharpen on the modulus: for u = 2 the imaginary part is the Nyquist-row/column remainder, small but not zero
+    if u == 2.0:
+        assert 1e-4 < np.abs(z.imag).max() < 0.2
+    usq = float(np.float32(np.float32(u) * np.float32(u)))
+    L = np.clip(np.abs(round(usq, 6) * z), 0.0, 1.0)
+    ref = np.stack([_sharpen_ref(L[c], float(np.float32(0.2))) for c in range(3)])
+    assert np.abs(out[:, 1:-1, 1:-1] - ref[:, 1:-1, 1:-1]).max() <= 1e-12      # (_sharpen_ref: interior pixels)
+
+
+def test_complex_path_selection_and_kat():
+    assert not O.uses_complex_path(4096, 64) and O.uses_complex_path(4608, 64)
+    assert not O.uses_complex_path(2048, 64, precision=1) and O.uses_complex_path(2304, 64, precision=1)
+    # a constant image stays constant; a cosine below Nyquist is resampled exactly (real result, no imaginary part)
+    W, H = 32, 16
+    x = np.arange(W)[None, :] + 0 * np.arange(H)[:, None]
+    planes = np.stack([np.full((H, W), 0.3), 0.5 + 0.25 * np.cos(2 * np.pi * 3 * x / W), 0.5 + 0.1 * np.cos(2 * np.pi * 5 * x / W)])
+    z, _, _ = O.upscale_planes_complex(planes, 2.0)
+    X = np.arange(2 * W)[None, :] + 0 * np.arange(2 * H)[:, None]
+    assert np.abs(4 * z[0] - 0.3).max() <= 1e-14
+    assert np.abs(4 * z[1] - (0.5 + 0.25 * np.cos(2 * np.pi * 3 * X / (2 * W)))).max() <= 1e-14
+    # through the size rule: 4608 x 8 takes the complex path inside orc_upscale_planes; pre = real part
+    rng = np.random.default_rng(3)
+    big = rng.random((3, 8, 4608))
+    pre, out, _ = O.upscale_planes(big, 2.0)
+    z2, out2, _ = O.upscale_planes_complex(big, 2.0)
+    assert np.array_equal(pre, z2.real) and np.array_equal(out, out2)
+
+
 # ------------------------------------------------------------------ golden vectors (tests/golden/make_golden.py)
 @pytest.mark.parametrize("name", ["g16x8_u2_p0", "g20x12_u2_p0", "g20x12_u2_p1", "g64x32_u2_p0", "g64x32_u2_p2", "gsample64_u2_p0"])
 def test_golden_vectors(name):

@@ -73,6 +73,8 @@ struct fftup_plan {
     bool tuned = false;
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
     bool mixed1080 = false;           // compile-time mixed-radix plans (1920x1080 -> 3840x2160)
+    bool cplx = false;                // non-R2C path (VR:1424 false): full complex transforms, uW beyond the R2C limit
+    int ncols = 0;                    // spectrum columns kept: W/2 + 1, or W on the non-R2C path
     int pairs_per_strip = 6;
     bool R_valid = false;             // pre-sharpen buffer holds the last frame (unfused path only)
 
@@ -237,11 +239,14 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         return fail(FFTUP_E_INVALID_ARG, "width/height (and upscaled sizes) must be even, upscale >= 1");
     if (!is_smooth(W) || !is_smooth(H) || !is_smooth(uW) || !is_smooth(uH))
         return fail(FFTUP_E_UNSUPPORTED_SIZE, "sizes must factor into 2,3,5,7 (vkFFT.h:4719-4726)");
-    // R2C rule of the reference: uW <= maxComputeSharedMemorySize/8 with 64 KB (VkResample.cpp:1424);
-    // beyond it the reference switches to its complex path, which is out of scope here.
-    // (complexSizeCalc = 16 for -p 1, VkResample.cpp:1334-1336, halves the limit)
-    if (uW > (cfg->precision == 1 ? 4096u : 8192u))
-        return fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width beyond the R2C limit (8192, 4096 for -p 1): non-R2C path not implemented (VkResample.cpp:1424)");
+    // R2C rule of the reference: uW <= maxComputeSharedMemorySize/8 with 64 KB (VkResample.cpp:1424; complexSizeCalc = 16
+    // for -p 1, VkResample.cpp:1334-1336, halves the limit); beyond it the full complex path runs
+    const bool cplx = uW > (cfg->precision == 1 ? 4096u : 8192u);
+    if (cplx && cfg->precision == 2)
+        return fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width beyond the R2C limit (8192) with -p 2: the non-R2C path is implemented for -p 0 and -p 1");
+    // (checked here, before any device access: gfx950 has 160 KB of LDS per workgroup)
+    if (cplx && 2 * (size_t)(cfg->precision == 1 ? 16 : 8) * (size_t)lpad_size((int)uW) > (size_t)160 * 1024)
+        return fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width too large: the two row buffers of the non-R2C path exceed the LDS");
 
     int ndev = fftup_device_count();
     if (ndev <= 0) return fail(FFTUP_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
@@ -253,6 +258,8 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
     P->ring = cfg->ring ? cfg->ring : 1;
     P->half = cfg->precision == 2;
     P->dbl = cfg->precision == 1;
+    P->cplx = cplx;
+    P->ncols = cplx ? (int)W : (int)(W / 2 + 1);
     P->esz = P->dbl ? 8 : (P->half ? 2 : 4);
     P->csz = P->dbl ? 16 : 8;
     P->device = cfg->device;
@@ -281,7 +288,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         // zero-padding ranges exactly as launchResample computes them (float math, uint32 store)
         const float u = cfg->upscale;
         P->zlx = (int)(W / 2);
-        P->zrx = (int)(uW / 2);
+        P->zrx = cplx ? (int)(uint32_t)((2 * u - 1) * (float)uW / (2 * u)) : (int)(uW / 2);      // VR:1498 / VR:1493
         P->zly = (int)(uint32_t)((float)uH / (2 * u));
         P->zry = (int)(uint32_t)((2 * u - 1) * (float)uH / (2 * u));
 
@@ -292,7 +299,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
 
         const size_t lds_max = P->prop.sharedMemPerBlock ? P->prop.sharedMemPerBlock : 65536;
         // size-specialised kernels: u == 2 and power-of-two sizes with instantiated plans
-        P->tuned = !P->dbl && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && uW == 2 * W && uH == 2 * H &&
+        P->tuned = !P->dbl && !cplx && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && uW == 2 * W && uH == 2 * H &&
                    (W == 512 || W == 1024 || W == 2048) && (H == 256 || H == 512 || H == 1024);
         P->TK = 0;
         if (P->tuned) {
@@ -320,7 +327,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             P->pairs_per_strip = std::max(2, (total_pairs + slots - 1) / slots);
         }
         if (const char* e = getenv("FFTUP_PAIRS_PER_STRIP")) P->pairs_per_strip = std::max(1, atoi(e));
-        P->NT = ((int)(W / 2 + 1) + P->TK - 1) / P->TK;
+        P->NT = (P->ncols + P->TK - 1) / P->TK;
         P->ldsRowF = 2 * P->csz * (size_t)lpad_size((int)W);
         P->ldsRowI = 2 * P->csz * (size_t)lpad_size((int)uW);
         if (P->ldsRowI > lds_max) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width too large for LDS"); goto bad; }
@@ -360,7 +367,8 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             return r ? r : dev_alloc(P, (void**)s2, P->csz * 3 * (size_t)P->NT * uH * P->TK);
         };
         PLAN_RC(alloc_spectra(&P->S1, &P->S2));
-        PLAN_RC(dev_alloc(P, &P->R, (size_t)3 * uW * uH * esz));
+        const size_t r_bytes = (size_t)3 * uW * uH * (cplx ? P->csz : esz);        // non-R2C path: complex pre-sharpen image
+        PLAN_RC(dev_alloc(P, &P->R, r_bytes));
         PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH));
         {
             int nl = 3;
@@ -372,7 +380,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
                 PLAN_TRY(hipStreamCreateWithFlags(&P->lanes[l].stream, hipStreamNonBlocking));
                 PLAN_TRY(hipEventCreateWithFlags(&P->lanes[l].done, hipEventDisableTiming));
                 PLAN_RC(alloc_spectra(&P->lanes[l].S1, &P->lanes[l].S2));
-                PLAN_RC(dev_alloc(P, &P->lanes[l].R, (size_t)3 * uW * uH * esz));
+                PLAN_RC(dev_alloc(P, &P->lanes[l].R, r_bytes));
             }
         }
 
@@ -388,6 +396,13 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         SET_LDS(k_col<1>, P->ldsCol);
         SET_LDS(k_row_c2r<false>, P->ldsRowI);
         SET_LDS(k_row_c2r<true>, P->ldsRowI);
+        if (cplx) {
+            if (P->dbl) { SET_LDS((k_row_c2c_fwd<IN_F64, double2>), P->ldsRowF); SET_LDS((k_row_c2c_inv<double2>), P->ldsRowI); }
+            else {
+                SET_LDS((k_row_c2c_fwd<IN_F32, float2>), P->ldsRowF); SET_LDS((k_row_c2c_fwd<IN_U8_F32, float2>), P->ldsRowF);
+                SET_LDS((k_row_c2c_inv<float2>), P->ldsRowI);
+            }
+        }
         if (P->dbl) {
             SET_LDS((k_row_r2c<IN_F64, double2>), P->ldsRowF);
             SET_LDS((k_col<8, double2>), P->ldsCol);
@@ -441,9 +456,9 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
     const double b_in = fused_u8 ? 1.0 : (double)P->esz;
     const double b_r = (double)P->esz, b_out = b_r, b_c = (double)P->csz;
     const double in = C * W * H * b_in;
-    const double S1 = C * (W / 2 + 1) * H * b_c;
-    const double S2 = C * (W / 2 + 1) * uH * b_c;
-    const double R = C * uW * uH * b_r;
+    const double S1 = C * P->ncols * H * b_c;
+    const double S2 = C * P->ncols * uH * b_c;
+    const double R = C * uW * uH * (P->cplx ? b_c : b_r);
     const double o = C * uW * uH * b_out;
     info->alg_bytes_per_frame = in + 2 * S1 + 2 * S2 + 2 * R + o;
     info->kernel_alg_bytes[0] = in + S1;
@@ -454,9 +469,9 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
     info->kernel_alg_bytes[3] = P->fused ? 0.0 : R + o;
     info->device_bytes = P->device_bytes;
     snprintf(info->device_name, sizeof info->device_name, "%s", P->prop.name);
-    snprintf(info->kernel_names[0], 64, "row_r2c");
+    snprintf(info->kernel_names[0], 64, P->cplx ? "row_c2c" : "row_r2c");
     snprintf(info->kernel_names[1], 64, "col_fwd_pad_inv");
-    snprintf(info->kernel_names[2], 64, P->fused ? "row_c2r_sharpen" : "row_c2r");
+    snprintf(info->kernel_names[2], 64, P->fused ? "row_c2r_sharpen" : (P->cplx ? "row_c2c_inv" : "row_c2r"));
     snprintf(info->kernel_names[3], 64, P->fused ? "-" : "sharpen");
     return FFTUP_OK;
 }
@@ -647,7 +662,7 @@ static int launch_frame_f64(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, 
         ColParamsT<double2> p{};
         p.S1 = (const double2*)P->lanes[P->cur].S1; p.S2 = (double2*)P->lanes[P->cur].S2;
         p.twH = (const double2*)P->twH; p.twUH = (const double2*)P->twUH; p.planH = P->planH; p.planUH = P->planUH;
-        p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.zly = P->zly; p.zry = P->zry;
+        p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.ncols = P->ncols; p.zly = P->zly; p.zry = P->zry;
         p.inv_norm = 1.0 / (double)P->uH;
         dim3 grid(P->NT, 3), block(P->thrCol);
         switch (P->TK) {
@@ -674,10 +689,63 @@ static int launch_frame_f64(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, 
     return FFTUP_OK;
 }
 
+// non-R2C path: four launches of size-generic kernels on complex data
+template <typename C> static int launch_frame_cplx(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
+{
+    hipStream_t st = P->lanes[P->cur].stream;
+    const int kind = P->in_kind[in_slot];
+    using S = scalar_t<C>;
+    if (which < 0 || which == 0) {
+        RowR2CParamsT<C> p{};
+        p.S1 = (C*)P->lanes[P->cur].S1; p.tw = (const C*)P->twW; p.plan = P->planW; p.W = (int)P->W; p.H = (int)P->H;
+        p.TK = P->TK; p.NT = P->NT;
+        dim3 grid(P->H, 3), block(P->thrW);
+        if (kind == 2) {
+            p.in = P->in_u8[in_slot]; p.in_row_stride = 3l * P->W; p.in_plane_stride = 0;
+            if constexpr (sizeof(S) == 4) hipLaunchKernelGGL((k_row_c2c_fwd<IN_U8_F32, C>), grid, block, P->ldsRowF, st, p);
+        } else {
+            p.in = P->in_planar[in_slot]; p.in_row_stride = P->W; p.in_plane_stride = (long)P->in_plane_stride;
+            if constexpr (sizeof(S) == 8) hipLaunchKernelGGL((k_row_c2c_fwd<IN_F64, C>), grid, block, P->ldsRowF, st, p);
+            else hipLaunchKernelGGL((k_row_c2c_fwd<IN_F32, C>), grid, block, P->ldsRowF, st, p);
+        }
+    }
+    if (which < 0 || which == 1) {
+        ColParamsT<C> p{};
+        p.S1 = (const C*)P->lanes[P->cur].S1; p.S2 = (C*)P->lanes[P->cur].S2; p.twH = (const C*)P->twH; p.twUH = (const C*)P->twUH;
+        p.planH = P->planH; p.planUH = P->planUH;
+        p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.ncols = P->ncols; p.zly = P->zly; p.zry = P->zry;
+        p.inv_norm = (S)(1.0 / (double)P->uH);
+        dim3 grid(P->NT, 3), block(P->thrCol);
+        switch (P->TK) {
+        case 8: hipLaunchKernelGGL((k_col<8, C>), grid, block, P->ldsCol, st, p); break;
+        case 4: hipLaunchKernelGGL((k_col<4, C>), grid, block, P->ldsCol, st, p); break;
+        case 2: hipLaunchKernelGGL((k_col<2, C>), grid, block, P->ldsCol, st, p); break;
+        default: hipLaunchKernelGGL((k_col<1, C>), grid, block, P->ldsCol, st, p); break;
+        }
+    }
+    if (which < 0 || which == 2) {
+        RowC2RParamsT<C> p{};
+        p.S2 = (const C*)P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = (const C*)P->twUW; p.plan = P->planUW;
+        p.W = (int)P->W; p.uW = (int)P->uW; p.uH = (int)P->uH; p.TK = P->TK; p.NT = P->NT; p.zlx = P->zlx; p.zrx = P->zrx;
+        p.inv_norm = (S)(1.0 / (double)P->uW);
+        hipLaunchKernelGGL((k_row_c2c_inv<C>), dim3(P->uH, 3), dim3(P->thrUW), P->ldsRowI, st, p);
+        P->R_valid = true;
+    }
+    if (which < 0 || which == 3) {
+        SharpenParams p{};
+        p.R = P->lanes[P->cur].R; p.out = P->out[out_slot]; p.uW = (int)P->uW; p.uH = (int)P->uH; p.upsq = P->upsq; p.coef = P->coef;
+        hipLaunchKernelGGL((k_sharpen_c<C>), dim3((P->uW + 255) / 256, P->uH, 3), dim3(256), 0, st, p);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FFTUP_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return FFTUP_OK;
+}
+
 static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
 {
     const int kind = P->in_kind[in_slot];
     if (kind == 0) return fail(FFTUP_E_NO_INPUT, "no input uploaded for this slot");
+    if (P->cplx) return P->dbl ? launch_frame_cplx<double2>(P, in_slot, out_slot, which) : launch_frame_cplx<float2>(P, in_slot, out_slot, which);
     if (P->dbl) return launch_frame_f64(P, in_slot, out_slot, which);
     if (P->tuned) {
         launch_frame_tuned(P, in_slot, out_slot, which);
@@ -717,7 +785,7 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
     if (which < 0 || which == 1) {
         ColParams p{};
         p.S1 = P->lanes[P->cur].S1; p.S2 = P->lanes[P->cur].S2; p.twH = P->twH; p.twUH = P->twUH; p.planH = P->planH; p.planUH = P->planUH;
-        p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.zly = P->zly; p.zry = P->zry;
+        p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.ncols = P->ncols; p.zly = P->zly; p.zry = P->zry;
         p.inv_norm = 1.0f / (float)P->uH;
         dim3 grid(P->NT, 3), block(P->thrCol);
         if (P->mixed1080) {
@@ -939,7 +1007,11 @@ int fftup_download_presharpen(fftup_plan* P, void* planes)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(P->lanes[P->last_lane].stream));
     }
-    HIP_TRY(hipMemcpyAsync(planes, P->lanes[P->last_lane].R, (size_t)3 * P->uW * P->uH * P->esz, hipMemcpyDeviceToHost, P->stream));
+    if (P->cplx)        // non-R2C path: the pre-sharpen image is complex; this tap returns its real parts
+        HIP_TRY(hipMemcpy2DAsync(planes, P->esz, P->lanes[P->last_lane].R, 2 * P->esz, P->esz, (size_t)3 * P->uW * P->uH,
+                                 hipMemcpyDeviceToHost, P->stream));
+    else
+        HIP_TRY(hipMemcpyAsync(planes, P->lanes[P->last_lane].R, (size_t)3 * P->uW * P->uH * P->esz, hipMemcpyDeviceToHost, P->stream));
     HIP_TRY(hipStreamSynchronize(P->stream));
     return FFTUP_OK;
 }
@@ -1083,7 +1155,7 @@ const char* fftup_strerror(int code)
     switch (code) {
     case FFTUP_OK: return "success";
     case FFTUP_E_INVALID_ARG: return "invalid argument";
-    case FFTUP_E_UNSUPPORTED_SIZE: return "unsupported size (not 2,3,5,7-smooth, or beyond the R2C limit)";
+    case FFTUP_E_UNSUPPORTED_SIZE: return "unsupported size (not 2,3,5,7-smooth, or a row too long for the LDS)";
     case FFTUP_E_UNSUPPORTED_PRECISION: return "unsupported precision";
     case FFTUP_E_NO_DEVICE: return "no usable HIP device";
     case FFTUP_E_HIP: return "HIP runtime error";

@@ -86,6 +86,7 @@ template <typename C> struct ColParamsT {
     StagePlan planH, planUH;
     int W, H, uH;
     int NT;
+    int ncols;               // kx columns present: W/2 + 1 (R2C plans) or W (non-R2C plans)
     int zly, zry;            // inverse read guard: rows [zly,zry) read as zero (VkResample.cpp:1494-1495)
     scalar_t<C> inv_norm;    // 1/uH
 };
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(1024) k_col(ColParamsT<C> p)
     const int tid = threadIdx.x, T = blockDim.x;
     const int tile = blockIdx.x, c = blockIdx.y;
     const int H = p.H, uH = p.uH;
-    const int ncol_valid = min(TK, p.W / 2 + 1 - tile * TK);
+    const int ncol_valid = min(TK, p.ncols - tile * TK);
     const C* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
     for (int e = tid; e < H * TK; e += T) {
         C v = mk<C>(S(0), S(0));
@@ -187,6 +188,61 @@ __global__ void __launch_bounds__(1024) k_row_c2r(RowC2RParamsT<C> p)
             R[uW + n] = v.y;
         }
     }
+}
+
+// ---------------------------------------------------------------- the non-R2C path
+// VkResample.cpp:1424: beyond uW = 8192 (4096 for -p 1) the reference drops R2C/C2R and runs full complex transforms on
+// a complex input whose imaginary parts it never initialises (VR:1620, 1647) -- defined as 0 here.  Same blocked
+// spectrum layout with all W columns; the column kernel is k_col (its shift is the y half of the four-quadrant shift
+// VR:527-546), the x half happens in the gather of the inverse row kernel together with the read guard
+// [W/2, (2u-1) uW / 2u) of VR:1497-1498.
+// grid (H, 3); dynamic LDS = 2 * lpad_size(W) complex
+template <int MODE, typename C = float2>
+__global__ void __launch_bounds__(1024) k_row_c2c_fwd(RowR2CParamsT<C> p)
+{
+    using S = scalar_t<C>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    C* a = (C*)smem;
+    C* b = a + lpad_size(p.W);
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int y = blockIdx.x, c = blockIdx.y;
+    const int W = p.W;
+    for (int n = tid; n < W; n += T) a[lpad(n)] = mk<C>((S)load_px<MODE>(p, c, y, n), S(0));
+    __syncthreads();
+    const C* Z = fft_lds<+1, 1>(a, b, p.plan, p.tw, tid, T);
+    const long tile_stride = (long)p.H * p.TK;
+    C* base = p.S1 + (long)c * p.NT * tile_stride + (long)y * p.TK;
+    for (int k = tid; k < W; k += T) base[(long)(k / p.TK) * tile_stride + (k % p.TK)] = Z[lpad(k)];
+}
+
+// grid (uH, 3); dynamic LDS = 2 * lpad_size(uW) complex.  R: complex [3][uH][uW].
+template <typename C = float2>
+__global__ void __launch_bounds__(1024) k_row_c2c_inv(RowC2RParamsT<C> p)
+{
+    using S = scalar_t<C>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    C* a = (C*)smem;
+    C* b = a + lpad_size(p.uW);
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int y = blockIdx.x, c = blockIdx.y;
+    const int uW = p.uW, W = p.W;
+    const long tile_stride = (long)p.uH * p.TK;
+    const C* base = p.S2 + (long)c * p.NT * tile_stride + (long)y * p.TK;
+    for (int kx = tid; kx < uW; kx += T) {
+        C v = mk<C>(S(0), S(0));
+        if (!(kx >= p.zlx && kx < p.zrx)) {
+            // columns >= W/2 of the forward spectrum sit uW - W further on (race-free form of the in-place shift)
+            int k = -1;
+            if (kx >= uW - W / 2) k = kx - (uW - W);
+            else if (kx < W) k = kx;
+            if (k >= 0) v = base[(long)(k / p.TK) * tile_stride + (k % p.TK)];
+        }
+        a[lpad(kx)] = v;
+    }
+    __syncthreads();
+    const C* z = fft_lds<-1, 1>(a, b, p.plan, p.tw, tid, T);
+    C* R = (C*)p.R + ((long)c * p.uH + y) * uW;
+    for (int n = tid; n < uW; n += T) R[n] = cscale(z[lpad(n)], p.inv_norm);
 }
 
 // ---------------------------------------------------------------- sharpen (VkResample.cpp:819-925)
@@ -381,6 +437,38 @@ __global__ void __launch_bounds__(256) k_pack_u8_f64(const double* planes, uint8
         else o = !(d > 0.0) ? 0 : (d >= 255.0 ? 255 : (uint8_t)d);
         rgb[((long)y * uW + x) * 3 + c] = o;
     }
+}
+
+// sharpen on the complex image of the non-R2C path: len = length(u^2 z) (VkResample.cpp:865-907 with vec2 inputs);
+// one thread = one pixel
+template <typename C = float2>
+__global__ void __launch_bounds__(256) k_sharpen_c(SharpenParams p)
+{
+    using S = scalar_t<C>;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, c = blockIdx.z;
+    const int uW = p.uW, uH = p.uH;
+    if (x >= uW) return;
+    const long plane = (long)uW * uH;
+    const C* R = (const C*)p.R + c * plane;
+    const int xs[3] = {x > 0 ? x - 1 : x, x, x + 1};
+    const int ys[3] = {y > 0 ? y - 1 : y, y, y + 1};
+    S len[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            long f = (long)ys[a] * uW + xs[b];       // x == uW wraps to the next row (quirk B5)
+            while (f >= plane) f -= uW;              // reads past the plane: same column, last row (see oracle)
+            const C z = R[f];
+            const S tr = (S)p.upsq * z.x, ti = (S)p.upsq * z.y;
+            S l;
+            if constexpr (sizeof(S) == 8) l = sqrt(tr * tr + ti * ti);
+            else l = __fsqrt_rn(tr * tr + ti * ti);
+            len[a * 3 + b] = l > S(1) ? S(1) : (l < S(0) ? S(0) : l);
+        }
+    if constexpr (sizeof(S) == 8) ((double*)p.out)[c * plane + (long)y * uW + x] = sharpen_px_f64(len, (double)p.coef);
+    else ((float*)p.out)[c * plane + (long)y * uW + x] = sharpen_px<false>(len, p.coef);
 }
 
 }  // namespace fftup

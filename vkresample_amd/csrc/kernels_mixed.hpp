@@ -1,7 +1,7 @@
-// kernels_mixed.hpp -- compile-time plans for the mixed-radix sizes of BASELINE config 4
-// (1920x1080 -> 3840x2160: radix 2/3/4/5/8 Stockham stages).  Same algorithm and LDS ping-pong layout as
-// kernels_generic.hpp; length, thread count and radix sequence are template constants, so the stage loops
-// unroll and all index arithmetic (including the k = j % Ns of the odd stages) folds at compile time.
+// kernels_mixed.hpp -- kernels for the mixed-radix sizes of BASELINE config 4 (1920x1080 -> 3840x2160):
+//   * register-resident row R2C (1920 = 15*8*16) and polyphase column (1080 = 9*8*15) kernels on the three-stage engine
+//     MrFftT of kernels_pow2.hpp; the fused C2R+sharpen kernel for 3840 is k_c2r_sharpen_g<FusedPlan3840>;
+//   * a stand-alone C2R for 3840 with compile-time radix-8/8/4/3/5 LDS ping-pong stages (two-launch path, pre-sharpen tap).
 #pragma once
 #include "fft_engine.hpp"
 #include "kernels_generic.hpp"
@@ -32,69 +32,6 @@ __device__ __forceinline__ float2* run_plan(CtPlan<N, T, R...>, float2* a, float
 {
     static_assert((R * ... * 1) == N, "radices must multiply to N");
     return fft_lds_ct<N, DIR, TK, T, 1, R...>(a, b, tw, tid);
-}
-
-// ---- row R2C (see k_row_r2c).  grid (H/2, 3), block PW::T, dynamic LDS 2*lpad_size(W) float2
-template <class PW, int MODE>
-__global__ void __launch_bounds__(PW::T) k_row_r2c_ct(RowR2CParams p)
-{
-    constexpr int W = PW::N, T = PW::T;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* a = (float2*)smem;
-    float2* b = a + lpad_size(W);
-    const int tid = threadIdx.x, j = blockIdx.x, c = blockIdx.y;
-    for (int n = tid; n < W; n += T)
-        a[lpad(n)] = make_float2(load_px<MODE>(p, c, 2 * j, n), load_px<MODE>(p, c, 2 * j + 1, n));
-    __syncthreads();
-    const float2* Z = run_plan<+1, 1>(PW{}, a, b, p.tw, tid);
-    const int TK = p.TK;
-    const long tile_stride = (long)p.H * TK;
-    float2* base = p.S1 + (long)c * p.NT * tile_stride + (long)(2 * j) * TK;
-    for (int k = tid; k <= W / 2; k += T) {
-        float2 zk = Z[lpad(k)];
-        float2 zn = Z[lpad(k == 0 ? 0 : W - k)];
-        float2 A = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-        float2 B = make_float2(0.5f * (zk.y + zn.y), 0.5f * (-zk.x + zn.x));
-        float2* dst = base + (long)(k / TK) * tile_stride + (k % TK);
-        dst[0] = A;
-        dst[TK] = B;
-    }
-}
-
-// ---- column, u = 2, polyphase form (see k_col_t in kernels_pow2.hpp for the derivation): forward FFT(H), multiplication by
-// t[k] = exp(-2 pi i k/2H) * (k < H/2 ? 1 : -1), inverse FFT(H) -> the ODD rows of the zero-padded 2H-row spectrum at
-// twice the reference's normalisation; the even rows are the rows of S1 and are never written.
-// grid (NT, 3), block PH::T, dynamic LDS 2*lpad_size(H*TK) float2
-template <class PH, int TK>
-__global__ void __launch_bounds__(PH::T) k_col_ct(ColParams p)
-{
-    constexpr int H = PH::N, T = PH::T;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* a = (float2*)smem;
-    float2* b = a + lpad_size(H * TK);
-    const int tid = threadIdx.x, tile = blockIdx.x, c = blockIdx.y;
-    const int ncol_valid = min(TK, p.W / 2 + 1 - tile * TK);
-    const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
-    for (int e = tid; e < H * TK; e += T) {
-        float2 v = make_float2(0.f, 0.f);
-        if ((e % TK) < ncol_valid) v = src[e];
-        a[lpad(e)] = v;
-    }
-    __syncthreads();
-    float2* F = run_plan<+1, TK>(PH{}, a, b, p.twH, tid);
-    float2* G = (F == a) ? b : a;
-    for (int e = tid; e < H * TK; e += T) {
-        const int ky = e / TK;
-        float2 t = twid<-1>(p.twUH[ky]);
-        if (ky >= H / 2) t = make_float2(-t.x, -t.y);
-        G[lpad(e)] = cmul(F[lpad(e)], t);
-    }
-    __syncthreads();
-    const float2* D = run_plan<-1, TK>(PH{}, G, F, p.twH, tid);
-    float2* dst = p.S2 + ((long)c * p.NT + tile) * H * TK;
-    constexpr float inv = 1.0f / (float)H;
-    for (int e = tid; e < H * TK; e += T)
-        if ((e % TK) < ncol_valid) dst[e] = cscale(D[lpad(e)], inv);
 }
 
 // ---- row C2R (see k_row_c2r), u = 2.  grid (uH/2, 3), block PUW::T, dynamic LDS 2*lpad_size(UW) float2
@@ -238,14 +175,7 @@ __global__ void __launch_bounds__(576) k_col_m1080(ColTParams p)
     }
 }
 
-#ifndef FFTUP_COLT
-#define FFTUP_COLT 1024
-#endif
-constexpr int COLT = FFTUP_COLT;
-// plans of the 1080p -> 2160p configuration
-using Plan1920 = CtPlan<1920, 256, 8, 8, 2, 3, 5>;
+// the stand-alone C2R of the 1080p plan (two-launch path and pre-sharpen tap)
 using Plan3840 = CtPlan<3840, 512, 8, 8, 4, 3, 5>;
-using Plan1080 = CtPlan<1080, COLT, 8, 3, 3, 3, 5>;      // x TK = 4 columns
-using Plan2160 = CtPlan<2160, COLT, 8, 2, 3, 3, 3, 5>;
 
 }  // namespace fftup
