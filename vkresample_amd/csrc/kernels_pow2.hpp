@@ -783,6 +783,7 @@ template <int UW_> struct FusedPlanPow2 {                   // radix-8 Stockham,
     static constexpr int UW = UW_, T = UW / 8, R0 = 8, NB0 = T, EOUT = 8, SOUT = T, VN = 8;
     static constexpr size_t XB = sizeof(float2) * lswz_size(UW);
     struct Tw { TwSet<UW, 8> t; };
+    static __device__ __forceinline__ int first_index(int lt) { return lt; }      // first-stage butterfly of thread lt
     static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { w.t.load(tw, j); }
     static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, int j, const Tw& w)
     {
@@ -915,6 +916,7 @@ struct FusedPlan3840 {                                      // 1920x1080 -> 3840
     static constexpr int UW = 3840, T = 256, R0 = 16, NB0 = F::NB0, EOUT = 15, SOUT = F::NB2, VN = F::VN;
     static constexpr size_t XB = (sizeof(float2) * lpad_size(3840) + 15) & ~(size_t)15;
     using Tw = F::Tw;
+    static __device__ __forceinline__ int first_index(int lt) { return lt < NB0 ? lt : NB0 - 1; }   // (threads beyond re-read)
     static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { F::load_tw(w, tw, j); }
     static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, int j, const Tw& w) { F::fft(v, buf, j, w); }
 };
@@ -984,7 +986,7 @@ __global__ void __launch_bounds__(PL::T, PL::T * 2 / 256 > 0 ? PL::T * 2 / 256 :
             In in;
             const int a = a0 + 2 * i;
             const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);       // rows past the plane: duplicate of the last row
-            const int jj = (NB0 == T) ? lt : min(lt, NB0 - 1);
+            const int jj = PL::first_index(lt);
 #pragma unroll
             for (int m = 0; m < NI; m++) {
                 in.a[m] = S2at(jj + NB0 * m, ya); in.am[m] = S2at(KH - jj - NB0 * m, ya);
