@@ -256,6 +256,9 @@ def main():
             "kernel_ms_timed_region": dict(zip(up.kernel_names, kms)),
             "roofline": {"bound": "hbm", "kernel": up.kernel_names[dom], "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": tsrc,
+                         # the same kernel priced by the bytes it really has to move (a fused launch never writes R)
+                         "achieved_real_bytes": up.kernel_min_bytes[dom] / (iso[dom] * 1e-3) / 1e9,
+                         "frac_real_bytes": up.kernel_min_bytes[dom] / (iso[dom] * 1e-3) / 8e12,
                          "achieved_overlapped": achieved_ovl,
                          "frame_achieved": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 1e9,      # per GPU
                          "frame_frac": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 8e12},

@@ -82,7 +82,10 @@ typedef struct fftup_info {
     uint32_t num_kernels;                /* launches per frame                                    */
     uint32_t tuned;                      /* 1 if size-specialised kernels are in use              */
     double   alg_bytes_per_frame;        /* B_alg of SURVEY 8(d) for this plan's I/O types        */
-    double   kernel_alg_bytes[FFTUP_NUM_KERNELS]; /* algorithmic bytes moved by each kernel      */
+    double   kernel_alg_bytes[FFTUP_NUM_KERNELS]; /* algorithmic bytes of each kernel: a fused C2R+sharpen
+                                                     launch keeps S2 + 2R + out although R never reaches HBM          */
+    double   kernel_min_bytes[FFTUP_NUM_KERNELS]; /* bytes each kernel has to move through HBM as implemented
+                                                     (e.g. fused: spectrum rows incl. strip halos + out)               */
     uint64_t device_bytes;               /* device memory owned by the plan ("VRAM per thread")   */
     char     device_name[256];
     char     kernel_names[FFTUP_NUM_KERNELS][64];

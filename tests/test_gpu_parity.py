@@ -231,7 +231,8 @@ def _report(tag, err, thr):
     return stats
 
 
-FULL_SIZE = [(2048, 1024, 0, 0), (2048, 1024, 0, 2), (1920, 1080, 0, 0), (1920, 1080, 0, 2), (2048, 1024, 2, 0), (2048, 1024, 2, 2)]
+FULL_SIZE = [(2048, 1024, 0, 0), (2048, 1024, 0, 2), (1920, 1080, 0, 0), (1920, 1080, 0, 2), (2048, 1024, 2, 0), (2048, 1024, 2, 2),
+             (1920, 1080, 2, 2)]
 
 
 @pytest.mark.parametrize("W,H,precision,flags", FULL_SIZE)

@@ -32,7 +32,8 @@ class Config(C.Structure):
 class Info(C.Structure):
     _fields_ = [("out_width", C.c_uint32), ("out_height", C.c_uint32), ("num_kernels", C.c_uint32),
                 ("tuned", C.c_uint32), ("alg_bytes_per_frame", C.c_double),
-                ("kernel_alg_bytes", C.c_double * FFTUP_NUM_KERNELS), ("device_bytes", C.c_uint64),
+                ("kernel_alg_bytes", C.c_double * FFTUP_NUM_KERNELS),
+                ("kernel_min_bytes", C.c_double * FFTUP_NUM_KERNELS), ("device_bytes", C.c_uint64),
                 ("device_name", C.c_char * 256), ("kernel_names", (C.c_char * 64) * FFTUP_NUM_KERNELS)]
 
 

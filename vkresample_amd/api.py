@@ -52,6 +52,7 @@ class Upscaler:
         self.ring = max(1, ring)
         self.alg_bytes_per_frame = info.alg_bytes_per_frame
         self.kernel_alg_bytes = list(info.kernel_alg_bytes)
+        self.kernel_min_bytes = list(info.kernel_min_bytes)
         self.kernel_names = [bytes(n).split(b"\0")[0].decode() for n in info.kernel_names]
         self.device_name = info.device_name.decode()
         self.device_bytes = info.device_bytes

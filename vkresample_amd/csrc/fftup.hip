@@ -467,6 +467,17 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
     // bytes stay S2 + 2R + out although R never reaches HBM
     info->kernel_alg_bytes[2] = P->fused ? S2 + 2 * R + o : S2 + R;
     info->kernel_alg_bytes[3] = P->fused ? 0.0 : R + o;
+    {
+        // what the launches really have to move: polyphase plans write/read only the odd half of S2; a fused strip
+        // re-reads one halo pair of spectrum rows
+        const bool poly = P->tuned || P->mixed1080;
+        const double S2w = poly ? S1 : S2;                            // odd rows only
+        const double halo = P->fused ? (double)(P->pairs_per_strip + 1) / P->pairs_per_strip : 1.0;
+        info->kernel_min_bytes[0] = in + S1;
+        info->kernel_min_bytes[1] = S1 + S2w;
+        info->kernel_min_bytes[2] = P->fused ? S2 * halo + o : S2 + R;
+        info->kernel_min_bytes[3] = P->fused ? 0.0 : R + o;
+    }
     info->device_bytes = P->device_bytes;
     snprintf(info->device_name, sizeof info->device_name, "%s", P->prop.name);
     snprintf(info->kernel_names[0], 64, P->cplx ? "row_c2c" : "row_r2c");

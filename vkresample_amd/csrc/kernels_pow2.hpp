@@ -112,6 +112,10 @@ template <bool WAVE> __device__ __forceinline__ void lds_sync()
 
 template <int R> __device__ __forceinline__ void twiddle_powers(float2* v, float2 w1)
 {
+    if constexpr ((FFTUP_KO & 128) != 0) {          // timing experiment: all powers = w1 (no power chain)
+#pragma unroll
+        for (int m = 1; m < R; m++) v[m] = cmul(v[m], w1);
+    } else
     if constexpr (R == 2) {
         v[1] = cmul(v[1], w1);
     } else if constexpr (R == 4) {
