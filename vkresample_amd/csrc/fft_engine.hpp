@@ -209,6 +209,43 @@ template <int DIR, typename C> __device__ __forceinline__ void bfly15(C* v)
     }
 }
 
+// radix 10 = 2 x 5 and radix 12 = 3 x 4 by the prime-factor mapping (coprime factors, no internal twiddles):
+// n = (N2 n1 + N1 n2) mod N,  k = (N2 (N2^-1 mod N1) k1 + N1 (N1^-1 mod N2) k2) mod N
+template <int DIR, typename C> __device__ __forceinline__ void bfly10(C* v)
+{
+    C y[5][2];
+#pragma unroll
+    for (int n2 = 0; n2 < 5; n2++) {
+        y[n2][0] = v[(2 * n2) % 10];                // n1 = 0
+        y[n2][1] = v[(5 + 2 * n2) % 10];            // n1 = 1
+        bfly2<DIR>(y[n2]);                          // -> y[n2][k1]
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 2; k1++) {
+        C z[5] = {y[0][k1], y[1][k1], y[2][k1], y[3][k1], y[4][k1]};
+        bfly5<DIR>(z);                              // -> z[k2]
+#pragma unroll
+        for (int k2 = 0; k2 < 5; k2++) v[(5 * k1 + 6 * k2) % 10] = z[k2];
+    }
+}
+template <int DIR, typename C> __device__ __forceinline__ void bfly12(C* v)
+{
+    C y[4][3];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) {
+#pragma unroll
+        for (int n1 = 0; n1 < 3; n1++) y[n2][n1] = v[(4 * n1 + 3 * n2) % 12];
+        bfly3<DIR>(y[n2]);                          // -> y[n2][k1]
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 3; k1++) {
+        C z[4] = {y[0][k1], y[1][k1], y[2][k1], y[3][k1]};
+        bfly4<DIR>(z);                              // -> z[k2]
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) v[(4 * k1 + 9 * k2) % 12] = z[k2];
+    }
+}
+
 template <int R, int DIR, typename C> __device__ __forceinline__ void bfly(C* v)
 {
     if constexpr (R == 2) bfly2<DIR>(v);
@@ -218,6 +255,8 @@ template <int R, int DIR, typename C> __device__ __forceinline__ void bfly(C* v)
     else if constexpr (R == 7) bfly7<DIR>(v);
     else if constexpr (R == 8) bfly8<DIR>(v);
     else if constexpr (R == 9) bfly9<DIR>(v);
+    else if constexpr (R == 10) bfly10<DIR>(v);
+    else if constexpr (R == 12) bfly12<DIR>(v);
     else if constexpr (R == 15) bfly15<DIR>(v);
     else if constexpr (R == 16) bfly16<DIR>(v);
 }

@@ -73,6 +73,7 @@ struct fftup_plan {
     bool tuned = false;
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
     bool mixed1080 = false;           // compile-time mixed-radix plans (1920x1080 -> 3840x2160)
+    bool plan3840_x16 = false;        // 1080p: fused kernel on the 16*16*15 plan (256 threads, 226 VGPRs) instead of 8*8*4*15
     bool cplx = false;                // non-R2C path (VR:1424 false): full complex transforms, uW beyond the R2C limit
     int ncols = 0;                    // spectrum columns kept: W/2 + 1, or W on the non-R2C path
     int pairs_per_strip = 6;
@@ -321,7 +322,8 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             // One strip (workgroup of uW/8 threads) per compute unit by default.  Two fit (FFTUP_G_PER_CU=2: the kernel
             // alone is 8 % faster), but one leaves half of every compute unit to the row and column kernels of the
             // frames on the other streams, and the frame time is what counts (measured: 82 vs 86 us).
-            int per_cu = P->mixed1080 ? 2 : 1;          // (the 3840 plan runs 256-thread workgroups: two = the same 8 waves)
+            if (const char* e = getenv("FFTUP_3840_X16")) P->plan3840_x16 = atoi(e) != 0;
+            int per_cu = (P->mixed1080 && P->plan3840_x16) ? 2 : 1;      // (the 16*16*15 plan runs 256-thread workgroups)
             if (const char* e = getenv("FFTUP_G_PER_CU")) per_cu = std::max(1, std::min(4, atoi(e)));
             const int total_pairs = 3 * (int)uH / 2, slots = std::max(1, P->prop.multiProcessorCount) * per_cu;
             P->pairs_per_strip = std::max(2, (total_pairs + slots - 1) / slots);
@@ -417,6 +419,8 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             SET_LDS((k_row_c2r_ct<Plan3840, true>), P->ldsRowI);
             SET_LDS((k_c2r_sharpen_g<FusedPlan3840, false, 4>), FusedGLds<FusedPlan3840>::TOTAL);
             SET_LDS((k_c2r_sharpen_g<FusedPlan3840, true, 4>), FusedGLds<FusedPlan3840>::TOTAL);
+            SET_LDS((k_c2r_sharpen_g<FusedPlan3840x16, false, 4>), FusedGLds<FusedPlan3840x16>::TOTAL);
+            SET_LDS((k_c2r_sharpen_g<FusedPlan3840x16, true, 4>), FusedGLds<FusedPlan3840x16>::TOTAL);
         }
         if (P->tuned) {
             switch (uW) {
@@ -802,7 +806,7 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         if (P->mixed1080) {
             ColTParams q{};
             q.S1 = P->lanes[P->cur].S1; q.S2 = P->lanes[P->cur].S2; q.twH = P->twH; q.twUH = P->twUH; q.W = (int)P->W; q.NT = P->NT;
-            hipLaunchKernelGGL(k_col_m1080, grid, dim3(576), P->ldsCol, P->lanes[P->cur].stream, q);
+            hipLaunchKernelGGL(k_col_m1080, grid, dim3(480), P->ldsCol, P->lanes[P->cur].stream, q);
         } else switch (P->TK) {
         case 8: hipLaunchKernelGGL(k_col<8>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
         case 4: hipLaunchKernelGGL(k_col<4>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
@@ -811,7 +815,8 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         }
     }
     if ((which < 0 || which == 2) && P->fused) {
-        launch_fused_t<FusedPlan3840>(P, fused_params(P, out_slot));     // (only the 3840 plan is fused on this path)
+        if (P->plan3840_x16) launch_fused_t<FusedPlan3840x16>(P, fused_params(P, out_slot));
+        else launch_fused_t<FusedPlan3840>(P, fused_params(P, out_slot));       // (only the 3840 plans are fused on this path)
         P->R_valid = false;
     } else if (which < 0 || which == 2 || which == 22) {                 // 22: pre-sharpen tap requested for a fused plan
         RowC2RParams p{};

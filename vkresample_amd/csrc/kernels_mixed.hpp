@@ -127,13 +127,15 @@ __global__ void __launch_bounds__(256) k_row_r2c_m1920(RowR2CTParams p)
     }
 }
 
-// ---- column, H = 1080 = 9 * 8 * 15, polyphase form (k_col_t): forward, phase, inverse, odd rows out.
-// grid (NT, 3), block 576 (4 columns x 144; 135 threads per column are used), LDS H*4 float2.
-__global__ void __launch_bounds__(576) k_col_m1080(ColTParams p)
+// ---- column, H = 1080 = 9 * 10 * 12, polyphase form (k_col_t): forward, phase, inverse, odd rows out.
+// Balanced radices: 120 / 108 / 90 butterflies per column and stage on 120 threads (9 * 8 * 15 would need 135 threads
+// per column and leave half of them idle in its radix-15 stage), 8 waves, which fit beside a fused-kernel strip.
+// grid (NT, 3), block 480 (4 columns x 120), LDS H*4 float2.
+__global__ void __launch_bounds__(480) k_col_m1080(ColTParams p)
 {
     constexpr int H = 1080, TK = 4;
-    using FF = MrFftT<H, +1, TK, 9, 8, 15, true>;
-    using FI = MrFftT<H, -1, TK, 9, 8, 15, false>;
+    using FF = MrFftT<H, +1, TK, 9, 10, 12, true>;
+    using FI = MrFftT<H, -1, TK, 9, 10, 12, false>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* buf = (float2*)smem;
     const int tid = threadIdx.x, col = tid % TK, j = tid / TK;
@@ -171,7 +173,7 @@ __global__ void __launch_bounds__(576) k_col_m1080(ColTParams p)
     constexpr float inv = 1.0f / (float)H;
     if (j < FI::NB2 && valid) {
 #pragma unroll
-        for (int m = 0; m < 15; m++) dst[(j + FI::NB2 * m) * TK + col] = cscale(v[m], inv);
+        for (int m = 0; m < 12; m++) dst[(j + FI::NB2 * m) * TK + col] = cscale(v[m], inv);
     }
 }
 

@@ -915,7 +915,90 @@ template <int N, int DIR, int TK, int R0, int R1, int R2, bool FINAL_TO_LDS> str
     }
 };
 
-struct FusedPlan3840 {                                      // 1920x1080 -> 3840x2160: rows of 3840 = 16 * 16 * 15, 256 threads
+// ---- any number of stages, at most 8 points per butterfly except the last: T threads run ceil(NB/T) butterflies per
+// stage, index map lswz.  3840 = 8 * 8 * 4 * 15 on 512 threads keeps the fused kernel at the register budget of the
+// power-of-two plans (the 16 * 16 * 15 plan needs 226 VGPRs: two of its workgroups fill a compute unit's register files
+// and nothing of the other streams runs beside them).
+template <int N, int DIR, int T, int... RS> struct MrFftN {
+    static constexpr int NST = sizeof...(RS);
+    static constexpr int rs(int s) { constexpr int r[] = {RS...}; return r[s]; }
+    static constexpr int ns(int s) { int n = 1; for (int i = 0; i < s; i++) n *= rs(i); return n; }
+    static constexpr int bpt(int s) { return (N / rs(s) + T - 1) / T; }
+    static constexpr int vn() { int m = 0; for (int s = 0; s < NST; s++) m = bpt(s) * rs(s) > m ? bpt(s) * rs(s) : m; return m; }
+    static constexpr int mb() { int m = 0; for (int s = 0; s < NST; s++) m = bpt(s) > m ? bpt(s) : m; return m; }
+    static constexpr int VN = vn(), MB = mb();
+    static_assert(ns(NST) == N && bpt(0) == 1 && bpt(NST - 1) == 1, "radices multiply to N; one butterfly per thread at both ends");
+    struct Tw { float2 w[NST - 1][MB]; };                    // base twiddle of stage s >= 1, butterfly b (table sign exp(+i..))
+    template <int S = 1> static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j)
+    {
+        if constexpr (S < NST) {
+            constexpr int R = rs(S), Ns = ns(S), NB = N / R;
+#pragma unroll
+            for (int b = 0; b < bpt(S); b++) {
+                const int jb = j + T * b;
+                w.w[S - 1][b] = tw[((jb < NB ? jb : 0) % Ns) * (N / (Ns * R))];
+            }
+            load_tw<S + 1>(w, tw, j);
+        }
+    }
+    // on entry v[m] = x[j + NB0*m], j < NB0; on return v[m] = X[j + NBlast*m], j < NBlast
+    template <int S = 0> static __device__ __forceinline__ void run(float2 (&v)[VN], float2* __restrict__ buf, int j, const Tw& w)
+    {
+        if constexpr (S < NST) {
+            constexpr int R = rs(S), Ns = ns(S), NB = N / R, BPT = bpt(S);
+            asm volatile("" : "+v"(j));                      // addresses of this stage are formed here, not hoisted and kept
+            if constexpr (S > 0) {
+#pragma unroll
+                for (int b = 0; b < BPT; b++) {
+                    const int jb = j + T * b;
+                    if (jb < NB) {
+#pragma unroll
+                        for (int m = 0; m < R; m++) v[b * R + m] = buf[lswz(jb + NB * m)];
+                    }
+                }
+                __syncthreads();                             // the buffer may be overwritten from here on
+            }
+#pragma unroll
+            for (int b = 0; b < BPT; b++) {
+                const int jb = j + T * b;
+                if (jb < NB) {
+                    if constexpr (S > 0) twiddle_all<R>(&v[b * R], twid<DIR>(w.w[S > 0 ? S - 1 : 0][b]));
+                    bfly<R, DIR>(&v[b * R]);
+                    if constexpr (S + 1 < NST) {
+                        const int k = jb % Ns, j0 = (jb - k) * R + k;
+#pragma unroll
+                        for (int m = 0; m < R; m++) buf[lswz(j0 + m * Ns)] = v[b * R + m];
+                    }
+                }
+            }
+            if constexpr (S + 1 < NST) {
+                __syncthreads();
+                run<S + 1>(v, buf, j, w);
+            }
+        }
+    }
+};
+struct FusedPlan3840 {                                      // 1920x1080 -> 3840x2160: rows of 3840 = 8 * 8 * 4 * 15, 512 threads
+    using F = MrFftN<3840, -1, 512, 8, 8, 4, 15>;
+    static constexpr int UW = 3840, T = 512, R0 = 8, NB0 = 480, EOUT = 15, SOUT = 256, VN = F::VN;
+    static constexpr size_t XB = sizeof(float2) * lswz_size(3840);
+    using Tw = F::Tw;
+    static __device__ __forceinline__ int first_index(int lt) { return lt < NB0 ? lt : NB0 - 1; }   // (threads beyond re-read)
+    static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { F::load_tw(w, tw, j); }
+    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, int j, const Tw& w)
+    {
+        // The base twiddles are loop-invariant, so the compiler would hoist all 27 power products of the three twiddled
+        // stages out of the strip loop and keep them (54 VGPRs: spills).  Re-defining the bases here makes the
+        // powers per-step work.
+        Tw t = w;
+#pragma unroll
+        for (int st = 0; st < F::NST - 1; st++)
+#pragma unroll
+            for (int b = 0; b < F::MB; b++) asm volatile("" : "+v"(t.w[st][b].x), "+v"(t.w[st][b].y));
+        F::run(v, buf, j, t);
+    }
+};
+struct FusedPlan3840x16 {                                   // the same rows as 16 * 16 * 15 on 256 threads (226 VGPRs; kept for comparison)
     using F = MrFft<3840, -1, 16, 16, 15>;
     static constexpr int UW = 3840, T = 256, R0 = 16, NB0 = F::NB0, EOUT = 15, SOUT = F::NB2, VN = F::VN;
     static constexpr size_t XB = (sizeof(float2) * lpad_size(3840) + 15) & ~(size_t)15;
