@@ -1187,7 +1187,8 @@ __global__ void __launch_bounds__(PL::T, PL::T * 2 / 256 > 0 ? PL::T * 2 / 256 :
                             }
                             // own four pixels (8 bytes) and the quads of both neighbours; the shifted pairs by v_alignbit
                             const LT* rp = rows[r] + x0;
-                            const uint2 q = *(const uint2*)rp, ql = *(const uint2*)(rp - 4), qr = *(const uint2*)(rp + 4);
+                            uint2 q = *(const uint2*)rp, ql = *(const uint2*)(rp - 4), qr = *(const uint2*)(rp + 4);
+                            asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(ql.x), "+v"(ql.y), "+v"(qr.x), "+v"(qr.y));   // keep them 8-byte reads
                             R[r].h01 = h2_bits(q.x);
                             R[r].h23 = h2_bits(q.y);
                             R[r].sa = h2_bits(__builtin_amdgcn_alignbit(q.x, ql.y, 16));        // (x0-1, x0)
@@ -1247,10 +1248,14 @@ __global__ void __launch_bounds__(PL::T, PL::T * 2 / 256 > 0 ? PL::T * 2 / 256 :
                         if constexpr ((FFTUP_KO & 8) != 0) {
                             for (int k = 0; k < 6; k++) t[r][k] = p.coef * (float)(x0 + k + r);
                         } else {
-                        const float4 q = *(const float4*)rp;
+                        // (all four components are pinned: left alone the compiler narrows the neighbour loads to the one
+                        // dword that is used, and single-dword reads 16 bytes apart are a 4-way bank conflict)
+                        float4 q = *(const float4*)rp, ql = *(const float4*)(rp - 4), qr = *(const float4*)(rp + 4);
+                        asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w), "+v"(ql.x), "+v"(ql.y), "+v"(ql.z), "+v"(ql.w),
+                                          "+v"(qr.x), "+v"(qr.y), "+v"(qr.z), "+v"(qr.w));
                         t[r][1] = q.x; t[r][2] = q.y; t[r][3] = q.z; t[r][4] = q.w;
-                        t[r][0] = (*(const float4*)(rp - 4)).w;
-                        t[r][5] = (*(const float4*)(rp + 4)).x;
+                        t[r][0] = ql.w;
+                        t[r][5] = qr.x;
                         }
                     }
                     if (x0 == 0) {                             // id_x_m clamp (VkResample.cpp:889)
