@@ -525,7 +525,7 @@ __device__ __forceinline__ float sharpen_eval_fast(float s4, float C, float mn0,
 // (a < b <=> mn + mx < 1 <=> mn < 1 - mx <=> 1 - mn > mx).
 typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2v mk2(float a, float b) { f2v r; r.x = a; r.y = b; return r; }
-__device__ __forceinline__ f2v sharpen_eval_pair(f2v N, f2v S, f2v Wv, f2v E, f2v C, f2v mn0, f2v mn1, f2v mx0, f2v mx1, float coef)
+__device__ __forceinline__ f2v sharpen_eval_pair(f2v N, f2v S, f2v WE, f2v C, f2v mn0, f2v mn1, f2v mx0, f2v mx1, float coef)
 {
     const f2v two = mk2(2.0f, 2.0f);
     const f2v smn = mn0 + mn1, smx = mx0 + mx1;
@@ -534,14 +534,33 @@ __device__ __forceinline__ f2v sharpen_eval_pair(f2v N, f2v S, f2v Wv, f2v E, f2
     const f2v d2 = mk2(fmaxf(v.x, smx.x), fmaxf(v.y, smx.y));                           // in [1, 2]
     const f2v pr = __builtin_elementwise_fma(n2, d2, mk2(1e-30f, 1e-30f));               // n2 = 0 -> r = 0, no NaN
     const f2v r = n2 * mk2(__builtin_amdgcn_rsqf(pr.x), __builtin_amdgcn_rsqf(pr.y));   // sqrt(n/d)
-    const f2v s4 = ((N + Wv) + E) + S;
+    const f2v s4 = (WE + N) + S;
     const f2v num = __builtin_elementwise_fma(mk2(-coef, -coef), r * s4, C);
     const f2v den = __builtin_elementwise_fma(mk2(-4.0f * coef, -4.0f * coef), r, mk2(1.0f, 1.0f));
     return num * mk2(__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y));
 }
 
+// one-lane addition the vectoriser cannot re-pack
+__device__ __forceinline__ float add1(float a, float b)
+{
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// One row of taps for four pixels: q = the pixels x0..x0+3 exactly as their 16-byte LDS read delivered them (a 4-aligned
+// register tuple, so (q.x, q.y) and (q.z, q.w) ARE the aligned pairs the packed operations want), l / r = the pixels
+// x0-1 / x0+4.  (A plain float[6] per row makes the compiler gather every row into six consecutive registers:
+// ~10 moves per row, a tenth of the kernel's vector instructions.)
+typedef float f4t __attribute__((ext_vector_type(4)));
+struct TapRow {
+    f4t q;
+    float l, r;
+    __device__ __forceinline__ float operator[](int k) const { return k == 0 ? l : k == 5 ? r : q[(k - 1) & 3]; }
+    __device__ __forceinline__ f2v lo() const { return __builtin_shufflevector(q, q, 0, 1); }
+    __device__ __forceinline__ f2v hi() const { return __builtin_shufflevector(q, q, 2, 3); }
+};
 // vertical 3-row minima / maxima of 6 columns (4 pixels + halo) for the window whose top row is t[w]
-__device__ __forceinline__ void sharpen_vminmax(const float (&t)[4][6], int w, float (&vmn)[6], float (&vmx)[6])
+__device__ __forceinline__ void sharpen_vminmax(const TapRow (&t)[4], int w, float (&vmn)[6], float (&vmx)[6])
 {
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -550,26 +569,24 @@ __device__ __forceinline__ void sharpen_vminmax(const float (&t)[4][6], int w, f
     }
 }
 // 4 output pixels of the window rows t[w..w+2] (7 three-input min/max per pixel: min/max are exact in any order)
-__device__ __forceinline__ void sharpen_quad_packed(const float (&t)[4][6], int w, const float (&vmn)[6], const float (&vmx)[6],
-                                                    float coef, float (&o)[4])
+__device__ __forceinline__ f4t sharpen_quad_packed(const TapRow (&t)[4], int w, const float (&vmn)[6], const float (&vmx)[6], float coef)
 {
+    const TapRow& c = t[w + 1];
     float mn0[4], mn1[4], mx0[4], mx1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         mn1[k] = fminf(fminf(vmn[k], vmn[k + 1]), vmn[k + 2]);                          // full 3x3
         mx1[k] = fmaxf(fmaxf(vmx[k], vmx[k + 1]), vmx[k + 2]);
-        mn0[k] = fminf(fminf(vmn[k + 1], t[w + 1][k]), t[w + 1][k + 2]);               // cross: N, C, S, W, E
-        mx0[k] = fmaxf(fmaxf(vmx[k + 1], t[w + 1][k]), t[w + 1][k + 2]);
+        mn0[k] = fminf(fminf(vmn[k + 1], c[k]), c[k + 2]);                              // cross: N, C, S, W, E
+        mx0[k] = fmaxf(fmaxf(vmx[k + 1], c[k]), c[k + 2]);
     }
-#pragma unroll
-    for (int k = 0; k < 4; k += 2) {
-        const f2v r = sharpen_eval_pair(mk2(t[w][k + 1], t[w][k + 2]), mk2(t[w + 2][k + 1], t[w + 2][k + 2]),
-                                        mk2(t[w + 1][k], t[w + 1][k + 1]), mk2(t[w + 1][k + 2], t[w + 1][k + 3]),
-                                        mk2(t[w + 1][k + 1], t[w + 1][k + 2]), mk2(mn0[k], mn0[k + 1]), mk2(mn1[k], mn1[k + 1]),
-                                        mk2(mx0[k], mx0[k + 1]), mk2(mx1[k], mx1[k + 1]), coef);
-        o[k] = r.x;
-        o[k + 1] = r.y;
-    }
+    // (W + E by one-lane additions: the horizontally shifted pairs (x-1, x) and (x+1, x+2) straddle the aligned register
+    // pairs the packed operations need, and building them costs more moves than a packed add saves)
+    const f2v r01 = sharpen_eval_pair(t[w].lo(), t[w + 2].lo(), mk2(add1(c[0], c[2]), add1(c[1], c[3])), c.lo(),
+                                      mk2(mn0[0], mn0[1]), mk2(mn1[0], mn1[1]), mk2(mx0[0], mx0[1]), mk2(mx1[0], mx1[1]), coef);
+    const f2v r23 = sharpen_eval_pair(t[w].hi(), t[w + 2].hi(), mk2(add1(c[2], c[4]), add1(c[3], c[5])), c.hi(),
+                                      mk2(mn0[2], mn0[3]), mk2(mn1[2], mn1[3]), mk2(mx0[2], mx0[3]), mk2(mx1[2], mx1[3]), coef);
+    return __builtin_shufflevector(r01, r23, 0, 1, 2, 3);
 }
 
 struct SharpenTParams {
@@ -1024,8 +1041,13 @@ template <class PL> struct FusedGLds {
     static constexpr size_t TOTAL = RED + 32 * sizeof(float);
 };
 
+#ifdef FFTUP_G_NUM_VGPR
+#define FFTUP_G_BOUNDS __launch_bounds__(PL::T) __attribute__((amdgpu_num_vgpr(FFTUP_G_NUM_VGPR)))
+#else
+#define FFTUP_G_BOUNDS __launch_bounds__(PL::T, PL::T * 2 / 256 > 0 ? PL::T * 2 / 256 : 1)
+#endif
 template <class PL, bool HALF, int TK>
-__global__ void __launch_bounds__(PL::T, PL::T * 2 / 256 > 0 ? PL::T * 2 / 256 : 1) k_c2r_sharpen_g(FusedParams p)
+__global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
 {
     constexpr int UW = PL::UW, T = PL::T, R0 = PL::R0, NB0 = PL::NB0, NI = R0 / 4, KH = UW / 4;
     constexpr int EOUT = PL::EOUT, SOUT = PL::SOUT, VN = PL::VN;
@@ -1232,12 +1254,12 @@ __global__ void __launch_bounds__(PL::T, PL::T * 2 / 256 > 0 ? PL::T * 2 / 256 :
                     if (UW % (4 * T) != 0 && x0 >= UW) continue;          // (wave-uniform: UW/4 is a multiple of 64)
                     // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
                     const float* rows[4] = {rowp(-2), (a == 0) ? rowp(0) : rowp(-1), rowp(0), rowp(1)};
-                    float t[4][6];
+                    TapRow t[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         if (r == 0 && !out0) {
-#pragma unroll
-                            for (int k = 0; k < 6; k++) t[0][k] = 0.f;
+                            t[0].q = (f4t)(0.f);
+                            t[0].l = t[0].r = 0.f;
                             continue;
                         }
                         // own four pixels and the quads of both neighbours: three conflict-free 16-byte reads, no cross-lane
@@ -1246,55 +1268,53 @@ __global__ void __launch_bounds__(PL::T, PL::T * 2 / 256 > 0 ? PL::T * 2 / 256 :
                         // range: LDS returns 0) and is replaced below.
                         const float* rp = rows[r] + x0;
                         if constexpr ((FFTUP_KO & 8) != 0) {
-                            for (int k = 0; k < 6; k++) t[r][k] = p.coef * (float)(x0 + k + r);
+                            for (int k = 0; k < 4; k++) t[r].q[k] = p.coef * (float)(x0 + k + 1 + r);
+                            t[r].l = p.coef * (float)(x0 + r);
+                            t[r].r = p.coef * (float)(x0 + 5 + r);
                         } else {
-                        // (all four components are pinned: left alone the compiler narrows the neighbour loads to the one
-                        // dword that is used, and single-dword reads 16 bytes apart are a 4-way bank conflict)
-                        float4 q = *(const float4*)rp, ql = *(const float4*)(rp - 4), qr = *(const float4*)(rp + 4);
-                        asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w), "+v"(ql.x), "+v"(ql.y), "+v"(ql.z), "+v"(ql.w),
-                                          "+v"(qr.x), "+v"(qr.y), "+v"(qr.z), "+v"(qr.w));
-                        t[r][1] = q.x; t[r][2] = q.y; t[r][3] = q.z; t[r][4] = q.w;
-                        t[r][0] = ql.w;
-                        t[r][5] = qr.x;
+                            // (whole tuples are pinned: left alone the compiler narrows the neighbour loads to the one dword
+                            // that is used, and single-dword reads 16 bytes apart are a 4-way bank conflict)
+                            f4t q = *(const f4t*)rp, ql = *(const f4t*)(rp - 4), qr = *(const f4t*)(rp + 4);
+                            asm volatile("" : "+v"(q), "+v"(ql), "+v"(qr));
+                            t[r].q = q;
+                            t[r].l = ql.w;
+                            t[r].r = qr.x;
                         }
                     }
                     if (x0 == 0) {                             // id_x_m clamp (VkResample.cpp:889)
 #pragma unroll
-                        for (int r = 0; r < 4; r++) t[r][0] = t[r][1];
+                        for (int r = 0; r < 4; r++) t[r].l = t[r].q.x;
                     }
                     if (x0 + 4 == UW) {
                         // row a-1 wraps into row a, which lives in the other buffer
-                        if (a != 0) t[1][5] = rowp(0)[0];
+                        if (a != 0) t[1].r = rowp(0)[0];
                         // SE tap of pixel (a, UW-1) is L(a+2, 0): past the plane it clamps to row uH-1; in the last step
                         // it is the corner sample; otherwise the pixel is finished next step (placeholder now)
-                        t[3][5] = rowp(1)[0];
+                        t[3].r = rowp(1)[0];
                         const int r2 = min(a + 2, uH - 1) - a;
-                        if (r2 <= 1) t[3][5] = rowp(r2)[0];
+                        if (r2 <= 1) t[3].r = rowp(r2)[0];
                         else if (s == npairs - 1) {
                             float sum = 0.f;
                             for (int w2 = 0; w2 < (T + 63) / 64; w2++) sum += red[w2];
-                            t[3][5] = to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq);
+                            t[3].r = to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq);
                         }
                     }
 #pragma unroll
                     for (int w = 0; w < 2; w++) {
                         if (w == 0 ? !out0 : !out1) continue;
-                        float o[4];
-                        if constexpr (false) {
-                        } else if constexpr ((FFTUP_KO & 1) != 0) {
-                            for (int k = 0; k < 4; k++) o[k] = t[w][k + 1] + t[w + 1][k] + t[w + 1][k + 2] + t[w + 2][k + 1] + t[w+1][k+1];
+                        f4t o;
+                        if constexpr ((FFTUP_KO & 1) != 0) {
+                            for (int k = 0; k < 4; k++) o[k] = t[w][k + 1] + t[w + 1][k] + t[w + 1][k + 2] + t[w + 2][k + 1] + t[w + 1][k + 1];
                         } else {
                             float vmn[6], vmx[6];
                             sharpen_vminmax(t, w, vmn, vmx);
-                            sharpen_quad_packed(t, w, vmn, vmx, p.coef, o);
+                            o = sharpen_quad_packed(t, w, vmn, vmx, p.coef);
                         }
                         const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
                         if constexpr ((FFTUP_KO & 4) != 0) {
                             if (o[0] + o[1] + o[2] + o[3] == 12345.f) ((float*)p.out)[row_of + x0] = o[0];
                         } else {
-                            typedef float f4v __attribute__((ext_vector_type(4)));
-                            f4v val = {o[0], o[1], o[2], o[3]};
-                            __builtin_nontemporal_store(val, (f4v*)((char*)((float*)p.out + row_of) + (unsigned)x0 * 4u));
+                            __builtin_nontemporal_store(o, (f4t*)((char*)((float*)p.out + row_of) + (unsigned)x0 * 4u));
                         }
                     }
                 }
