@@ -1,6 +1,6 @@
 #!/bin/bash
 # prints per-kernel VGPR/SGPR/LDS/occupancy of the HIP library (compile only)
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -o /tmp/_ru.so vkresample_amd/csrc/fftup.hip -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -fPIC -shared -fvisibility=hidden -o /tmp/_ru.so vkresample_amd/csrc/fftup.hip -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import sys,re,subprocess
 cur=None; rows=[]
 for l in sys.stdin:

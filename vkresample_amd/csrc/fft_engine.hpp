@@ -75,14 +75,19 @@ template <int DIR, typename C> __device__ __forceinline__ void bfly8(C* v)
     C o[4] = {v[1], v[3], v[5], v[7]};
     bfly4<DIR>(e);
     bfly4<DIR>(o);
-    // w^q, w = exp(DIR*2 pi i/8)
-    C o1 = cscale(cadd(o[1], mul_i<DIR>(o[1])), h);            // (1 + DIR*i)/sqrt2
+    // w^q, w = exp(DIR*2 pi i/8): o1 = h t1, t1 = (1 + DIR*i) o[1]; o3 = h t3, t3 = (-1 + DIR*i) o[3].  The scaling is
+    // folded into the final additions as explicit fused multiply-adds (one rounding less than scale-then-add, and the
+    // same instructions whatever the contraction mode: the library is built with -ffp-contract=on, so that results do
+    // not depend on which fusions the optimiser happens to find in a particular instantiation).
+    C t1 = cadd(o[1], mul_i<DIR>(o[1]));
     C o2 = mul_i<DIR>(o[2]);
-    C o3 = cscale(csub(mul_i<DIR>(o[3]), o[3]), h);            // (-1 + DIR*i)/sqrt2
+    C t3 = csub(mul_i<DIR>(o[3]), o[3]);
     v[0] = cadd(e[0], o[0]); v[4] = csub(e[0], o[0]);
-    v[1] = cadd(e[1], o1);   v[5] = csub(e[1], o1);
+    v[1] = mk<C>(ffma(h, t1.x, e[1].x), ffma(h, t1.y, e[1].y));
+    v[5] = mk<C>(ffma(-h, t1.x, e[1].x), ffma(-h, t1.y, e[1].y));
     v[2] = cadd(e[2], o2);   v[6] = csub(e[2], o2);
-    v[3] = cadd(e[3], o3);   v[7] = csub(e[3], o3);
+    v[3] = mk<C>(ffma(h, t3.x, e[3].x), ffma(h, t3.y, e[3].y));
+    v[7] = mk<C>(ffma(-h, t3.x, e[3].x), ffma(-h, t3.y, e[3].y));
 }
 template <int DIR, typename C> __device__ __forceinline__ void bfly3(C* v)
 {

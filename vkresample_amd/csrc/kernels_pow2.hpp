@@ -45,6 +45,25 @@ __device__ __forceinline__ int lswz(int i) { return i ^ ((i >> 3) & 15); }
 __host__ __device__ constexpr int lswz_size(int n) { return (n + 15) & ~15; }
 // LDS element index of point idx of sequence col (TK interleaved sequences)
 template <int TK> __device__ __forceinline__ int lidx(int idx, int col) { return lswz(idx * TK + col); }
+// The map is linear over GF(2), and the R elements a thread touches in one exchange are A + q*S with S a power of two
+// and the bits of the q field clear in A, so lswz(A + q*S) = lswz(A) ^ lswz(q*S): one swizzled byte address per
+// exchange, and per element an exclusive-or with a constant < 128 bytes (bits 0..3 of the index) plus a constant that
+// goes into the instruction's offset field -- instead of a shift, an and/xor and a scaled add per element.  Needs the
+// buffer 128-byte aligned (so that adding its base commutes with the exclusive-or); done on raw 32-bit LDS addresses.
+constexpr int lswz_c(int i) { return i ^ ((i >> 3) & 15); }
+typedef float lds_f2raw __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) lds_f2raw lds_f2;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p; }
+__device__ __forceinline__ void lds_put(unsigned a0, int C, float2 v)
+{
+    lds_f2raw r = {v.x, v.y};
+    *(lds_f2*)(size_t)((a0 ^ (unsigned)((C & 15) * 8)) + (unsigned)((C & ~15) * 8)) = r;
+}
+__device__ __forceinline__ float2 lds_get(unsigned a0, int C)
+{
+    const lds_f2raw r = *(const lds_f2*)(size_t)((a0 ^ (unsigned)((C & 15) * 8)) + (unsigned)((C & ~15) * 8));
+    return make_float2(r.x, r.y);
+}
 
 // ---- twiddles.  Stage with Ns > 1 of butterfly j needs exp(DIR*2 pi i*m*k/(Ns*R)), k = j % Ns,
 // m < R.  Every thread fetches ONE base twiddle per stage from the table, all of them up front
@@ -110,27 +129,40 @@ template <bool WAVE> __device__ __forceinline__ void lds_sync()
     }
 }
 
+// z * w in two packed instructions: t = (-z.y w.y, z.y w.x), then (z.x w.x + t.x, z.x w.y + t.y) -- the same three
+// roundings as cmul().  (Left to itself the compiler spends four: it negates and swaps z into a fresh register pair
+// first, or keeps a second, rotated copy of every twiddle.)
+__device__ __forceinline__ float2 cmul_tw(float2 z, float2 w)
+{
+    typedef float cf2 __attribute__((ext_vector_type(2)));
+    const cf2 zv = {z.x, z.y}, wv = {w.x, w.y};
+    cf2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(zv), "v"(wv));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(zv), "v"(wv), "v"(t));
+    return make_float2(r.x, r.y);
+}
+
 template <int R> __device__ __forceinline__ void twiddle_powers(float2* v, float2 w1)
 {
     if constexpr ((FFTUP_KO & 128) != 0) {          // timing experiment: all powers = w1 (no power chain)
 #pragma unroll
-        for (int m = 1; m < R; m++) v[m] = cmul(v[m], w1);
+        for (int m = 1; m < R; m++) v[m] = cmul_tw(v[m], w1);
     } else
     if constexpr (R == 2) {
-        v[1] = cmul(v[1], w1);
+        v[1] = cmul_tw(v[1], w1);
     } else if constexpr (R == 4) {
         float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
-        v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3);
+        v[1] = cmul_tw(v[1], w1); v[2] = cmul_tw(v[2], w2); v[3] = cmul_tw(v[3], w3);
     } else {
         float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
         float2 w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
-        v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
-        v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7);
+        v[1] = cmul_tw(v[1], w1); v[2] = cmul_tw(v[2], w2); v[3] = cmul_tw(v[3], w3); v[4] = cmul_tw(v[4], w4);
+        v[5] = cmul_tw(v[5], w5); v[6] = cmul_tw(v[6], w6); v[7] = cmul_tw(v[7], w7);
         if constexpr (R == 16) {
             float2 w8 = cmul(w4, w4);
-            v[8] = cmul(v[8], w8); v[9] = cmul(v[9], cmul(w8, w1)); v[10] = cmul(v[10], cmul(w5, w5));
-            v[11] = cmul(v[11], cmul(w8, w3)); v[12] = cmul(v[12], cmul(w6, w6)); v[13] = cmul(v[13], cmul(w8, w5));
-            v[14] = cmul(v[14], cmul(w7, w7)); v[15] = cmul(v[15], cmul(w8, w7));
+            v[8] = cmul_tw(v[8], w8); v[9] = cmul_tw(v[9], cmul(w8, w1)); v[10] = cmul_tw(v[10], cmul(w5, w5));
+            v[11] = cmul_tw(v[11], cmul(w8, w3)); v[12] = cmul_tw(v[12], cmul(w6, w6)); v[13] = cmul_tw(v[13], cmul(w8, w5));
+            v[14] = cmul_tw(v[14], cmul(w7, w7)); v[15] = cmul_tw(v[15], cmul(w8, w7));
         }
     }
 }
@@ -172,13 +204,15 @@ __device__ __forceinline__ void reg_scatter(const float2 (&v)[E], float2* __rest
 {
     constexpr int Tc = N / E;
     constexpr int NB = E / R;
+    const unsigned base = lds_addr(buf);
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         const int j = p + b * Tc;
         const int k = j & (Ns - 1);
         const int j0 = (j - k) * R + k;
+        const unsigned a0 = base + 8u * (unsigned)lidx<TK>(j0, col);       // bits of q*Ns*TK are clear in j0*TK + col
 #pragma unroll
-        for (int q = 0; q < R; q++) buf[lidx<TK>(j0 + q * Ns, col)] = v[b + q * NB];
+        for (int q = 0; q < R; q++) lds_put(a0, lswz_c(q * Ns * TK), v[b + q * NB]);
     }
 }
 
@@ -186,8 +220,9 @@ template <int N, int E, int TK>
 __device__ __forceinline__ void reg_gather(float2 (&v)[E], const float2* __restrict__ buf, int p, int col)
 {
     constexpr int Tc = N / E;
+    const unsigned a0 = lds_addr(buf) + 8u * (unsigned)lidx<TK>(p, col);    // p < Tc: bits of i*Tc*TK are clear
 #pragma unroll
-    for (int i = 0; i < E; i++) v[i] = buf[lidx<TK>(p + Tc * i, col)];
+    for (int i = 0; i < E; i++) v[i] = lds_get(a0, lswz_c(i * Tc * TK));
 }
 
 // ---- all stages.  On entry v[i] = x[p + Tc*i].  If FINAL_TO_LDS the result X is left in LDS in
@@ -235,7 +270,7 @@ template <int W, int MODE, int TK>
 __global__ void __launch_bounds__(W / 8) k_row_r2c_t(RowR2CTParams p)
 {
     constexpr int E = 8, T = W / E;
-    __shared__ float2 buf[lswz_size(W)];
+    __shared__ __attribute__((aligned(128))) float2 buf[lswz_size(W)];      // (128: reg_scatter / reg_gather)
     const int tid = threadIdx.x, c = blockIdx.y;
     const int j = blockIdx.x;      // (an XCD-aware pair order -- pairs 2i, 2i+1 on one XCD -- measured no gain)
     float2 v[E];
@@ -310,7 +345,7 @@ template <int H, int TK>
 __global__ void __launch_bounds__(TK* H / 8) k_col_t(ColTParams p)
 {
     constexpr int Tc = H / 8;                        // threads per column
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     float2* buf = (float2*)smem;
     const int tid = threadIdx.x;
     const int col = tid % TK, pp = tid / TK;
@@ -350,7 +385,7 @@ template <int UW, bool HALF_OUT, int TK, bool WIDE>
 __global__ void __launch_bounds__(UW / 8) k_row_c2r_t(RowC2RTParams p)
 {
     constexpr int E = 8, T = UW / E;                 // T = UW/8; W/2 = UW/4 = 2T
-    __shared__ float2 buf[lswz_size(UW)];
+    __shared__ __attribute__((aligned(128))) float2 buf[lswz_size(UW)];
     const int tid = threadIdx.x, j = blockIdx.x, c = blockIdx.y;
     const long tile_stride = (long)(p.uH / 2) * TK;
     const long roff = (long)c * p.NT * tile_stride + (long)j * TK;
@@ -1056,7 +1091,7 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
     constexpr float inv = 0.5f / (float)UW;         // 1/2: the spectrum rows carry twice the reference's scale (k_col_t)
     using L = FusedGLds<PL>;
     using LT = typename std::conditional<HALF, _Float16, float>::type;      // L rows in LDS: binary16 for -p 2
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
     float* red = (float*)(smem + L::RED);      // [0..15] corner partial sums, [16] corner DC term, [20..21] deferred-pixel taps
     int lt = threadIdx.x;                       // (made opaque at the phase entries, see FFTUP_OPQ)
     const int uH = p.uH;
@@ -1080,7 +1115,8 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
         const float2* base = p.S1 + (long)c * p.NT * (long)tile_stride32;
         // spectrum row `row` of the 2H-row buffer: even rows are rows of S1, odd rows live odd_delta elements further on
         auto S2at = [&](int k, int row) -> float2 {
-            const unsigned off = ((unsigned)(k / TK) * tile_stride32 + (unsigned)(row >> 1) * TK + (unsigned)(k % TK) +
+            // (k >= 0; 24-bit multiply: full rate, v_mul_lo_u32 is quarter rate; both factors are far below 2^24)
+            const unsigned off = (__umul24((unsigned)k / TK, tile_stride32) + (unsigned)(row >> 1) * TK + ((unsigned)k % TK) +
                                   (unsigned)(row & 1) * p.odd_delta) * (unsigned)sizeof(float2);
             return *(const float2*)((const char*)base + off);
         };
