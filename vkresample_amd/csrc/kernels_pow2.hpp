@@ -554,7 +554,7 @@ __device__ __forceinline__ float sharpen_eval_fast(float s4, float C, float mn0,
 
 // ---- two pixels per operation.  The vector ALUs of gfx950 issue one instruction per wave every four cycles whatever it
 // does; v_pk_add/mul/fma_f32 retire two lanes' worth of fp32 work in that slot, so the filter is written on pairs of
-// pixels: 13 packed + 8 scalar (min, max, v_rsq, v_rcp have no packed form) operations per pair instead of 2 x 22.
+// pixels: 12 packed + 8 one-lane (min, W+E, v_rsq, v_rcp) operations per pair instead of 2 x 22.
 // Same formula as sharpen_eval_fast with the two exact halvings dropped (everything is carried doubled:
 // smn = 2 mn, smx = 2 mx) and the a < b selection written as n = min(mn, 1 - mx), d = max(1 - mn, mx)
 // (a < b <=> mn + mx < 1 <=> mn < 1 - mx <=> 1 - mn > mx).
@@ -564,9 +564,11 @@ __device__ __forceinline__ f2v sharpen_eval_pair(f2v N, f2v S, f2v WE, f2v C, f2
 {
     const f2v two = mk2(2.0f, 2.0f);
     const f2v smn = mn0 + mn1, smx = mx0 + mx1;
-    const f2v u = two - smx, v = two - smn;
+    const f2v u = two - smx;
     const f2v n2 = mk2(fminf(smn.x, u.x), fminf(smn.y, u.y));
-    const f2v d2 = mk2(fmaxf(v.x, smx.x), fmaxf(v.y, smx.y));                           // in [1, 2]
+    // d = max(1 - mn, mx) = 1 - min(mn, 1 - mx) = 1 - n, bit for bit: when the minimum is u = 2 - smx, smx >= 1 and both
+    // subtractions are exact (Sterbenz); when it is smn, 2 - n2 IS 2 - smn
+    const f2v d2 = two - n2;                                                            // in [1, 2]
     const f2v pr = __builtin_elementwise_fma(n2, d2, mk2(1e-30f, 1e-30f));               // n2 = 0 -> r = 0, no NaN
     const f2v r = n2 * mk2(__builtin_amdgcn_rsqf(pr.x), __builtin_amdgcn_rsqf(pr.y));   // sqrt(n/d)
     const f2v s4 = (WE + N) + S;
@@ -783,52 +785,67 @@ __device__ __forceinline__ void sharpen_quad(const float (&t)[3][6], float coef,
 // algebra as sharpen_eval_pair: values carried doubled (2 - smx = 2 (1 - mx) exactly), n = min(mn, 1 - mx),
 // d = max(1 - mn, mx).  The inner quotient is the native binary16 reciprocal plus one residual step, the root the
 // native binary16 square root (1 ulp; the Vulkan spec allows the reference's own fp16 division 2.5 ulp), the final
-// quotient is formed in fp32 and rounded once.  k_sharpen_t keeps the exactly rounded sequence, bit for bit against the oracle.
+// quotient again reciprocal plus residual step.  k_sharpen_t keeps the exactly rounded sequence, bit for bit against the oracle.
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ h2v h2_bits(unsigned u) { return __builtin_bit_cast(h2v, u); }
 __device__ __forceinline__ unsigned bits_h2(h2v h) { return __builtin_bit_cast(unsigned, h); }
 __device__ __forceinline__ h2v h2_splat(float f) { const _Float16 x = (_Float16)f; h2v r = {x, x}; return r; }
+// gfx950 has three-input packed binary16 minimum / maximum (IEEE-754-2019 minimum/maximum; the operands here are
+// finite and non-negative, where they agree with min/max): half the instructions of the two-input forms
+__device__ __forceinline__ h2v pk_min3(h2v a, h2v b, h2v c)
+{
+    h2v r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ h2v pk_max3(h2v a, h2v b, h2v c)
+{
+    h2v r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// a / b in packed binary16: native reciprocal plus one residual step -- RN(a / b) but for rare ties
+__device__ __forceinline__ h2v pk_div(h2v a, h2v b)
+{
+#pragma clang fp contract(off)
+    const h2v rc = {(_Float16)__builtin_amdgcn_rcph(b.x), (_Float16)__builtin_amdgcn_rcph(b.y)};
+    const h2v q = a * rc;
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(-q, b, a), rc, q);
+}
 __device__ __forceinline__ h2v sharpen_eval_pair_half(h2v N, h2v S, h2v Wv, h2v E, h2v C, h2v mn0, h2v mn1, h2v mx0, h2v mx1, h2v ncoef)
 {
 #pragma clang fp contract(off)
     const h2v one = {(_Float16)1.0f, (_Float16)1.0f}, two = {(_Float16)2.0f, (_Float16)2.0f}, four = {(_Float16)4.0f, (_Float16)4.0f};
     const h2v smn = mn0 + mn1, smx = mx0 + mx1;
-    const h2v u = two - smx, v = two - smn;
-    const h2v n2 = __builtin_elementwise_min(smn, u), d2 = __builtin_elementwise_max(v, smx);     // d2 in [1, 2]
-    const h2v rc = {(_Float16)__builtin_amdgcn_rcph(d2.x), (_Float16)__builtin_amdgcn_rcph(d2.y)};
-    const h2v qa = n2 * rc;
-    const h2v q = __builtin_elementwise_fma(__builtin_elementwise_fma(-qa, d2, n2), rc, qa);     // residual step: RN(n2/d2) but for rare ties
+    const h2v u = two - smx;
+    const h2v n2 = __builtin_elementwise_min(smn, u);
+    const h2v d2 = two - n2;                           // = max(2 - smn, smx) exactly (see sharpen_eval_pair); in [1, 2]
+    const h2v q = pk_div(n2, d2);
     const h2v r = {(_Float16)__builtin_amdgcn_sqrth(q.x), (_Float16)__builtin_amdgcn_sqrth(q.y)};
     const h2v scale = ncoef * r;
     const h2v s4 = ((N + Wv) + E) + S;
     const h2v prod = scale * s4;
     const h2v num = C + prod;
     const h2v den = one + scale * four;                // 4 * scale is exact: one rounding either way
-    const float q0 = (float)num.x * __builtin_amdgcn_rcpf((float)den.x), q1 = (float)num.y * __builtin_amdgcn_rcpf((float)den.y);
-    h2v o = {(_Float16)q0, (_Float16)q1};
-    return o;
+    return pk_div(num, den);
 }
 // one window (three rows) of four pixels: P[r] = the five column pairs (-1,0) (0,1) (1,2) (2,3) (3,4) of row r
 struct H2Row { h2v sa, h01, sb, h23, sc; };
 __device__ __forceinline__ void sharpen_quad_half(const H2Row& r0, const H2Row& r1, const H2Row& r2, h2v ncoef, h2v& o01, h2v& o23)
 {
-#define V3MIN(f) __builtin_elementwise_min(__builtin_elementwise_min(r0.f, r1.f), r2.f)
-#define V3MAX(f) __builtin_elementwise_max(__builtin_elementwise_max(r0.f, r1.f), r2.f)
+#define V3MIN(f) pk_min3(r0.f, r1.f, r2.f)
+#define V3MAX(f) pk_max3(r0.f, r1.f, r2.f)
     const h2v na = V3MIN(sa), nb = V3MIN(h01), nc = V3MIN(sb), nd = V3MIN(h23), ne = V3MIN(sc);
     const h2v xa = V3MAX(sa), xb = V3MAX(h01), xc = V3MAX(sb), xd = V3MAX(h23), xe = V3MAX(sc);
 #undef V3MIN
 #undef V3MAX
     // pixels 0,1: columns (-1,0) (0,1) (1,2); cross = N, C, S (the vertical triple of the centre pair) and W, E
-    const h2v mn1a = __builtin_elementwise_min(__builtin_elementwise_min(na, nb), nc);
-    const h2v mx1a = __builtin_elementwise_max(__builtin_elementwise_max(xa, xb), xc);
-    const h2v mn0a = __builtin_elementwise_min(__builtin_elementwise_min(nb, r1.sa), r1.sb);
-    const h2v mx0a = __builtin_elementwise_max(__builtin_elementwise_max(xb, r1.sa), r1.sb);
+    const h2v mn1a = pk_min3(na, nb, nc), mx1a = pk_max3(xa, xb, xc);
+    const h2v mn0a = pk_min3(nb, r1.sa, r1.sb), mx0a = pk_max3(xb, r1.sa, r1.sb);
     o01 = sharpen_eval_pair_half(r0.h01, r2.h01, r1.sa, r1.sb, r1.h01, mn0a, mn1a, mx0a, mx1a, ncoef);
     // pixels 2,3: columns (1,2) (2,3) (3,4)
-    const h2v mn1b = __builtin_elementwise_min(__builtin_elementwise_min(nc, nd), ne);
-    const h2v mx1b = __builtin_elementwise_max(__builtin_elementwise_max(xc, xd), xe);
-    const h2v mn0b = __builtin_elementwise_min(__builtin_elementwise_min(nd, r1.sb), r1.sc);
-    const h2v mx0b = __builtin_elementwise_max(__builtin_elementwise_max(xd, r1.sb), r1.sc);
+    const h2v mn1b = pk_min3(nc, nd, ne), mx1b = pk_max3(xc, xd, xe);
+    const h2v mn0b = pk_min3(nd, r1.sb, r1.sc), mx0b = pk_max3(xd, r1.sb, r1.sc);
     o23 = sharpen_eval_pair_half(r0.h23, r2.h23, r1.sb, r1.sc, r1.h23, mn0b, mn1b, mx0b, mx1b, ncoef);
 }
 
@@ -1365,14 +1382,25 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                     const float r10 = (float)r1[0], r00 = (float)r0[0];
                     const float ne = (a - 2 == 0) ? r10 : (float)r2[0];
                     const float pn0 = red[20], pn1 = red[21];
-                    const float tt[3][6] = {{pn0, pn0, pn1, ne, ne, ne},
-                                            {(float)r2[UW - 2], (float)r2[UW - 2], (float)r2[UW - 1], r10, r10, r10},
-                                            {(float)r1[UW - 2], (float)r1[UW - 2], (float)r1[UW - 1], r00, r00, r00}};
-                    float o[4];
-                    sharpen_quad<HALF>(tt, p.coef, o);
                     const long of = c * plane + (long)(a - 2) * UW + (UW - 1);
-                    if constexpr (HALF) ((__half*)p.out)[of] = __float2half_rn(o[1]);
-                    else ((float*)p.out)[of] = o[1];
+                    if constexpr (HALF) {
+                        // the same packed evaluation as the other pixels of the row, both lanes carrying this pixel
+                        auto sp = [](float v) { const _Float16 x = (_Float16)v; h2v r = {x, x}; return r; };   // (exact: binary16 values)
+                        const h2v a0 = sp(pn0), a1 = sp(pn1), a2 = sp(ne), b0 = sp((float)r2[UW - 2]), b1 = sp((float)r2[UW - 1]), b2 = sp(r10);
+                        const h2v c0 = sp((float)r1[UW - 2]), c1 = sp((float)r1[UW - 1]), c2 = sp(r00);
+                        const h2v n0 = pk_min3(a0, b0, c0), n1 = pk_min3(a1, b1, c1), n2 = pk_min3(a2, b2, c2);
+                        const h2v x0 = pk_max3(a0, b0, c0), x1 = pk_max3(a1, b1, c1), x2 = pk_max3(a2, b2, c2);
+                        const h2v o = sharpen_eval_pair_half(a1, c1, b0, b2, b1, pk_min3(n1, b0, b2), pk_min3(n0, n1, n2),
+                                                             pk_max3(x1, b0, b2), pk_max3(x0, x1, x2), h2_splat(-p.coef));
+                        ((_Float16*)p.out)[of] = o.x;
+                    } else {
+                        const float tt[3][6] = {{pn0, pn0, pn1, ne, ne, ne},
+                                                {(float)r2[UW - 2], (float)r2[UW - 2], (float)r2[UW - 1], r10, r10, r10},
+                                                {(float)r1[UW - 2], (float)r1[UW - 2], (float)r1[UW - 1], r00, r00, r00}};
+                        float o[4];
+                        sharpen_quad<HALF>(tt, p.coef, o);
+                        ((float*)p.out)[of] = o[1];
+                    }
                 }
                 const LT* rn = (a == 0) ? rowp(0) : rowp(-1);
                 red[20] = (float)rn[UW - 2];
