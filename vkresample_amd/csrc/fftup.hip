@@ -319,9 +319,10 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         if (P->mixed1080) P->ldsCol = sizeof(float2) * (size_t)H * 4;                        // k_col_m1080: one in-place buffer
         P->fused = (P->tuned || P->mixed1080) && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
         {
-            // One strip (workgroup of uW/8 threads) per compute unit by default.  Two fit (FFTUP_G_PER_CU=2: the kernel
-            // alone is 8 % faster), but one leaves half of every compute unit to the row and column kernels of the
-            // frames on the other streams, and the frame time is what counts (measured: 82 vs 86 us).
+            // One strip (workgroup of uW/8 threads) per compute unit: the rest of every compute unit is left to the row and
+            // column kernels of the frames on the other streams, and the frame time is what counts.
+            // FFTUP_G_PER_CU only sets the strip length (strips = units * per_cu); how many workgroups are resident is
+            // the hardware's business (the power-of-two plans take 96 KB of LDS: one per unit).
             if (const char* e = getenv("FFTUP_3840_X16")) P->plan3840_x16 = atoi(e) != 0;
             int per_cu = (P->mixed1080 && P->plan3840_x16) ? 2 : 1;      // (the 16*16*15 plan runs 256-thread workgroups)
             if (const char* e = getenv("FFTUP_G_PER_CU")) per_cu = std::max(1, std::min(4, atoi(e)));

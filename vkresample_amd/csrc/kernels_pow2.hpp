@@ -248,6 +248,27 @@ __device__ __forceinline__ void reg_fft(float2 (&v)[E], float2* __restrict__ buf
     }
 }
 
+// ---- the same with TWO exchange buffers: the exchange of stage s goes through z when an even number of exchanges follows
+// it, else through c.  A buffer is rewritten two exchanges after it was read, with the barrier of the exchange in
+// between, so ONE barrier per exchange suffices (scatter, barrier, gather) -- and the last exchange always uses z, which
+// leaves c free for the caller's output while slower waves still gather.  Returns with v[i] = X[p + Tc*i].
+template <int N, int E, int DIR, int S = 0>
+__device__ __forceinline__ void reg_fft_pp(float2 (&v)[E], float2* __restrict__ c, float2* __restrict__ z, int p, const TwSet<N, E, 8>& tws)
+{
+    constexpr int Ns = stage_ns(N, S, 8);
+    constexpr int R = stage_radix(N, Ns, 8);
+    constexpr int NE = num_stages(N, 8) - 1;             // exchanges
+    static_assert(E % R == 0, "radix must divide the per-thread point count");
+    reg_butterflies<N, E, R, Ns, DIR>(v, tws.w[S > 0 ? S - 1 : 0]);
+    if constexpr (Ns * R != N) {
+        float2* __restrict__ b = ((NE - 1 - S) % 2 == 0) ? z : c;
+        reg_scatter<N, E, R, Ns, 1>(v, b, p, 0);
+        __syncthreads();
+        reg_gather<N, E, 1>(v, b, p, 0);
+        reg_fft_pp<N, E, DIR, S + 1>(v, c, z, p, tws);
+    }
+}
+
 // =================================================================================== row R2C
 struct RowR2CTParams {
     const void* in;
@@ -855,12 +876,17 @@ __device__ __forceinline__ void sharpen_quad_half(const H2Row& r0, const H2Row& 
 template <int UW_> struct FusedPlanPow2 {                   // radix-8 Stockham, 8 points per thread (reg_fft)
     static constexpr int UW = UW_, T = UW / 8, R0 = 8, NB0 = T, EOUT = 8, SOUT = T, VN = 8;
     static constexpr size_t XB = sizeof(float2) * lswz_size(UW);
+    // NBUF = 3: a third LDS buffer z, used by the transform only.  The exchanges alternate z, c, z (c = the buffer that
+    // receives this pair's L rows), one barrier each; the first one writes z, which nobody has read since the last
+    // gather of the previous step, so the step needs no barrier at its end either: 4 barriers per step instead of 9.
+    static constexpr int NBUF = 3;
+    static_assert((num_stages(UW, 8) - 1) % 2 == 1, "the first exchange must go through z");
     struct Tw { TwSet<UW, 8> t; };
     static __device__ __forceinline__ int first_index(int lt) { return lt; }      // first-stage butterfly of thread lt
     static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { w.t.load(tw, j); }
-    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, int j, const Tw& w)
+    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w)
     {
-        reg_fft<UW, 8, -1, 1, false>(v, buf, j, 0, w.t);      // its last barrier follows the last gather
+        reg_fft_pp<UW, 8, -1>(v, buf, zbuf, j, w.t);
     }
 };
 
@@ -1051,10 +1077,11 @@ struct FusedPlan3840 {                                      // 1920x1080 -> 3840
     using F = MrFftN<3840, -1, 512, 8, 8, 4, 15>;
     static constexpr int UW = 3840, T = 512, R0 = 8, NB0 = 480, EOUT = 15, SOUT = 256, VN = F::VN;
     static constexpr size_t XB = sizeof(float2) * lswz_size(3840);
+    static constexpr int NBUF = 2;                          // in-place exchanges (two barriers each), no third buffer
     using Tw = F::Tw;
     static __device__ __forceinline__ int first_index(int lt) { return lt < NB0 ? lt : NB0 - 1; }   // (threads beyond re-read)
     static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { F::load_tw(w, tw, j); }
-    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, int j, const Tw& w)
+    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2*, int j, const Tw& w)
     {
         // The base twiddles are loop-invariant, so the compiler would hoist all 27 power products of the three twiddled
         // stages out of the strip loop and keep them (54 VGPRs: spills).  Re-defining the bases here makes the
@@ -1074,22 +1101,24 @@ struct FusedPlan3840x16 {                                   // the same rows as 
     using Tw = F::Tw;
     static __device__ __forceinline__ int first_index(int lt) { return lt < NB0 ? lt : NB0 - 1; }   // (threads beyond re-read)
     static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { F::load_tw(w, tw, j); }
-    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, int j, const Tw& w) { F::fft(v, buf, j, w); }
+    static constexpr int NBUF = 2;
+    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2*, int j, const Tw& w) { F::fft(v, buf, j, w); }
 };
 
 // ---------------------------------------------------------------------------------------------------
 // Fused C2R + sharpen: a workgroup of T = UW/8 threads owns a strip and alternates, all
-// threads together, between transforming row pair s and sharpening the two output rows that pair completes.  Two such
-// workgroups live on a compute unit (70 KB of LDS, <= 128 VGPRs each); they are not synchronised with each other, so
-// one's barrier-free sharpen phase (a long run of arithmetic) fills the gaps the other's transform leaves at its
-// exchange barriers.  No role split, no barrier counting: every thread reaches the same __syncthreads().
-//   LDS: two exchange buffers X[0], X[1]; pair s is transformed in X[s&1], which then holds its two L rows; the rows of
-//   pair s-1 (X[(s-1)&1]) are the "ring".  The spectrum rows of pair s+1 are prefetched into REGISTERS while pair s is
+// threads together, between transforming row pair s and sharpening the two output rows that pair completes.  One such
+// workgroup runs per compute unit (<= 128 VGPRs, 64-96 KB of LDS): the rest of the unit is left to the row and column
+// kernels of the frames on the other streams.  No role split, no barrier counting: every thread reaches the same
+// __syncthreads().
+//   LDS: X[0], X[1]; pair s is transformed in X[s&1], which then holds its two L rows; the rows of pair s-1
+//   (X[(s-1)&1]) are the "ring"; plans with NBUF = 3 exchange through a third buffer as well and need no barrier at
+//   the end of a step (FusedPlanPow2).  The spectrum rows of pair s+1 are prefetched into REGISTERS while pair s is
 //   processed (every thread loads the 8 values its first butterfly needs, mirrored ones included), so no LDS staging
 //   and -- loads being older than the output stores of the same step -- no wait on a store, ever (vmcnt is in order).
 template <class PL> struct FusedGLds {
     static constexpr size_t XB = PL::XB;
-    static constexpr size_t RED = 2 * XB;
+    static constexpr size_t RED = PL::NBUF * XB;            // X[0], X[1] (L rows, alternating), [the transform's z buffer]
     static constexpr size_t TOTAL = RED + 32 * sizeof(float);
 };
 
@@ -1209,7 +1238,7 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
             }
             if constexpr ((FFTUP_KO & 32) == 0)
             in = load_pair(min(s + 1, npairs - 1));                                 // lands during this step (last step: a harmless re-read)
-            if constexpr ((FFTUP_KO & 2) == 0) PL::fft(v, buf, lt, tws);
+            if constexpr ((FFTUP_KO & 2) == 0) PL::fft(v, buf, (float2*)(smem + 2 * L::XB), lt, tws);
             settle(in);
             if constexpr (HALF) {
                 // C2R output stored as binary16 (vkFFT.h:7289-7290), then |u^2 g| clamped, each step rounded like the shader's
@@ -1406,7 +1435,9 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                 red[20] = (float)rn[UW - 2];
                 red[21] = (float)rn[UW - 1];
             }
-            __syncthreads();        // the ring rows are dead: the next transform exchanges through their buffer
+            // two-buffer plans: the ring rows are dead and the next transform exchanges through their buffer.  Three-buffer
+            // plans write that buffer only behind the next step's first exchange barrier (FusedPlanPow2).
+            if constexpr (PL::NBUF == 2) __syncthreads();
         }
     }
 }
