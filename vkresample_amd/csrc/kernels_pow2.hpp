@@ -897,14 +897,17 @@ template <int UW_> struct FusedPlanPow2 {                   // radix-8 Stockham,
 // (lpad(16 j + m) = 17 j + m, lpad(j + NB m) = lpad(j) + (NB + NB/16) m, lpad(16 (j-k+m) + k) = 17 (j-k) + k + 17 m),
 // i.e. an immediate of the ds instruction: no address arithmetic in the stages.  The scatters are conflict-free, the
 // gathers pay one extra LDS cycle per 32 lanes for the padding (tools/lds_conflicts.py).
-template <int R> __device__ __forceinline__ void twiddle_all(float2* v, float2 w1)      // v[m] *= w1^m, m < R <= 16
+template <int R, bool PK = true> __device__ __forceinline__ void twiddle_all(float2* v, float2 w1)      // v[m] *= w1^m, m < R <= 16
 {
-    const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2), w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
-    const float2 w8 = cmul(w4, w4);
-    const float2 ws[16] = {make_float2(1.f, 0.f), w1, w2, w3, w4, w5, w6, w7, w8, cmul(w8, w1), cmul(w5, w5), cmul(w8, w3),
-                           cmul(w6, w6), cmul(w8, w5), cmul(w7, w7), cmul(w8, w7)};
+    // PK: through cmul_tw, the power chain as well -- its results are born as aligned register pairs, which is what the
+    // packed multiplies want (from plain cmul they would have to be moved together first).  Same roundings either way.
+    auto mul = [](float2 a, float2 b) { if constexpr (PK) return cmul_tw(a, b); else return cmul(a, b); };
+    const float2 w2 = mul(w1, w1), w3 = mul(w2, w1), w4 = mul(w2, w2), w5 = mul(w4, w1), w6 = mul(w3, w3), w7 = mul(w4, w3);
+    const float2 w8 = mul(w4, w4);
+    const float2 ws[16] = {make_float2(1.f, 0.f), w1, w2, w3, w4, w5, w6, w7, w8, mul(w8, w1), mul(w5, w5), mul(w8, w3),
+                           mul(w6, w6), mul(w8, w5), mul(w7, w7), mul(w8, w7)};
 #pragma unroll
-    for (int m = 1; m < R; m++) v[m] = cmul(v[m], ws[m]);
+    for (int m = 1; m < R; m++) v[m] = mul(v[m], ws[m]);
 }
 template <int N, int DIR, int R0, int R1, int R2> struct MrFft {
     static constexpr int NB0 = N / R0, NB1 = N / R1, NB2 = N / R2;
@@ -1010,6 +1013,9 @@ template <int N, int DIR, int TK, int R0, int R1, int R2, bool FINAL_TO_LDS> str
     }
 };
 
+#ifndef FFTUP_3840_PKTW
+#define FFTUP_3840_PKTW 1
+#endif
 // ---- any number of stages, at most 8 points per butterfly except the last: T threads run ceil(NB/T) butterflies per
 // stage, index map lswz.  3840 = 8 * 8 * 4 * 15 on 512 threads keeps the fused kernel at the register budget of the
 // power-of-two plans (the 16 * 16 * 15 plan needs 226 VGPRs: two of its workgroups fill a compute unit's register files
@@ -1036,11 +1042,18 @@ template <int N, int DIR, int T, int... RS> struct MrFftN {
             load_tw<S + 1>(w, tw, j);
         }
     }
-    // on entry v[m] = x[j + NB0*m], j < NB0; on return v[m] = X[j + NBlast*m], j < NBlast
-    template <int S = 0> static __device__ __forceinline__ void run(float2 (&v)[VN], float2* __restrict__ buf, int j, const Tw& w)
+    // on entry v[m] = x[j + NB0*m], j < NB0; on return v[m] = X[j + NBlast*m], j < NBlast.
+    // The exchange behind stage s goes through z when an even number of exchanges follows it, else through c (see
+    // reg_fft_pp: one barrier per exchange, the last one through z).
+    static constexpr bool pow2(int n) { return (n & (n - 1)) == 0; }
+    // INPLACE: one buffer (c), two barriers per exchange.
+    template <bool INPLACE, int S = 0>
+    static __device__ __forceinline__ void run(float2 (&v)[VN], float2* __restrict__ c, float2* __restrict__ z, int j, const Tw& w)
     {
         if constexpr (S < NST) {
-            constexpr int R = rs(S), Ns = ns(S), NB = N / R, BPT = bpt(S);
+            constexpr int R = rs(S), Ns = ns(S), NB = N / R, BPT = bpt(S), NE = NST - 1;
+            float2* __restrict__ const bin = (!INPLACE && (NE - S) % 2 == 0) ? z : c;           // exchange S-1
+            float2* __restrict__ const bout = (!INPLACE && (NE - 1 - S) % 2 == 0) ? z : c;      // exchange S
             asm volatile("" : "+v"(j));                      // addresses of this stage are formed here, not hoisted and kept
             if constexpr (S > 0) {
 #pragma unroll
@@ -1048,27 +1061,34 @@ template <int N, int DIR, int T, int... RS> struct MrFftN {
                     const int jb = j + T * b;
                     if (jb < NB) {
 #pragma unroll
-                        for (int m = 0; m < R; m++) v[b * R + m] = buf[lswz(jb + NB * m)];
+                        for (int m = 0; m < R; m++) v[b * R + m] = bin[lswz(jb + NB * m)];
                     }
                 }
-                __syncthreads();                             // the buffer may be overwritten from here on
+                if constexpr (INPLACE) __syncthreads();      // the buffer may be overwritten from here on
             }
 #pragma unroll
             for (int b = 0; b < BPT; b++) {
                 const int jb = j + T * b;
                 if (jb < NB) {
-                    if constexpr (S > 0) twiddle_all<R>(&v[b * R], twid<DIR>(w.w[S > 0 ? S - 1 : 0][b]));
+                    if constexpr (S > 0) twiddle_all<R, FFTUP_3840_PKTW != 0>(&v[b * R], twid<DIR>(w.w[S > 0 ? S - 1 : 0][b]));
                     bfly<R, DIR>(&v[b * R]);
                     if constexpr (S + 1 < NST) {
                         const int k = jb % Ns, j0 = (jb - k) * R + k;
+                        if constexpr (pow2(R) && pow2(Ns)) {
+                            // bits of m*Ns are clear in j0: lswz(j0 + m*Ns) = lswz(j0) ^ lswz(m*Ns) (see lds_put)
+                            const unsigned a0 = lds_addr(bout) + 8u * (unsigned)lswz(j0);
 #pragma unroll
-                        for (int m = 0; m < R; m++) buf[lswz(j0 + m * Ns)] = v[b * R + m];
+                            for (int m = 0; m < R; m++) lds_put(a0, lswz_c(m * Ns), v[b * R + m]);
+                        } else {
+#pragma unroll
+                            for (int m = 0; m < R; m++) bout[lswz(j0 + m * Ns)] = v[b * R + m];
+                        }
                     }
                 }
             }
             if constexpr (S + 1 < NST) {
                 __syncthreads();
-                run<S + 1>(v, buf, j, w);
+                run<INPLACE, S + 1>(v, c, z, j, w);
             }
         }
     }
@@ -1077,11 +1097,18 @@ struct FusedPlan3840 {                                      // 1920x1080 -> 3840
     using F = MrFftN<3840, -1, 512, 8, 8, 4, 15>;
     static constexpr int UW = 3840, T = 512, R0 = 8, NB0 = 480, EOUT = 15, SOUT = 256, VN = F::VN;
     static constexpr size_t XB = sizeof(float2) * lswz_size(3840);
-    static constexpr int NBUF = 2;                          // in-place exchanges (two barriers each), no third buffer
+#ifndef FFTUP_3840_NBUF
+#define FFTUP_3840_NBUF 2
+#endif
+    // NBUF = 3 (exchanges alternate z, c, z with one barrier each, as in FusedPlanPow2) makes this kernel 5 % faster on its
+    // own and the frame 2 % slower: with 61 KB of LDS two of these workgroups share a compute unit whenever consecutive
+    // frames' launches overlap, with 92 KB they cannot (measured).
+    static constexpr int NBUF = FFTUP_3840_NBUF;
+    static_assert((F::NST - 1) % 2 == 1 && XB % 128 == 0, "the first exchange must go through z; lds_put needs 128-byte aligned buffers");
     using Tw = F::Tw;
     static __device__ __forceinline__ int first_index(int lt) { return lt < NB0 ? lt : NB0 - 1; }   // (threads beyond re-read)
     static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { F::load_tw(w, tw, j); }
-    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2*, int j, const Tw& w)
+    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w)
     {
         // The base twiddles are loop-invariant, so the compiler would hoist all 27 power products of the three twiddled
         // stages out of the strip loop and keep them (54 VGPRs: spills).  Re-defining the bases here makes the
@@ -1091,7 +1118,7 @@ struct FusedPlan3840 {                                      // 1920x1080 -> 3840
         for (int st = 0; st < F::NST - 1; st++)
 #pragma unroll
             for (int b = 0; b < F::MB; b++) asm volatile("" : "+v"(t.w[st][b].x), "+v"(t.w[st][b].y));
-        F::run(v, buf, j, t);
+        F::template run<NBUF == 2>(v, buf, zbuf, j, t);
     }
 };
 struct FusedPlan3840x16 {                                   // the same rows as 16 * 16 * 15 on 256 threads (226 VGPRs; kept for comparison)
@@ -1140,6 +1167,12 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
     extern __shared__ __attribute__((aligned(128))) char smem[];
     float* red = (float*)(smem + L::RED);      // [0..15] corner partial sums, [16] corner DC term, [20..21] deferred-pixel taps
     int lt = threadIdx.x;                       // (made opaque at the phase entries, see FFTUP_OPQ)
+#ifndef FFTUP_G_PRIO
+#define FFTUP_G_PRIO 3
+#endif
+    // This kernel sets the frame time; the row and column kernels of the frames on the other streams run beside it on
+    // the same SIMDs with a lot of slack.  Instruction issue priority to this one's waves.
+    if constexpr (FFTUP_G_PRIO != 0) __builtin_amdgcn_s_setprio(FFTUP_G_PRIO);
     const int uH = p.uH;
     const int pairs_per_plane = uH / 2;
     const long plane = (long)UW * uH;
