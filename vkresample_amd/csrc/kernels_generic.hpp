@@ -20,9 +20,18 @@ enum InMode { IN_F32 = 0, IN_F16 = 1, IN_U8_F32 = 2, IN_U8_F16 = 3, IN_F64 = 4 }
 
 // VkResample.cpp:1644  x = float(double(v)/255.0)   -- fp32 division is correctly rounded here
 // and agrees with the double-rounded reference expression for all 256 inputs (tests check it).
-__device__ __forceinline__ float cvt_u8_f32(uint8_t v) { return __fdiv_rn((float)v, 255.0f); }
+// RN(v / 255) in three instructions instead of the ten of an IEEE division: q0 = v c, c = RN(1/255); the residual
+// v - 255 q0 is exact in one fma; one correction step.  Equal to the division for all 256 codes (tests/test_gpu_parity.py
+// compares every code with the oracle; the same three operations in C: 0 mismatches, the bare product has 126).
+__device__ __forceinline__ float div255(float x)
+{
+    const float c = 1.0f / 255.0f;
+    const float q0 = x * c;
+    return fmaf(fmaf(-255.0f, q0, x), c, q0);
+}
+__device__ __forceinline__ float cvt_u8_f32(uint8_t v) { return div255((float)v); }
 // VkResample.cpp:1676  x = half((float)half(v)/255.0)  (round to nearest even)
-__device__ __forceinline__ float cvt_u8_f16(uint8_t v) { return __half2float(__float2half_rn(__fdiv_rn((float)v, 255.0f))); }
+__device__ __forceinline__ float cvt_u8_f16(uint8_t v) { return __half2float(__float2half_rn(div255((float)v))); }
 
 template <typename C> struct RowR2CParamsT {
     const void* in;          // planar float/half/double (row stride, plane stride in elements) or u8 RGB (row stride bytes)
@@ -339,7 +348,7 @@ __global__ void __launch_bounds__(256) k_unpack_u8(const uint8_t* rgb, long row_
     const uint8_t* s = rgb + (long)y * row_stride_bytes + 3l * x;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        if constexpr (HALF) ((__half*)planes)[c * plane_stride + (long)y * W + x] = __float2half_rn(__fdiv_rn((float)s[c], 255.0f));
+        if constexpr (HALF) ((__half*)planes)[c * plane_stride + (long)y * W + x] = __float2half_rn(div255((float)s[c]));
         else ((float*)planes)[c * plane_stride + (long)y * W + x] = cvt_u8_f32(s[c]);
     }
 }

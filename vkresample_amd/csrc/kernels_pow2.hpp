@@ -151,18 +151,18 @@ template <int R> __device__ __forceinline__ void twiddle_powers(float2* v, float
     if constexpr (R == 2) {
         v[1] = cmul_tw(v[1], w1);
     } else if constexpr (R == 4) {
-        float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+        float2 w2 = cmul_tw(w1, w1), w3 = cmul_tw(w2, w1);
         v[1] = cmul_tw(v[1], w1); v[2] = cmul_tw(v[2], w2); v[3] = cmul_tw(v[3], w3);
     } else {
-        float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
-        float2 w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+        float2 w2 = cmul_tw(w1, w1), w3 = cmul_tw(w2, w1), w4 = cmul_tw(w2, w2);
+        float2 w5 = cmul_tw(w4, w1), w6 = cmul_tw(w3, w3), w7 = cmul_tw(w4, w3);
         v[1] = cmul_tw(v[1], w1); v[2] = cmul_tw(v[2], w2); v[3] = cmul_tw(v[3], w3); v[4] = cmul_tw(v[4], w4);
         v[5] = cmul_tw(v[5], w5); v[6] = cmul_tw(v[6], w6); v[7] = cmul_tw(v[7], w7);
         if constexpr (R == 16) {
-            float2 w8 = cmul(w4, w4);
-            v[8] = cmul_tw(v[8], w8); v[9] = cmul_tw(v[9], cmul(w8, w1)); v[10] = cmul_tw(v[10], cmul(w5, w5));
-            v[11] = cmul_tw(v[11], cmul(w8, w3)); v[12] = cmul_tw(v[12], cmul(w6, w6)); v[13] = cmul_tw(v[13], cmul(w8, w5));
-            v[14] = cmul_tw(v[14], cmul(w7, w7)); v[15] = cmul_tw(v[15], cmul(w8, w7));
+            float2 w8 = cmul_tw(w4, w4);
+            v[8] = cmul_tw(v[8], w8); v[9] = cmul_tw(v[9], cmul_tw(w8, w1)); v[10] = cmul_tw(v[10], cmul_tw(w5, w5));
+            v[11] = cmul_tw(v[11], cmul_tw(w8, w3)); v[12] = cmul_tw(v[12], cmul_tw(w6, w6)); v[13] = cmul_tw(v[13], cmul_tw(w8, w5));
+            v[14] = cmul_tw(v[14], cmul_tw(w7, w7)); v[15] = cmul_tw(v[15], cmul_tw(w8, w7));
         }
     }
 }
