@@ -24,6 +24,9 @@
 #ifndef FFTUP_OPQ
 #define FFTUP_OPQ 1
 #endif
+#ifndef FFTUP_PK_BFLY
+#define FFTUP_PK_BFLY 1
+#endif
 #ifndef FFTUP_KO
 #define FFTUP_KO 0          // timing experiments only (results invalid): 1 no sharpen arithmetic, 2 no transform, 4 no output stores, 8 no tap loads
 #endif
@@ -142,6 +145,58 @@ __device__ __forceinline__ float2 cmul_tw(float2 z, float2 w)
     return make_float2(r.x, r.y);
 }
 
+// ---- radix-4 / radix-8 butterflies written on register pairs: every complex addition is ONE v_pk_add_f32, a +- i b
+// included (op_sel swaps b's halves, neg_lo / neg_hi puts the sign), the 1/sqrt2 rotations are two v_pk_fma_f32 each.
+// Same operations and roundings as bfly4 / bfly8 of fft_engine.hpp; the compiler, given those, builds the operands of
+// the rotations with register moves (~50 per transform of the fused kernel).
+typedef float pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2 pk_add(pk2 a, pk2 b) { return a + b; }
+__device__ __forceinline__ pk2 pk_sub(pk2 a, pk2 b) { return a - b; }
+template <int SGN> __device__ __forceinline__ pk2 pk_addi(pk2 a, pk2 b)      // a + SGN * i * b
+{
+    pk2 r;
+    if constexpr (SGN > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int SGN> __device__ __forceinline__ pk2 pk_fmah(pk2 t, pk2 e)         // e + SGN * t / sqrt2
+{
+    const pk2 h = {0.70710678118654752440f, 0.70710678118654752440f};
+    pk2 r;
+    if constexpr (SGN > 0) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(t), "s"(h), "v"(e));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(t), "s"(h), "v"(e));
+    return r;
+}
+template <int DIR> __device__ __forceinline__ void bfly4_pk(pk2& a0, pk2& a1, pk2& a2, pk2& a3)
+{
+    const pk2 t0 = pk_add(a0, a2), t1 = pk_sub(a0, a2), t2 = pk_add(a1, a3), d = pk_sub(a1, a3);
+    a0 = pk_add(t0, t2);
+    a2 = pk_sub(t0, t2);
+    a1 = pk_addi<DIR>(t1, d);
+    a3 = pk_addi<-DIR>(t1, d);
+}
+template <int DIR> __device__ __forceinline__ void bfly8_pk(float2* v)
+{
+    pk2 e0 = {v[0].x, v[0].y}, e1 = {v[2].x, v[2].y}, e2 = {v[4].x, v[4].y}, e3 = {v[6].x, v[6].y};
+    pk2 o0 = {v[1].x, v[1].y}, o1 = {v[3].x, v[3].y}, o2 = {v[5].x, v[5].y}, o3 = {v[7].x, v[7].y};
+    bfly4_pk<DIR>(e0, e1, e2, e3);
+    bfly4_pk<DIR>(o0, o1, o2, o3);
+    const pk2 t1 = pk_addi<DIR>(o1, o1);                   // (1 + DIR i) o1
+    const pk2 u3 = pk_addi<-DIR>(o3, o3);                  // (1 - DIR i) o3 = -((-1 + DIR i) o3)
+    const pk2 r0 = pk_add(e0, o0), r4 = pk_sub(e0, o0);
+    const pk2 r1 = pk_fmah<1>(t1, e1), r5 = pk_fmah<-1>(t1, e1);
+    const pk2 r2 = pk_addi<DIR>(e2, o2), r6 = pk_addi<-DIR>(e2, o2);
+    const pk2 r3 = pk_fmah<-1>(u3, e3), r7 = pk_fmah<1>(u3, e3);
+    v[0] = make_float2(r0.x, r0.y); v[1] = make_float2(r1.x, r1.y); v[2] = make_float2(r2.x, r2.y); v[3] = make_float2(r3.x, r3.y);
+    v[4] = make_float2(r4.x, r4.y); v[5] = make_float2(r5.x, r5.y); v[6] = make_float2(r6.x, r6.y); v[7] = make_float2(r7.x, r7.y);
+}
+// butterflies of the register-resident kernels
+template <int R, int DIR> __device__ __forceinline__ void bfly_reg(float2* v)
+{
+    if constexpr (R == 8 && FFTUP_PK_BFLY) bfly8_pk<DIR>(v);
+    else bfly<R, DIR>(v);
+}
+
 template <int R> __device__ __forceinline__ void twiddle_powers(float2* v, float2 w1)
 {
     if constexpr ((FFTUP_KO & 128) != 0) {          // timing experiment: all powers = w1 (no power chain)
@@ -168,7 +223,7 @@ template <int R> __device__ __forceinline__ void twiddle_powers(float2* v, float
 }
 
 // ---- one stage on registers: E/R butterflies of radix R (compile-time recursion over b)
-template <int N, int E, int R, int Ns, int DIR, int B>
+template <int N, int E, int R, int Ns, int DIR, int B, bool PKB = true>
 __device__ __forceinline__ void butterfly_b(float2 (&v)[E], float2 wbase)
 {
     constexpr int Tc = N / E;
@@ -183,19 +238,21 @@ __device__ __forceinline__ void butterfly_b(float2 (&v)[E], float2 wbase)
             if constexpr (Ns > Tc && B > 0) w1 = cmul(w1, twid<DIR>(rot32<B * (32 / E)>()));
             twiddle_powers<R>(w, w1);
         }
-        bfly<R, DIR>(w);
+        // (PKB = false: the generic form, which the compiler can fold when inputs are known zeros; measured: no gain)
+        if constexpr (PKB) bfly_reg<R, DIR>(w);
+        else bfly<R, DIR>(w);
 #pragma unroll
         for (int m = 0; m < R; m++) v[B + m * NB] = w[m];
-        butterfly_b<N, E, R, Ns, DIR, B + 1>(v, wbase);
+        butterfly_b<N, E, R, Ns, DIR, B + 1, PKB>(v, wbase);
     }
 }
 
-template <int N, int E, int R, int Ns, int DIR>
+template <int N, int E, int R, int Ns, int DIR, bool PKB = true>
 __device__ __forceinline__ void reg_butterflies(float2 (&v)[E], float2 wbase)
 {
     constexpr int Tc = N / E;
     static_assert(Ns <= Tc || Ns * R == N, "per-butterfly twiddle offsets are only derived for the last stage");
-    butterfly_b<N, E, R, Ns, DIR, 0>(v, wbase);
+    butterfly_b<N, E, R, Ns, DIR, 0, PKB>(v, wbase);
 }
 
 // ---- Stockham autosort scatter of a stage's outputs into LDS
@@ -1071,7 +1128,7 @@ template <int N, int DIR, int T, int... RS> struct MrFftN {
                 const int jb = j + T * b;
                 if (jb < NB) {
                     if constexpr (S > 0) twiddle_all<R, FFTUP_3840_PKTW != 0>(&v[b * R], twid<DIR>(w.w[S > 0 ? S - 1 : 0][b]));
-                    bfly<R, DIR>(&v[b * R]);
+                    bfly_reg<R, DIR>(&v[b * R]);
                     if constexpr (S + 1 < NST) {
                         const int k = jb % Ns, j0 = (jb - k) * R + k;
                         if constexpr (pow2(R) && pow2(Ns)) {
