@@ -1202,8 +1202,8 @@ struct FusedPlan3840x16 {                                   // the same rows as 
 //   and -- loads being older than the output stores of the same step -- no wait on a store, ever (vmcnt is in order).
 template <class PL> struct FusedGLds {
     static constexpr size_t XB = PL::XB;
-    static constexpr size_t RED = PL::NBUF * XB;            // X[0], X[1] (L rows, alternating), [the transform's z buffer]
-    static constexpr size_t TOTAL = RED + 32 * sizeof(float);
+    static constexpr size_t RED = (PL::NBUF == 3 ? 2 : PL::NBUF) * XB;      // corner partial sums: in z when there is one (free at strip start)
+    static constexpr size_t TOTAL = PL::NBUF * XB + (PL::NBUF == 3 ? 0 : 32 * sizeof(float));   // X[0], X[1] (L rows, alternating), [z]
 };
 
 #ifdef FFTUP_G_NUM_VGPR
@@ -1222,7 +1222,7 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
     using L = FusedGLds<PL>;
     using LT = typename std::conditional<HALF, _Float16, float>::type;      // L rows in LDS: binary16 for -p 2
     extern __shared__ __attribute__((aligned(128))) char smem[];
-    float* red = (float*)(smem + L::RED);      // [0..15] corner partial sums, [16] corner DC term, [20..21] deferred-pixel taps
+    float* red = (float*)(smem + L::RED);      // [0..15] corner partial sums, [16] corner DC term (strip start only)
     int lt = threadIdx.x;                       // (made opaque at the phase entries, see FFTUP_OPQ)
 #ifndef FFTUP_G_PRIO
 #define FFTUP_G_PRIO 3
@@ -1304,6 +1304,15 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
         In in = load_pair(0);
         settle(in);
         __syncthreads();            // red[] published; the previous segment's last reads of X[] are over
+        // the corner sample L(y1+1, 0) (SE tap of the strip's last pixel), kept in a register by every thread
+        float corner = 0.f;
+        if (need_corner) {
+            float sum = 0.f;
+            for (int w2 = 0; w2 < (T + 63) / 64; w2++) sum += red[w2];
+            corner = (red[16] + 2.0f * sum) * inv;
+        }
+        if constexpr (PL::NBUF == 3) __syncthreads();       // red[] lives in z: all reads before the first exchange writes it
+        float pn0 = 0.f, pn1 = 0.f;                         // thread T-1: taps (a-3 | a-1 clamped, UW-2 / UW-1) of the deferred pixel
 
         for (int s = 0; s < npairs; s++) {
             const int a = a0 + 2 * s;
@@ -1402,9 +1411,7 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                             const int r2 = min(a + 2, uH - 1) - a;
                             if (r2 <= 1) set_hi(R[3].sc, rowp(r2)[0]);
                             else if (s == npairs - 1) {
-                                float sum = 0.f;
-                                for (int w2 = 0; w2 < (T + 63) / 64; w2++) sum += red[w2];
-                                set_hi(R[3].sc, (LT)to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq));
+                                set_hi(R[3].sc, (LT)to_L<HALF>(corner, p.upsq));
                             }
                         }
 #pragma unroll
@@ -1466,9 +1473,7 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                         const int r2 = min(a + 2, uH - 1) - a;
                         if (r2 <= 1) t[3].r = rowp(r2)[0];
                         else if (s == npairs - 1) {
-                            float sum = 0.f;
-                            for (int w2 = 0; w2 < (T + 63) / 64; w2++) sum += red[w2];
-                            t[3].r = to_L<HALF>((red[16] + 2.0f * sum) * inv, p.upsq);
+                            t[3].r = to_L<HALF>(corner, p.upsq);
                         }
                     }
 #pragma unroll
@@ -1500,7 +1505,6 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                     const LT* r0 = rowp(0);
                     const float r10 = (float)r1[0], r00 = (float)r0[0];
                     const float ne = (a - 2 == 0) ? r10 : (float)r2[0];
-                    const float pn0 = red[20], pn1 = red[21];
                     const long of = c * plane + (long)(a - 2) * UW + (UW - 1);
                     if constexpr (HALF) {
                         // the same packed evaluation as the other pixels of the row, both lanes carrying this pixel
@@ -1522,8 +1526,8 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                     }
                 }
                 const LT* rn = (a == 0) ? rowp(0) : rowp(-1);
-                red[20] = (float)rn[UW - 2];
-                red[21] = (float)rn[UW - 1];
+                pn0 = (float)rn[UW - 2];
+                pn1 = (float)rn[UW - 1];
             }
             // two-buffer plans: the ring rows are dead and the next transform exchanges through their buffer.  Three-buffer
             // plans write that buffer only behind the next step's first exchange barrier (FusedPlanPow2).
