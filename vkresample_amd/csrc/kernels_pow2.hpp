@@ -24,6 +24,9 @@
 #ifndef FFTUP_OPQ
 #define FFTUP_OPQ 1
 #endif
+#ifndef FFTUP_COL_WAVES
+#define FFTUP_COL_WAVES 8     // k_col_t: 8 waves per SIMD = 64 VGPRs: four 512-thread workgroups per CU, all 771 of a frame resident at once
+#endif
 #ifndef FFTUP_PK_BFLY
 #define FFTUP_PK_BFLY 1
 #endif
@@ -420,7 +423,7 @@ __device__ __forceinline__ void col_phase(float2 (&v)[8], const float2* __restri
 // from S1.  Both halves are kept at TWICE the reference's normalisation (S1 as it is, odd rows D/H instead of D/2H);
 // the consumers fold the 1/2 into their final scale.  Exact for every column vector, Nyquist row included.
 template <int H, int TK>
-__global__ void __launch_bounds__(TK* H / 8) k_col_t(ColTParams p)
+__global__ void __launch_bounds__(TK* H / 8, FFTUP_COL_WAVES) k_col_t(ColTParams p)
 {
     constexpr int Tc = H / 8;                        // threads per column
     extern __shared__ __attribute__((aligned(128))) char smem[];
