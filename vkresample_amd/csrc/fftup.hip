@@ -73,7 +73,7 @@ struct fftup_plan {
     bool tuned = false;
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
     bool mixed1080 = false;           // compile-time mixed-radix plans (1920x1080 -> 3840x2160)
-    bool plan3840_x16 = false;        // 1080p: fused kernel on the 16*16*15 plan (256 threads, 226 VGPRs) instead of 8*8*4*15
+    bool plan3840_x16 = true;         // 1080p: fused kernel on the 16*16*15 plan (256 threads, 120 VGPRs); false: 8*8*4*15 on 512 threads
     bool cplx = false;                // non-R2C path (VR:1424 false): full complex transforms, uW beyond the R2C limit
     int ncols = 0;                    // spectrum columns kept: W/2 + 1, or W on the non-R2C path
     int pairs_per_strip = 6;
@@ -324,7 +324,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             // FFTUP_G_PER_CU only sets the strip length (strips = units * per_cu); how many workgroups are resident is
             // the hardware's business (the power-of-two plans take 96 KB of LDS: one per unit).
             if (const char* e = getenv("FFTUP_3840_X16")) P->plan3840_x16 = atoi(e) != 0;
-            int per_cu = (P->mixed1080 && P->plan3840_x16) ? 2 : 1;      // (the 16*16*15 plan runs 256-thread workgroups)
+            int per_cu = 1;
             if (const char* e = getenv("FFTUP_G_PER_CU")) per_cu = std::max(1, std::min(4, atoi(e)));
             const int total_pairs = 3 * (int)uH / 2, slots = std::max(1, P->prop.multiProcessorCount) * per_cu;
             P->pairs_per_strip = std::max(2, (total_pairs + slots - 1) / slots);

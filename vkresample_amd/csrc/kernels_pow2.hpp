@@ -980,21 +980,24 @@ template <int N, int DIR, int R0, int R1, int R2> struct MrFft {
         w.w2 = tw[(j < NB2 ? j : 0) % NS2 * (N / (NS2 * R2))];
     }
     static_assert(R0 == 16 && R1 == 16 && NB1 % 16 == 0 && NB2 % 16 == 0, "offsets below assume 16-aligned strides");
-    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, int j, const Tw& w)
+    // zbuf != buf: the first exchange goes through zbuf (nobody has read it since the previous transform's first gather),
+    // so no barrier is needed between its gather and the second exchange's scatter into buf.
+    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w)
     {
-        float2* const g = buf + lpad(j);                     // gather base of stages 1 and 2
+        float2* const g = buf + lpad(j);                     // gather base of stage 2
         if (j < NB0) {
             bfly<R0, DIR>(v);
-            float2* const d = buf + 17 * j;
+            float2* const d = zbuf + 17 * j;
 #pragma unroll
             for (int m = 0; m < R0; m++) d[m] = v[m];
         }
         __syncthreads();
         if (j < NB1) {
+            float2* const g0 = zbuf + lpad(j);
 #pragma unroll
-            for (int m = 0; m < R1; m++) v[m] = g[(NB1 + NB1 / 16) * m];
+            for (int m = 0; m < R1; m++) v[m] = g0[(NB1 + NB1 / 16) * m];
         }
-        __syncthreads();
+        if (zbuf == buf) __syncthreads();                    // (uniform; in place: the buffer may be overwritten from here on)
         if (j < NB1) {
             twiddle_all<R1>(v, twid<DIR>(w.w1));
             bfly<R1, DIR>(v);
@@ -1077,9 +1080,10 @@ template <int N, int DIR, int TK, int R0, int R1, int R2, bool FINAL_TO_LDS> str
 #define FFTUP_3840_PKTW 1
 #endif
 // ---- any number of stages, at most 8 points per butterfly except the last: T threads run ceil(NB/T) butterflies per
-// stage, index map lswz.  3840 = 8 * 8 * 4 * 15 on 512 threads keeps the fused kernel at the register budget of the
-// power-of-two plans (the 16 * 16 * 15 plan needs 226 VGPRs: two of its workgroups fill a compute unit's register files
-// and nothing of the other streams runs beside them).
+// stage, index map lswz.  3840 = 8 * 8 * 4 * 15 on 512 threads (FFTUP_3840_X16=0).  Written when the 16 * 16 * 15 plan
+// still needed 226 VGPRs; since the butterflies run on register pairs that plan needs 120 and is the default again:
+// one 256-thread workgroup per compute unit (ONE wave per SIMD) runs a strip as fast as this plan's 512 threads do and
+// leaves more issue slots to the kernels beside it (frame 78 -> 75 us).
 template <int N, int DIR, int T, int... RS> struct MrFftN {
     static constexpr int NST = sizeof...(RS);
     static constexpr int rs(int s) { constexpr int r[] = {RS...}; return r[s]; }
@@ -1181,15 +1185,23 @@ struct FusedPlan3840 {                                      // 1920x1080 -> 3840
         F::template run<NBUF == 2>(v, buf, zbuf, j, t);
     }
 };
-struct FusedPlan3840x16 {                                   // the same rows as 16 * 16 * 15 on 256 threads (226 VGPRs; kept for comparison)
+struct FusedPlan3840x16 {                                   // the same rows as 16 * 16 * 15 on 256 threads, 120 VGPRs: the default (fftup.hip)
     using F = MrFft<3840, -1, 16, 16, 15>;
     static constexpr int UW = 3840, T = 256, R0 = 16, NB0 = F::NB0, EOUT = 15, SOUT = F::NB2, VN = F::VN;
     static constexpr size_t XB = (sizeof(float2) * lpad_size(3840) + 15) & ~(size_t)15;
     using Tw = F::Tw;
     static __device__ __forceinline__ int first_index(int lt) { return lt < NB0 ? lt : NB0 - 1; }   // (threads beyond re-read)
     static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { F::load_tw(w, tw, j); }
-    static constexpr int NBUF = 2;
-    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2*, int j, const Tw& w) { F::fft(v, buf, j, w); }
+#ifndef FFTUP_3840X16_NBUF
+#define FFTUP_3840X16_NBUF 2
+#endif
+    // NBUF = 3 (first exchange through z, second through the L-row buffer: 4 barriers per step instead of 6) changes
+    // nothing for the kernel alone (77 us) and costs 98 instead of 65 KB of LDS: frame 75 -> 87 us.  Kept at 2.
+    static constexpr int NBUF = FFTUP_3840X16_NBUF;
+    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w)
+    {
+        F::fft(v, buf, NBUF == 3 ? zbuf : buf, j, w);
+    }
 };
 
 // ---------------------------------------------------------------------------------------------------
