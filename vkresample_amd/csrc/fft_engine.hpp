@@ -137,6 +137,76 @@ template <int DIR, typename C> __device__ __forceinline__ void bfly7(C* v)
     v[2] = cadd(p2, q2); v[5] = csub(p2, q2);
     v[3] = cadd(p3, q3); v[4] = csub(p3, q3);
 }
+// ---------------------------------------------------------------- the same butterflies on register PAIRS (fp32, gfx950)
+// C = pk2: one complex number = one aligned VGPR pair, every complex addition ONE v_pk_add_f32 -- a +- i b included
+// (op_sel swaps b's halves, neg_lo / neg_hi puts the sign) -- real constants come from a scalar register pair.  Same
+// operations and roundings as the float2 forms above.  These overloads are picked by the composite butterflies below
+// (bfly10 / bfly12 / bfly15) when they are instantiated with C = pk2.
+typedef float pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2 pk_add(pk2 a, pk2 b) { return a + b; }
+__device__ __forceinline__ pk2 pk_sub(pk2 a, pk2 b) { return a - b; }
+template <int SGN> __device__ __forceinline__ pk2 pk_addi(pk2 a, pk2 b)      // a + SGN * i * b
+{
+    pk2 r;
+    if constexpr (SGN > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ pk2 pk_mulc(pk2 t, float c)                         // t * c
+{
+    const pk2 cc = {c, c};
+    pk2 r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(t), "s"(cc));
+    return r;
+}
+template <int NEG_E = 0> __device__ __forceinline__ pk2 pk_fmac(pk2 t, float c, pk2 e)     // t * c + e   (NEG_E: t * c - e)
+{
+    const pk2 cc = {c, c};
+    pk2 r;
+    if constexpr (NEG_E == 0) asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(t), "s"(cc), "v"(e));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(t), "s"(cc), "v"(e));
+    return r;
+}
+template <int DIR> __device__ __forceinline__ void bfly2(pk2* v)
+{
+    const pk2 a = v[0], b = v[1];
+    v[0] = pk_add(a, b);
+    v[1] = pk_sub(a, b);
+}
+template <int DIR> __device__ __forceinline__ void bfly4(pk2* v)
+{
+    const pk2 t0 = pk_add(v[0], v[2]), t1 = pk_sub(v[0], v[2]), t2 = pk_add(v[1], v[3]), d = pk_sub(v[1], v[3]);
+    v[0] = pk_add(t0, t2);
+    v[2] = pk_sub(t0, t2);
+    v[1] = pk_addi<DIR>(t1, d);
+    v[3] = pk_addi<-DIR>(t1, d);
+}
+template <int DIR> __device__ __forceinline__ void bfly3(pk2* v)
+{
+    const pk2 t1 = pk_add(v[1], v[2]);
+    const pk2 t2 = pk_fmac(t1, -0.5f, v[0]);
+    const pk2 ds = pk_mulc(pk_sub(v[1], v[2]), 0.86602540378443864676f);
+    v[0] = pk_add(v[0], t1);
+    v[1] = pk_addi<DIR>(t2, ds);
+    v[2] = pk_addi<-DIR>(t2, ds);
+}
+template <int DIR> __device__ __forceinline__ void bfly5(pk2* v)
+{
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    const pk2 a = v[0];
+    const pk2 t1 = pk_add(v[1], v[4]), t2 = pk_add(v[2], v[3]), t3 = pk_sub(v[1], v[4]), t4 = pk_sub(v[2], v[3]);
+    const pk2 p1 = pk_fmac(t2, c2, pk_fmac(t1, c1, a));
+    const pk2 p2 = pk_fmac(t2, c1, pk_fmac(t1, c2, a));
+    const pk2 q1 = pk_fmac(t3, s1, pk_mulc(t4, s2));               // s1 t3 + s2 t4
+    const pk2 q2 = pk_fmac<1>(t3, s2, pk_mulc(t4, s1));            // s2 t3 - s1 t4
+    v[0] = pk_add(a, pk_add(t1, t2));
+    v[1] = pk_addi<DIR>(p1, q1);
+    v[4] = pk_addi<-DIR>(p1, q1);
+    v[2] = pk_addi<DIR>(p2, q2);
+    v[3] = pk_addi<-DIR>(p2, q2);
+}
+
 // cos/sin of 2 pi q / 16 and 2 pi q / 9 (q as used by bfly16 / bfly9)
 template <int DIR, int Q, typename C> __device__ __forceinline__ C rot16c(C a)
 {

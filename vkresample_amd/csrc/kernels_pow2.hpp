@@ -152,16 +152,6 @@ __device__ __forceinline__ float2 cmul_tw(float2 z, float2 w)
 // included (op_sel swaps b's halves, neg_lo / neg_hi puts the sign), the 1/sqrt2 rotations are two v_pk_fma_f32 each.
 // Same operations and roundings as bfly4 / bfly8 of fft_engine.hpp; the compiler, given those, builds the operands of
 // the rotations with register moves (~50 per transform of the fused kernel).
-typedef float pk2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ pk2 pk_add(pk2 a, pk2 b) { return a + b; }
-__device__ __forceinline__ pk2 pk_sub(pk2 a, pk2 b) { return a - b; }
-template <int SGN> __device__ __forceinline__ pk2 pk_addi(pk2 a, pk2 b)      // a + SGN * i * b
-{
-    pk2 r;
-    if constexpr (SGN > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 template <int SGN> __device__ __forceinline__ pk2 pk_fmah(pk2 t, pk2 e)         // e + SGN * t / sqrt2
 {
     const pk2 h = {0.70710678118654752440f, 0.70710678118654752440f};
@@ -193,11 +183,62 @@ template <int DIR> __device__ __forceinline__ void bfly8_pk(float2* v)
     v[0] = make_float2(r0.x, r0.y); v[1] = make_float2(r1.x, r1.y); v[2] = make_float2(r2.x, r2.y); v[3] = make_float2(r3.x, r3.y);
     v[4] = make_float2(r4.x, r4.y); v[5] = make_float2(r5.x, r5.y); v[6] = make_float2(r6.x, r6.y); v[7] = make_float2(r7.x, r7.y);
 }
+// z * exp(DIR 2 pi i Q/16), the constant in a scalar register pair: two packed instructions (as cmul_tw)
+template <int DIR, int Q> __device__ __forceinline__ pk2 pk_rot16(pk2 z)
+{
+    static_assert(Q >= 0 && Q < 10, "bfly16 needs Q = 1, 2, 3, 6, 9");
+    constexpr float c[10] = {1.0f, 0.92387953251128675613f, 0.70710678118654752440f, 0.38268343236508977173f, 0.0f,
+                             -0.38268343236508977173f, -0.70710678118654752440f, -0.92387953251128675613f, -1.0f,
+                             -0.92387953251128675613f};
+    constexpr float sn[10] = {0.0f, 0.38268343236508977173f, 0.70710678118654752440f, 0.92387953251128675613f, 1.0f,
+                              0.92387953251128675613f, 0.70710678118654752440f, 0.38268343236508977173f, 0.0f,
+                              -0.38268343236508977173f};
+    const pk2 w = {c[Q], DIR > 0 ? sn[Q] : -sn[Q]};
+    pk2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(z), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(z), "s"(w), "v"(t));
+    return r;
+}
+template <int SGN> __device__ __forceinline__ pk2 pk_muli(pk2 b)               // SGN * i * b
+{
+    pk2 r;
+    if constexpr (SGN > 0) asm("v_pk_add_f32 %0, 0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(b));
+    else asm("v_pk_add_f32 %0, 0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(b));
+    return r;
+}
+// radix 16 = 4 x 4 exactly as bfly16 of fft_engine.hpp (n = 4 n1 + n2, k = k1 + 4 k2), on register pairs
+template <int DIR> __device__ __forceinline__ void bfly16_pk(float2* v)
+{
+    pk2 y[4][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) {
+#pragma unroll
+        for (int n1 = 0; n1 < 4; n1++) y[n2][n1] = pk2{v[4 * n1 + n2].x, v[4 * n1 + n2].y};
+        bfly4_pk<DIR>(y[n2][0], y[n2][1], y[n2][2], y[n2][3]);
+    }
+    y[1][1] = pk_rot16<DIR, 1>(y[1][1]); y[1][2] = pk_rot16<DIR, 2>(y[1][2]); y[1][3] = pk_rot16<DIR, 3>(y[1][3]);
+    y[2][1] = pk_rot16<DIR, 2>(y[2][1]); y[2][2] = pk_muli<DIR>(y[2][2]);      y[2][3] = pk_rot16<DIR, 6>(y[2][3]);
+    y[3][1] = pk_rot16<DIR, 3>(y[3][1]); y[3][2] = pk_rot16<DIR, 6>(y[3][2]); y[3][3] = pk_rot16<DIR, 9>(y[3][3]);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) {
+        bfly4_pk<DIR>(y[0][k1], y[1][k1], y[2][k1], y[3][k1]);
+        v[k1] = make_float2(y[0][k1].x, y[0][k1].y); v[k1 + 4] = make_float2(y[1][k1].x, y[1][k1].y);
+        v[k1 + 8] = make_float2(y[2][k1].x, y[2][k1].y); v[k1 + 12] = make_float2(y[3][k1].x, y[3][k1].y);
+    }
+}
 // butterflies of the register-resident kernels
 template <int R, int DIR> __device__ __forceinline__ void bfly_reg(float2* v)
 {
     if constexpr (R == 8 && FFTUP_PK_BFLY) bfly8_pk<DIR>(v);
-    else bfly<R, DIR>(v);
+    else if constexpr (R == 16 && FFTUP_PK_BFLY) bfly16_pk<DIR>(v);
+    else if constexpr ((R == 2 || R == 3 || R == 4 || R == 5 || R == 10 || R == 12 || R == 15) && FFTUP_PK_BFLY) {
+        pk2 z[R];                                            // the generic composites on register pairs (fft_engine.hpp)
+#pragma unroll
+        for (int m = 0; m < R; m++) z[m] = pk2{v[m].x, v[m].y};
+        bfly<R, DIR>(z);
+#pragma unroll
+        for (int m = 0; m < R; m++) v[m] = make_float2(z[m].x, z[m].y);
+    } else bfly<R, DIR>(v);
 }
 
 template <int R> __device__ __forceinline__ void twiddle_powers(float2* v, float2 w1)
@@ -986,7 +1027,7 @@ template <int N, int DIR, int R0, int R1, int R2> struct MrFft {
     {
         float2* const g = buf + lpad(j);                     // gather base of stage 2
         if (j < NB0) {
-            bfly<R0, DIR>(v);
+            bfly_reg<R0, DIR>(v);
             float2* const d = zbuf + 17 * j;
 #pragma unroll
             for (int m = 0; m < R0; m++) d[m] = v[m];
@@ -1000,7 +1041,7 @@ template <int N, int DIR, int R0, int R1, int R2> struct MrFft {
         if (zbuf == buf) __syncthreads();                    // (uniform; in place: the buffer may be overwritten from here on)
         if (j < NB1) {
             twiddle_all<R1>(v, twid<DIR>(w.w1));
-            bfly<R1, DIR>(v);
+            bfly_reg<R1, DIR>(v);
             const int k = j % NS1;
             float2* const d = buf + 17 * (j - k) + k;
 #pragma unroll
@@ -1014,7 +1055,7 @@ template <int N, int DIR, int R0, int R1, int R2> struct MrFft {
         __syncthreads();                                     // the buffer may be overwritten from here on
         if (j < NB2) {
             twiddle_all<R2>(v, twid<DIR>(w.w2));             // k = j (NS2 * R2 = N)
-            bfly<R2, DIR>(v);
+            bfly_reg<R2, DIR>(v);
         }
     }
 };
@@ -1039,7 +1080,7 @@ template <int N, int DIR, int TK, int R0, int R1, int R2, bool FINAL_TO_LDS> str
     {
         float2* const g = buf + j * TK + col;
         if (j < NB0) {
-            bfly<R0, DIR>(v);
+            bfly_reg<R0, DIR>(v);
             float2* const d = buf + j * R0 * TK + col;
 #pragma unroll
             for (int m = 0; m < R0; m++) d[m * TK] = v[m];
@@ -1052,7 +1093,7 @@ template <int N, int DIR, int TK, int R0, int R1, int R2, bool FINAL_TO_LDS> str
         __syncthreads();
         if (j < NB1) {
             twiddle_all<R1>(v, twid<DIR>(w.w1));
-            bfly<R1, DIR>(v);
+            bfly_reg<R1, DIR>(v);
             const int k = j % NS1;
             float2* const d = buf + ((j - k) * R1 + k) * TK + col;
 #pragma unroll
@@ -1066,7 +1107,7 @@ template <int N, int DIR, int TK, int R0, int R1, int R2, bool FINAL_TO_LDS> str
         __syncthreads();
         if (j < NB2) {
             twiddle_all<R2>(v, twid<DIR>(w.w2));             // k = j (NS2 * R2 = N)
-            bfly<R2, DIR>(v);
+            bfly_reg<R2, DIR>(v);
             if constexpr (FINAL_TO_LDS) {
 #pragma unroll
                 for (int m = 0; m < R2; m++) g[m * NB2 * TK] = v[m];
