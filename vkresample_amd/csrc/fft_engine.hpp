@@ -207,6 +207,36 @@ template <int DIR> __device__ __forceinline__ void bfly5(pk2* v)
     v[3] = pk_addi<-DIR>(p2, q2);
 }
 
+// z * (c + i s), the constant in a scalar register pair: two packed instructions
+__device__ __forceinline__ pk2 pk_cmulc(pk2 z, float c, float sn)
+{
+    const pk2 w = {c, sn};
+    pk2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]" : "=v"(t) : "v"(z), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(z), "s"(w), "v"(t));
+    return r;
+}
+// radix 9 = 3 x 3 as bfly9 below, on register pairs
+template <int DIR> __device__ __forceinline__ void bfly9(pk2* v)
+{
+    constexpr float c[5] = {1.0f, 0.76604444311897803520f, 0.17364817766693034885f, -0.5f, -0.93969262078590838405f};
+    constexpr float sn[5] = {0.0f, 0.64278760968653932632f, 0.98480775301220805937f, 0.86602540378443864676f, 0.34202014332566873304f};
+    pk2 y[3][3];
+#pragma unroll
+    for (int n2 = 0; n2 < 3; n2++) {
+        y[n2][0] = v[n2]; y[n2][1] = v[3 + n2]; y[n2][2] = v[6 + n2];
+        bfly3<DIR>(y[n2]);
+    }
+    y[1][1] = pk_cmulc(y[1][1], c[1], DIR > 0 ? sn[1] : -sn[1]); y[1][2] = pk_cmulc(y[1][2], c[2], DIR > 0 ? sn[2] : -sn[2]);
+    y[2][1] = pk_cmulc(y[2][1], c[2], DIR > 0 ? sn[2] : -sn[2]); y[2][2] = pk_cmulc(y[2][2], c[4], DIR > 0 ? sn[4] : -sn[4]);
+#pragma unroll
+    for (int k1 = 0; k1 < 3; k1++) {
+        pk2 z[3] = {y[0][k1], y[1][k1], y[2][k1]};
+        bfly3<DIR>(z);
+        v[k1] = z[0]; v[k1 + 3] = z[1]; v[k1 + 6] = z[2];
+    }
+}
+
 // cos/sin of 2 pi q / 16 and 2 pi q / 9 (q as used by bfly16 / bfly9)
 template <int DIR, int Q, typename C> __device__ __forceinline__ C rot16c(C a)
 {

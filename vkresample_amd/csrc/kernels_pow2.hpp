@@ -231,7 +231,7 @@ template <int R, int DIR> __device__ __forceinline__ void bfly_reg(float2* v)
 {
     if constexpr (R == 8 && FFTUP_PK_BFLY) bfly8_pk<DIR>(v);
     else if constexpr (R == 16 && FFTUP_PK_BFLY) bfly16_pk<DIR>(v);
-    else if constexpr ((R == 2 || R == 3 || R == 4 || R == 5 || R == 10 || R == 12 || R == 15) && FFTUP_PK_BFLY) {
+    else if constexpr ((R == 2 || R == 3 || R == 4 || R == 5 || R == 9 || R == 10 || R == 12 || R == 15) && FFTUP_PK_BFLY) {
         pk2 z[R];                                            // the generic composites on register pairs (fft_engine.hpp)
 #pragma unroll
         for (int m = 0; m < R; m++) z[m] = pk2{v[m].x, v[m].y};
