@@ -1256,11 +1256,42 @@ struct FusedPlan3840x16 {                                   // the same rows as 
 //   the end of a step (FusedPlanPow2).  The spectrum rows of pair s+1 are prefetched into REGISTERS while pair s is
 //   processed (every thread loads the 8 values its first butterfly needs, mirrored ones included), so no LDS staging
 //   and -- loads being older than the output stores of the same step -- no wait on a store, ever (vmcnt is in order).
+#ifndef FFTUP_RING_REGS
+#define FFTUP_RING_REGS 1
+#endif
 template <class PL> struct FusedGLds {
     static constexpr size_t XB = PL::XB;
-    static constexpr size_t RED = (PL::NBUF == 3 ? 2 : PL::NBUF) * XB;      // corner partial sums: in z when there is one (free at strip start)
-    static constexpr size_t TOTAL = PL::NBUF * XB + (PL::NBUF == 3 ? 0 : 32 * sizeof(float));   // X[0], X[1] (L rows, alternating), [z]
+    // RR: the ring rows (the L rows of the previous pair) stay in the registers of the threads that read them as taps in
+    // the previous step -- no second L-row buffer: LDS = the L rows of the current pair + the transform's z buffer.
+    // (Three-buffer plans whose sharpen passes tile the row exactly, at most two passes: 12 / 8 registers per pass.)
+    static constexpr bool RR = FFTUP_RING_REGS && PL::NBUF == 3 && PL::UW % (4 * PL::T) == 0 && PL::UW / (4 * PL::T) <= 2;
+    static constexpr size_t ZOFF = (RR ? 1 : 2) * XB;                       // the transform's z buffer (three-buffer plans)
+    static constexpr size_t RED = PL::NBUF == 3 ? ZOFF : 2 * XB;            // corner partial sums: in z when there is one (free at strip start)
+    static constexpr size_t TOTAL = RR ? 2 * XB : PL::NBUF * XB + (PL::NBUF == 3 ? 0 : 32 * sizeof(float));
 };
+
+// The one pixel per row pair that has to wait for the next pair, (y, UW-1): its SE tap is L(y+2, 0).  Taps: row y-1
+// (n0, n1 | ne), row y (m0, m1 | me), row y+1 (s0, s1 | se) at x = UW-2, UW-1 | the wrapped right neighbour.
+template <bool HALF>
+__device__ __forceinline__ void deferred_pixel(const FusedParams& p, long of, float n0, float n1, float ne, float m0, float m1, float me,
+                                               float s0, float s1, float se)
+{
+    if constexpr (HALF) {
+        // the same packed evaluation as the other pixels of the row, both lanes carrying this pixel
+        auto sp = [](float v) { const _Float16 x = (_Float16)v; h2v r = {x, x}; return r; };   // (exact: binary16 values)
+        const h2v a0 = sp(n0), a1 = sp(n1), a2 = sp(ne), b0 = sp(m0), b1 = sp(m1), b2 = sp(me), c0 = sp(s0), c1 = sp(s1), c2 = sp(se);
+        const h2v mn0 = pk_min3(a0, b0, c0), mn1 = pk_min3(a1, b1, c1), mn2 = pk_min3(a2, b2, c2);
+        const h2v mx0 = pk_max3(a0, b0, c0), mx1 = pk_max3(a1, b1, c1), mx2 = pk_max3(a2, b2, c2);
+        const h2v o = sharpen_eval_pair_half(a1, c1, b0, b2, b1, pk_min3(mn1, b0, b2), pk_min3(mn0, mn1, mn2),
+                                             pk_max3(mx1, b0, b2), pk_max3(mx0, mx1, mx2), h2_splat(-p.coef));
+        ((_Float16*)p.out)[of] = o.x;
+    } else {
+        const float tt[3][6] = {{n0, n0, n1, ne, ne, ne}, {m0, m0, m1, me, me, me}, {s0, s0, s1, se, se, se}};
+        float o[4];
+        sharpen_quad<false>(tt, p.coef, o);
+        ((float*)p.out)[of] = o[1];
+    }
+}
 
 #ifdef FFTUP_G_NUM_VGPR
 #define FFTUP_G_BOUNDS __launch_bounds__(PL::T) __attribute__((amdgpu_num_vgpr(FFTUP_G_NUM_VGPR)))
@@ -1281,10 +1312,10 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
     float* red = (float*)(smem + L::RED);      // [0..15] corner partial sums, [16] corner DC term (strip start only)
     int lt = threadIdx.x;                       // (made opaque at the phase entries, see FFTUP_OPQ)
 #ifndef FFTUP_G_PRIO
-#define FFTUP_G_PRIO 3
+#define FFTUP_G_PRIO 0
 #endif
-    // This kernel sets the frame time; the row and column kernels of the frames on the other streams run beside it on
-    // the same SIMDs with a lot of slack.  Instruction issue priority to this one's waves.
+    // (-DFFTUP_G_PRIO=1..3: issue priority for this kernel's waves over the row and column kernels that run beside it.
+    // Measured at 0, 1 and 3 in all three configurations: no difference beyond +-0.5 %.)
     if constexpr (FFTUP_G_PRIO != 0) __builtin_amdgcn_s_setprio(FFTUP_G_PRIO);
     const int uH = p.uH;
     const int pairs_per_plane = uH / 2;
@@ -1369,12 +1400,20 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
         }
         if constexpr (PL::NBUF == 3) __syncthreads();       // red[] lives in z: all reads before the first exchange writes it
         float pn0 = 0.f, pn1 = 0.f;                         // thread T-1: taps (a-3 | a-1 clamped, UW-2 / UW-1) of the deferred pixel
+        constexpr bool RR = L::RR;
+        using SavedRow = typename std::conditional<HALF, H2Row, TapRow>::type;
+        SavedRow sv[RR ? NPASS : 1][2];                     // RR: tap rows a, a+1 of the previous step = ring rows a-2, a-1 of this one
+        float lprev0 = 0.f;                                 // RR, thread T-1: L(a-2, 0)
+        if constexpr (RR) {
+#pragma unroll
+            for (int h = 0; h < NPASS; h++) sv[h][0] = sv[h][1] = SavedRow{};
+        }
 
         for (int s = 0; s < npairs; s++) {
             const int a = a0 + 2 * s;
-            float2* buf = (float2*)(smem + (s & 1) * L::XB);
+            float2* buf = (float2*)(smem + (RR ? 0 : (s & 1)) * L::XB);
             LT* cur = (LT*)buf;                                                     // rows a, a+1 after the transform
-            const LT* ring = (const LT*)(smem + ((s + 1) & 1) * L::XB);             // rows a-2, a-1
+            const LT* ring = (const LT*)(smem + ((s + 1) & 1) * L::XB);             // rows a-2, a-1 (not RR)
             // ================= transform of pair s
             if constexpr ((FFTUP_OPQ & 1) != 0) asm volatile("" : "+v"(lt));
             float2 v[VN];
@@ -1393,7 +1432,7 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
             }
             if constexpr ((FFTUP_KO & 32) == 0)
             in = load_pair(min(s + 1, npairs - 1));                                 // lands during this step (last step: a harmless re-read)
-            if constexpr ((FFTUP_KO & 2) == 0) PL::fft(v, buf, (float2*)(smem + 2 * L::XB), lt, tws);
+            if constexpr ((FFTUP_KO & 2) == 0) PL::fft(v, buf, (float2*)(smem + L::ZOFF), lt, tws);
             settle(in);
             if constexpr (HALF) {
                 // C2R output stored as binary16 (vkFFT.h:7289-7290), then |u^2 g| clamped, each step rounded like the shader's
@@ -1425,21 +1464,48 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
             __syncthreads();                                                        // L rows a, a+1 visible
             // ================= sharpen rows a-1 and a
             if constexpr ((FFTUP_OPQ & 2) != 0) asm volatile("" : "+v"(lt));
-            auto rowp = [&](int r) -> const LT* { return r < 0 ? ring + (r + 2) * UW : cur + r * UW; };
+            auto rowp = [&](int r) -> const LT* { return r < 0 ? ring + (r + 2) * UW : cur + r * UW; };      // (r < 0: not RR)
             const bool out0 = (a - 1) >= y0 && (a - 1) < y1;                        // row y = a-1
             const bool out1 = a >= y0 && a < y1;                                    // row y = a
+            if constexpr (RR) {
+                // the deferred pixel first: it needs the ring rows as the previous step left them
+                if (lt == T - 1) {
+                    const float r00 = (float)rowp(0)[0];
+                    const SavedRow& R2 = sv[NPASS - 1][0];      // row a-2, pixels UW-4 .. UW-1 and L(a-1, 0)
+                    const SavedRow& R1 = sv[NPASS - 1][1];      // row a-1
+                    float r2a, r2b, r1a, r1b, r10;
+                    if constexpr (HALF) { r2a = (float)R2.h23.x; r2b = (float)R2.h23.y; r1a = (float)R1.h23.x; r1b = (float)R1.h23.y; r10 = (float)R2.sc.y; }
+                    else { r2a = R2.q.z; r2b = R2.q.w; r1a = R1.q.z; r1b = R1.q.w; r10 = R2.r; }
+                    if (s > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1)
+                        deferred_pixel<HALF>(p, c * plane + (long)(a - 2) * UW + (UW - 1), pn0, pn1, (a - 2 == 0) ? r10 : lprev0,
+                                             r2a, r2b, r10, r1a, r1b, r00);
+                    if (a == 0) { pn0 = (float)rowp(0)[UW - 2]; pn1 = (float)rowp(0)[UW - 1]; }
+                    else { pn0 = r1a; pn1 = r1b; }
+                    lprev0 = r00;
+                }
+            }
             if constexpr (HALF) {
-                if (out0 || out1) {
+                if (out0 || out1 || RR) {
                     const h2v ncoef = h2_splat(-p.coef);
-#pragma unroll 1
-                    for (int h = 0; h < NPASS; h++) {
+                    auto pass = [&](auto hc) __attribute__((always_inline)) {
+                        const int h = hc;                                  // (a constant when called with an integral_constant)
                         const int x0 = 4 * (lt + T * h);
-                        if (UW % (4 * T) != 0 && x0 >= UW) continue;      // (wave-uniform: UW/4 is a multiple of 64)
+                        if (UW % (4 * T) != 0 && x0 >= UW) return;        // (wave-uniform: UW/4 is a multiple of 64)
                         // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
-                        const LT* rows[4] = {rowp(-2), (a == 0) ? rowp(0) : rowp(-1), rowp(0), rowp(1)};
+                        const LT* rows[4] = {RR ? nullptr : rowp(-2), RR ? nullptr : ((a == 0) ? rowp(0) : rowp(-1)), rowp(0), rowp(1)};
                         H2Row R[4];
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
+                        for (int r = 3; r >= 0; r--) {
+                            if constexpr (RR) {
+                                if (r < 2) {
+                                    R[r] = sv[h][r];
+                                    if (r == 1 && a == 0) {     // (a real, wave-uniform branch: top strip, first step only)
+                                        asm volatile("");
+                                        R[1].sa = R[2].sa; R[1].h01 = R[2].h01; R[1].sb = R[2].sb; R[1].h23 = R[2].h23; R[1].sc = R[2].sc;
+                                    }
+                                    continue;
+                                }
+                            }
                             if (r == 0 && !out0) {
                                 R[0].sa = R[0].h01 = R[0].sb = R[0].h23 = R[0].sc = h2_splat(0.f);
                                 continue;
@@ -1453,10 +1519,7 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                             R[r].sa = h2_bits(__builtin_amdgcn_alignbit(q.x, ql.y, 16));        // (x0-1, x0)
                             R[r].sb = h2_bits(__builtin_amdgcn_alignbit(q.y, q.x, 16));         // (x0+1, x0+2)
                             R[r].sc = h2_bits(__builtin_amdgcn_alignbit(qr.x, q.y, 16));        // (x0+3, x0+4)
-                        }
-                        if (x0 == 0) {                         // id_x_m clamp (VkResample.cpp:889)
-#pragma unroll
-                            for (int r = 0; r < 4; r++) R[r].sa = h2_bits((bits_h2(R[r].h01) & 0xffffu) * 0x10001u);
+                            if (x0 == 0) R[r].sa = h2_bits((bits_h2(R[r].h01) & 0xffffu) * 0x10001u);      // id_x_m clamp (VkResample.cpp:889)
                         }
                         if (x0 + 4 == UW) {
                             auto set_hi = [](h2v& d, LT v) { d.y = v; };
@@ -1470,6 +1533,7 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                                 set_hi(R[3].sc, (LT)to_L<HALF>(corner, p.upsq));
                             }
                         }
+                        if constexpr (RR) { sv[h][0] = R[2]; sv[h][1] = R[3]; }
 #pragma unroll
                         for (int w = 0; w < 2; w++) {
                             if (w == 0 ? !out0 : !out1) continue;
@@ -1479,19 +1543,36 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                             f2v val = {__builtin_bit_cast(float, o01), __builtin_bit_cast(float, o23)};
                             __builtin_nontemporal_store(val, (f2v*)((char*)((__half*)p.out + row_of) + (unsigned)x0 * 2u));
                         }
+                    };
+                    if constexpr (RR) {                                    // saved rows are registers: the pass index must be static
+                        pass(std::integral_constant<int, 0>{});
+                        if constexpr (NPASS > 1) pass(std::integral_constant<int, 1>{});
+                    } else {
+#pragma unroll 1
+                        for (int h = 0; h < NPASS; h++) pass(h);
                     }
                 }
             } else {
-            if (out0 || out1) {
-#pragma unroll 1
-                for (int h = 0; h < NPASS; h++) {
+            if (out0 || out1 || RR) {
+                auto pass = [&](auto hc) __attribute__((always_inline)) {
+                    const int h = hc;                                      // (a constant when called with an integral_constant)
                     const int x0 = 4 * (lt + T * h);
-                    if (UW % (4 * T) != 0 && x0 >= UW) continue;          // (wave-uniform: UW/4 is a multiple of 64)
+                    if (UW % (4 * T) != 0 && x0 >= UW) return;            // (wave-uniform: UW/4 is a multiple of 64)
                     // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
-                    const float* rows[4] = {rowp(-2), (a == 0) ? rowp(0) : rowp(-1), rowp(0), rowp(1)};
+                    const float* rows[4] = {RR ? nullptr : rowp(-2), RR ? nullptr : ((a == 0) ? rowp(0) : rowp(-1)), rowp(0), rowp(1)};
                     TapRow t[4];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
+                    for (int r = 3; r >= 0; r--) {
+                        if constexpr (RR) {
+                            if (r < 2) {
+                                t[r] = sv[h][r];
+                                if (r == 1 && a == 0) {         // (a real, wave-uniform branch: top strip, first step only)
+                                    asm volatile("");
+                                    t[1].q = t[2].q; t[1].l = t[2].l; t[1].r = t[2].r;
+                                }
+                                continue;
+                            }
+                        }
                         if (r == 0 && !out0) {
                             t[0].q = (f4t)(0.f);
                             t[0].l = t[0].r = 0.f;
@@ -1515,10 +1596,7 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                             t[r].l = ql.w;
                             t[r].r = qr.x;
                         }
-                    }
-                    if (x0 == 0) {                             // id_x_m clamp (VkResample.cpp:889)
-#pragma unroll
-                        for (int r = 0; r < 4; r++) t[r].l = t[r].q.x;
+                        if (x0 == 0) t[r].l = t[r].q.x;            // id_x_m clamp (VkResample.cpp:889)
                     }
                     if (x0 + 4 == UW) {
                         // row a-1 wraps into row a, which lives in the other buffer
@@ -1532,6 +1610,7 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                             t[3].r = to_L<HALF>(corner, p.upsq);
                         }
                     }
+                    if constexpr (RR) { sv[h][0] = t[2]; sv[h][1] = t[3]; }
 #pragma unroll
                     for (int w = 0; w < 2; w++) {
                         if (w == 0 ? !out0 : !out1) continue;
@@ -1550,40 +1629,29 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                             __builtin_nontemporal_store(o, (f4t*)((char*)((float*)p.out + row_of) + (unsigned)x0 * 4u));
                         }
                     }
+                };
+                if constexpr (RR) {
+                    pass(std::integral_constant<int, 0>{});
+                    if constexpr (NPASS > 1) pass(std::integral_constant<int, 1>{});
+                } else {
+#pragma unroll 1
+                    for (int h = 0; h < NPASS; h++) pass(h);
                 }
             }
             }
-            if (lt == T - 1) {
-                // finish the pixel deferred by the previous pair: (a-2, UW-1); L(a,0) is known now
-                if (s > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1) {
+            if constexpr (!RR) {
+                if (lt == T - 1) {
+                    // finish the pixel deferred by the previous pair: (a-2, UW-1); L(a,0) is known now
                     const LT* r2 = rowp(-2);
                     const LT* r1 = rowp(-1);
-                    const LT* r0 = rowp(0);
-                    const float r10 = (float)r1[0], r00 = (float)r0[0];
-                    const float ne = (a - 2 == 0) ? r10 : (float)r2[0];
-                    const long of = c * plane + (long)(a - 2) * UW + (UW - 1);
-                    if constexpr (HALF) {
-                        // the same packed evaluation as the other pixels of the row, both lanes carrying this pixel
-                        auto sp = [](float v) { const _Float16 x = (_Float16)v; h2v r = {x, x}; return r; };   // (exact: binary16 values)
-                        const h2v a0 = sp(pn0), a1 = sp(pn1), a2 = sp(ne), b0 = sp((float)r2[UW - 2]), b1 = sp((float)r2[UW - 1]), b2 = sp(r10);
-                        const h2v c0 = sp((float)r1[UW - 2]), c1 = sp((float)r1[UW - 1]), c2 = sp(r00);
-                        const h2v n0 = pk_min3(a0, b0, c0), n1 = pk_min3(a1, b1, c1), n2 = pk_min3(a2, b2, c2);
-                        const h2v x0 = pk_max3(a0, b0, c0), x1 = pk_max3(a1, b1, c1), x2 = pk_max3(a2, b2, c2);
-                        const h2v o = sharpen_eval_pair_half(a1, c1, b0, b2, b1, pk_min3(n1, b0, b2), pk_min3(n0, n1, n2),
-                                                             pk_max3(x1, b0, b2), pk_max3(x0, x1, x2), h2_splat(-p.coef));
-                        ((_Float16*)p.out)[of] = o.x;
-                    } else {
-                        const float tt[3][6] = {{pn0, pn0, pn1, ne, ne, ne},
-                                                {(float)r2[UW - 2], (float)r2[UW - 2], (float)r2[UW - 1], r10, r10, r10},
-                                                {(float)r1[UW - 2], (float)r1[UW - 2], (float)r1[UW - 1], r00, r00, r00}};
-                        float o[4];
-                        sharpen_quad<HALF>(tt, p.coef, o);
-                        ((float*)p.out)[of] = o[1];
-                    }
+                    const float r10 = (float)r1[0], r00 = (float)rowp(0)[0];
+                    if (s > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1)
+                        deferred_pixel<HALF>(p, c * plane + (long)(a - 2) * UW + (UW - 1), pn0, pn1, (a - 2 == 0) ? r10 : (float)r2[0],
+                                             (float)r2[UW - 2], (float)r2[UW - 1], r10, (float)r1[UW - 2], (float)r1[UW - 1], r00);
+                    const LT* rn = (a == 0) ? rowp(0) : rowp(-1);
+                    pn0 = (float)rn[UW - 2];
+                    pn1 = (float)rn[UW - 1];
                 }
-                const LT* rn = (a == 0) ? rowp(0) : rowp(-1);
-                pn0 = (float)rn[UW - 2];
-                pn1 = (float)rn[UW - 1];
             }
             // two-buffer plans: the ring rows are dead and the next transform exchanges through their buffer.  Three-buffer
             // plans write that buffer only behind the next step's first exchange barrier (FusedPlanPow2).
