@@ -981,6 +981,7 @@ template <int UW_> struct FusedPlanPow2 {                   // radix-8 Stockham,
     // receives this pair's L rows), one barrier each; the first one writes z, which nobody has read since the last
     // gather of the previous step, so the step needs no barrier at its end either: 4 barriers per step instead of 9.
     static constexpr int NBUF = 3;
+    static constexpr bool RING_REGS = true;
     static_assert((num_stages(UW, 8) - 1) % 2 == 1, "the first exchange must go through z");
     struct Tw { TwSet<UW, 8> t; };
     static __device__ __forceinline__ int first_index(int lt) { return lt; }      // first-stage butterfly of thread lt
@@ -1209,6 +1210,7 @@ struct FusedPlan3840 {                                      // 1920x1080 -> 3840
     // own and the frame 2 % slower: with 61 KB of LDS two of these workgroups share a compute unit whenever consecutive
     // frames' launches overlap, with 92 KB they cannot (measured).
     static constexpr int NBUF = FFTUP_3840_NBUF;
+    static constexpr bool RING_REGS = true;
     static_assert((F::NST - 1) % 2 == 1 && XB % 128 == 0, "the first exchange must go through z; lds_put needs 128-byte aligned buffers");
     using Tw = F::Tw;
     static __device__ __forceinline__ int first_index(int lt) { return lt < NB0 ? lt : NB0 - 1; }   // (threads beyond re-read)
@@ -1236,9 +1238,13 @@ struct FusedPlan3840x16 {                                   // the same rows as 
 #ifndef FFTUP_3840X16_NBUF
 #define FFTUP_3840X16_NBUF 2
 #endif
+#ifndef FFTUP_3840X16_RR
+#define FFTUP_3840X16_RR 1
+#endif
     // NBUF = 3 (first exchange through z, second through the L-row buffer: 4 barriers per step instead of 6) changes
     // nothing for the kernel alone (77 us) and costs 98 instead of 65 KB of LDS: frame 75 -> 87 us.  Kept at 2.
     static constexpr int NBUF = FFTUP_3840X16_NBUF;
+    static constexpr bool RING_REGS = FFTUP_3840X16_RR;
     static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w)
     {
         F::fft(v, buf, NBUF == 3 ? zbuf : buf, j, w);
@@ -1263,11 +1269,12 @@ template <class PL> struct FusedGLds {
     static constexpr size_t XB = PL::XB;
     // RR: the ring rows (the L rows of the previous pair) stay in the registers of the threads that read them as taps in
     // the previous step -- no second L-row buffer: LDS = the L rows of the current pair + the transform's z buffer.
-    // (Three-buffer plans whose sharpen passes tile the row exactly, at most two passes: 12 / 8 registers per pass.)
-    static constexpr bool RR = FFTUP_RING_REGS && PL::NBUF == 3 && PL::UW % (4 * PL::T) == 0 && PL::UW / (4 * PL::T) <= 2;
-    static constexpr size_t ZOFF = (RR ? 1 : 2) * XB;                       // the transform's z buffer (three-buffer plans)
-    static constexpr size_t RED = PL::NBUF == 3 ? ZOFF : 2 * XB;            // corner partial sums: in z when there is one (free at strip start)
-    static constexpr size_t TOTAL = RR ? 2 * XB : PL::NBUF * XB + (PL::NBUF == 3 ? 0 : 32 * sizeof(float));
+    // (12 registers per sharpen pass for fp32, 10 for binary16; plans opt in with RING_REGS, at most four passes.)
+    static constexpr bool RR = FFTUP_RING_REGS && PL::RING_REGS && (PL::UW + 4 * PL::T - 1) / (4 * PL::T) <= 4;
+    static constexpr size_t NX = RR ? 1 : 2;                                // L-row buffers
+    static constexpr size_t ZOFF = NX * XB;                                 // the transform's z buffer (three-buffer plans)
+    static constexpr size_t RED = NX * XB;                                  // corner partial sums: in z when there is one (free at strip start)
+    static constexpr size_t TOTAL = (NX + (PL::NBUF == 3 ? 1 : 0)) * XB + (PL::NBUF == 3 ? 0 : 32 * sizeof(float));
 };
 
 // The one pixel per row pair that has to wait for the next pair, (y, UW-1): its SE tap is L(y+2, 0).  Taps: row y-1
@@ -1468,11 +1475,13 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
             const bool out0 = (a - 1) >= y0 && (a - 1) < y1;                        // row y = a-1
             const bool out1 = a >= y0 && a < y1;                                    // row y = a
             if constexpr (RR) {
-                // the deferred pixel first: it needs the ring rows as the previous step left them
-                if (lt == T - 1) {
+                // the deferred pixel first: it needs the ring rows as the previous step left them; by the thread that owns
+                // the last four pixels of a row
+                constexpr int LT_LAST = (UW / 4 - 1) % T, H_LAST = (UW / 4 - 1) / T;
+                if (lt == LT_LAST) {
                     const float r00 = (float)rowp(0)[0];
-                    const SavedRow& R2 = sv[NPASS - 1][0];      // row a-2, pixels UW-4 .. UW-1 and L(a-1, 0)
-                    const SavedRow& R1 = sv[NPASS - 1][1];      // row a-1
+                    const SavedRow& R2 = sv[H_LAST][0];         // row a-2, pixels UW-4 .. UW-1 and L(a-1, 0)
+                    const SavedRow& R1 = sv[H_LAST][1];         // row a-1
                     float r2a, r2b, r1a, r1b, r10;
                     if constexpr (HALF) { r2a = (float)R2.h23.x; r2b = (float)R2.h23.y; r1a = (float)R1.h23.x; r1b = (float)R1.h23.y; r10 = (float)R2.sc.y; }
                     else { r2a = R2.q.z; r2b = R2.q.w; r1a = R1.q.z; r1b = R1.q.w; r10 = R2.r; }
@@ -1547,6 +1556,8 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                     if constexpr (RR) {                                    // saved rows are registers: the pass index must be static
                         pass(std::integral_constant<int, 0>{});
                         if constexpr (NPASS > 1) pass(std::integral_constant<int, 1>{});
+                        if constexpr (NPASS > 2) pass(std::integral_constant<int, 2>{});
+                        if constexpr (NPASS > 3) pass(std::integral_constant<int, 3>{});
                     } else {
 #pragma unroll 1
                         for (int h = 0; h < NPASS; h++) pass(h);
@@ -1633,6 +1644,8 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                 if constexpr (RR) {
                     pass(std::integral_constant<int, 0>{});
                     if constexpr (NPASS > 1) pass(std::integral_constant<int, 1>{});
+                    if constexpr (NPASS > 2) pass(std::integral_constant<int, 2>{});
+                    if constexpr (NPASS > 3) pass(std::integral_constant<int, 3>{});
                 } else {
 #pragma unroll 1
                     for (int h = 0; h < NPASS; h++) pass(h);
