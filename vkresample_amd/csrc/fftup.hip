@@ -322,7 +322,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             // One strip (workgroup of uW/8 threads) per compute unit: the rest of every compute unit is left to the row and
             // column kernels of the frames on the other streams, and the frame time is what counts.
             // FFTUP_G_PER_CU only sets the strip length (strips = units * per_cu); how many workgroups are resident is
-            // the hardware's business (the power-of-two plans take 96 KB of LDS: one per unit).
+            // the hardware's business (the power-of-two plans take 64 KB of LDS and 96 VGPRs x 8 waves).
             if (const char* e = getenv("FFTUP_3840_X16")) P->plan3840_x16 = atoi(e) != 0;
             int per_cu = 1;
             if (const char* e = getenv("FFTUP_G_PER_CU")) per_cu = std::max(1, std::min(4, atoi(e)));

@@ -977,7 +977,7 @@ __device__ __forceinline__ void sharpen_quad_half(const H2Row& r0, const H2Row& 
 template <int UW_> struct FusedPlanPow2 {                   // radix-8 Stockham, 8 points per thread (reg_fft)
     static constexpr int UW = UW_, T = UW / 8, R0 = 8, NB0 = T, EOUT = 8, SOUT = T, VN = 8;
     static constexpr size_t XB = sizeof(float2) * lswz_size(UW);
-    // NBUF = 3: a third LDS buffer z, used by the transform only.  The exchanges alternate z, c, z (c = the buffer that
+    // NBUF = 3: an LDS buffer z used by the transform only.  The exchanges alternate z, c, z (c = the buffer that
     // receives this pair's L rows), one barrier each; the first one writes z, which nobody has read since the last
     // gather of the previous step, so the step needs no barrier at its end either: 4 barriers per step instead of 9.
     static constexpr int NBUF = 3;
@@ -1254,12 +1254,13 @@ struct FusedPlan3840x16 {                                   // the same rows as 
 // ---------------------------------------------------------------------------------------------------
 // Fused C2R + sharpen: a workgroup of T = UW/8 threads owns a strip and alternates, all
 // threads together, between transforming row pair s and sharpening the two output rows that pair completes.  One such
-// workgroup runs per compute unit (<= 128 VGPRs, 64-96 KB of LDS): the rest of the unit is left to the row and column
-// kernels of the frames on the other streams.  No role split, no barrier counting: every thread reaches the same
-// __syncthreads().
-//   LDS: X[0], X[1]; pair s is transformed in X[s&1], which then holds its two L rows; the rows of pair s-1
-//   (X[(s-1)&1]) are the "ring"; plans with NBUF = 3 exchange through a third buffer as well and need no barrier at
-//   the end of a step (FusedPlanPow2).  The spectrum rows of pair s+1 are prefetched into REGISTERS while pair s is
+// workgroup runs per compute unit by default (<= 96 VGPRs and 64 KB of LDS for the power-of-two plans): the rest of the
+// unit is left to the row and column kernels of the frames on the other streams and to the next frame's strip.  No role
+// split, no barrier counting: every thread reaches the same __syncthreads().
+//   LDS: the L rows of the pair in flight (buffer c, which is also one of the transform's exchange buffers); the rows of
+//   pair s-1 -- the "ring" -- live in registers (RR, FusedGLds) or, without RR, in a second L-row buffer (X[s&1] /
+//   X[(s-1)&1] alternating); plans with NBUF = 3 exchange through a buffer z as well and need no barrier at the end
+//   of a step (FusedPlanPow2).  The spectrum rows of pair s+1 are prefetched into REGISTERS while pair s is
 //   processed (every thread loads the 8 values its first butterfly needs, mirrored ones included), so no LDS staging
 //   and -- loads being older than the output stores of the same step -- no wait on a store, ever (vmcnt is in order).
 #ifndef FFTUP_RING_REGS
@@ -1666,8 +1667,8 @@ __global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
                     pn1 = (float)rn[UW - 1];
                 }
             }
-            // two-buffer plans: the ring rows are dead and the next transform exchanges through their buffer.  Three-buffer
-            // plans write that buffer only behind the next step's first exchange barrier (FusedPlanPow2).
+            // NBUF = 2 (in-place exchanges): the next transform's first scatter goes into the buffer the sharpen just read.
+            // NBUF = 3: that buffer is first written behind the next step's first exchange barrier (FusedPlanPow2).
             if constexpr (PL::NBUF == 2) __syncthreads();
         }
     }
