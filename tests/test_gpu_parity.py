@@ -11,6 +11,8 @@ Tolerances (north_star: "within 1e-4 rel-err"):
       oracle's own fp16 value, sharpened output max |err| <= 8e-3 (a one-ulp flip of an fp16 input moves the fp16-arithmetic filter by a few ulps), relative L2 <= 1e-3.
 The last output row reads stale padding memory in the reference (quirk B5) and is excluded.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -604,3 +606,54 @@ def test_plans_in_concurrent_host_threads():
         assert got[t][-1] == 2 and want[t][-1] == 2
         for a, b in zip(got[t][:-1], want[t][:-1]):
             assert np.array_equal(a, b)
+
+
+def _run_env(env, W, H, precision, dist="N", flags=0):
+    """Output planes of one frame with plan-creation environment switches set (read by fftup_plan_create)."""
+    from vkresample_amd import synth
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        rgb = synth.frame(3, W, H, dist)
+        with _up(W, H, 2.0, precision, 0.2, 0, flags) as up:
+            up.upload_rgb8(rgb)
+            up.execute(1)
+            return up.download_planar().copy()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("W,H", [(512, 256), (2048, 1024), (1920, 1080)])
+@pytest.mark.parametrize("precision", [0, 2])
+def test_fused_output_independent_of_strip_length(W, H, precision):
+    """The fused C2R+sharpen kernel cuts the frame into strips of row pairs; every strip recomputes one halo pair, keeps
+    the previous pair's rows in registers, defers its last pixel per row pair and takes the corner sample of its last row
+    from a reduction.  None of that may depend on where the cuts fall: strips of 3, 5, 7 and 50 pairs (the last one
+    crossing plane boundaries) agree with the default (one strip per compute unit) to rounding.  Not bit for bit: the
+    first strip of a plane pairs rows (0,1), (2,3) ..., the others (odd, even), two rows of a pair share one complex
+    transform and its rounding errors, and the corner sample comes from a sum instead of the transform -- measured
+    <= 1.8e-6 (fp32), 61 pixels in 1.5 M one or two binary16 ulps apart (-p 2).  A wrong halo, tap or cut costs >= 1e-3."""
+    ref = _run_env({}, W, H, precision).astype(np.float64)
+    for pairs in (3, 5, 7, 50):
+        got = _run_env({"FFTUP_PAIRS_PER_STRIP": str(pairs)}, W, H, precision).astype(np.float64)
+        d = np.abs(ref - got)
+        if precision == 0:
+            assert d.max() <= 5e-6, "pairs_per_strip = %d: %g" % (pairs, d.max())
+        else:
+            assert d.max() <= 4e-3 and (d != 0).mean() <= 2e-4, "pairs_per_strip = %d: %g, %g" % (pairs, d.max(), (d != 0).mean())
+
+
+@pytest.mark.parametrize("precision", [0, 2])
+def test_1080p_fused_plans_agree(precision):
+    """1920x1080: the 16*16*15 plan on 256 threads (default) and the 8*8*4*15 plan on 512 threads (FFTUP_3840_X16=0) are
+    different factorizations of the same transform: equal up to fp32 rounding, and both within tolerance of the oracle
+    (test_full_size_vs_oracle runs the default)."""
+    a = _run_env({}, 1920, 1080, precision).astype(np.float64)
+    b = _run_env({"FFTUP_3840_X16": "0"}, 1920, 1080, precision).astype(np.float64)
+    d = np.abs(a[:, :, :-1] - b[:, :, :-1]) if a.ndim == 3 else np.abs(a - b)
+    tol = 2e-4 if precision == 0 else 4e-3
+    assert d.max() <= tol and (d > (1e-5 if precision == 0 else 1e-3)).mean() <= 1e-3
