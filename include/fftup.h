@@ -70,7 +70,9 @@ typedef struct fftup_config {
  *   FFTUP_STREAMS=n          HIP streams consecutive frames of fftup_execute_ring / fftup_submit_rgb8 alternate on
  *                            (default 3, 1..4); fftup_execute always uses one
  *   FFTUP_G_PER_CU=n         strips (workgroups) of the fused C2R+sharpen kernel per compute unit (default 1)
- *   FFTUP_PAIRS_PER_STRIP=n  row pairs per workgroup of the fused C2R+sharpen kernel (default: pairs / compute units) */
+ *   FFTUP_PAIRS_PER_STRIP=n  row pairs per workgroup of the fused C2R+sharpen kernel (default: pairs / compute units)
+ *   FFTUP_3840_X16=0|1       1920x1080 -u 2: fused kernel on the 16*16*15 plan, 256 threads (1, default) or the
+ *                            8*8*4*15 plan, 512 threads (0); same results up to fp32 rounding (tests) */
 
 typedef struct fftup_plan fftup_plan;   /* opaque; replaces VkGPU + 2x VkFFTApplication +
                                            2x VkShiftApplication + the three device buffers      */
