@@ -638,7 +638,7 @@ def test_fused_output_independent_of_strip_length(W, H, precision):
     transform and its rounding errors, and the corner sample comes from a sum instead of the transform -- measured
     <= 1.8e-6 (fp32), 61 pixels in 1.5 M one or two binary16 ulps apart (-p 2).  A wrong halo, tap or cut costs >= 1e-3."""
     ref = _run_env({}, W, H, precision).astype(np.float64)
-    for pairs in (3, 5, 7, 50):
+    for pairs in ((1, 2, 3, 5, 7, 50) if W == 512 else (3, 5, 7, 50)):
         got = _run_env({"FFTUP_PAIRS_PER_STRIP": str(pairs)}, W, H, precision).astype(np.float64)
         d = np.abs(ref - got)
         if precision == 0:
