@@ -1301,13 +1301,10 @@ __device__ __forceinline__ void deferred_pixel(const FusedParams& p, long of, fl
     }
 }
 
-#ifdef FFTUP_G_NUM_VGPR
-#define FFTUP_G_BOUNDS __launch_bounds__(PL::T) __attribute__((amdgpu_num_vgpr(FFTUP_G_NUM_VGPR)))
-#else
-#define FFTUP_G_BOUNDS __launch_bounds__(PL::T, PL::T * 2 / 256 > 0 ? PL::T * 2 / 256 : 1)
-#endif
+// (second argument: waves per SIMD the register allocation must allow -- 4 for 512 threads = 128 VGPRs, so that two strips
+// can share a compute unit; tighter caps were tried: 80 VGPRs spill in fp32 and buy nothing in binary16)
 template <class PL, bool HALF, int TK>
-__global__ void FFTUP_G_BOUNDS k_c2r_sharpen_g(FusedParams p)
+__global__ void __launch_bounds__(PL::T, PL::T * 2 / 256 > 0 ? PL::T * 2 / 256 : 1) k_c2r_sharpen_g(FusedParams p)
 {
     constexpr int UW = PL::UW, T = PL::T, R0 = PL::R0, NB0 = PL::NB0, NI = R0 / 4, KH = UW / 4;
     constexpr int EOUT = PL::EOUT, SOUT = PL::SOUT, VN = PL::VN;
