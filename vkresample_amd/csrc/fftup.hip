@@ -334,9 +334,12 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         P->ldsRowF = 2 * P->csz * (size_t)lpad_size((int)W);
         P->ldsRowI = 2 * P->csz * (size_t)lpad_size((int)uW);
         if (P->ldsRowI > lds_max) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width too large for LDS"); goto bad; }
-        P->thrW = std::min(1024, std::max(64, round_up((int)W / 8, 64)));
-        P->thrUW = std::min(1024, std::max(64, round_up((int)uW / 8, 64)));
-        P->thrCol = std::min(1024, std::max(64, round_up((int)uH * P->TK / 8, 64)));
+        {
+            const int tmax = P->dbl ? GenericMaxThreads<double2>::value : GenericMaxThreads<float2>::value;
+            P->thrW = std::min(tmax, std::max(64, round_up((int)W / 8, 64)));
+            P->thrUW = std::min(tmax, std::max(64, round_up((int)uW / 8, 64)));
+            P->thrCol = std::min(tmax, std::max(64, round_up((int)uH * P->TK / 8, 64)));
+        }
 
         P->upsq = const_via_percent_f((double)(cfg->upscale * cfg->upscale), P->half);   // VkResample.cpp:1615
         P->coef = const_via_percent_f((double)cfg->sharpen, P->half);                    // VkResample.cpp:1616

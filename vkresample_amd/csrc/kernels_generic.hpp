@@ -33,6 +33,10 @@ __device__ __forceinline__ float cvt_u8_f32(uint8_t v) { return div255((float)v)
 // VkResample.cpp:1676  x = half((float)half(v)/255.0)  (round to nearest even)
 __device__ __forceinline__ float cvt_u8_f16(uint8_t v) { return __half2float(__float2half_rn(div255((float)v))); }
 
+// Workgroup size limit of the size-generic kernels: 1024 threads (128 VGPRs) for float2, 512 (256 VGPRs) for double2 --
+// at 128 the double instantiations spill (fftup.hip clamps its thread counts accordingly).
+template <typename C> struct GenericMaxThreads { static constexpr int value = sizeof(C) > 8 ? 512 : 1024; };
+
 template <typename C> struct RowR2CParamsT {
     const void* in;          // planar float/half/double (row stride, plane stride in elements) or u8 RGB (row stride bytes)
     C* S1;                   // blocked half spectrum, H rows
@@ -61,7 +65,7 @@ template <int MODE, typename P> __device__ __forceinline__ auto load_px(const P&
 
 // grid (H/2, 3); dynamic LDS = 2 * lpad_size(W) complex
 template <int MODE, typename C = float2>
-__global__ void __launch_bounds__(1024) k_row_r2c(RowR2CParamsT<C> p)
+__global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_r2c(RowR2CParamsT<C> p)
 {
     using S = scalar_t<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -103,7 +107,7 @@ using ColParams = ColParamsT<float2>;
 
 // grid (NT, 3); dynamic LDS = 2 * lpad_size(uH*TK) complex
 template <int TK, typename C = float2>
-__global__ void __launch_bounds__(1024) k_col(ColParamsT<C> p)
+__global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_col(ColParamsT<C> p)
 {
     using S = scalar_t<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -155,7 +159,7 @@ using RowC2RParams = RowC2RParamsT<float2>;
 
 // grid (uH/2, 3); dynamic LDS = 2 * lpad_size(uW) complex
 template <bool HALF_OUT, typename C = float2>
-__global__ void __launch_bounds__(1024) k_row_c2r(RowC2RParamsT<C> p)
+__global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_c2r(RowC2RParamsT<C> p)
 {
     using S = scalar_t<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(1024) k_row_c2r(RowC2RParamsT<C> p)
 // [W/2, (2u-1) uW / 2u) of VR:1497-1498.
 // grid (H, 3); dynamic LDS = 2 * lpad_size(W) complex
 template <int MODE, typename C = float2>
-__global__ void __launch_bounds__(1024) k_row_c2c_fwd(RowR2CParamsT<C> p)
+__global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_c2c_fwd(RowR2CParamsT<C> p)
 {
     using S = scalar_t<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -226,7 +230,7 @@ __global__ void __launch_bounds__(1024) k_row_c2c_fwd(RowR2CParamsT<C> p)
 
 // grid (uH, 3); dynamic LDS = 2 * lpad_size(uW) complex.  R: complex [3][uH][uW].
 template <typename C = float2>
-__global__ void __launch_bounds__(1024) k_row_c2c_inv(RowC2RParamsT<C> p)
+__global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_c2c_inv(RowC2RParamsT<C> p)
 {
     using S = scalar_t<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
