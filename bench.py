@@ -27,6 +27,7 @@ PRESETS = {
     "config2": dict(width=2048, height=1024, precision=0, fuse_u8=False),
     "config3": dict(width=2048, height=1024, precision=2, fuse_u8=True),
     "config4": dict(width=1920, height=1080, precision=0, fuse_u8=False),
+    "720p": dict(width=1280, height=720, precision=0, fuse_u8=False),          # not a BASELINE config: second mixed-radix plan
     # 512 synthetic 2048x1024 frames, -u 2 -p 2, sharded over 8 GPUs: 64 frames per rank and step
     "config5": dict(width=2048, height=1024, precision=2, fuse_u8=True, frames_per_step=64),
 }

@@ -234,7 +234,7 @@ def _report(tag, err, thr):
 
 
 FULL_SIZE = [(2048, 1024, 0, 0), (2048, 1024, 0, 2), (1920, 1080, 0, 0), (1920, 1080, 0, 2), (2048, 1024, 2, 0), (2048, 1024, 2, 2),
-             (1920, 1080, 2, 2)]
+             (1920, 1080, 2, 2), (1280, 720, 0, 0), (1280, 720, 0, 2), (1280, 720, 2, 0), (1280, 720, 2, 2)]
 
 
 @pytest.mark.parametrize("W,H,precision,flags", FULL_SIZE)
@@ -348,11 +348,15 @@ def test_golden_vectors_gpu(name):
         assert np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 8e-3
 
 
-def test_mixed_radix_plans_equal_generic():
-    """compile-time 1920x1080 plans (radix 8/4/3/5) vs the size-generic kernels on the same frame"""
+@pytest.mark.parametrize("W,H", [(1920, 1080), (1280, 720)])
+def test_mixed_radix_plans_equal_generic(W, H):
+    """compile-time mixed-radix plans (1920x1080: 15*8*16 / 9*10*12 / 16*16*15; 1280x720: 5*16*16 / 9*8*10 / 16*16*10)
+    vs the size-generic kernels on the same frame"""
     from vkresample_amd import FLAG_GENERIC_KERNELS
-    (pre, out, u8), _ = _run(1920, 1080, 2.0, 0, "N", seed=5)
-    (pre2, out2, u82), _ = _run(1920, 1080, 2.0, 0, "N", seed=5, flags=FLAG_GENERIC_KERNELS)
+    with _up(W, H, 2.0, 0) as up:
+        assert up.tuned
+    (pre, out, u8), _ = _run(W, H, 2.0, 0, "N", seed=5)
+    (pre2, out2, u82), _ = _run(W, H, 2.0, 0, "N", seed=5, flags=FLAG_GENERIC_KERNELS)
     assert np.abs(pre - pre2).max() * 4 <= 2e-6
     assert np.abs(out - out2).max() <= 1e-4
 
@@ -627,7 +631,7 @@ def _run_env(env, W, H, precision, dist="N", flags=0):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("W,H", [(512, 256), (2048, 1024), (1920, 1080)])
+@pytest.mark.parametrize("W,H", [(512, 256), (2048, 1024), (1920, 1080), (1280, 720)])
 @pytest.mark.parametrize("precision", [0, 2])
 def test_fused_output_independent_of_strip_length(W, H, precision):
     """The fused C2R+sharpen kernel cuts the frame into strips of row pairs; every strip recomputes one halo pair, keeps

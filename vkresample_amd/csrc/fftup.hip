@@ -72,7 +72,7 @@ struct fftup_plan {
     float upsq = 0, coef = 0;
     bool tuned = false;
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
-    bool mixed1080 = false;           // compile-time mixed-radix plans (1920x1080 -> 3840x2160)
+    int mixed = 0;                    // compile-time mixed-radix plans: 1 = 1920x1080 -> 3840x2160, 2 = 1280x720 -> 2560x1440
     bool plan3840_x16 = true;         // 1080p: fused kernel on the 16*16*15 plan (256 threads, 120 VGPRs); false: 8*8*4*15 on 512 threads
     bool cplx = false;                // non-R2C path (VR:1424 false): full complex transforms, uW beyond the R2C limit
     int ncols = 0;                    // spectrum columns kept: W/2 + 1, or W on the non-R2C path
@@ -314,10 +314,12 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             }
         }
         if (!P->TK) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled height too large for LDS"); goto bad; }
-        P->mixed1080 = !P->dbl && !P->tuned && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && W == 1920 && H == 1080 && uW == 3840 &&
-                       uH == 2160 && P->TK == 4;
-        if (P->mixed1080) P->ldsCol = sizeof(float2) * (size_t)H * 4;                        // k_col_m1080: one in-place buffer
-        P->fused = (P->tuned || P->mixed1080) && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
+        if (!P->dbl && !cplx && !P->tuned && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && uW == 2 * W && uH == 2 * H && P->TK >= 4) {
+            if (W == MixedCfg1080::W && H == MixedCfg1080::H) P->mixed = 1;
+            if (W == MixedCfg720::W && H == MixedCfg720::H) P->mixed = 2;
+        }
+        if (P->mixed) { P->TK = 4; P->ldsCol = sizeof(float2) * (size_t)H * 4; }             // k_col_m: one in-place buffer
+        P->fused = (P->tuned || P->mixed) && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
         {
             // One strip (workgroup of uW/8 threads) per compute unit: the rest of every compute unit is left to the row and
             // column kernels of the frames on the other streams, and the frame time is what counts.
@@ -364,7 +366,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         // kernel addresses both with 32-bit offsets from one base)
         const size_t s1_elems = (size_t)3 * P->NT * H * P->TK;
         auto alloc_spectra = [&](float2** s1, float2** s2) -> int {
-            if (P->tuned || P->mixed1080) {
+            if (P->tuned || P->mixed) {
                 int r = dev_alloc(P, (void**)s1, P->csz * 2 * s1_elems);
                 *s2 = r ? nullptr : *s1 + s1_elems;
                 return r;
@@ -417,21 +419,17 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             SET_LDS((k_col<1, double2>), P->ldsCol);
             SET_LDS((k_row_c2r<false, double2>), P->ldsRowI);
         }
-        if (P->mixed1080) {
-            SET_LDS(k_col_m1080, P->ldsCol);
-            SET_LDS((k_row_c2r_ct<Plan3840, false>), P->ldsRowI);
-            SET_LDS((k_row_c2r_ct<Plan3840, true>), P->ldsRowI);
-            SET_LDS((k_c2r_sharpen_g<FusedPlan3840, false, 4>), FusedGLds<FusedPlan3840>::TOTAL);
-            SET_LDS((k_c2r_sharpen_g<FusedPlan3840, true, 4>), FusedGLds<FusedPlan3840>::TOTAL);
-            SET_LDS((k_c2r_sharpen_g<FusedPlan3840x16, false, 4>), FusedGLds<FusedPlan3840x16>::TOTAL);
-            SET_LDS((k_c2r_sharpen_g<FusedPlan3840x16, true, 4>), FusedGLds<FusedPlan3840x16>::TOTAL);
-        }
+#define SET_FUSED(PL, TKK) SET_LDS((k_c2r_sharpen_g<PL, false, TKK>), FusedGLds<PL>::TOTAL); SET_LDS((k_c2r_sharpen_g<PL, true, TKK>), FusedGLds<PL>::TOTAL)
+#define SET_MIXED(CFG) SET_LDS(k_col_m<CFG>, P->ldsCol); SET_LDS((k_row_c2r_ct<CFG::CT, false>), P->ldsRowI); \
+        SET_LDS((k_row_c2r_ct<CFG::CT, true>), P->ldsRowI); SET_FUSED(CFG::FUSED, 4)
+        if (P->mixed == 1) { SET_MIXED(MixedCfg1080); SET_FUSED(FusedPlan3840, 4); }
+        if (P->mixed == 2) { SET_MIXED(MixedCfg720); }
+#undef SET_MIXED
         if (P->tuned) {
             switch (uW) {
-#define SET_FUSED(PL) SET_LDS((k_c2r_sharpen_g<PL, false, TUNED_TK>), FusedGLds<PL>::TOTAL); SET_LDS((k_c2r_sharpen_g<PL, true, TUNED_TK>), FusedGLds<PL>::TOTAL)
-            case 1024: SET_FUSED(FusedPlanPow2<1024>); break;
-            case 2048: SET_FUSED(FusedPlanPow2<2048>); break;
-            default: SET_FUSED(FusedPlanPow2<4096>); break;
+            case 1024: SET_FUSED(FusedPlanPow2<1024>, TUNED_TK); break;
+            case 2048: SET_FUSED(FusedPlanPow2<2048>, TUNED_TK); break;
+            default: SET_FUSED(FusedPlanPow2<4096>, TUNED_TK); break;
             }
             switch (H) {
             case 256: SET_LDS((k_col_t<256, TUNED_TK>), P->ldsCol); break;
@@ -439,6 +437,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             default: SET_LDS((k_col_t<1024, TUNED_TK>), P->ldsCol); break;
             }
         }
+#undef SET_FUSED
 #undef SET_LDS
     }
     *out = P;
@@ -457,7 +456,7 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
     info->out_width = P->uW;
     info->out_height = P->uH;
     info->num_kernels = P->fused ? 3 : 4;
-    info->tuned = (P->tuned || P->mixed1080) ? 1 : 0;
+    info->tuned = (P->tuned || P->mixed) ? 1 : 0;
     // B_alg = in + 2*S1 + 2*S2 + 2*R + out
     const double C = 3.0, W = P->W, H = P->H, uW = P->uW, uH = P->uH;
     const bool fused_u8 = fuse_u8(P);
@@ -478,7 +477,7 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
     {
         // what the launches really have to move: polyphase plans write/read only the odd half of S2; a fused strip
         // re-reads one halo pair of spectrum rows
-        const bool poly = P->tuned || P->mixed1080;
+        const bool poly = P->tuned || P->mixed;
         const double S2w = poly ? S1 : S2;                            // odd rows only
         const double halo = P->fused ? (double)(P->pairs_per_strip + 1) / P->pairs_per_strip : 1.0;
         info->kernel_min_bytes[0] = in + S1;
@@ -760,6 +759,29 @@ template <typename C> static int launch_frame_cplx(fftup_plan* P, uint32_t in_sl
     return FFTUP_OK;
 }
 
+// row R2C / stand-alone C2R launches of the register-resident mixed-radix plans (kernels_mixed.hpp)
+template <class CFG> static void launch_row_mixed(fftup_plan* P, uint32_t in_slot, int kind)
+{
+    RowR2CTParams q{};
+    q.S1 = P->lanes[P->cur].S1; q.tw = P->twW; q.H = (int)P->H; q.NT = P->NT;
+    int mode;
+    if (kind == 2) { q.in = P->in_u8[in_slot]; q.in_row_stride = 3l * P->W; q.in_plane_stride = 0; mode = P->half ? IN_U8_F16 : IN_U8_F32; }
+    else { q.in = P->in_planar[in_slot]; q.in_row_stride = P->W; q.in_plane_stride = (long)P->in_plane_stride; mode = P->half ? IN_F16 : IN_F32; }
+    hipStream_t st = P->lanes[P->cur].stream;
+    const dim3 grid(P->H / 2, 3), block(CFG::ROW_T);
+    switch (mode) {
+    case IN_F32: hipLaunchKernelGGL((k_row_r2c_m<CFG, IN_F32>), grid, block, 0, st, q); break;
+    case IN_F16: hipLaunchKernelGGL((k_row_r2c_m<CFG, IN_F16>), grid, block, 0, st, q); break;
+    case IN_U8_F32: hipLaunchKernelGGL((k_row_r2c_m<CFG, IN_U8_F32>), grid, block, 0, st, q); break;
+    default: hipLaunchKernelGGL((k_row_r2c_m<CFG, IN_U8_F16>), grid, block, 0, st, q); break;
+    }
+}
+template <class CT> static void launch_c2r_ct(fftup_plan* P, dim3 grid, const RowC2RParams& p)
+{
+    if (P->half) hipLaunchKernelGGL((k_row_c2r_ct<CT, true>), grid, dim3(CT::T), P->ldsRowI, P->lanes[P->cur].stream, p);
+    else hipLaunchKernelGGL((k_row_c2r_ct<CT, false>), grid, dim3(CT::T), P->ldsRowI, P->lanes[P->cur].stream, p);
+}
+
 static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
 {
     const int kind = P->in_kind[in_slot];
@@ -778,19 +800,8 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         p.S1 = P->lanes[P->cur].S1; p.tw = P->twW; p.plan = P->planW; p.W = (int)P->W; p.H = (int)P->H;
         p.TK = P->TK; p.NT = P->NT;
         dim3 grid(P->H / 2, 3), block(P->thrW);
-        if (P->mixed1080) {
-            RowR2CTParams q{};
-            q.S1 = P->lanes[P->cur].S1; q.tw = P->twW; q.H = (int)P->H; q.NT = P->NT;
-            int mode;
-            if (kind == 2) { q.in = P->in_u8[in_slot]; q.in_row_stride = 3l * P->W; q.in_plane_stride = 0; mode = P->half ? IN_U8_F16 : IN_U8_F32; }
-            else { q.in = P->in_planar[in_slot]; q.in_row_stride = P->W; q.in_plane_stride = (long)P->in_plane_stride; mode = P->half ? IN_F16 : IN_F32; }
-            hipStream_t st = P->lanes[P->cur].stream;
-            switch (mode) {
-            case IN_F32: hipLaunchKernelGGL((k_row_r2c_m1920<IN_F32>), grid, dim3(256), 0, st, q); break;
-            case IN_F16: hipLaunchKernelGGL((k_row_r2c_m1920<IN_F16>), grid, dim3(256), 0, st, q); break;
-            case IN_U8_F32: hipLaunchKernelGGL((k_row_r2c_m1920<IN_U8_F32>), grid, dim3(256), 0, st, q); break;
-            default: hipLaunchKernelGGL((k_row_r2c_m1920<IN_U8_F16>), grid, dim3(256), 0, st, q); break;
-            }
+        if (P->mixed) {
+            if (P->mixed == 1) launch_row_mixed<MixedCfg1080>(P, in_slot, kind); else launch_row_mixed<MixedCfg720>(P, in_slot, kind);
         } else if (kind == 2) {
             p.in = P->in_u8[in_slot]; p.in_row_stride = 3l * P->W; p.in_plane_stride = 0;
             if (P->half) hipLaunchKernelGGL(k_row_r2c<IN_U8_F16>, grid, block, P->ldsRowF, P->lanes[P->cur].stream, p);
@@ -807,10 +818,11 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.ncols = P->ncols; p.zly = P->zly; p.zry = P->zry;
         p.inv_norm = 1.0f / (float)P->uH;
         dim3 grid(P->NT, 3), block(P->thrCol);
-        if (P->mixed1080) {
+        if (P->mixed) {
             ColTParams q{};
             q.S1 = P->lanes[P->cur].S1; q.S2 = P->lanes[P->cur].S2; q.twH = P->twH; q.twUH = P->twUH; q.W = (int)P->W; q.NT = P->NT;
-            hipLaunchKernelGGL(k_col_m1080, grid, dim3(480), P->ldsCol, P->lanes[P->cur].stream, q);
+            if (P->mixed == 1) hipLaunchKernelGGL(k_col_m<MixedCfg1080>, grid, dim3(4 * MixedCfg1080::COL_TPC), P->ldsCol, P->lanes[P->cur].stream, q);
+            else hipLaunchKernelGGL(k_col_m<MixedCfg720>, grid, dim3(4 * MixedCfg720::COL_TPC), P->ldsCol, P->lanes[P->cur].stream, q);
         } else switch (P->TK) {
         case 8: hipLaunchKernelGGL(k_col<8>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
         case 4: hipLaunchKernelGGL(k_col<4>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
@@ -819,8 +831,9 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         }
     }
     if ((which < 0 || which == 2) && P->fused) {
-        if (P->plan3840_x16) launch_fused_t<FusedPlan3840x16>(P, fused_params(P, out_slot));
-        else launch_fused_t<FusedPlan3840>(P, fused_params(P, out_slot));       // (only the 3840 plans are fused on this path)
+        if (P->mixed == 2) launch_fused_t<MixedCfg720::FUSED>(P, fused_params(P, out_slot));
+        else if (P->plan3840_x16) launch_fused_t<MixedCfg1080::FUSED>(P, fused_params(P, out_slot));
+        else launch_fused_t<FusedPlan3840>(P, fused_params(P, out_slot));       // (only the mixed plans are fused on this path)
         P->R_valid = false;
     } else if (which < 0 || which == 2 || which == 22) {                 // 22: pre-sharpen tap requested for a fused plan
         RowC2RParams p{};
@@ -828,9 +841,8 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         p.uH = (int)P->uH; p.TK = P->TK; p.NT = P->NT; p.zlx = P->zlx; p.zrx = P->zrx;
         p.inv_norm = 1.0f / (float)P->uW;
         dim3 grid(P->uH / 2, 3), block(P->thrUW);
-        if (P->mixed1080) {
-            if (P->half) hipLaunchKernelGGL((k_row_c2r_ct<Plan3840, true>), grid, dim3(Plan3840::T), P->ldsRowI, P->lanes[P->cur].stream, p);
-            else hipLaunchKernelGGL((k_row_c2r_ct<Plan3840, false>), grid, dim3(Plan3840::T), P->ldsRowI, P->lanes[P->cur].stream, p);
+        if (P->mixed) {
+            if (P->mixed == 1) launch_c2r_ct<MixedCfg1080::CT>(P, grid, p); else launch_c2r_ct<MixedCfg720::CT>(P, grid, p);
         } else if (P->half) hipLaunchKernelGGL(k_row_c2r<true>, grid, block, P->ldsRowI, P->lanes[P->cur].stream, p);
         else hipLaunchKernelGGL(k_row_c2r<false>, grid, block, P->ldsRowI, P->lanes[P->cur].stream, p);
         P->R_valid = true;

@@ -1,7 +1,7 @@
-// kernels_mixed.hpp -- kernels for the mixed-radix sizes of BASELINE config 4 (1920x1080 -> 3840x2160):
-//   * register-resident row R2C (1920 = 15*8*16) and polyphase column (1080 = 9*8*15) kernels on the three-stage engine
-//     MrFftT of kernels_pow2.hpp; the fused C2R+sharpen kernel for 3840 is k_c2r_sharpen_g<FusedPlan3840>;
-//   * a stand-alone C2R for 3840 with compile-time radix-8/8/4/3/5 LDS ping-pong stages (two-launch path, pre-sharpen tap).
+// kernels_mixed.hpp -- kernels for the mixed-radix sizes (1920x1080 -> 3840x2160 = BASELINE config 4, 1280x720 -> 2560x1440):
+//   * register-resident row R2C (1920 = 15*8*16, 1280 = 5*16*16) and polyphase column (1080 = 9*10*12, 720 = 9*8*10) kernels
+//     on the three-stage engine MrFftT of kernels_pow2.hpp; the fused C2R+sharpen kernel is k_c2r_sharpen_g<FusedPlanMr16<..>>;
+//   * a stand-alone C2R with compile-time radix LDS ping-pong stages (two-launch path, pre-sharpen tap).
 #pragma once
 #include "fft_engine.hpp"
 #include "kernels_generic.hpp"
@@ -84,15 +84,18 @@ __global__ void __launch_bounds__(PUW::T) k_row_c2r_ct(RowC2RParams p)
     }
 }
 
-// =================================================================================== register-resident 1080p kernels
+// =================================================================================== register-resident mixed-radix kernels
 // One butterfly per thread and stage, the points in registers, one in-place LDS buffer (MrFftT in kernels_pow2.hpp).
+// A size is described by a configuration struct (MixedCfg1080, MixedCfg720 below): row radices (first one odd: the
+// stage-0 scatter then spreads over all LDS slots without an index map), column radices, threads per column.
 
-// ---- row R2C, W = 1920 = 15 * 8 * 16.  grid (H/2, 3), block 256, LDS W float2.
-template <int MODE>
-__global__ void __launch_bounds__(256) k_row_r2c_m1920(RowR2CTParams p)
+// ---- row R2C, W = RR0 * RR1 * RR2.  grid (H/2, 3), block CFG::ROW_T, LDS W float2.
+template <class CFG, int MODE>
+__global__ void __launch_bounds__(CFG::ROW_T) k_row_r2c_m(RowR2CTParams p)
 {
-    constexpr int W = 1920, TK = 4;
-    using F = MrFftT<W, +1, 1, 15, 8, 16, true>;
+    constexpr int W = CFG::W, TK = 4, T = CFG::ROW_T, R0 = CFG::RR0;
+    using F = MrFftT<W, +1, 1, CFG::RR0, CFG::RR1, CFG::RR2, true>;
+    static_assert(T >= F::NB0 && T >= F::NB1 && T >= F::NB2, "one butterfly per thread and stage");
     __shared__ float2 buf[W];
     const int tid = threadIdx.x, c = blockIdx.y, j = blockIdx.x;
     typename F::Tw tw;
@@ -100,7 +103,7 @@ __global__ void __launch_bounds__(256) k_row_r2c_m1920(RowR2CTParams p)
     float2 v[F::VN];
     if (tid < F::NB0) {
 #pragma unroll
-        for (int m = 0; m < 15; m++)
+        for (int m = 0; m < R0; m++)
             v[m] = make_float2(load_px_t<MODE>(p, c, 2 * j, tid + F::NB0 * m), load_px_t<MODE>(p, c, 2 * j + 1, tid + F::NB0 * m));
     }
     F::run(v, buf, tid, 0, tw);
@@ -108,7 +111,7 @@ __global__ void __launch_bounds__(256) k_row_r2c_m1920(RowR2CTParams p)
     const long tile_stride = (long)p.H * TK;
     float2* base = p.S1 + (long)c * p.NT * tile_stride + (long)(2 * j) * TK;
     constexpr int NTILE = (W / 2 + 1 + TK - 1) / TK;
-    for (int g = tid; g < NTILE * TK; g += 256) {
+    for (int g = tid; g < NTILE * TK; g += T) {
         const int tile = g / TK, l = g % TK;
         const bool isB = l >= TK / 2;
         const int kk = (l % (TK / 2)) * 2;
@@ -127,15 +130,17 @@ __global__ void __launch_bounds__(256) k_row_r2c_m1920(RowR2CTParams p)
     }
 }
 
-// ---- column, H = 1080 = 9 * 10 * 12, polyphase form (k_col_t): forward, phase, inverse, odd rows out.
-// Balanced radices: 120 / 108 / 90 butterflies per column and stage on 120 threads (9 * 8 * 15 would need 135 threads
-// per column and leave half of them idle in its radix-15 stage), 8 waves, which fit beside a fused-kernel strip.
-// grid (NT, 3), block 480 (4 columns x 120), LDS H*4 float2.
-__global__ void __launch_bounds__(480) k_col_m1080(ColTParams p)
+// ---- column, H = CR0 * CR1 * CR2, polyphase form (k_col_t): forward, phase, inverse, odd rows out.
+// grid (NT, 3), block 4 * CFG::COL_TPC (4 columns x threads per column), LDS H*4 float2.
+// 1080 = 9 * 10 * 12: balanced radices, 120 / 108 / 90 butterflies per column and stage on 120 threads (9 * 8 * 15 would
+// need 135 threads per column and leave half of them idle in its radix-15 stage), 8 waves, which fit beside a strip.
+template <class CFG>
+__global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_m(ColTParams p)
 {
-    constexpr int H = 1080, TK = 4;
-    using FF = MrFftT<H, +1, TK, 9, 10, 12, true>;
-    using FI = MrFftT<H, -1, TK, 9, 10, 12, false>;
+    constexpr int H = CFG::H, TK = 4, R0 = CFG::CR0, R2 = CFG::CR2;
+    using FF = MrFftT<H, +1, TK, CFG::CR0, CFG::CR1, CFG::CR2, true>;
+    using FI = MrFftT<H, -1, TK, CFG::CR0, CFG::CR1, CFG::CR2, false>;
+    static_assert(CFG::COL_TPC >= FF::NB0 && CFG::COL_TPC >= FF::NB1 && CFG::COL_TPC >= FF::NB2, "one butterfly per thread and stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* buf = (float2*)smem;
     const int tid = threadIdx.x, col = tid % TK, j = tid / TK;
@@ -148,21 +153,17 @@ __global__ void __launch_bounds__(480) k_col_m1080(ColTParams p)
     float2 v[FF::VN];
     if (j < FF::NB0) {
 #pragma unroll
-        for (int m = 0; m < 9; m++) v[m] = valid ? src[(j + FF::NB0 * m) * TK + col] : make_float2(0.f, 0.f);
+        for (int m = 0; m < R0; m++) v[m] = valid ? src[(j + FF::NB0 * m) * TK + col] : make_float2(0.f, 0.f);
     }
     FF::run(v, buf, j, col, tw);                             // F[k] in natural order in LDS
     if (j < FI::NB0) {
-        // t[k] = exp(-2 pi i k/2H) * (k < H/2 ? 1 : -1), k = j + 120 m: exp(-2 pi i j/2H) times the 18th roots of unity
+        // t[k] = exp(-2 pi i k/2H) * (k < H/2 ? 1 : -1), k = j + NB0 m: exp(-2 pi i j/2H) times the (2 R0)-th roots of
+        // unity exp(-2 pi i m/2R0) (NB0/2H = 1/2R0), taken from the same table: twUH[NB0 m]
         const float2 w = twid<-1>(ph);
 #pragma unroll
-        for (int m = 0; m < 9; m++) {
+        for (int m = 0; m < R0; m++) {
             const float2 f = buf[(j + FI::NB0 * m) * TK + col];
-            // k >= H/2 = 540 <=> m >= 5 (j < 120) except m = 4 with j >= 60: handled by the runtime sign below
-            constexpr float c18[9] = {1.f, 0.93969262078590838f, 0.76604444311897804f, 0.5f, 0.17364817766693035f,
-                                      -0.17364817766693035f, -0.5f, -0.76604444311897804f, -0.93969262078590838f};
-            constexpr float s18[9] = {0.f, 0.34202014332566873f, 0.64278760968653933f, 0.86602540378443865f, 0.98480775301220806f,
-                                      0.98480775301220806f, 0.86602540378443865f, 0.64278760968653933f, 0.34202014332566873f};
-            float2 t = cmul(w, make_float2(c18[m], -s18[m]));
+            float2 t = (m == 0) ? w : cmul(w, twid<-1>(p.twUH[FI::NB0 * m]));
             if (j + FI::NB0 * m >= H / 2) t = make_float2(-t.x, -t.y);
             v[m] = cmul(f, t);
         }
@@ -173,11 +174,26 @@ __global__ void __launch_bounds__(480) k_col_m1080(ColTParams p)
     constexpr float inv = 1.0f / (float)H;
     if (j < FI::NB2 && valid) {
 #pragma unroll
-        for (int m = 0; m < 12; m++) dst[(j + FI::NB2 * m) * TK + col] = cscale(v[m], inv);
+        for (int m = 0; m < R2; m++) dst[(j + FI::NB2 * m) * TK + col] = cscale(v[m], inv);
     }
 }
 
-// the stand-alone C2R of the 1080p plan (two-launch path and pre-sharpen tap)
+// ---- the sizes.  CT = the stand-alone C2R plan (two-launch path and pre-sharpen tap), FUSED = the default fused plan.
 using Plan3840 = CtPlan<3840, 512, 8, 8, 4, 3, 5>;
+using Plan2560 = CtPlan<2560, 512, 8, 8, 8, 5>;
+struct MixedCfg1080 {                 // 1920 x 1080 -> 3840 x 2160 (BASELINE config 4)
+    static constexpr int W = 1920, H = 1080;
+    static constexpr int RR0 = 15, RR1 = 8, RR2 = 16, ROW_T = 256;
+    static constexpr int CR0 = 9, CR1 = 10, CR2 = 12, COL_TPC = 120;
+    using CT = Plan3840;
+    using FUSED = FusedPlan3840x16;
+};
+struct MixedCfg720 {                  // 1280 x 720 -> 2560 x 1440
+    static constexpr int W = 1280, H = 720;
+    static constexpr int RR0 = 5, RR1 = 16, RR2 = 16, ROW_T = 256;
+    static constexpr int CR0 = 9, CR1 = 8, CR2 = 10, COL_TPC = 90;
+    using CT = Plan2560;
+    using FUSED = FusedPlanMr16<2560, 10>;
+};
 
 }  // namespace fftup

@@ -1228,21 +1228,24 @@ struct FusedPlan3840 {                                      // 1920x1080 -> 3840
         F::template run<NBUF == 2>(v, buf, zbuf, j, t);
     }
 };
-struct FusedPlan3840x16 {                                   // the same rows as 16 * 16 * 15 on 256 threads, 120 VGPRs: the default (fftup.hip)
-    using F = MrFft<3840, -1, 16, 16, 15>;
-    static constexpr int UW = 3840, T = 256, R0 = 16, NB0 = F::NB0, EOUT = 15, SOUT = F::NB2, VN = F::VN;
-    static constexpr size_t XB = (sizeof(float2) * lpad_size(3840) + 15) & ~(size_t)15;
-    using Tw = F::Tw;
-    static __device__ __forceinline__ int first_index(int lt) { return lt < NB0 ? lt : NB0 - 1; }   // (threads beyond re-read)
-    static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { F::load_tw(w, tw, j); }
 #ifndef FFTUP_3840X16_NBUF
 #define FFTUP_3840X16_NBUF 2
 #endif
 #ifndef FFTUP_3840X16_RR
 #define FFTUP_3840X16_RR 1
 #endif
+// Rows of UW = 16 * 16 * R2 = 256 * R2 points on 256 threads -- one wave per SIMD -- R2 points per thread in the last stage
+// (3840: R2 = 15, the default for 1920x1080; 2560: R2 = 10 for 1280x720).  120 VGPRs + the ring rows.
+template <int UW_, int R2_> struct FusedPlanMr16 {
+    using F = MrFft<UW_, -1, 16, 16, R2_>;
+    static constexpr int UW = UW_, T = 256, R0 = 16, NB0 = F::NB0, EOUT = R2_, SOUT = F::NB2, VN = F::VN;
+    static_assert(F::NB2 == T && F::NB0 <= T && F::NB1 <= T, "one butterfly per thread and stage, all threads in the last one");
+    static constexpr size_t XB = (sizeof(float2) * lpad_size(UW) + 15) & ~(size_t)15;
+    using Tw = typename F::Tw;
+    static __device__ __forceinline__ int first_index(int lt) { return lt < NB0 ? lt : NB0 - 1; }   // (threads beyond re-read)
+    static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { F::load_tw(w, tw, j); }
     // NBUF = 3 (first exchange through z, second through the L-row buffer: 4 barriers per step instead of 6) changes
-    // nothing for the kernel alone (77 us) and costs 98 instead of 65 KB of LDS: frame 75 -> 87 us.  Kept at 2.
+    // nothing for the kernel alone (77 us at 3840) and costs 98 instead of 65 KB of LDS: frame 75 -> 87 us.  Kept at 2.
     static constexpr int NBUF = FFTUP_3840X16_NBUF;
     static constexpr bool RING_REGS = FFTUP_3840X16_RR;
     static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w)
@@ -1250,6 +1253,7 @@ struct FusedPlan3840x16 {                                   // the same rows as 
         F::fft(v, buf, NBUF == 3 ? zbuf : buf, j, w);
     }
 };
+using FusedPlan3840x16 = FusedPlanMr16<3840, 15>;
 
 // ---------------------------------------------------------------------------------------------------
 // Fused C2R + sharpen: a workgroup of T = UW/8 threads owns a strip and alternates, all
