@@ -71,6 +71,8 @@ typedef struct fftup_config {
  *                            (default 3, 1..4); fftup_execute always uses one
  *   FFTUP_G_PER_CU=n         strips (workgroups) of the fused C2R+sharpen kernel per compute unit (default 1)
  *   FFTUP_PAIRS_PER_STRIP=n  row pairs per workgroup of the fused C2R+sharpen kernel (default: pairs / compute units)
+ *   FFTUP_JIT=0|1            run-time specialised plans (default 1); FFTUP_JIT_VERBOSE=1 prints why one fell back;
+ *                            FFTUP_KERNEL_DIR / FFTUP_CACHE_DIR: kernel headers / code-object cache (jit.hpp)
  *   FFTUP_3840_X16=0|1       1920x1080 -u 2: fused kernel on the 16*16*15 plan, 256 threads (1, default) or the
  *                            8*8*4*15 plan, 512 threads (0); same results up to fp32 rounding (tests) */
 
@@ -82,7 +84,7 @@ enum { FFTUP_NUM_KERNELS = 4 };          /* row R2C, column fwd+pad+inv, row C2R
 typedef struct fftup_info {
     uint32_t out_width, out_height;      /* uW, uH                                                */
     uint32_t num_kernels;                /* launches per frame                                    */
-    uint32_t tuned;                      /* 1 if size-specialised kernels are in use              */
+    uint32_t tuned;                      /* 1: ahead-of-time size-specialised kernels, 2: specialised at plan time (hipRTC), 0: size-generic */
     double   alg_bytes_per_frame;        /* B_alg of SURVEY 8(d) for this plan's I/O types        */
     double   kernel_alg_bytes[FFTUP_NUM_KERNELS]; /* algorithmic bytes of each kernel: a fused C2R+sharpen
                                                      launch keeps S2 + 2R + out although R never reaches HBM          */
@@ -103,6 +105,16 @@ FFTUP_API int fftup_plan_create(fftup_plan** out, const fftup_config* cfg);
 /* deleteVulkanFFT x2, deleteShiftApp x2, buffer frees (VR:1759-1771) */
 FFTUP_API void fftup_plan_destroy(fftup_plan* plan);
 FFTUP_API int fftup_plan_info(const fftup_plan* plan, fftup_info* info);
+
+/* Run-time specialised plans (csrc/jit.hpp; the counterpart of VkFFT generating and compiling its shaders for the
+ * requested size at plan time, VF:4707-5189 + the GLSL generator, glslang in VkResample's link line).  A -u 2 plan
+ * (-p 0 / -p 2) whose size has no ahead-of-time kernels gets its row, column and fused C2R+sharpen kernels
+ * instantiated for exactly that size through hipRTC inside fftup_plan_create; fftup_info.tuned is then 2.  FFTUP_JIT=0
+ * or FFTUP_FLAG_GENERIC_KERNELS keeps such plans on the size-generic kernels (as does a missing libhiprtc.so).
+ * fftup_jit_check does the same WITHOUT a device: picks the factorizations, compiles for `arch` (NULL: gfx950) and
+ * writes a one-line description.  FFTUP_E_UNSUPPORTED_SIZE: no specialised factorization (the generic kernels run that
+ * size); FFTUP_E_HIP: hipRTC unavailable or compilation failed (fftup_last_error has the log). */
+FFTUP_API int fftup_jit_check(uint32_t width, uint32_t height, uint32_t precision, const char* arch, char* desc, size_t desclen);
 
 /* host pack loop + transferDataFromCPU (VR:1636-1688).  rgb: interleaved 8-bit RGB, H rows of
  * row_stride_bytes (>= 3*W).  Blocking, like the reference. */

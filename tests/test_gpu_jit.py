@@ -1,0 +1,103 @@
+"""Run-time specialised plans (csrc/jit.hpp): a -u 2 size without ahead-of-time kernels gets its row, column and fused
+C2R+sharpen kernels instantiated through hipRTC at plan time.  Parity against the oracle (same tolerances as
+test_gpu_parity.test_full_size_vs_oracle) and against the size-generic kernels on the same frame, for sizes that
+exercise every plan family: three-stage mixed-radix rows/columns, power-of-two rows/columns, the 16*16*R fused plans,
+the N-stage fused plans (four stages, several butterflies per thread), the stand-alone C2R of the pre-sharpen tap."""
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+from test_gpu_parity import _rel_l2, _report, _run, _up
+
+pytestmark = pytest.mark.gpu
+
+# (W, H): row plan / column plan / fused plan as chosen by jit.hpp
+JIT_SIZES = [
+    (640, 480),     # 10*8*8 / 5*8*12 / 16*16*5
+    (720, 576),     # 9*8*10 / 9*8*8 / 12*8*15 on 128 threads
+    (1000, 1000),   # 10*10*10 (even first radix) / 10*10*10 / 8*5*5*10 (four stages)
+    (1024, 768),    # power of two / 8*8*12 / FusedPlanPow2<2048>
+    (1280, 1024),   # 10*8*16 / power of two / 16*16*10
+    (1600, 900),    # 10*10*16 / 9*10*10 / 16*2*10*10: 5 butterflies of radix 2 per thread
+    (896, 504),     # radix 7: 7*8*16 / 7*8*9 / 16*16*7
+    (128, 64),      # smallest sizes that are specialised
+]
+
+
+@pytest.mark.parametrize("W,H", JIT_SIZES)
+@pytest.mark.parametrize("precision,flags", [(0, 0), (0, 2), (2, 2)])
+def test_specialised_plan_vs_oracle(W, H, precision, flags):
+    with _up(W, H, 2.0, precision, 0.2, 0, flags) as up:
+        assert up.tuned and up.specialised_at_plan_time, "plan fell back to the size-generic kernels"
+    (pre, out, u8), (opre, oout, ou8) = _run(W, H, 2.0, precision, "N", flags=flags, seed=W + H)
+    tag = "jit %dx%d p%d flags%d" % (W, H, precision, flags)
+    if precision == 0:
+        so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 1e-4)
+        assert _rel_l2(pre, opre) <= 1e-5 and np.abs(pre - opre).max() * 4 <= 1e-4
+        assert so["p99.99"] <= 1e-4 and so["max"] <= 1e-3 and so["count_above"] <= 1e-4 * so["n"]
+        d = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
+        assert d.max() <= 1 and (d != 0).mean() <= 5e-3
+    else:
+        ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
+        assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
+        so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 2.0 ** -10)
+        assert so["max"] <= 8e-3 and so["p99"] <= 2.0 ** -10 and so["p99.99"] <= 4e-3
+
+
+@pytest.mark.parametrize("W,H", [(640, 480), (1000, 1000), (1600, 900)])
+def test_specialised_equals_generic(W, H):
+    """same frame through the specialised plan and through the size-generic kernels (FFTUP_FLAG_GENERIC_KERNELS)"""
+    from vkresample_amd import FLAG_GENERIC_KERNELS
+    (pre, out, _), _ = _run(W, H, 2.0, 0, "U", seed=3)
+    with _up(W, H, 2.0, 0, 0.2, 0, FLAG_GENERIC_KERNELS) as up:
+        assert not up.tuned
+    (pre2, out2, _), _ = _run(W, H, 2.0, 0, "U", seed=3, flags=FLAG_GENERIC_KERNELS)
+    assert np.abs(pre - pre2).max() * 4 <= 4e-6
+    assert np.percentile(np.abs(out - out2), 99.99) <= 1e-5
+
+
+def test_specialisation_can_be_switched_off(monkeypatch):
+    monkeypatch.setenv("FFTUP_JIT", "0")
+    with _up(640, 480, 2.0, 0) as up:
+        assert not up.tuned
+
+
+def test_pinned_factorizations(monkeypatch):
+    """FFTUP_JIT_ROW / _COL / _FUSED pin a factorization (experiments): other valid choices give the same pixels up to
+    fp32 rounding"""
+    from vkresample_amd import synth
+    rgb = synth.frame(9, 640, 480, "N")
+
+    def run():
+        with _up(640, 480, 2.0, 0) as up:
+            assert up.specialised_at_plan_time
+            up.upload_rgb8(rgb)
+            up.execute(1)
+            return up.download_planar().astype(np.float64)
+    ref = run()
+    monkeypatch.setenv("FFTUP_JIT_ROW", "5,8,16")
+    monkeypatch.setenv("FFTUP_JIT_COL", "15,4,8")
+    monkeypatch.setenv("FFTUP_JIT_FUSED", "192:8,10,16")
+    got = run()
+    assert np.percentile(np.abs(ref - got), 99.99) <= 1e-5 and np.abs(ref - got).max() <= 2e-4
+
+
+def test_ring_batch_on_specialised_plan():
+    """batched mode (three streams, ring of slots) on a specialised plan: every slot equals the single-frame result"""
+    from vkresample_amd import synth
+    W, H = 720, 576
+    frames = [synth.frame(20 + s, W, H, "N") for s in range(3)]
+    single = []
+    for f in frames:
+        with _up(W, H, 2.0, 0) as up:
+            up.upload_rgb8(f)
+            up.execute(1)
+            single.append(up.download_planar().copy())
+    with _up(W, H, 2.0, 0, ring=3) as up:
+        for s, f in enumerate(frames):
+            up.upload_rgb8(f, slot=s)
+        up.execute_ring(9, 0)
+        for s in range(3):
+            assert np.array_equal(up.download_planar(s), single[s])

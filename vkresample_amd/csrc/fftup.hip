@@ -14,6 +14,7 @@
 #include "kernels_generic.hpp"
 #include "kernels_pow2.hpp"
 #include "kernels_mixed.hpp"
+#include "jit.hpp"
 
 using namespace fftup;
 
@@ -72,7 +73,9 @@ struct fftup_plan {
     float upsq = 0, coef = 0;
     bool tuned = false;
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
-    int mixed = 0;                    // compile-time mixed-radix plans: 1 = 1920x1080 -> 3840x2160, 2 = 1280x720 -> 2560x1440
+    int mixed = 0;                    // compile-time mixed-radix plans: 1 = 1920x1080 -> 3840x2160, 2 = 1280x720 -> 2560x1440,
+                                      // 3 = specialised at plan time for this size (jit.hpp), kernels in `jit`
+    fftup_jit::Module* jit = nullptr;
     bool plan3840_x16 = true;         // 1080p: fused kernel on the 16*16*15 plan (256 threads, 120 VGPRs); false: 8*8*4*15 on 512 threads
     bool cplx = false;                // non-R2C path (VR:1424 false): full complex transforms, uW beyond the R2C limit
     int ncols = 0;                    // spectrum columns kept: W/2 + 1, or W on the non-R2C path
@@ -184,6 +187,18 @@ static bool fuse_u8(const fftup_plan* P) { return (P->cfg.flags & FFTUP_FLAG_FUS
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+static bool jit_enabled()
+{
+    const char* e = getenv("FFTUP_JIT");
+    return !e || atoi(e) != 0;
+}
+static std::vector<int> stage_radices(const StagePlan& p)
+{
+    std::vector<int> r;
+    for (int s = 0; s < p.nstages; s++) r.push_back(p.radix[s]);
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -204,6 +219,22 @@ int fftup_device_name(int device, char* buf, size_t buflen)
     return FFTUP_OK;
 }
 
+int fftup_jit_check(uint32_t width, uint32_t height, uint32_t precision, const char* arch, char* desc, size_t desclen)
+{
+    if (desc && desclen) desc[0] = 0;
+    if (precision != 0 && precision != 2) return fail(FFTUP_E_UNSUPPORTED_PRECISION, "run-time specialised plans exist for -p 0 and -p 2");
+    if (width < 2 || height < 2 || (width & 1) || (height & 1) || width > 65536 || height > 65536 || !is_smooth(width) || !is_smooth(height))
+        return fail(FFTUP_E_UNSUPPORTED_SIZE, "sizes must be even and factor into 2,3,5,7");
+    fftup_jit::Choice ch;
+    if (2 * width > 8192 || !fftup_jit::choose((int)width, (int)height, precision == 2, stage_radices(make_stage_plan(2 * width)), ch))
+        return fail(FFTUP_E_UNSUPPORTED_SIZE, "no specialised factorization for this size: the size-generic kernels run it");
+    if (desc && desclen) snprintf(desc, desclen, "%s", fftup_jit::describe(ch).c_str());
+    fftup_jit::Binary bin;
+    std::string err;
+    if (!fftup_jit::compile(ch, arch ? arch : "gfx950", bin, err)) return fail(FFTUP_E_HIP, err);
+    return FFTUP_OK;
+}
+
 void fftup_plan_destroy(fftup_plan* P)
 {
     if (!P) return;
@@ -216,6 +247,7 @@ void fftup_plan_destroy(fftup_plan* P)
     for (auto& qs : P->q)
         if (qs.done) (void)hipEventDestroy(qs.done);
     for (void* p : P->allocs) (void)hipFree(p);
+    delete P->jit;
     if (P->ev0) (void)hipEventDestroy(P->ev0);
     if (P->ev1) (void)hipEventDestroy(P->ev1);
     if (P->stream) (void)hipStreamDestroy(P->stream);
@@ -319,6 +351,17 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             if (W == MixedCfg720::W && H == MixedCfg720::H) P->mixed = 2;
         }
         if (P->mixed) { P->TK = 4; P->ldsCol = sizeof(float2) * (size_t)H * 4; }             // k_col_m: one in-place buffer
+        // any other -u 2 size: kernels specialised for it now (the counterpart of VkFFT generating its shaders at plan time)
+        if (!P->dbl && !cplx && !P->tuned && !P->mixed && !(cfg->flags & (FFTUP_FLAG_GENERIC_KERNELS | FFTUP_FLAG_UNFUSED_SHARPEN)) &&
+            uW == 2 * W && uH == 2 * H && jit_enabled()) {
+            fftup_jit::Choice ch;
+            std::string jerr;
+            if (fftup_jit::choose((int)W, (int)H, P->half, stage_radices(P->planUW), ch)) {
+                P->jit = fftup_jit::load(ch, P->prop.gcnArchName, jerr);
+                if (P->jit) { P->mixed = 3; P->TK = 4; P->ldsCol = ch.col_lds; }
+                else if (getenv("FFTUP_JIT_VERBOSE")) fprintf(stderr, "fftup: run-time specialisation failed, size-generic kernels in use: %s\n", jerr.c_str());
+            }
+        }
         P->fused = (P->tuned || P->mixed) && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
         {
             // One strip (workgroup of uW/8 threads) per compute unit: the rest of every compute unit is left to the row and
@@ -456,7 +499,7 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
     info->out_width = P->uW;
     info->out_height = P->uH;
     info->num_kernels = P->fused ? 3 : 4;
-    info->tuned = (P->tuned || P->mixed) ? 1 : 0;
+    info->tuned = P->mixed == 3 ? 2 : ((P->tuned || P->mixed) ? 1 : 0);
     // B_alg = in + 2*S1 + 2*S2 + 2*R + out
     const double C = 3.0, W = P->W, H = P->H, uW = P->uW, uH = P->uH;
     const bool fused_u8 = fuse_u8(P);
@@ -795,12 +838,20 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         if (e != hipSuccess) return fail(FFTUP_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
         return FFTUP_OK;
     }
+    hipError_t jerr = hipSuccess;       // launches from a run-time specialised code object report their errors directly
     if (which < 0 || which == 0) {
         RowR2CParams p{};
         p.S1 = P->lanes[P->cur].S1; p.tw = P->twW; p.plan = P->planW; p.W = (int)P->W; p.H = (int)P->H;
         p.TK = P->TK; p.NT = P->NT;
         dim3 grid(P->H / 2, 3), block(P->thrW);
-        if (P->mixed) {
+        if (P->mixed == 3 && P->jit->choice.row_kind != 2) {
+            RowR2CTParams q{};
+            q.S1 = P->lanes[P->cur].S1; q.tw = P->twW; q.H = (int)P->H; q.NT = P->NT;
+            if (kind == 2) { q.in = P->in_u8[in_slot]; q.in_row_stride = 3l * P->W; q.in_plane_stride = 0; }
+            else { q.in = P->in_planar[in_slot]; q.in_row_stride = P->W; q.in_plane_stride = (long)P->in_plane_stride; }
+            jerr = fftup_jit::launch(P->jit->fn[kind == 2 ? fftup_jit::K_ROW_U8 : fftup_jit::K_ROW_PLANAR], grid, dim3(P->jit->choice.row_block), 0,
+                                     P->lanes[P->cur].stream, q);
+        } else if (P->mixed == 1 || P->mixed == 2) {
             if (P->mixed == 1) launch_row_mixed<MixedCfg1080>(P, in_slot, kind); else launch_row_mixed<MixedCfg720>(P, in_slot, kind);
         } else if (kind == 2) {
             p.in = P->in_u8[in_slot]; p.in_row_stride = 3l * P->W; p.in_plane_stride = 0;
@@ -821,7 +872,8 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         if (P->mixed) {
             ColTParams q{};
             q.S1 = P->lanes[P->cur].S1; q.S2 = P->lanes[P->cur].S2; q.twH = P->twH; q.twUH = P->twUH; q.W = (int)P->W; q.NT = P->NT;
-            if (P->mixed == 1) hipLaunchKernelGGL(k_col_m<MixedCfg1080>, grid, dim3(4 * MixedCfg1080::COL_TPC), P->ldsCol, P->lanes[P->cur].stream, q);
+            if (P->mixed == 3) jerr = fftup_jit::launch(P->jit->fn[fftup_jit::K_COL], grid, dim3(P->jit->choice.col_block), P->ldsCol, P->lanes[P->cur].stream, q);
+            else if (P->mixed == 1) hipLaunchKernelGGL(k_col_m<MixedCfg1080>, grid, dim3(4 * MixedCfg1080::COL_TPC), P->ldsCol, P->lanes[P->cur].stream, q);
             else hipLaunchKernelGGL(k_col_m<MixedCfg720>, grid, dim3(4 * MixedCfg720::COL_TPC), P->ldsCol, P->lanes[P->cur].stream, q);
         } else switch (P->TK) {
         case 8: hipLaunchKernelGGL(k_col<8>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
@@ -831,7 +883,12 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         }
     }
     if ((which < 0 || which == 2) && P->fused) {
-        if (P->mixed == 2) launch_fused_t<MixedCfg720::FUSED>(P, fused_params(P, out_slot));
+        if (P->mixed == 3) {
+            const FusedParams fp = fused_params(P, out_slot);
+            const int total_pairs = 3 * (int)P->uH / 2;
+            jerr = fftup_jit::launch(P->jit->fn[fftup_jit::K_FUSED], dim3((total_pairs + fp.pairs_per_strip - 1) / fp.pairs_per_strip),
+                                     dim3(P->jit->choice.fused_t), P->jit->choice.fused_lds, P->lanes[P->cur].stream, fp);
+        } else if (P->mixed == 2) launch_fused_t<MixedCfg720::FUSED>(P, fused_params(P, out_slot));
         else if (P->plan3840_x16) launch_fused_t<MixedCfg1080::FUSED>(P, fused_params(P, out_slot));
         else launch_fused_t<FusedPlan3840>(P, fused_params(P, out_slot));       // (only the mixed plans are fused on this path)
         P->R_valid = false;
@@ -842,7 +899,9 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         p.inv_norm = 1.0f / (float)P->uW;
         dim3 grid(P->uH / 2, 3), block(P->thrUW);
         if (P->mixed) {
-            if (P->mixed == 1) launch_c2r_ct<MixedCfg1080::CT>(P, grid, p); else launch_c2r_ct<MixedCfg720::CT>(P, grid, p);
+            if (P->mixed == 3) jerr = fftup_jit::launch(P->jit->fn[fftup_jit::K_C2R_CT], grid, dim3(P->jit->choice.ct_t), P->ldsRowI, P->lanes[P->cur].stream, p);
+            else if (P->mixed == 1) launch_c2r_ct<MixedCfg1080::CT>(P, grid, p);
+            else launch_c2r_ct<MixedCfg720::CT>(P, grid, p);
         } else if (P->half) hipLaunchKernelGGL(k_row_c2r<true>, grid, block, P->ldsRowI, P->lanes[P->cur].stream, p);
         else hipLaunchKernelGGL(k_row_c2r<false>, grid, block, P->ldsRowI, P->lanes[P->cur].stream, p);
         P->R_valid = true;
@@ -859,6 +918,7 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         else hipLaunchKernelGGL(k_sharpen<false>, grid, block, 0, P->lanes[P->cur].stream, p);
     }
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = jerr;
     if (e != hipSuccess) return fail(FFTUP_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return FFTUP_OK;
 }

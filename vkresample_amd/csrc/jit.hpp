@@ -1,0 +1,497 @@
+// jit.hpp -- run-time specialised plans (host side).
+//
+// The reference treats every 2*3*5*7-smooth size as first class because VkFFT GENERATES its shaders for the requested
+// size at plan time and compiles them with glslang (vkFFT.h:4707-5189 scheduler, :6200-7700 generator, VkResample.cpp
+// links glslang for it).  The MI355X-native counterpart: the register-resident kernels of kernels_pow2.hpp /
+// kernels_mixed.hpp are C++ templates over the size and its radix factorisation; for a -u 2 plan whose size has no
+// ahead-of-time instantiation, fftup_plan_create picks factorizations (choose()), writes a ten-line translation unit
+// that names the instantiations, compiles it for the plan's device with hipRTC (the ROCm run-time compiler, loaded with
+// dlopen -- no link-time dependency, and without it the plan silently stays on the size-generic kernels), and launches
+// the kernels from the loaded code object.  Code objects are cached in memory and on disk
+// ($FFTUP_CACHE_DIR, else $XDG_CACHE_HOME/fftup, else ~/.cache/fftup), keyed by a hash of the translation unit, the
+// compiler options, the hipRTC version and the kernel headers' text.
+//
+// The kernel headers are read from $FFTUP_KERNEL_DIR, else from csrc/ next to libfftup.so.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace fftup_jit {
+
+// radices the register engines have butterflies for (fft_engine.hpp bfly<R>, kernels_pow2.hpp twiddle_all<R>)
+static const int kRadices[] = {2, 3, 4, 5, 7, 8, 9, 10, 12, 15, 16};
+
+struct Choice {
+    int W = 0, H = 0, UW = 0;
+    bool half = false;
+    int row_kind = -1;                 // 0: k_row_r2c_t<W> (power of two, 8 points per thread); 1: k_row_r2c_m (three stages); 2: k_row_r2c (not specialised)
+    int rr[3] = {0, 0, 0}, row_t = 0;
+    int col_kind = -1;                 // 0: k_col_t<H>; 1: k_col_m (three stages)
+    int cr[3] = {0, 0, 0}, col_tpc = 0;
+    int fused_kind = -1;               // 0: FusedPlanPow2<UW>; 1: FusedPlanMr16<UW, UW/256>; 2: FusedPlanN<UW, T, 2, radices...>
+    std::vector<int> fr;
+    int fused_t = 0;
+    std::vector<int> ct;               // stand-alone C2R (pre-sharpen tap): CtPlan<UW, ct_t, radices...>
+    int ct_t = 0;
+    // launch geometry derived from the above (what the device-side templates compute for themselves)
+    int row_block = 0, col_block = 0;
+    size_t col_lds = 0, fused_lds = 0, ct_lds = 0;
+};
+
+static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+static bool is_radix(int r) { for (int s : kRadices) if (s == r) return true; return false; }
+
+// "r0,r1,..." (optionally "T:r0,r1,...") from an environment variable: experiments and tests pin a factorization
+static bool env_radices(const char* name, std::vector<int>& r, int* threads)
+{
+    const char* e = getenv(name);
+    if (!e || !*e) return false;
+    r.clear();
+    std::string s = e;
+    const size_t colon = s.find(':');
+    if (colon != std::string::npos) { if (threads) *threads = atoi(s.substr(0, colon).c_str()); s = s.substr(colon + 1); }
+    size_t pos = 0;
+    while (pos < s.size()) {
+        r.push_back(atoi(s.c_str() + pos));
+        const size_t c = s.find(',', pos);
+        if (c == std::string::npos) break;
+        pos = c + 1;
+    }
+    return !r.empty();
+}
+
+// Every stage moves all n points through LDS once and multiplies them by twiddles, whatever its radix, so the work of a
+// factorization is decided by its NUMBER of stages; between factorizations with equally many stages the lane slots
+// count (threads x points per thread, idle lanes included): balanced radices need the fewest threads.
+
+// three stages, one butterfly per thread and stage (MrFftT): n = r0 * r1 * r2, tk interleaved sequences per workgroup,
+// at most tmax threads per sequence.  An odd first radix spreads the stage-0 scatter over the LDS banks without an
+// index map; an even one costs bank conflicts in that scatter (2-way for 10 and 12 with one sequence, 4- to 16-way with four).
+static bool choose3(int n, int tk, int tmax, int r[3], int* threads, const char* env)
+{
+    std::vector<int> pin;
+    if (env_radices(env, pin, nullptr) && pin.size() == 3 && pin[0] * pin[1] * pin[2] == n && is_radix(pin[0]) && is_radix(pin[1]) && is_radix(pin[2])) {
+        r[0] = pin[0]; r[1] = pin[1]; r[2] = pin[2];
+        *threads = std::max(n / r[0], std::max(n / r[1], n / r[2]));
+        return *threads <= tmax;
+    }
+    double best = 0;
+    int best_min = 0;
+    bool found = false;
+    for (int a : kRadices) {
+        if (n % a) continue;
+        for (int b : kRadices) {
+            if ((n / a) % b || !is_radix(n / a / b)) continue;
+            const int c = n / a / b;
+            const int T = std::max(n / a, std::max(n / b, n / c));
+            if (T > tmax) continue;
+            double cost = (double)T * (a + b + c);
+            if (a % 2 == 0) cost *= (tk > 1) ? 2.0 : ((a == 10 || a == 12) ? 1.25 : 1.5);
+            const int mn = std::min(a, std::min(b, c));
+            if (!found || cost < best || (cost == best && mn > best_min)) { best = cost; best_min = mn; found = true; r[0] = a; r[1] = b; r[2] = c; *threads = T; }
+        }
+    }
+    return found;
+}
+
+// any number of stages on T threads (MrFftN / FusedPlanN): first radix a multiple of 4, one butterfly per thread in the
+// first and the last stage, at most 16 points per thread in between.  Fewest stages first (every stage is an LDS
+// exchange with two workgroup barriers), then the fewest lane slots, then the largest smallest radix.
+static bool choose_fused_n(int n, std::vector<int>& out, int* threads)
+{
+    {
+        int T = 0;
+        std::vector<int> pin;
+        if (env_radices("FFTUP_JIT_FUSED", pin, &T) && T >= 64 && T <= 1024 && T % 64 == 0) {
+            long prod = 1;
+            bool ok = pin.size() >= 2 && pin[0] % 4 == 0;
+            for (int q : pin) { ok &= is_radix(q); prod *= q; }
+            if (ok && prod == n && T >= n / pin[0] && T >= n / pin.back()) { out = pin; *threads = T; return true; }
+        }
+    }
+    bool found = false;
+    int best_ns = 0, best_min = 0;
+    double best = 0;
+    std::vector<int> cur;
+    auto eval = [&]() {
+        const int ns = (int)cur.size();
+        if (ns < 2 || cur[0] % 4) return;
+        const int tmin = std::max(n / cur[0], n / cur[ns - 1]);
+        for (int T = (tmin + 63) / 64 * 64; T <= 1024; T += 64) {
+            int vn = 0, mn = 99;
+            double cost = 0;
+            for (int s = 0; s < ns; s++) {
+                const int bpt = (n / cur[s] + T - 1) / T;
+                vn = std::max(vn, bpt * cur[s]);
+                mn = std::min(mn, cur[s]);
+                cost += (double)bpt * T * cur[s];
+            }
+            if (vn > 16) continue;
+            if (T > 512) cost *= 1.5;                                          // 64-VGPR territory
+            if ((n + 4 * T - 1) / (4 * T) > 4) cost *= 1.3;                    // ring rows no longer fit the registers
+            if (!found || ns < best_ns || (ns == best_ns && (cost < best || (cost == best && mn > best_min)))) {
+                found = true; best_ns = ns; best = cost; best_min = mn; out = cur; *threads = T;
+            }
+            break;
+        }
+    };
+    // depth-first over ordered factorizations of at most five factors
+    struct Rec {
+        static void go(int m, std::vector<int>& cur, const std::function<void()>& leaf)
+        {
+            if (m == 1) { leaf(); return; }
+            if (cur.size() >= 5) return;
+            for (int r : kRadices)
+                if (m % r == 0) { cur.push_back(r); go(m / r, cur, leaf); cur.pop_back(); }
+        }
+    };
+    Rec::go(n, cur, eval);
+    return found;
+}
+
+// Factorizations for a W x H -> 2W x 2H plan.  false: some dimension has no supported factorization (the plan then
+// stays on the size-generic kernels).  ct_radices: the stage list of the size-generic plan for 2W (radices <= 8).
+static bool choose(int W, int H, bool half, const std::vector<int>& ct_radices, Choice& c)
+{
+    c.W = W; c.H = H; c.UW = 2 * W; c.half = half;
+    if (W < 64 || H < 64 || W > 4096 || H > 4096) return false;
+    // ---- row R2C
+    if (is_pow2(W) && W >= 256) { c.row_kind = 0; c.row_block = W / 8; }
+    else if (choose3(W, 1, 1024, c.rr, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 1; c.row_t = (c.row_t + 63) / 64 * 64; c.row_block = c.row_t; }
+    else c.row_kind = 2;               // no three-stage factorization: the size-generic row kernel (same S1 layout) stays
+    // ---- column (four columns per workgroup)
+    if (is_pow2(H) && H >= 128 && H <= 2048) {
+        c.col_kind = 0; c.col_block = 4 * H / 8; c.col_lds = sizeof(float2) * (size_t)((H * 4 + 15) & ~15);      // lswz_size
+    } else if (choose3(H, 4, 256, c.cr, &c.col_tpc, "FFTUP_JIT_COL")) {
+        c.col_kind = 1; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)H * 4;
+    } else return false;
+    // ---- fused C2R + sharpen
+    const int UW = c.UW;
+    size_t xb = sizeof(float2) * (size_t)((UW + 15) & ~15);                    // lswz_size(UW)
+    int nbuf = 2;
+    if (UW == 1024 || UW == 2048 || UW == 4096) { c.fused_kind = 0; c.fused_t = UW / 8; nbuf = 3; }
+    else {
+        const bool mr16 = UW % 256 == 0 && is_radix(UW / 256) && !getenv("FFTUP_JIT_FUSED");
+        if (mr16) {
+            c.fused_kind = 1; c.fused_t = 256;
+            xb = (sizeof(float2) * (size_t)(UW + (UW >> 4) + 1) + 15) & ~(size_t)15;                               // lpad_size(UW)
+        } else if (choose_fused_n(UW, c.fr, &c.fused_t)) c.fused_kind = 2;
+        else return false;
+    }
+    {
+        const int npass = (UW + 4 * c.fused_t - 1) / (4 * c.fused_t);
+        const size_t nx = npass <= 4 ? 1 : 2;                                  // FusedGLds::RR
+        c.fused_lds = (nx + (nbuf == 3 ? 1 : 0)) * xb + (nbuf == 3 ? 0 : 32 * sizeof(float));
+        if (c.fused_lds > 160 * 1024) return false;
+    }
+    // ---- stand-alone C2R for the pre-sharpen tap (LDS ping-pong, compile-time radices)
+    c.ct = ct_radices;
+    c.ct_t = std::min(1024, std::max(64, (UW / 8 + 63) / 64 * 64));
+    c.ct_lds = 2 * sizeof(float2) * (size_t)(UW + (UW >> 4) + 1);
+    return true;
+}
+
+static std::string join(const std::vector<int>& v)
+{
+    std::string s;
+    for (size_t i = 0; i < v.size(); i++) s += (i ? ", " : "") + std::to_string(v[i]);
+    return s;
+}
+
+enum { K_ROW_PLANAR = 0, K_ROW_U8, K_COL, K_FUSED, K_C2R_CT, K_COUNT };
+
+// the translation unit and the name expressions of its five kernels
+static std::string make_source(const Choice& c, std::string names[K_COUNT])
+{
+    const std::string W = std::to_string(c.W), H = std::to_string(c.H), UW = std::to_string(c.UW);
+    std::string s;
+    s += "// generated by fftup (jit.hpp): " + W + "x" + H + " -> " + UW + "x" + std::to_string(2 * c.H) + (c.half ? ", binary16 storage\n" : ", fp32\n");
+    s += "#include \"kernels_mixed.hpp\"\nnamespace fftup {\n";
+    s += "struct JitCfg {\n    static constexpr int W = " + W + ", H = " + H + ";\n";
+    if (c.row_kind == 1)
+        s += "    static constexpr int RR0 = " + std::to_string(c.rr[0]) + ", RR1 = " + std::to_string(c.rr[1]) + ", RR2 = " + std::to_string(c.rr[2]) +
+             ", ROW_T = " + std::to_string(c.row_t) + ";\n";
+    if (c.col_kind == 1)
+        s += "    static constexpr int CR0 = " + std::to_string(c.cr[0]) + ", CR1 = " + std::to_string(c.cr[1]) + ", CR2 = " + std::to_string(c.cr[2]) +
+             ", COL_TPC = " + std::to_string(c.col_tpc) + ";\n";
+    s += "};\n";
+    if (c.fused_kind == 0) s += "using JitFused = FusedPlanPow2<" + UW + ">;\n";
+    else if (c.fused_kind == 1) s += "using JitFused = FusedPlanMr16<" + UW + ", " + std::to_string(c.UW / 256) + ">;\n";
+    else s += "using JitFused = FusedPlanN<" + UW + ", " + std::to_string(c.fused_t) + ", 2, " + join(c.fr) + ">;\n";
+    s += "using JitCT = CtPlan<" + UW + ", " + std::to_string(c.ct_t) + ", " + join(c.ct) + ">;\n";
+    s += "static_assert(FusedGLds<JitFused>::TOTAL == " + std::to_string(c.fused_lds) + " && JitFused::T == " + std::to_string(c.fused_t) +
+         ", \"host and device disagree on the fused kernel's geometry\");\n";
+    s += "}\n";
+    const std::string fm = c.half ? "fftup::IN_F16" : "fftup::IN_F32", um = c.half ? "fftup::IN_U8_F16" : "fftup::IN_U8_F32";
+    const std::string hb = c.half ? "true" : "false";
+    if (c.row_kind == 2) {
+        names[K_ROW_PLANAR] = names[K_ROW_U8] = "";
+    } else if (c.row_kind == 0) {
+        names[K_ROW_PLANAR] = "fftup::k_row_r2c_t<" + W + ", " + fm + ", 4>";
+        names[K_ROW_U8] = "fftup::k_row_r2c_t<" + W + ", " + um + ", 4>";
+    } else {
+        names[K_ROW_PLANAR] = "fftup::k_row_r2c_m<fftup::JitCfg, " + fm + ">";
+        names[K_ROW_U8] = "fftup::k_row_r2c_m<fftup::JitCfg, " + um + ">";
+    }
+    names[K_COL] = c.col_kind == 0 ? "fftup::k_col_t<" + H + ", 4>" : "fftup::k_col_m<fftup::JitCfg>";
+    names[K_FUSED] = "fftup::k_c2r_sharpen_g<fftup::JitFused, " + hb + ", 4>";
+    names[K_C2R_CT] = "fftup::k_row_c2r_ct<fftup::JitCT, " + hb + ">";
+    return s;
+}
+
+static std::string describe(const Choice& c)
+{
+    std::string s = "row ";
+    s += c.row_kind == 2 ? "generic" : c.row_kind == 0 ? "pow2/8" : std::to_string(c.rr[0]) + "*" + std::to_string(c.rr[1]) + "*" + std::to_string(c.rr[2]);
+    s += " x" + std::to_string(c.row_block) + ", col ";
+    s += c.col_kind == 0 ? "pow2/8" : std::to_string(c.cr[0]) + "*" + std::to_string(c.cr[1]) + "*" + std::to_string(c.cr[2]);
+    s += " x" + std::to_string(c.col_block) + ", fused ";
+    if (c.fused_kind == 0) s += "pow2/8";
+    else if (c.fused_kind == 1) s += "16*16*" + std::to_string(c.UW / 256);
+    else for (size_t i = 0; i < c.fr.size(); i++) s += (i ? "*" : "") + std::to_string(c.fr[i]);
+    s += " x" + std::to_string(c.fused_t) + " (" + std::to_string(c.fused_lds) + " B LDS)";
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------ hipRTC through dlopen
+struct Rtc {
+    void* lib = nullptr;
+    hiprtcResult (*CreateProgram)(hiprtcProgram*, const char*, const char*, int, const char**, const char**) = nullptr;
+    hiprtcResult (*AddNameExpression)(hiprtcProgram, const char*) = nullptr;
+    hiprtcResult (*CompileProgram)(hiprtcProgram, int, const char**) = nullptr;
+    hiprtcResult (*GetProgramLogSize)(hiprtcProgram, size_t*) = nullptr;
+    hiprtcResult (*GetProgramLog)(hiprtcProgram, char*) = nullptr;
+    hiprtcResult (*GetCodeSize)(hiprtcProgram, size_t*) = nullptr;
+    hiprtcResult (*GetCode)(hiprtcProgram, char*) = nullptr;
+    hiprtcResult (*GetLoweredName)(hiprtcProgram, const char*, const char**) = nullptr;
+    hiprtcResult (*DestroyProgram)(hiprtcProgram*) = nullptr;
+    hiprtcResult (*Version)(int*, int*) = nullptr;
+    bool ok = false;
+};
+
+static const Rtc& rtc()
+{
+    static Rtc r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        bool all = true;
+#define FFTUP_RTC_SYM(field, sym) all &= ((*(void**)&r.field = dlsym(r.lib, sym)) != nullptr)
+        FFTUP_RTC_SYM(CreateProgram, "hiprtcCreateProgram");
+        FFTUP_RTC_SYM(AddNameExpression, "hiprtcAddNameExpression");
+        FFTUP_RTC_SYM(CompileProgram, "hiprtcCompileProgram");
+        FFTUP_RTC_SYM(GetProgramLogSize, "hiprtcGetProgramLogSize");
+        FFTUP_RTC_SYM(GetProgramLog, "hiprtcGetProgramLog");
+        FFTUP_RTC_SYM(GetCodeSize, "hiprtcGetCodeSize");
+        FFTUP_RTC_SYM(GetCode, "hiprtcGetCode");
+        FFTUP_RTC_SYM(GetLoweredName, "hiprtcGetLoweredName");
+        FFTUP_RTC_SYM(DestroyProgram, "hiprtcDestroyProgram");
+        FFTUP_RTC_SYM(Version, "hiprtcVersion");
+#undef FFTUP_RTC_SYM
+        r.ok = all;
+    });
+    return r;
+}
+
+static uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull)
+{
+    for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ull; }
+    return h;
+}
+
+static bool read_file(const std::string& path, std::string& out)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[65536];
+    size_t n;
+    out.clear();
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    fclose(f);
+    return true;
+}
+
+static void kernel_dir_anchor() {}
+static std::string kernel_dir()
+{
+    if (const char* e = getenv("FFTUP_KERNEL_DIR")) return e;
+    Dl_info info;
+    if (dladdr((void*)&kernel_dir_anchor, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        const size_t slash = p.rfind('/');
+        return (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/csrc";
+    }
+    return "csrc";
+}
+
+static std::string cache_dir()
+{
+    std::string d;
+    if (const char* e = getenv("FFTUP_CACHE_DIR")) d = e;
+    else if (const char* x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/fftup";
+    else if (const char* h = getenv("HOME")) d = std::string(h) + "/.cache/fftup";
+    else return "";
+    // (mkdir -p of the last two components; failures simply disable the disk cache)
+    const size_t slash = d.rfind('/');
+    if (slash != std::string::npos && slash > 0) (void)mkdir(d.substr(0, slash).c_str(), 0755);
+    (void)mkdir(d.c_str(), 0755);
+    return d;
+}
+
+// a compiled translation unit: code object + the lowered names of its kernels
+struct Binary {
+    std::string code;
+    std::string lowered[K_COUNT];
+};
+
+static bool load_cached(const std::string& path, Binary& b)
+{
+    std::string raw;
+    if (!read_file(path, raw) || raw.size() < 16 || raw.compare(0, 6, "FJIT1\n") != 0) return false;
+    size_t off = 6;
+    auto rd = [&](void* dst, size_t n) { if (off + n > raw.size()) return false; memcpy(dst, raw.data() + off, n); off += n; return true; };
+    for (int k = 0; k < K_COUNT; k++) {
+        uint32_t len;
+        if (!rd(&len, 4) || off + len > raw.size()) return false;
+        b.lowered[k].assign(raw.data() + off, len);
+        off += len;
+    }
+    uint64_t cs;
+    if (!rd(&cs, 8) || off + cs != raw.size()) return false;
+    b.code.assign(raw.data() + off, cs);
+    return true;
+}
+
+static void store_cached(const std::string& path, const Binary& b)
+{
+    const std::string tmp = path + "." + std::to_string((long)getpid()) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    bool ok = fwrite("FJIT1\n", 1, 6, f) == 6;
+    for (int k = 0; k < K_COUNT; k++) {
+        const uint32_t len = (uint32_t)b.lowered[k].size();
+        ok &= fwrite(&len, 4, 1, f) == 1 && fwrite(b.lowered[k].data(), 1, len, f) == len;
+    }
+    const uint64_t cs = b.code.size();
+    ok &= fwrite(&cs, 8, 1, f) == 1 && fwrite(b.code.data(), 1, cs, f) == cs;
+    ok &= fclose(f) == 0;
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
+}
+
+// compile (or fetch) the translation unit of `c` for `arch` ("gfx950:sramecc+:xnack-").  No device needed.
+static bool compile(const Choice& c, const std::string& arch, Binary& out, std::string& err)
+{
+    const Rtc& R = rtc();
+    if (!R.ok) { err = "hipRTC (libhiprtc.so) not available"; return false; }
+    const std::string kdir = kernel_dir();
+    std::string hdr_text, one;
+    for (const char* h : {"fft_engine.hpp", "kernels_generic.hpp", "kernels_pow2.hpp", "kernels_mixed.hpp"}) {
+        if (!read_file(kdir + "/" + h, one)) { err = "kernel header " + kdir + "/" + h + " not found (set FFTUP_KERNEL_DIR)"; return false; }
+        hdr_text += one;
+    }
+    std::string names[K_COUNT];
+    const std::string src = make_source(c, names);
+    const char* rocm = getenv("ROCM_PATH");
+    const std::string inc_rocm = std::string("-I") + (rocm ? rocm : "/opt/rocm") + "/include", inc_k = "-I" + kdir;
+    const std::string arch_opt = "--offload-arch=" + arch;
+    // the flags of the ahead-of-time build (__graft_entry__.py): results must not depend on which of the two compiled a kernel
+    const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=on", inc_k.c_str(), inc_rocm.c_str()};
+    int vmaj = 0, vmin = 0;
+    R.Version(&vmaj, &vmin);
+    uint64_t key = fnv1a(src);
+    for (const char* o : opts) key = fnv1a(o, key);
+    key = fnv1a(std::to_string(vmaj) + "." + std::to_string(vmin), key);
+    key = fnv1a(hdr_text, key);
+    char keyhex[32];
+    snprintf(keyhex, sizeof keyhex, "%016llx", (unsigned long long)key);
+
+    static std::mutex mu;
+    static std::map<uint64_t, Binary> memo;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = memo.find(key);
+    if (it != memo.end()) { out = it->second; return true; }
+    const std::string cdir = cache_dir();
+    const std::string cpath = cdir.empty() ? "" : cdir + "/" + keyhex + ".fjit";
+    if (!cpath.empty() && load_cached(cpath, out)) { memo[key] = out; return true; }
+
+    hiprtcProgram prog = nullptr;
+    if (R.CreateProgram(&prog, src.c_str(), "fftup_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return false; }
+    for (int k = 0; k < K_COUNT; k++) if (!names[k].empty()) R.AddNameExpression(prog, names[k].c_str());
+    const hiprtcResult rc = R.CompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        R.GetProgramLogSize(prog, &ls);
+        std::string log(ls, '\0');
+        if (ls) R.GetProgramLog(prog, &log[0]);
+        err = "hipRTC compilation failed (" + describe(c) + "): " + log.substr(0, 2000);
+        R.DestroyProgram(&prog);
+        return false;
+    }
+    size_t cs = 0;
+    R.GetCodeSize(prog, &cs);
+    out.code.assign(cs, '\0');
+    R.GetCode(prog, &out.code[0]);
+    bool ok = cs > 0;
+    for (int k = 0; k < K_COUNT; k++) {
+        if (names[k].empty()) continue;
+        const char* low = nullptr;
+        ok &= R.GetLoweredName(prog, names[k].c_str(), &low) == HIPRTC_SUCCESS && low;
+        if (low) out.lowered[k] = low;
+    }
+    R.DestroyProgram(&prog);
+    if (!ok) { err = "hipRTC returned no code / no lowered names"; return false; }
+    memo[key] = out;
+    if (!cpath.empty()) store_cached(cpath, out);
+    return true;
+}
+
+// a code object loaded on one device
+struct Module {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn[K_COUNT] = {};
+    Choice choice;
+    ~Module() { if (mod) (void)hipModuleUnload(mod); }
+};
+
+static Module* load(const Choice& c, const std::string& arch, std::string& err)
+{
+    Binary b;
+    if (!compile(c, arch, b, err)) return nullptr;
+    Module* m = new Module();
+    m->choice = c;
+    hipError_t e = hipModuleLoadData(&m->mod, b.code.data());
+    if (e != hipSuccess) { err = std::string("hipModuleLoadData: ") + hipGetErrorString(e); m->mod = nullptr; delete m; return nullptr; }
+    for (int k = 0; k < K_COUNT; k++) {
+        if (b.lowered[k].empty()) continue;
+        e = hipModuleGetFunction(&m->fn[k], m->mod, b.lowered[k].c_str());
+        if (e != hipSuccess) { err = "hipModuleGetFunction(" + b.lowered[k] + "): " + hipGetErrorString(e); delete m; return nullptr; }
+    }
+    return m;
+}
+
+template <class Params>
+static hipError_t launch(hipFunction_t f, dim3 grid, dim3 block, size_t lds, hipStream_t st, Params p)
+{
+    void* args[] = {&p};
+    return hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, block.x, block.y, block.z, (unsigned)lds, st, args, nullptr);
+}
+
+}  // namespace fftup_jit

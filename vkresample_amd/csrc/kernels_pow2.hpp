@@ -1065,7 +1065,8 @@ template <int N, int DIR, int R0, int R1, int R2> struct MrFft {
 // consecutive elements -- every access is a per-thread base plus an immediate.  Element (i, col) lives at i*TK + col.
 struct MrTw { float2 w1, w2; };                             // base twiddles of stages 1 and 2 (table sign exp(+i..))
 template <int N, int DIR, int TK, int R0, int R1, int R2, bool FINAL_TO_LDS> struct MrFftT {
-    static_assert(R0 % 2 == 1 && R0 * R1 * R2 == N, "first radix odd (bank spread without a map); radices multiply to N");
+    // (an odd first radix spreads the stage-0 scatter over the banks without a map; even ones work, with conflicts)
+    static_assert(R0 * R1 * R2 == N, "radices multiply to N");
     static constexpr int NB0 = N / R0, NB1 = N / R1, NB2 = N / R2;
     static constexpr int NS1 = R0, NS2 = R0 * R1;
     static constexpr int VN = (R0 > R1 ? (R0 > R2 ? R0 : R2) : (R1 > R2 ? R1 : R2));
@@ -1199,27 +1200,33 @@ template <int N, int DIR, int T, int... RS> struct MrFftN {
         }
     }
 };
-struct FusedPlan3840 {                                      // 1920x1080 -> 3840x2160: rows of 3840 = 8 * 8 * 4 * 15, 512 threads
-    using F = MrFftN<3840, -1, 512, 8, 8, 4, 15>;
-    static constexpr int UW = 3840, T = 512, R0 = 8, NB0 = 480, EOUT = 15, SOUT = 256, VN = F::VN;
-    static constexpr size_t XB = sizeof(float2) * lswz_size(3840);
 #ifndef FFTUP_3840_NBUF
 #define FFTUP_3840_NBUF 2
 #endif
-    // NBUF = 3 (exchanges alternate z, c, z with one barrier each, as in FusedPlanPow2) makes this kernel 5 % faster on its
-    // own and the frame 2 % slower: with 61 KB of LDS two of these workgroups share a compute unit whenever consecutive
+// Rows of any length UW = R0 * ... on T threads, any number of stages (MrFftN): what the run-time specialised plans
+// (jit.hpp) instantiate when no three-stage 16 * 16 * R2 plan exists, and the 8 * 8 * 4 * 15 plan of 1920x1080 on 512
+// threads (FFTUP_3840_X16=0).  R0 must be a multiple of 4 (the non-zero quarter of the spectrum fills whole first-stage
+// inputs), T >= UW/R0 and T >= UW/Rlast.
+template <int UW_, int T_, int NBUF_, int... RS> struct FusedPlanN {
+    using F = MrFftN<UW_, -1, T_, RS...>;
+    static constexpr int UW = UW_, T = T_, R0 = F::rs(0), NB0 = UW / R0, EOUT = F::rs(F::NST - 1), SOUT = UW / EOUT, VN = F::VN;
+    static constexpr size_t XB = sizeof(float2) * lswz_size(UW);
+    // NBUF = 3 (exchanges alternate z, c, z with one barrier each, as in FusedPlanPow2) makes the 3840 kernel 5 % faster on
+    // its own and the frame 2 % slower: with 61 KB of LDS two of these workgroups share a compute unit whenever consecutive
     // frames' launches overlap, with 92 KB they cannot (measured).
-    static constexpr int NBUF = FFTUP_3840_NBUF;
+    static constexpr int NBUF = NBUF_;
     static constexpr bool RING_REGS = true;
-    static_assert((F::NST - 1) % 2 == 1 && XB % 128 == 0, "the first exchange must go through z; lds_put needs 128-byte aligned buffers");
-    using Tw = F::Tw;
+    static_assert(R0 % 4 == 0 && T >= NB0 && T >= SOUT, "first radix a multiple of 4; one butterfly per thread at both ends");
+    static_assert(NBUF == 2 || (F::NST - 1) % 2 == 1, "three buffers: the first exchange must go through z");
+    static_assert(XB % 128 == 0, "lds_put needs 128-byte aligned buffers");
+    using Tw = typename F::Tw;
     static __device__ __forceinline__ int first_index(int lt) { return lt < NB0 ? lt : NB0 - 1; }   // (threads beyond re-read)
     static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { F::load_tw(w, tw, j); }
     static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w)
     {
-        // The base twiddles are loop-invariant, so the compiler would hoist all 27 power products of the three twiddled
-        // stages out of the strip loop and keep them (54 VGPRs: spills).  Re-defining the bases here makes the
-        // powers per-step work.
+        // The base twiddles are loop-invariant, so the compiler would hoist all power products of the twiddled stages
+        // out of the strip loop and keep them (54 VGPRs for 8 * 8 * 4 * 15: spills).  Re-defining the bases here makes
+        // the powers per-step work.
         Tw t = w;
 #pragma unroll
         for (int st = 0; st < F::NST - 1; st++)
@@ -1228,6 +1235,7 @@ struct FusedPlan3840 {                                      // 1920x1080 -> 3840
         F::template run<NBUF == 2>(v, buf, zbuf, j, t);
     }
 };
+using FusedPlan3840 = FusedPlanN<3840, 512, FFTUP_3840_NBUF, 8, 8, 4, 15>;     // 1920x1080 -> 3840x2160, rows of 3840 = 8 * 8 * 4 * 15
 #ifndef FFTUP_3840X16_NBUF
 #define FFTUP_3840X16_NBUF 2
 #endif
