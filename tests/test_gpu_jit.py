@@ -23,6 +23,10 @@ JIT_SIZES = [
     (1600, 900),    # 10*10*16 / 9*10*10 / 16*2*10*10: 5 butterflies of radix 2 per thread
     (896, 504),     # radix 7: 7*8*16 / 7*8*9 / 16*16*7
     (128, 64),      # smallest sizes that are specialised
+    (2000, 1250),   # no three-stage factorization: N-stage row 8*5*5*10, column 5*5*5*10 on 1024 threads, fused 8*5*10*10
+    (486, 294),     # 9*2*3*9 / 7*2*3*7 / 12*9*9
+    (3584, 2016),   # 16*2*7*16 / 12*2*7*12 / 8*8*16*7 on 1024 threads
+    (3840, 2160),   # 4K -> 8K: 15*16*16 / 15*12*12 on 720 threads / 8*8*10*12 on 960 threads, 61 KB of LDS
 ]
 
 

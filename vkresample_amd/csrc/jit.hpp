@@ -38,13 +38,16 @@ static const int kRadices[] = {2, 3, 4, 5, 7, 8, 9, 10, 12, 15, 16};
 struct Choice {
     int W = 0, H = 0, UW = 0;
     bool half = false;
-    int row_kind = -1;                 // 0: k_row_r2c_t<W> (power of two, 8 points per thread); 1: k_row_r2c_m (three stages); 2: k_row_r2c (not specialised)
+    int row_kind = -1;                 // 0: k_row_r2c_t<W> (power of two, 8 points per thread); 1: k_row_r2c_m (three stages); 2: k_row_r2c (not specialised); 3: k_row_r2c_n
     int rr[3] = {0, 0, 0}, row_t = 0;
-    int col_kind = -1;                 // 0: k_col_t<H>; 1: k_col_m (three stages)
+    std::vector<int> rn, cn;           // kind 3: k_row_r2c_n / k_col_n (N stages)
+    int col_kind = -1;                 // 0: k_col_t<H>; 1: k_col_m (three stages); 3: k_col_n (N stages)
     int cr[3] = {0, 0, 0}, col_tpc = 0;
     int fused_kind = -1;               // 0: FusedPlanPow2<UW>; 1: FusedPlanMr16<UW, UW/256>; 2: FusedPlanN<UW, T, 2, radices...>
     std::vector<int> fr;
     int fused_t = 0;
+    int fused_wpe = 0;                 // kind 2: waves per SIMD the fused kernel's register allocation must allow
+    bool fused_rr = true;              // kind 2: ring rows in registers
     std::vector<int> ct;               // stand-alone C2R (pre-sharpen tap): CtPlan<UW, ct_t, radices...>
     int ct_t = 0;
     // launch geometry derived from the above (what the device-side templates compute for themselves)
@@ -109,8 +112,11 @@ static bool choose3(int n, int tk, int tmax, int r[3], int* threads, const char*
 }
 
 // any number of stages on T threads (MrFftN / FusedPlanN): first radix a multiple of 4, one butterfly per thread in the
-// first and the last stage, at most 16 points per thread in between.  Fewest stages first (every stage is an LDS
-// exchange with two workgroup barriers), then the fewest lane slots, then the largest smallest radix.
+// first and the last stage, at most 16 points per thread in between.  Measured over a dozen sizes (profiles/
+// r02_jit_factorizations.txt): a first radix of 8 -- every thread of a UW/8-thread workgroup loads and transforms its own
+// eight inputs -- beats 16 (half the threads idle in the prefetch and in the first stage) by 10-25 %, even at one stage
+// more; after that the fewest stages (every stage is an LDS exchange with two workgroup barriers), the fewest lane
+// slots, the largest smallest radix.
 static bool choose_fused_n(int n, std::vector<int>& out, int* threads)
 {
     {
@@ -124,9 +130,10 @@ static bool choose_fused_n(int n, std::vector<int>& out, int* threads)
         }
     }
     bool found = false;
-    int best_ns = 0, best_min = 0;
+    int best_ns = 0, best_min = 0, best_r0 = 0;
     double best = 0;
     std::vector<int> cur;
+    auto r0_rank = [](int r0) { return r0 == 8 ? 0 : r0 == 12 ? 1 : r0 == 16 ? 2 : 3; };
     auto eval = [&]() {
         const int ns = (int)cur.size();
         if (ns < 2 || cur[0] % 4) return;
@@ -143,13 +150,64 @@ static bool choose_fused_n(int n, std::vector<int>& out, int* threads)
             if (vn > 16) continue;
             if (T > 512) cost *= 1.5;                                          // 64-VGPR territory
             if ((n + 4 * T - 1) / (4 * T) > 4) cost *= 1.3;                    // ring rows no longer fit the registers
-            if (!found || ns < best_ns || (ns == best_ns && (cost < best || (cost == best && mn > best_min)))) {
-                found = true; best_ns = ns; best = cost; best_min = mn; out = cur; *threads = T;
-            }
+            const int rk = r0_rank(cur[0]);
+            mn = std::min(mn, 4);                                              // radix-2/3 stages: all exchange, hardly any arithmetic
+            const bool better = !found || rk < best_r0 ||
+                                (rk == best_r0 && (ns < best_ns || (ns == best_ns && (mn > best_min || (mn == best_min && cost < best)))));
+            if (better) { found = true; best_r0 = rk; best_ns = ns; best = cost; best_min = mn; out = cur; *threads = T; }
             break;
         }
     };
     // depth-first over ordered factorizations of at most five factors
+    struct Rec {
+        static void go(int m, std::vector<int>& cur, const std::function<void()>& leaf)
+        {
+            if (m == 1) { leaf(); return; }
+            if (cur.size() >= 5) return;
+            for (int r : kRadices)
+                if (m % r == 0) { cur.push_back(r); go(m / r, cur, leaf); cur.pop_back(); }
+        }
+    };
+    Rec::go(n, cur, eval);
+    return found;
+}
+
+// any number of stages for the row and column kernels (MrFftNT, XOR index map: no preference for odd first radices):
+// one butterfly per thread in the first and the last stage, at most 16 points per thread, T a multiple of `granule`.
+static bool choose_n(int n, int tmax, int granule, std::vector<int>& out, int* threads, const char* env)
+{
+    {
+        std::vector<int> pin;
+        if (env_radices(env, pin, nullptr) && pin.size() >= 2) {
+            long prod = 1;
+            bool ok = true;
+            for (int q : pin) { ok &= is_radix(q); prod *= q; }
+            const int T = ok && prod == n ? (std::max(n / pin[0], n / pin.back()) + granule - 1) / granule * granule : 0;
+            if (T > 0 && T <= tmax) { out = pin; *threads = T; return true; }
+        }
+    }
+    bool found = false;
+    int best_ns = 0, best_min = 0;
+    double best = 0;
+    std::vector<int> cur;
+    auto eval = [&]() {
+        const int ns = (int)cur.size();
+        if (ns < 2) return;
+        const int T = (std::max(n / cur[0], n / cur[ns - 1]) + granule - 1) / granule * granule;
+        if (T > tmax) return;
+        int vn = 0, mn = 99;
+        double cost = 0;
+        for (int s = 0; s < ns; s++) {
+            const int bpt = (n / cur[s] + T - 1) / T;
+            vn = std::max(vn, bpt * cur[s]);
+            mn = std::min(mn, cur[s]);
+            cost += (double)bpt * T * cur[s];
+        }
+        if (vn > 16) return;
+        if (!found || ns < best_ns || (ns == best_ns && (cost < best || (cost == best && mn > best_min)))) {
+            found = true; best_ns = ns; best = cost; best_min = mn; out = cur; *threads = T;
+        }
+    };
     struct Rec {
         static void go(int m, std::vector<int>& cur, const std::function<void()>& leaf)
         {
@@ -172,12 +230,15 @@ static bool choose(int W, int H, bool half, const std::vector<int>& ct_radices, 
     // ---- row R2C
     if (is_pow2(W) && W >= 256) { c.row_kind = 0; c.row_block = W / 8; }
     else if (choose3(W, 1, 1024, c.rr, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 1; c.row_t = (c.row_t + 63) / 64 * 64; c.row_block = c.row_t; }
-    else c.row_kind = 2;               // no three-stage factorization: the size-generic row kernel (same S1 layout) stays
+    else if (choose_n(W, 1024, 64, c.rn, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 3; c.row_block = c.row_t; }
+    else c.row_kind = 2;               // no supported factorization: the size-generic row kernel (same S1 layout) stays
     // ---- column (four columns per workgroup)
     if (is_pow2(H) && H >= 128 && H <= 2048) {
         c.col_kind = 0; c.col_block = 4 * H / 8; c.col_lds = sizeof(float2) * (size_t)((H * 4 + 15) & ~15);      // lswz_size
     } else if (choose3(H, 4, 256, c.cr, &c.col_tpc, "FFTUP_JIT_COL")) {
         c.col_kind = 1; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)H * 4;
+    } else if (choose_n(H, 256, 16, c.cn, &c.col_tpc, "FFTUP_JIT_COL")) {
+        c.col_kind = 3; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * 4 + 15) & ~15);
     } else return false;
     // ---- fused C2R + sharpen
     const int UW = c.UW;
@@ -189,12 +250,16 @@ static bool choose(int W, int H, bool half, const std::vector<int>& ct_radices, 
         if (mr16) {
             c.fused_kind = 1; c.fused_t = 256;
             xb = (sizeof(float2) * (size_t)(UW + (UW >> 4) + 1) + 15) & ~(size_t)15;                               // lpad_size(UW)
-        } else if (choose_fused_n(UW, c.fr, &c.fused_t)) c.fused_kind = 2;
-        else return false;
+        } else if (choose_fused_n(UW, c.fr, &c.fused_t)) {
+            c.fused_kind = 2;
+            // two strips per compute unit (128 VGPRs at 512 threads) unless load() finds the kernel spilling
+            if (c.fused_wpe <= 0) c.fused_wpe = std::max((c.fused_t + 255) / 256, std::min(c.fused_t * 2 / 256, 4));      // >= 128 VGPRs
+            if (const char* e = getenv("FFTUP_JIT_FUSED_OPT")) { int w = 0, r = 1; if (sscanf(e, "%d,%d", &w, &r) == 2) { c.fused_wpe = std::max(1, w); c.fused_rr = r != 0; } }
+        } else return false;
     }
     {
         const int npass = (UW + 4 * c.fused_t - 1) / (4 * c.fused_t);
-        const size_t nx = npass <= 4 ? 1 : 2;                                  // FusedGLds::RR
+        const size_t nx = (npass <= 4 && (c.fused_kind != 2 || c.fused_rr)) ? 1 : 2;    // FusedGLds::RR
         c.fused_lds = (nx + (nbuf == 3 ? 1 : 0)) * xb + (nbuf == 3 ? 0 : 32 * sizeof(float));
         if (c.fused_lds > 160 * 1024) return false;
     }
@@ -228,10 +293,16 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT])
     if (c.col_kind == 1)
         s += "    static constexpr int CR0 = " + std::to_string(c.cr[0]) + ", CR1 = " + std::to_string(c.cr[1]) + ", CR2 = " + std::to_string(c.cr[2]) +
              ", COL_TPC = " + std::to_string(c.col_tpc) + ";\n";
+    if (c.row_kind == 3)
+        s += "    static constexpr int ROW_T = " + std::to_string(c.row_t) + ";\n    using RowN = MrFftNT<W, +1, ROW_T, 1, " + join(c.rn) + ">;\n";
+    if (c.col_kind == 3)
+        s += "    static constexpr int COL_TPC = " + std::to_string(c.col_tpc) + ";\n    using ColF = MrFftNT<H, +1, COL_TPC, 4, " + join(c.cn) +
+             ">;\n    using ColI = MrFftNT<H, -1, COL_TPC, 4, " + join(c.cn) + ">;\n";
     s += "};\n";
     if (c.fused_kind == 0) s += "using JitFused = FusedPlanPow2<" + UW + ">;\n";
     else if (c.fused_kind == 1) s += "using JitFused = FusedPlanMr16<" + UW + ", " + std::to_string(c.UW / 256) + ">;\n";
-    else s += "using JitFused = FusedPlanN<" + UW + ", " + std::to_string(c.fused_t) + ", 2, " + join(c.fr) + ">;\n";
+    else s += "using JitFused = FusedPlanN<" + UW + ", " + std::to_string(c.fused_t) + ", 2, " + std::to_string(c.fused_wpe) + ", " + (c.fused_rr ? "true" : "false") +
+              ", " + join(c.fr) + ">;\n";
     s += "using JitCT = CtPlan<" + UW + ", " + std::to_string(c.ct_t) + ", " + join(c.ct) + ">;\n";
     s += "static_assert(FusedGLds<JitFused>::TOTAL == " + std::to_string(c.fused_lds) + " && JitFused::T == " + std::to_string(c.fused_t) +
          ", \"host and device disagree on the fused kernel's geometry\");\n";
@@ -244,10 +315,11 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT])
         names[K_ROW_PLANAR] = "fftup::k_row_r2c_t<" + W + ", " + fm + ", 4>";
         names[K_ROW_U8] = "fftup::k_row_r2c_t<" + W + ", " + um + ", 4>";
     } else {
-        names[K_ROW_PLANAR] = "fftup::k_row_r2c_m<fftup::JitCfg, " + fm + ">";
-        names[K_ROW_U8] = "fftup::k_row_r2c_m<fftup::JitCfg, " + um + ">";
+        const std::string k = c.row_kind == 3 ? "fftup::k_row_r2c_n" : "fftup::k_row_r2c_m";
+        names[K_ROW_PLANAR] = k + "<fftup::JitCfg, " + fm + ">";
+        names[K_ROW_U8] = k + "<fftup::JitCfg, " + um + ">";
     }
-    names[K_COL] = c.col_kind == 0 ? "fftup::k_col_t<" + H + ", 4>" : "fftup::k_col_m<fftup::JitCfg>";
+    names[K_COL] = c.col_kind == 0 ? "fftup::k_col_t<" + H + ", 4>" : c.col_kind == 3 ? "fftup::k_col_n<fftup::JitCfg>" : "fftup::k_col_m<fftup::JitCfg>";
     names[K_FUSED] = "fftup::k_c2r_sharpen_g<fftup::JitFused, " + hb + ", 4>";
     names[K_C2R_CT] = "fftup::k_row_c2r_ct<fftup::JitCT, " + hb + ">";
     return s;
@@ -256,14 +328,17 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT])
 static std::string describe(const Choice& c)
 {
     std::string s = "row ";
-    s += c.row_kind == 2 ? "generic" : c.row_kind == 0 ? "pow2/8" : std::to_string(c.rr[0]) + "*" + std::to_string(c.rr[1]) + "*" + std::to_string(c.rr[2]);
+    auto star = [](const std::vector<int>& v) { std::string t; for (size_t i = 0; i < v.size(); i++) t += (i ? "*" : "") + std::to_string(v[i]); return t; };
+    s += c.row_kind == 2 ? "generic" : c.row_kind == 0 ? "pow2/8" : c.row_kind == 3 ? star(c.rn) : std::to_string(c.rr[0]) + "*" + std::to_string(c.rr[1]) + "*" + std::to_string(c.rr[2]);
     s += " x" + std::to_string(c.row_block) + ", col ";
-    s += c.col_kind == 0 ? "pow2/8" : std::to_string(c.cr[0]) + "*" + std::to_string(c.cr[1]) + "*" + std::to_string(c.cr[2]);
+    s += c.col_kind == 0 ? "pow2/8" : c.col_kind == 3 ? star(c.cn) : std::to_string(c.cr[0]) + "*" + std::to_string(c.cr[1]) + "*" + std::to_string(c.cr[2]);
     s += " x" + std::to_string(c.col_block) + ", fused ";
     if (c.fused_kind == 0) s += "pow2/8";
     else if (c.fused_kind == 1) s += "16*16*" + std::to_string(c.UW / 256);
     else for (size_t i = 0; i < c.fr.size(); i++) s += (i ? "*" : "") + std::to_string(c.fr[i]);
-    s += " x" + std::to_string(c.fused_t) + " (" + std::to_string(c.fused_lds) + " B LDS)";
+    s += " x" + std::to_string(c.fused_t) + " (" + std::to_string(c.fused_lds) + " B LDS";
+    if (c.fused_kind == 2) s += ", " + std::to_string(c.fused_wpe) + " waves/SIMD" + (c.fused_rr ? "" : ", ring rows in LDS");
+    s += ")";
     return s;
 }
 
@@ -409,6 +484,13 @@ static bool compile(const Choice& c, const std::string& arch, Binary& out, std::
     }
     std::string names[K_COUNT];
     const std::string src = make_source(c, names);
+    if (const char* dump = getenv("FFTUP_JIT_DUMP")) {       // the generated translation unit, for inspection (tools/jit_resources.sh)
+        if (FILE* f = fopen(dump, "w")) {
+            fputs(src.c_str(), f);
+            for (int k = 0; k < K_COUNT; k++) if (!names[k].empty()) fprintf(f, "template __global__ decltype(%s) %s;\n", names[k].c_str(), names[k].c_str());
+            fclose(f);
+        }
+    }
     const char* rocm = getenv("ROCM_PATH");
     const std::string inc_rocm = std::string("-I") + (rocm ? rocm : "/opt/rocm") + "/include", inc_k = "-I" + kdir;
     const std::string arch_opt = "--offload-arch=" + arch;
@@ -471,7 +553,31 @@ struct Module {
     ~Module() { if (mod) (void)hipModuleUnload(mod); }
 };
 
-static Module* load(const Choice& c, const std::string& arch, std::string& err)
+static Module* load_once(const Choice& c, const std::string& arch, std::string& err);
+
+// the fused kernel's scratch bytes per lane (register spills), 0 if unknown
+static int fused_scratch(const Module* m);
+
+// Load the plan's code object; when the fused kernel of an N-stage plan spills under the two-strips-per-unit register
+// bound, rebuild it for one strip per unit (twice the registers), then with the ring rows in LDS.
+static Module* load(Choice c, const std::string& arch, std::string& err)
+{
+    // `choose` filled the geometry for c.fused_wpe / c.fused_rr as they are; the variants below only change those two
+    for (;;) {
+        Module* m = load_once(c, arch, err);
+        if (!m || c.fused_kind != 2 || getenv("FFTUP_JIT_FUSED_OPT") || fused_scratch(m) == 0) return m;
+        const int one_strip = std::max(1, c.fused_t / 256);
+        const int npass = (c.UW + 4 * c.fused_t - 1) / (4 * c.fused_t);
+        if (c.fused_wpe > one_strip) c.fused_wpe = one_strip;
+        else if (c.fused_rr && npass <= 4 && 2 * (c.fused_lds - 32 * sizeof(float)) + 32 * sizeof(float) <= 160 * 1024) {
+            c.fused_rr = false;
+            c.fused_lds = 2 * (c.fused_lds - 32 * sizeof(float)) + 32 * sizeof(float);
+        } else return m;                                                        // nothing left to relax: it runs, with spills
+        delete m;
+    }
+}
+
+static Module* load_once(const Choice& c, const std::string& arch, std::string& err)
 {
     Binary b;
     if (!compile(c, arch, b, err)) return nullptr;
@@ -485,6 +591,13 @@ static Module* load(const Choice& c, const std::string& arch, std::string& err)
         if (e != hipSuccess) { err = "hipModuleGetFunction(" + b.lowered[k] + "): " + hipGetErrorString(e); delete m; return nullptr; }
     }
     return m;
+}
+
+static int fused_scratch(const Module* m)
+{
+    int bytes = 0;
+    if (hipFuncGetAttribute(&bytes, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, m->fn[K_FUSED]) != hipSuccess) return 0;
+    return bytes;
 }
 
 template <class Params>

@@ -178,6 +178,107 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_m(ColTParams p)
     }
 }
 
+// =================================================================================== N-stage register-resident kernels
+// The same two kernels on the N-stage engine MrFftNT (any radix list, several butterflies per thread in the middle
+// stages, XOR index map): what a run-time specialised plan (jit.hpp) uses for a length without a three-stage
+// factorization (2000 = 8*5*5*10, 3584 = 8*8*8*7, ...).  CFG::RowN = MrFftNT<W, +1, ROW_T, 1, radices...>,
+// CFG::ColF / CFG::ColI = MrFftNT<H, +1 / -1, COL_TPC, 4, radices...>.
+
+// ---- row R2C.  grid (H/2, 3), block CFG::ROW_T, LDS lswz_size(W) float2.
+template <class CFG, int MODE>
+__global__ void __launch_bounds__(CFG::ROW_T) k_row_r2c_n(RowR2CTParams p)
+{
+    using F = typename CFG::RowN;
+    constexpr int W = CFG::W, TK = 4, T = CFG::ROW_T, R0 = F::rs(0), NB0 = W / R0, RL = F::rs(F::NST - 1), NBL = W / RL;
+    static_assert(T >= NB0 && T >= NBL, "one butterfly per thread in the first and the last stage");
+    __shared__ __attribute__((aligned(128))) float2 buf[lswz_size(W)];
+    const int tid = threadIdx.x, c = blockIdx.y, j = blockIdx.x;
+    typename F::Tw tw;
+    F::load_tw(tw, p.tw, tid);
+    float2 v[F::VN];
+    if (tid < NB0) {
+#pragma unroll
+        for (int m = 0; m < R0; m++)
+            v[m] = make_float2(load_px_t<MODE>(p, c, 2 * j, tid + NB0 * m), load_px_t<MODE>(p, c, 2 * j + 1, tid + NB0 * m));
+    }
+    F::template run<true>(v, buf, buf, tid, tw);            // (in place: the last gather is behind a barrier)
+    if (tid < NBL) {
+#pragma unroll
+        for (int m = 0; m < RL; m++) buf[lswz(tid + NBL * m)] = v[m];
+    }
+    __syncthreads();
+    // unpack (vkFFT.h:4292-4323), as k_row_r2c_m
+    const long tile_stride = (long)p.H * TK;
+    float2* base = p.S1 + (long)c * p.NT * tile_stride + (long)(2 * j) * TK;
+    constexpr int NTILE = (W / 2 + 1 + TK - 1) / TK;
+    for (int g = tid; g < NTILE * TK; g += T) {
+        const int tile = g / TK, l = g % TK;
+        const bool isB = l >= TK / 2;
+        const int kk = (l % (TK / 2)) * 2;
+        float2 o[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int k = tile * TK + kk + e;
+            float2 r = make_float2(0.f, 0.f);
+            if (k <= W / 2) {
+                const float2 zk = buf[lswz(k)], zn = buf[lswz(k == 0 ? 0 : W - k)];
+                r = isB ? make_float2(0.5f * (zk.y + zn.y), 0.5f * (-zk.x + zn.x)) : make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+            }
+            o[e] = r;
+        }
+        *(float4*)(base + (long)tile * tile_stride + (isB ? TK : 0) + kk) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+    }
+}
+
+// ---- column, polyphase form (k_col_t).  grid (NT, 3), block 4 * CFG::COL_TPC, LDS lswz_size(4 H) float2.
+template <class CFG>
+__global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_n(ColTParams p)
+{
+    using FF = typename CFG::ColF;
+    using FI = typename CFG::ColI;
+    constexpr int H = CFG::H, TK = 4, TC = CFG::COL_TPC, R0 = FF::rs(0), NB0 = H / R0, RL = FF::rs(FF::NST - 1), NBL = H / RL;
+    static_assert(TC >= NB0 && TC >= NBL, "one butterfly per thread in the first and the last stage");
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+    float2* buf = (float2*)smem;
+    const int tid = threadIdx.x, col = tid % TK, j = tid / TK;
+    const int tile = blockIdx.x, c = blockIdx.y;
+    const bool valid = tile * TK + col <= p.W / 2;
+    const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
+    typename FF::Tw twf;
+    typename FI::Tw twi;
+    FF::load_tw(twf, p.twH, j);
+    FI::load_tw(twi, p.twH, j);
+    float2 v[FF::VN];
+    if (j < NB0) {
+#pragma unroll
+        for (int m = 0; m < R0; m++) v[m] = valid ? src[(j + NB0 * m) * TK + col] : make_float2(0.f, 0.f);
+    }
+    FF::template run<true>(v, buf, buf, j, twf, col);
+    if (j < NBL) {
+#pragma unroll
+        for (int m = 0; m < RL; m++) buf[lidx<TK>(j + NBL * m, col)] = v[m];       // F[k] in natural order
+    }
+    __syncthreads();
+    if (j < NB0) {
+        // t[k] = exp(-2 pi i k/2H) * (k < H/2 ? 1 : -1), straight from the table of 2H-th roots
+#pragma unroll
+        for (int m = 0; m < R0; m++) {
+            const int k = j + NB0 * m;
+            float2 t = twid<-1>(p.twUH[k]);
+            if (k >= H / 2) t = make_float2(-t.x, -t.y);
+            v[m] = cmul(buf[lidx<TK>(k, col)], t);
+        }
+    }
+    __syncthreads();
+    FI::template run<true>(v, buf, buf, j, twi, col);
+    float2* dst = p.S2 + ((long)c * p.NT + tile) * H * TK;
+    constexpr float inv = 1.0f / (float)H;
+    if (j < NBL && valid) {
+#pragma unroll
+        for (int m = 0; m < RL; m++) dst[(j + NBL * m) * TK + col] = cscale(v[m], inv);
+    }
+}
+
 // ---- the sizes.  CT = the stand-alone C2R plan (two-launch path and pre-sharpen tap), FUSED = the default fused plan.
 using Plan3840 = CtPlan<3840, 512, 8, 8, 4, 3, 5>;
 using Plan2560 = CtPlan<2560, 512, 8, 8, 8, 5>;

@@ -982,6 +982,7 @@ template <int UW_> struct FusedPlanPow2 {                   // radix-8 Stockham,
     // gather of the previous step, so the step needs no barrier at its end either: 4 barriers per step instead of 9.
     static constexpr int NBUF = 3;
     static constexpr bool RING_REGS = true;
+    static constexpr int WPE = T * 2 / 256 > 0 ? T * 2 / 256 : 1;      // two strips can share a compute unit
     static_assert((num_stages(UW, 8) - 1) % 2 == 1, "the first exchange must go through z");
     struct Tw { TwSet<UW, 8> t; };
     static __device__ __forceinline__ int first_index(int lt) { return lt; }      // first-stage butterfly of thread lt
@@ -1127,7 +1128,7 @@ template <int N, int DIR, int TK, int R0, int R1, int R2, bool FINAL_TO_LDS> str
 // still needed 226 VGPRs; since the butterflies run on register pairs that plan needs 120 and is the default again:
 // one 256-thread workgroup per compute unit (ONE wave per SIMD) runs a strip as fast as this plan's 512 threads do and
 // leaves more issue slots to the kernels beside it (frame 78 -> 75 us).
-template <int N, int DIR, int T, int... RS> struct MrFftN {
+template <int N, int DIR, int T, int TK, int... RS> struct MrFftNT {
     static constexpr int NST = sizeof...(RS);
     static constexpr int rs(int s) { constexpr int r[] = {RS...}; return r[s]; }
     static constexpr int ns(int s) { int n = 1; for (int i = 0; i < s; i++) n *= rs(i); return n; }
@@ -1154,8 +1155,9 @@ template <int N, int DIR, int T, int... RS> struct MrFftN {
     // reg_fft_pp: one barrier per exchange, the last one through z).
     static constexpr bool pow2(int n) { return (n & (n - 1)) == 0; }
     // INPLACE: one buffer (c), two barriers per exchange.
+    // (TK interleaved sequences: element i of sequence col lives at lswz(i*TK + col); j = butterfly index within the sequence)
     template <bool INPLACE, int S = 0>
-    static __device__ __forceinline__ void run(float2 (&v)[VN], float2* __restrict__ c, float2* __restrict__ z, int j, const Tw& w)
+    static __device__ __forceinline__ void run(float2 (&v)[VN], float2* __restrict__ c, float2* __restrict__ z, int j, const Tw& w, int col = 0)
     {
         if constexpr (S < NST) {
             constexpr int R = rs(S), Ns = ns(S), NB = N / R, BPT = bpt(S), NE = NST - 1;
@@ -1168,7 +1170,7 @@ template <int N, int DIR, int T, int... RS> struct MrFftN {
                     const int jb = j + T * b;
                     if (jb < NB) {
 #pragma unroll
-                        for (int m = 0; m < R; m++) v[b * R + m] = bin[lswz(jb + NB * m)];
+                        for (int m = 0; m < R; m++) v[b * R + m] = bin[lidx<TK>(jb + NB * m, col)];
                     }
                 }
                 if constexpr (INPLACE) __syncthreads();      // the buffer may be overwritten from here on
@@ -1183,23 +1185,25 @@ template <int N, int DIR, int T, int... RS> struct MrFftN {
                         const int k = jb % Ns, j0 = (jb - k) * R + k;
                         if constexpr (pow2(R) && pow2(Ns)) {
                             // bits of m*Ns are clear in j0: lswz(j0 + m*Ns) = lswz(j0) ^ lswz(m*Ns) (see lds_put)
-                            const unsigned a0 = lds_addr(bout) + 8u * (unsigned)lswz(j0);
+                            const unsigned a0 = lds_addr(bout) + 8u * (unsigned)lidx<TK>(j0, col);
 #pragma unroll
-                            for (int m = 0; m < R; m++) lds_put(a0, lswz_c(m * Ns), v[b * R + m]);
+                            for (int m = 0; m < R; m++) lds_put(a0, lswz_c(m * Ns * TK), v[b * R + m]);
                         } else {
 #pragma unroll
-                            for (int m = 0; m < R; m++) bout[lswz(j0 + m * Ns)] = v[b * R + m];
+                            for (int m = 0; m < R; m++) bout[lidx<TK>(j0 + m * Ns, col)] = v[b * R + m];
                         }
                     }
                 }
             }
             if constexpr (S + 1 < NST) {
                 __syncthreads();
-                run<INPLACE, S + 1>(v, c, z, j, w);
+                run<INPLACE, S + 1>(v, c, z, j, w, col);
             }
         }
     }
 };
+template <int N, int DIR, int T, int... RS> using MrFftN = MrFftNT<N, DIR, T, 1, RS...>;
+
 #ifndef FFTUP_3840_NBUF
 #define FFTUP_3840_NBUF 2
 #endif
@@ -1207,7 +1211,7 @@ template <int N, int DIR, int T, int... RS> struct MrFftN {
 // (jit.hpp) instantiate when no three-stage 16 * 16 * R2 plan exists, and the 8 * 8 * 4 * 15 plan of 1920x1080 on 512
 // threads (FFTUP_3840_X16=0).  R0 must be a multiple of 4 (the non-zero quarter of the spectrum fills whole first-stage
 // inputs), T >= UW/R0 and T >= UW/Rlast.
-template <int UW_, int T_, int NBUF_, int... RS> struct FusedPlanN {
+template <int UW_, int T_, int NBUF_, int WPE_, bool RR_, int... RS> struct FusedPlanN {
     using F = MrFftN<UW_, -1, T_, RS...>;
     static constexpr int UW = UW_, T = T_, R0 = F::rs(0), NB0 = UW / R0, EOUT = F::rs(F::NST - 1), SOUT = UW / EOUT, VN = F::VN;
     static constexpr size_t XB = sizeof(float2) * lswz_size(UW);
@@ -1215,7 +1219,8 @@ template <int UW_, int T_, int NBUF_, int... RS> struct FusedPlanN {
     // its own and the frame 2 % slower: with 61 KB of LDS two of these workgroups share a compute unit whenever consecutive
     // frames' launches overlap, with 92 KB they cannot (measured).
     static constexpr int NBUF = NBUF_;
-    static constexpr bool RING_REGS = true;
+    static constexpr bool RING_REGS = RR_;                 // false: the previous pair's L rows in a second LDS buffer instead of 12 registers per pass
+    static constexpr int WPE = WPE_;                       // waves per SIMD the register allocation must allow (launch bound)
     static_assert(R0 % 4 == 0 && T >= NB0 && T >= SOUT, "first radix a multiple of 4; one butterfly per thread at both ends");
     static_assert(NBUF == 2 || (F::NST - 1) % 2 == 1, "three buffers: the first exchange must go through z");
     static_assert(XB % 128 == 0, "lds_put needs 128-byte aligned buffers");
@@ -1235,7 +1240,7 @@ template <int UW_, int T_, int NBUF_, int... RS> struct FusedPlanN {
         F::template run<NBUF == 2>(v, buf, zbuf, j, t);
     }
 };
-using FusedPlan3840 = FusedPlanN<3840, 512, FFTUP_3840_NBUF, 8, 8, 4, 15>;     // 1920x1080 -> 3840x2160, rows of 3840 = 8 * 8 * 4 * 15
+using FusedPlan3840 = FusedPlanN<3840, 512, FFTUP_3840_NBUF, 4, true, 8, 8, 4, 15>;     // 1920x1080 -> 3840x2160, rows of 3840 = 8 * 8 * 4 * 15
 #ifndef FFTUP_3840X16_NBUF
 #define FFTUP_3840X16_NBUF 2
 #endif
@@ -1256,6 +1261,7 @@ template <int UW_, int R2_> struct FusedPlanMr16 {
     // nothing for the kernel alone (77 us at 3840) and costs 98 instead of 65 KB of LDS: frame 75 -> 87 us.  Kept at 2.
     static constexpr int NBUF = FFTUP_3840X16_NBUF;
     static constexpr bool RING_REGS = FFTUP_3840X16_RR;
+    static constexpr int WPE = 2;
     static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w)
     {
         F::fft(v, buf, NBUF == 3 ? zbuf : buf, j, w);
@@ -1316,7 +1322,7 @@ __device__ __forceinline__ void deferred_pixel(const FusedParams& p, long of, fl
 // (second argument: waves per SIMD the register allocation must allow -- 4 for 512 threads = 128 VGPRs, so that two strips
 // can share a compute unit; tighter caps were tried: 80 VGPRs spill in fp32 and buy nothing in binary16)
 template <class PL, bool HALF, int TK>
-__global__ void __launch_bounds__(PL::T, PL::T * 2 / 256 > 0 ? PL::T * 2 / 256 : 1) k_c2r_sharpen_g(FusedParams p)
+__global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
 {
     constexpr int UW = PL::UW, T = PL::T, R0 = PL::R0, NB0 = PL::NB0, NI = R0 / 4, KH = UW / 4;
     constexpr int EOUT = PL::EOUT, SOUT = PL::SOUT, VN = PL::VN;
