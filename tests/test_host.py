@@ -162,7 +162,8 @@ def test_jit_check_compiles_without_a_device(tmp_path, monkeypatch):
         assert expect in buf.value.decode(), buf.value
     files = list((tmp_path / "cache").glob("*.fjit"))
     assert len(files) == 3 and all(f.stat().st_size > 10000 for f in files)
-    assert lib.fftup_jit_check(2000, 2000, 0, None, buf, 256) == 2          # FFTUP_E_UNSUPPORTED_SIZE: generic kernels run it
+    assert lib.fftup_jit_check(2000, 1250, 0, None, buf, 256) == 0 and "row 8*5*5*10" in buf.value.decode()       # N-stage kernels
+    assert lib.fftup_jit_check(4000, 3000, 0, None, buf, 256) == 2          # FFTUP_E_UNSUPPORTED_SIZE: the generic kernels run it
     assert lib.fftup_jit_check(640, 480, 1, None, buf, 256) == 3            # FFTUP_E_UNSUPPORTED_PRECISION
     # a pinned factorization that does not multiply to the size is ignored; a valid one is used
     monkeypatch.setenv("FFTUP_JIT_ROW", "5,8,16")

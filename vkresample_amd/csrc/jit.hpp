@@ -204,8 +204,11 @@ static bool choose_n(int n, int tmax, int granule, std::vector<int>& out, int* t
             cost += (double)bpt * T * cur[s];
         }
         if (vn > 16) return;
-        if (!found || ns < best_ns || (ns == best_ns && (cost < best || (cost == best && mn > best_min)))) {
-            found = true; best_ns = ns; best = cost; best_min = mn; out = cur; *threads = T;
+        // rows (one sequence per workgroup): no radix-2/3 stage if it can be avoided (3584 = 8*8*8*7 runs 15 % faster than
+        // 16*2*7*16); columns: the fewest lane slots decide (four sequences per workgroup: the block size is what hurts)
+        const int mnk = granule >= 64 ? std::min(mn, 4) : 0;
+        if (!found || ns < best_ns || (ns == best_ns && (mnk > best_min || (mnk == best_min && cost < best)))) {
+            found = true; best_ns = ns; best = cost; best_min = mnk; out = cur; *threads = T;
         }
     };
     struct Rec {
