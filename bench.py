@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--upscale", type=float, default=2.0)
     ap.add_argument("--precision", type=int, default=0, help="0 = fp32 (headline), 1 = fp64, 2 = fp16 memory")
     ap.add_argument("--fuse-u8", action="store_true", help="row kernel reads uint8 RGB directly")
+    ap.add_argument("--generic", action="store_true", help="size-generic kernels (FFTUP_FLAG_GENERIC_KERNELS): no tuned, no plan-time specialised plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the bounded CPU-baseline sample (~15 s on 128 threads)")
     ap.add_argument("--profile-iters", type=int, default=50)
@@ -133,7 +134,7 @@ def main():
     if v.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
     dev = local_rank % v.device_count()
-    flags = v.FLAG_FUSE_U8_LOAD if args.fuse_u8 else 0
+    flags = (v.FLAG_FUSE_U8_LOAD if args.fuse_u8 else 0) | (v.FLAG_GENERIC_KERNELS if args.generic else 0)
     up = v.Upscaler(args.width, args.height, args.upscale, args.precision, 0.2, dev, flags, args.ring)
     # distinct frames per rank and slot: rank r owns frames r*ring .. r*ring+ring-1 of the job
     for s in range(args.ring):
@@ -246,7 +247,7 @@ def main():
                                       "uint8 RGB (fused load)" if args.fuse_u8 and args.precision != 1 else "planar fp%d" % {0: 32, 1: 64, 2: 16}[args.precision]),
                        "preset": args.preset or "config2", "frames_per_step": args.frames_per_step,
                        "sharding": "independent frames, no collective",
-                       "kernels": "tuned" if up.tuned else "generic", "streams": args.streams, "device": up.device_name},
+                       "kernels": ("plan-time" if up.specialised_at_plan_time else "tuned") if up.tuned else "generic", "streams": args.streams, "device": up.device_name},
             "repeats": len(region_s), "region_s": region_s, "timed_region_s_median": dt,
             "ms_per_frame": wall_frame_ms, "ms_per_frame_device_events": frame_ms,
             "frame_alg_bytes": up.alg_bytes_per_frame, "B_min": b_min,

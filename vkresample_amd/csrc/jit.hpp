@@ -11,7 +11,10 @@
 // ($FFTUP_CACHE_DIR, else $XDG_CACHE_HOME/fftup, else ~/.cache/fftup), keyed by a hash of the translation unit, the
 // compiler options, the hipRTC version and the kernel headers' text.
 //
-// The kernel headers are read from $FFTUP_KERNEL_DIR, else from csrc/ next to libfftup.so.
+// The kernel headers' text is embedded in the library at build time (kernel_sources.inc, written by
+// __graft_entry__.build() from the very files the ahead-of-time kernels are compiled from) and handed to hipRTC as
+// in-memory headers; $FFTUP_KERNEL_DIR overrides it with a directory (development), and a library built without the
+// generated file reads csrc/ next to libfftup.so.
 #pragma once
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -30,7 +33,16 @@
 #include <string>
 #include <vector>
 
+#if __has_include("kernel_sources.inc")
+#include "kernel_sources.inc"          // static const char* const fftup_kernel_sources[][2] = {{name, text}, ...}
+#define FFTUP_HAVE_EMBEDDED_SOURCES 1
+#else
+#define FFTUP_HAVE_EMBEDDED_SOURCES 0
+#endif
+
 namespace fftup_jit {
+
+static const char* const kHeaderNames[] = {"fft_engine.hpp", "kernels_generic.hpp", "kernels_pow2.hpp", "kernels_mixed.hpp"};
 
 // radices the register engines have butterflies for (fft_engine.hpp bfly<R>, kernels_pow2.hpp twiddle_all<R>)
 static const int kRadices[] = {2, 3, 4, 5, 7, 8, 9, 10, 12, 15, 16};
@@ -479,12 +491,24 @@ static bool compile(const Choice& c, const std::string& arch, Binary& out, std::
 {
     const Rtc& R = rtc();
     if (!R.ok) { err = "hipRTC (libhiprtc.so) not available"; return false; }
-    const std::string kdir = kernel_dir();
-    std::string hdr_text, one;
-    for (const char* h : {"fft_engine.hpp", "kernels_generic.hpp", "kernels_pow2.hpp", "kernels_mixed.hpp"}) {
-        if (!read_file(kdir + "/" + h, one)) { err = "kernel header " + kdir + "/" + h + " not found (set FFTUP_KERNEL_DIR)"; return false; }
-        hdr_text += one;
+    // kernel headers: embedded text (default) or a directory
+    std::vector<std::string> hdr(4);
+    std::string kdir;
+    const bool from_dir = getenv("FFTUP_KERNEL_DIR") || !FFTUP_HAVE_EMBEDDED_SOURCES;
+    if (from_dir) {
+        kdir = kernel_dir();
+        for (int i = 0; i < 4; i++)
+            if (!read_file(kdir + "/" + kHeaderNames[i], hdr[i])) { err = "kernel header " + kdir + "/" + kHeaderNames[i] + " not found (set FFTUP_KERNEL_DIR)"; return false; }
     }
+#if FFTUP_HAVE_EMBEDDED_SOURCES
+    else {
+        for (int i = 0; i < 4; i++)
+            for (const auto& e : fftup_kernel_sources)
+                if (!strcmp(e[0], kHeaderNames[i])) hdr[i] = e[1];
+    }
+#endif
+    std::string hdr_text;
+    for (const auto& h : hdr) hdr_text += h;
     std::string names[K_COUNT];
     const std::string src = make_source(c, names);
     if (const char* dump = getenv("FFTUP_JIT_DUMP")) {       // the generated translation unit, for inspection (tools/jit_resources.sh)
@@ -495,10 +519,10 @@ static bool compile(const Choice& c, const std::string& arch, Binary& out, std::
         }
     }
     const char* rocm = getenv("ROCM_PATH");
-    const std::string inc_rocm = std::string("-I") + (rocm ? rocm : "/opt/rocm") + "/include", inc_k = "-I" + kdir;
+    const std::string inc_rocm = std::string("-I") + (rocm ? rocm : "/opt/rocm") + "/include";
     const std::string arch_opt = "--offload-arch=" + arch;
     // the flags of the ahead-of-time build (__graft_entry__.py): results must not depend on which of the two compiled a kernel
-    const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=on", inc_k.c_str(), inc_rocm.c_str()};
+    const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=on", inc_rocm.c_str()};
     int vmaj = 0, vmin = 0;
     R.Version(&vmaj, &vmin);
     uint64_t key = fnv1a(src);
@@ -518,7 +542,9 @@ static bool compile(const Choice& c, const std::string& arch, Binary& out, std::
     if (!cpath.empty() && load_cached(cpath, out)) { memo[key] = out; return true; }
 
     hiprtcProgram prog = nullptr;
-    if (R.CreateProgram(&prog, src.c_str(), "fftup_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return false; }
+    const char* hdr_ptr[4] = {hdr[0].c_str(), hdr[1].c_str(), hdr[2].c_str(), hdr[3].c_str()};
+    const char* hdr_names[4] = {kHeaderNames[0], kHeaderNames[1], kHeaderNames[2], kHeaderNames[3]};
+    if (R.CreateProgram(&prog, src.c_str(), "fftup_jit.hip", 4, hdr_ptr, hdr_names) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return false; }
     for (int k = 0; k < K_COUNT; k++) if (!names[k].empty()) R.AddNameExpression(prog, names[k].c_str());
     const hiprtcResult rc = R.CompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
     if (rc != HIPRTC_SUCCESS) {
