@@ -1,4 +1,4 @@
-"""Run-time specialised plans (csrc/jit.hpp): a -u 2 size without ahead-of-time kernels gets its row, column and fused
+"""Run-time specialised plans (csrc/jit.hpp): a size with an integer upscale factor and no ahead-of-time kernels gets its row, column and fused
 C2R+sharpen kernels instantiated through hipRTC at plan time.  Parity against the oracle (same tolerances as
 test_gpu_parity.test_full_size_vs_oracle) and against the size-generic kernels on the same frame, for sizes that
 exercise every plan family: three-stage mixed-radix rows/columns, power-of-two rows/columns, the 16*16*R fused plans,
@@ -40,6 +40,40 @@ def test_specialised_plan_vs_oracle(W, H, precision, flags):
     if precision == 0:
         so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 1e-4)
         assert _rel_l2(pre, opre) <= 1e-5 and np.abs(pre - opre).max() * 4 <= 1e-4
+        assert so["p99.99"] <= 1e-4 and so["max"] <= 1e-3 and so["count_above"] <= 1e-4 * so["n"]
+        d = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
+        assert d.max() <= 1 and (d != 0).mean() <= 5e-3
+    else:
+        ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
+        assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
+        so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 2.0 ** -10)
+        assert so["max"] <= 8e-3 and so["p99"] <= 2.0 ** -10 and so["p99.99"] <= 4e-3
+
+
+# integer upscale factors other than 2: U - 1 residue transforms in the column kernel (k_col_u), first radix of the fused
+# kernel a multiple of 2U
+U_CASES = [
+    (640, 480, 3.0),     # fused 12*10*16
+    (640, 480, 4.0),     # fused 16*16*10 (FusedPlanMr16, NI = 2)
+    (1024, 512, 4.0),    # FusedPlanPow2<4096> with one non-zero input per first-stage butterfly
+    (1280, 720, 3.0),    # fused 12*4*5*16
+    (960, 540, 4.0),     # 540p -> 2160p
+    (640, 480, 5.0),     # first radix 10
+    (256, 128, 8.0),     # first radix 16, NI = 1
+    (2048, 1024, 3.0),   # 6144 x 3072
+]
+
+
+@pytest.mark.parametrize("W,H,u", U_CASES)
+@pytest.mark.parametrize("precision,flags", [(0, 0), (2, 2)])
+def test_specialised_integer_factor_vs_oracle(W, H, u, precision, flags):
+    with _up(W, H, u, precision, 0.2, 0, flags) as up:
+        assert up.tuned and up.specialised_at_plan_time, "plan fell back to the size-generic kernels"
+    (pre, out, u8), (opre, oout, ou8) = _run(W, H, u, precision, "N", flags=flags, seed=W + H)
+    tag = "jit %dx%d u%g p%d flags%d" % (W, H, u, precision, flags)
+    if precision == 0:
+        so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 1e-4)
+        assert _rel_l2(pre, opre) <= 1e-5 and np.abs(pre - opre).max() * u * u <= 1e-4
         assert so["p99.99"] <= 1e-4 and so["max"] <= 1e-3 and so["count_above"] <= 1e-4 * so["n"]
         d = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
         assert d.max() <= 1 and (d != 0).mean() <= 5e-3

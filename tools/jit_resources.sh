@@ -1,7 +1,7 @@
 #!/bin/bash
 # registers / scratch / LDS of the kernels of a run-time specialised plan, compiled offline:
-#   tools/jit_resources.sh <W> <H> [precision]      (FFTUP_JIT_ROW / _COL / _FUSED pins are honoured)
-W=$1; H=$2; P=${3:-0}
+#   tools/jit_resources.sh <W> <H> [precision] [upscale]      (FFTUP_JIT_ROW / _COL / _FUSED pins are honoured)
+W=$1; H=$2; P=${3:-0}; U=${4:-2}
 cd "$(dirname "$0")/.."
 FFTUP_CACHE_DIR=/tmp/jit_res_cache FFTUP_JIT_DUMP=/tmp/jit_res_$$.hip python - <<PY
 import ctypes as C, sys
@@ -11,7 +11,7 @@ lib = _lib.load()
 buf = C.create_string_buffer(512)
 import os, shutil
 shutil.rmtree("/tmp/jit_res_cache", ignore_errors=True)
-rc = lib.fftup_jit_check($W, $H, $P, None, buf, 512)
+rc = lib.fftup_jit_check($W, $H, $U, $P, None, buf, 512)
 print(rc, buf.value.decode(), lib.fftup_last_error().decode()[:500] if rc else "")
 PY
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on --cuda-device-only -c -Ivkresample_amd/csrc -o /tmp/jit_res_$$.o /tmp/jit_res_$$.hip -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '

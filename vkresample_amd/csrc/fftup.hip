@@ -76,6 +76,7 @@ struct fftup_plan {
     int mixed = 0;                    // compile-time mixed-radix plans: 1 = 1920x1080 -> 3840x2160, 2 = 1280x720 -> 2560x1440,
                                       // 3 = specialised at plan time for this size (jit.hpp), kernels in `jit`
     fftup_jit::Module* jit = nullptr;
+    int U = 2;                        // integer upscale factor of a polyphase plan (tuned / mixed): S1 + U-1 residue buffers
     bool plan3840_x16 = true;         // 1080p: fused kernel on the 16*16*15 plan (256 threads, 120 VGPRs); false: 8*8*4*15 on 512 threads
     bool cplx = false;                // non-R2C path (VR:1424 false): full complex transforms, uW beyond the R2C limit
     int ncols = 0;                    // spectrum columns kept: W/2 + 1, or W on the non-R2C path
@@ -219,14 +220,15 @@ int fftup_device_name(int device, char* buf, size_t buflen)
     return FFTUP_OK;
 }
 
-int fftup_jit_check(uint32_t width, uint32_t height, uint32_t precision, const char* arch, char* desc, size_t desclen)
+int fftup_jit_check(uint32_t width, uint32_t height, uint32_t upscale, uint32_t precision, const char* arch, char* desc, size_t desclen)
 {
     if (desc && desclen) desc[0] = 0;
     if (precision != 0 && precision != 2) return fail(FFTUP_E_UNSUPPORTED_PRECISION, "run-time specialised plans exist for -p 0 and -p 2");
     if (width < 2 || height < 2 || (width & 1) || (height & 1) || width > 65536 || height > 65536 || !is_smooth(width) || !is_smooth(height))
         return fail(FFTUP_E_UNSUPPORTED_SIZE, "sizes must be even and factor into 2,3,5,7");
     fftup_jit::Choice ch;
-    if (2 * width > 8192 || !fftup_jit::choose((int)width, (int)height, precision == 2, stage_radices(make_stage_plan(2 * width)), ch))
+    if (upscale < 2 || upscale > 8 || upscale * width > 8192 || !is_smooth(upscale) ||
+        !fftup_jit::choose((int)width, (int)height, (int)upscale, precision == 2, stage_radices(make_stage_plan(upscale * width)), ch))
         return fail(FFTUP_E_UNSUPPORTED_SIZE, "no specialised factorization for this size: the size-generic kernels run it");
     if (desc && desclen) snprintf(desc, desclen, "%s", fftup_jit::describe(ch).c_str());
     fftup_jit::Binary bin;
@@ -351,15 +353,18 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             if (W == MixedCfg720::W && H == MixedCfg720::H) P->mixed = 2;
         }
         if (P->mixed) { P->TK = 4; P->ldsCol = sizeof(float2) * (size_t)H * 4; }             // k_col_m: one in-place buffer
-        // any other -u 2 size: kernels specialised for it now (the counterpart of VkFFT generating its shaders at plan time)
-        if (!P->dbl && !cplx && !P->tuned && !P->mixed && !(cfg->flags & (FFTUP_FLAG_GENERIC_KERNELS | FFTUP_FLAG_UNFUSED_SHARPEN)) &&
-            uW == 2 * W && uH == 2 * H && jit_enabled()) {
-            fftup_jit::Choice ch;
-            std::string jerr;
-            if (fftup_jit::choose((int)W, (int)H, P->half, stage_radices(P->planUW), ch)) {
-                P->jit = fftup_jit::load(ch, P->prop.gcnArchName, jerr);
-                if (P->jit) { P->mixed = 3; P->TK = 4; P->ldsCol = ch.col_lds; }
-                else if (getenv("FFTUP_JIT_VERBOSE")) fprintf(stderr, "fftup: run-time specialisation failed, size-generic kernels in use: %s\n", jerr.c_str());
+        // any other size with an integer upscale factor: kernels specialised for it now (the counterpart of VkFFT
+        // generating its shaders at plan time)
+        if (!P->dbl && !cplx && !P->tuned && !P->mixed && !(cfg->flags & (FFTUP_FLAG_GENERIC_KERNELS | FFTUP_FLAG_UNFUSED_SHARPEN)) && jit_enabled()) {
+            const int U = (int)(uW / W);
+            if (U >= 2 && U <= 8 && (float)U == cfg->upscale && uW == (uint32_t)U * W && uH == (uint32_t)U * H) {
+                fftup_jit::Choice ch;
+                std::string jerr;
+                if (fftup_jit::choose((int)W, (int)H, U, P->half, stage_radices(P->planUW), ch)) {
+                    P->jit = fftup_jit::load(ch, P->prop.gcnArchName, jerr);
+                    if (P->jit) { P->mixed = 3; P->U = U; P->TK = 4; P->ldsCol = P->jit->choice.col_lds; }
+                    else if (getenv("FFTUP_JIT_VERBOSE")) fprintf(stderr, "fftup: run-time specialisation failed, size-generic kernels in use: %s\n", jerr.c_str());
+                }
             }
         }
         P->fused = (P->tuned || P->mixed) && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
@@ -410,7 +415,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         const size_t s1_elems = (size_t)3 * P->NT * H * P->TK;
         auto alloc_spectra = [&](float2** s1, float2** s2) -> int {
             if (P->tuned || P->mixed) {
-                int r = dev_alloc(P, (void**)s1, P->csz * 2 * s1_elems);
+                int r = dev_alloc(P, (void**)s1, P->csz * (size_t)P->U * s1_elems);       // S1 + the U-1 residue buffers
                 *s2 = r ? nullptr : *s1 + s1_elems;
                 return r;
             }
@@ -521,7 +526,7 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
         // what the launches really have to move: polyphase plans write/read only the odd half of S2; a fused strip
         // re-reads one halo pair of spectrum rows
         const bool poly = P->tuned || P->mixed;
-        const double S2w = poly ? S1 : S2;                            // odd rows only
+        const double S2w = poly ? S1 * (P->U - 1) : S2;               // odd rows (residues 1..U-1) only
         const double halo = P->fused ? (double)(P->pairs_per_strip + 1) / P->pairs_per_strip : 1.0;
         info->kernel_min_bytes[0] = in + S1;
         info->kernel_min_bytes[1] = S1 + S2w;

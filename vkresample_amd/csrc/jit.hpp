@@ -49,11 +49,12 @@ static const int kRadices[] = {2, 3, 4, 5, 7, 8, 9, 10, 12, 15, 16};
 
 struct Choice {
     int W = 0, H = 0, UW = 0;
+    int U = 2;                         // integer upscale factor
     bool half = false;
     int row_kind = -1;                 // 0: k_row_r2c_t<W> (power of two, 8 points per thread); 1: k_row_r2c_m (three stages); 2: k_row_r2c (not specialised); 3: k_row_r2c_n
     int rr[3] = {0, 0, 0}, row_t = 0;
     std::vector<int> rn, cn;           // kind 3: k_row_r2c_n / k_col_n (N stages)
-    int col_kind = -1;                 // 0: k_col_t<H>; 1: k_col_m (three stages); 3: k_col_n (N stages)
+    int col_kind = -1;                 // 0: k_col_t<H>; 1: k_col_m (three stages); 3: k_col_n (N stages); 4: k_col_u (N stages, U - 1 residues)
     int cr[3] = {0, 0, 0}, col_tpc = 0;
     int fused_kind = -1;               // 0: FusedPlanPow2<UW>; 1: FusedPlanMr16<UW, UW/256>; 2: FusedPlanN<UW, T, 2, radices...>
     std::vector<int> fr;
@@ -125,18 +126,18 @@ static bool choose3(int n, int tk, int tmax, int r[3], int* threads, const char*
 
 // any number of stages on T threads (MrFftN / FusedPlanN): first radix a multiple of 4, one butterfly per thread in the
 // first and the last stage, at most 16 points per thread in between.  Measured over a dozen sizes (profiles/
-// r02_jit_factorizations.txt): a first radix of 8 -- every thread of a UW/8-thread workgroup loads and transforms its own
+// r02_k_jit_factorizations.txt): a first radix of 8 -- every thread of a UW/8-thread workgroup loads and transforms its own
 // eight inputs -- beats 16 (half the threads idle in the prefetch and in the first stage) by 10-25 %, even at one stage
 // more; after that the fewest stages (every stage is an LDS exchange with two workgroup barriers), the fewest lane
 // slots, the largest smallest radix.
-static bool choose_fused_n(int n, std::vector<int>& out, int* threads)
+static bool choose_fused_n(int n, int U, std::vector<int>& out, int* threads)
 {
     {
         int T = 0;
         std::vector<int> pin;
         if (env_radices("FFTUP_JIT_FUSED", pin, &T) && T >= 64 && T <= 1024 && T % 64 == 0) {
             long prod = 1;
-            bool ok = pin.size() >= 2 && pin[0] % 4 == 0;
+            bool ok = pin.size() >= 2 && pin[0] % (2 * U) == 0;
             for (int q : pin) { ok &= is_radix(q); prod *= q; }
             if (ok && prod == n && T >= n / pin[0] && T >= n / pin.back()) { out = pin; *threads = T; return true; }
         }
@@ -148,7 +149,7 @@ static bool choose_fused_n(int n, std::vector<int>& out, int* threads)
     auto r0_rank = [](int r0) { return r0 == 8 ? 0 : r0 == 12 ? 1 : r0 == 16 ? 2 : 3; };
     auto eval = [&]() {
         const int ns = (int)cur.size();
-        if (ns < 2 || cur[0] % 4) return;
+        if (ns < 2 || cur[0] % (2 * U)) return;
         const int tmin = std::max(n / cur[0], n / cur[ns - 1]);
         for (int T = (tmin + 63) / 64 * 64; T <= 1024; T += 64) {
             int vn = 0, mn = 99;
@@ -238,17 +239,20 @@ static bool choose_n(int n, int tmax, int granule, std::vector<int>& out, int* t
 
 // Factorizations for a W x H -> 2W x 2H plan.  false: some dimension has no supported factorization (the plan then
 // stays on the size-generic kernels).  ct_radices: the stage list of the size-generic plan for 2W (radices <= 8).
-static bool choose(int W, int H, bool half, const std::vector<int>& ct_radices, Choice& c)
+static bool choose(int W, int H, int U, bool half, const std::vector<int>& ct_radices, Choice& c)
 {
-    c.W = W; c.H = H; c.UW = 2 * W; c.half = half;
-    if (W < 64 || H < 64 || W > 4096 || H > 4096) return false;
+    c.W = W; c.H = H; c.U = U; c.UW = U * W; c.half = half;
+    if (W < 64 || H < 64 || W > 4096 || H > 4096 || U < 2 || c.UW > 8192) return false;
     // ---- row R2C
     if (is_pow2(W) && W >= 256) { c.row_kind = 0; c.row_block = W / 8; }
     else if (choose3(W, 1, 1024, c.rr, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 1; c.row_t = (c.row_t + 63) / 64 * 64; c.row_block = c.row_t; }
     else if (choose_n(W, 1024, 64, c.rn, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 3; c.row_block = c.row_t; }
     else c.row_kind = 2;               // no supported factorization: the size-generic row kernel (same S1 layout) stays
     // ---- column (four columns per workgroup)
-    if (is_pow2(H) && H >= 128 && H <= 2048) {
+    if (U > 2) {
+        if (!choose_n(H, 256, 16, c.cn, &c.col_tpc, "FFTUP_JIT_COL")) return false;
+        c.col_kind = 4; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * 4 + 15) & ~15);
+    } else if (is_pow2(H) && H >= 128 && H <= 2048) {
         c.col_kind = 0; c.col_block = 4 * H / 8; c.col_lds = sizeof(float2) * (size_t)((H * 4 + 15) & ~15);      // lswz_size
     } else if (choose3(H, 4, 256, c.cr, &c.col_tpc, "FFTUP_JIT_COL")) {
         c.col_kind = 1; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)H * 4;
@@ -259,13 +263,13 @@ static bool choose(int W, int H, bool half, const std::vector<int>& ct_radices, 
     const int UW = c.UW;
     size_t xb = sizeof(float2) * (size_t)((UW + 15) & ~15);                    // lswz_size(UW)
     int nbuf = 2;
-    if (UW == 1024 || UW == 2048 || UW == 4096) { c.fused_kind = 0; c.fused_t = UW / 8; nbuf = 3; }
+    if ((UW == 1024 || UW == 2048 || UW == 4096) && 8 % (2 * U) == 0) { c.fused_kind = 0; c.fused_t = UW / 8; nbuf = 3; }
     else {
-        const bool mr16 = UW % 256 == 0 && is_radix(UW / 256) && !getenv("FFTUP_JIT_FUSED");
+        const bool mr16 = UW % 256 == 0 && is_radix(UW / 256) && 16 % (2 * U) == 0 && !getenv("FFTUP_JIT_FUSED");
         if (mr16) {
             c.fused_kind = 1; c.fused_t = 256;
             xb = (sizeof(float2) * (size_t)(UW + (UW >> 4) + 1) + 15) & ~(size_t)15;                               // lpad_size(UW)
-        } else if (choose_fused_n(UW, c.fr, &c.fused_t)) {
+        } else if (choose_fused_n(UW, U, c.fr, &c.fused_t)) {
             c.fused_kind = 2;
             // two strips per compute unit (128 VGPRs at 512 threads) unless load() finds the kernel spilling
             if (c.fused_wpe <= 0) c.fused_wpe = std::max((c.fused_t + 255) / 256, std::min(c.fused_t * 2 / 256, 4));      // >= 128 VGPRs
@@ -299,7 +303,7 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT])
 {
     const std::string W = std::to_string(c.W), H = std::to_string(c.H), UW = std::to_string(c.UW);
     std::string s;
-    s += "// generated by fftup (jit.hpp): " + W + "x" + H + " -> " + UW + "x" + std::to_string(2 * c.H) + (c.half ? ", binary16 storage\n" : ", fp32\n");
+    s += "// generated by fftup (jit.hpp): " + W + "x" + H + " -> " + UW + "x" + std::to_string(c.U * c.H) + (c.half ? ", binary16 storage\n" : ", fp32\n");
     s += "#include \"kernels_mixed.hpp\"\nnamespace fftup {\n";
     s += "struct JitCfg {\n    static constexpr int W = " + W + ", H = " + H + ";\n";
     if (c.row_kind == 1)
@@ -310,7 +314,7 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT])
              ", COL_TPC = " + std::to_string(c.col_tpc) + ";\n";
     if (c.row_kind == 3)
         s += "    static constexpr int ROW_T = " + std::to_string(c.row_t) + ";\n    using RowN = MrFftNT<W, +1, ROW_T, 1, " + join(c.rn) + ">;\n";
-    if (c.col_kind == 3)
+    if (c.col_kind == 3 || c.col_kind == 4)
         s += "    static constexpr int COL_TPC = " + std::to_string(c.col_tpc) + ";\n    using ColF = MrFftNT<H, +1, COL_TPC, 4, " + join(c.cn) +
              ">;\n    using ColI = MrFftNT<H, -1, COL_TPC, 4, " + join(c.cn) + ">;\n";
     s += "};\n";
@@ -334,19 +338,21 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT])
         names[K_ROW_PLANAR] = k + "<fftup::JitCfg, " + fm + ">";
         names[K_ROW_U8] = k + "<fftup::JitCfg, " + um + ">";
     }
-    names[K_COL] = c.col_kind == 0 ? "fftup::k_col_t<" + H + ", 4>" : c.col_kind == 3 ? "fftup::k_col_n<fftup::JitCfg>" : "fftup::k_col_m<fftup::JitCfg>";
-    names[K_FUSED] = "fftup::k_c2r_sharpen_g<fftup::JitFused, " + hb + ", 4>";
-    names[K_C2R_CT] = "fftup::k_row_c2r_ct<fftup::JitCT, " + hb + ">";
+    const std::string U = std::to_string(c.U);
+    names[K_COL] = c.col_kind == 0 ? "fftup::k_col_t<" + H + ", 4>" : c.col_kind == 3 ? "fftup::k_col_n<fftup::JitCfg>" :
+                   c.col_kind == 4 ? "fftup::k_col_u<fftup::JitCfg, " + U + ">" : "fftup::k_col_m<fftup::JitCfg>";
+    names[K_FUSED] = "fftup::k_c2r_sharpen_g<fftup::JitFused, " + hb + ", 4, " + U + ">";
+    names[K_C2R_CT] = "fftup::k_row_c2r_ct<fftup::JitCT, " + hb + ", " + U + ">";
     return s;
 }
 
 static std::string describe(const Choice& c)
 {
-    std::string s = "row ";
+    std::string s = c.U == 2 ? "row " : "u" + std::to_string(c.U) + " row ";
     auto star = [](const std::vector<int>& v) { std::string t; for (size_t i = 0; i < v.size(); i++) t += (i ? "*" : "") + std::to_string(v[i]); return t; };
     s += c.row_kind == 2 ? "generic" : c.row_kind == 0 ? "pow2/8" : c.row_kind == 3 ? star(c.rn) : std::to_string(c.rr[0]) + "*" + std::to_string(c.rr[1]) + "*" + std::to_string(c.rr[2]);
     s += " x" + std::to_string(c.row_block) + ", col ";
-    s += c.col_kind == 0 ? "pow2/8" : c.col_kind == 3 ? star(c.cn) : std::to_string(c.cr[0]) + "*" + std::to_string(c.cr[1]) + "*" + std::to_string(c.cr[2]);
+    s += c.col_kind == 0 ? "pow2/8" : c.col_kind >= 3 ? star(c.cn) : std::to_string(c.cr[0]) + "*" + std::to_string(c.cr[1]) + "*" + std::to_string(c.cr[2]);
     s += " x" + std::to_string(c.col_block) + ", fused ";
     if (c.fused_kind == 0) s += "pow2/8";
     else if (c.fused_kind == 1) s += "16*16*" + std::to_string(c.UW / 256);

@@ -35,36 +35,41 @@ __device__ __forceinline__ float2* run_plan(CtPlan<N, T, R...>, float2* a, float
 }
 
 // ---- row C2R (see k_row_c2r), u = 2.  grid (uH/2, 3), block PUW::T, dynamic LDS 2*lpad_size(UW) float2
-template <class PUW, bool HALF_OUT>
+// (U: integer upscale factor, see k_c2r_sharpen_g; output row y = row y/U of spectrum buffer y%U, buffers p.S2 - p.S1 apart)
+template <class PUW, bool HALF_OUT, int U = 2>
 __global__ void __launch_bounds__(PUW::T) k_row_c2r_ct(RowC2RParams p)
 {
-    constexpr int UW = PUW::N, T = PUW::T, KH = UW / 4;       // kx = 0..W/2 = UW/4 non-zero
+    constexpr int UW = PUW::N, T = PUW::T, KH = UW / (2 * U);       // kx = 0..W/2 = UW/2U non-zero
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* a = (float2*)smem;
     float2* b = a + lpad_size(UW);
     const int tid = threadIdx.x, j = blockIdx.x, c = blockIdx.y;
     const int TK = p.TK;
-    // polyphase column pass: row 2j is row j of S1, row 2j+1 is row j of the odd-row buffer (both at twice the scale)
-    const long tile_stride = (long)(p.uH / 2) * TK;
-    const long roff = (long)c * p.NT * tile_stride + (long)j * TK;
+    // polyphase column pass: row 2j is row j of S1, row 2j+1 is row j of the odd-row buffer (both at twice the scale);
+    // in general row y is row y/U of buffer y%U
+    const long tile_stride = (long)(p.uH / U) * TK;
+    const long delta = p.S2 - p.S1;
+    const int ya = 2 * j, yb = 2 * j + 1;
+    const float2* rowA = p.S1 + (ya % U) * delta + (long)c * p.NT * tile_stride + (long)(ya / U) * TK;
+    const float2* rowB = p.S1 + (yb % U) * delta + (long)c * p.NT * tile_stride + (long)(yb / U) * TK;
     for (int k = tid + 1; k <= UW / 2; k += T) {
         float2 A = make_float2(0.f, 0.f), B = A;
         if (k <= KH) {
-            const long o = roff + (long)(k / TK) * tile_stride + (k % TK);
-            A = p.S1[o];
-            B = p.S2[o];
+            const long o = (long)(k / TK) * tile_stride + (k % TK);
+            A = rowA[o];
+            B = rowB[o];
         }
         a[lpad(k)] = make_float2(A.x - B.y, A.y + B.x);
         a[lpad(UW - k)] = make_float2(A.x + B.y, -A.y + B.x);
     }
     if (tid == 0) {
-        float2 A = p.S1[roff], B = p.S2[roff];
+        float2 A = rowA[0], B = rowB[0];
         a[lpad(0)] = make_float2(A.x - B.y, A.y + B.x);
     }
     __syncthreads();
     const float2* z = run_plan<-1, 1>(PUW{}, a, b, p.tw, tid);
     const long plane = (long)UW * p.uH;
-    constexpr float inv = 0.5f / (float)UW;
+    constexpr float inv = (1.0f / (float)U) / (float)UW;
     // 4 consecutive points per thread: 16-byte (8-byte for half) stores
     for (int n0 = tid * 4; n0 < UW; n0 += T * 4) {
         float2 q[4];
@@ -276,6 +281,69 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_n(ColTParams p)
     if (j < NBL && valid) {
 #pragma unroll
         for (int m = 0; m < RL; m++) dst[(j + NBL * m) * TK + col] = cscale(v[m], inv);
+    }
+}
+
+// ---- column for an integer upscale factor U > 2: one forward transform, U-1 residue transforms.
+// Output row n = U m + r of the zero-padded inverse (length U H) is, for r = 0, H times the column itself (never
+// written: the row kernels read S1) and for r = 1..U-1 the length-H transform of F[k] t_r[k],
+//   t_r[k] = exp(-2 pi i r k / UH) * (k < H/2 ? 1 : exp(+2 pi i r / U))
+// (the upper half of the spectrum sits (U-1) H rows higher).  U = 2 is the odd-row transform of k_col_t.  Residue buffer
+// r lives (r-1) * buf_stride elements behind p.S2, all at U times the reference's normalisation (D / H).
+template <class CFG, int U>
+__global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_u(ColTParams p)
+{
+    using FF = typename CFG::ColF;
+    using FI = typename CFG::ColI;
+    constexpr int H = CFG::H, TK = 4, TC = CFG::COL_TPC, R0 = FF::rs(0), NB0 = H / R0, RL = FF::rs(FF::NST - 1), NBL = H / RL;
+    static_assert(TC >= NB0 && TC >= NBL, "one butterfly per thread in the first and the last stage");
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+    float2* buf = (float2*)smem;
+    const int tid = threadIdx.x, col = tid % TK, j = tid / TK;
+    const int tile = blockIdx.x, c = blockIdx.y;
+    const bool valid = tile * TK + col <= p.W / 2;
+    const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
+    typename FF::Tw twf;
+    typename FI::Tw twi;
+    FF::load_tw(twf, p.twH, j);
+    FI::load_tw(twi, p.twH, j);
+    float2 v[FF::VN], f[R0];
+    if (j < NB0) {
+#pragma unroll
+        for (int m = 0; m < R0; m++) v[m] = valid ? src[(j + NB0 * m) * TK + col] : make_float2(0.f, 0.f);
+    }
+    FF::template run<true>(v, buf, buf, j, twf, col);
+    if (j < NBL) {
+#pragma unroll
+        for (int m = 0; m < RL; m++) buf[lidx<TK>(j + NBL * m, col)] = v[m];       // F[k] in natural order
+    }
+    __syncthreads();
+    if (j < NB0) {
+#pragma unroll
+        for (int m = 0; m < R0; m++) f[m] = buf[lidx<TK>(j + NB0 * m, col)];       // kept in registers over the residues
+    }
+    __syncthreads();
+    const long buf_stride = (long)3 * p.NT * H * TK;
+    constexpr float inv = 1.0f / (float)H;
+#pragma unroll 1
+    for (int r = 1; r < U; r++) {
+        if (j < NB0) {
+            const float2 hi = twid<+1>(p.twUH[r * H]);                              // exp(+2 pi i r/U) from the table of UH-th roots
+#pragma unroll
+            for (int m = 0; m < R0; m++) {
+                const int k = j + NB0 * m;
+                float2 t = twid<-1>(p.twUH[r * k]);                                 // r k < U H
+                if (k >= H / 2) t = cmul(t, hi);
+                v[m] = cmul(f[m], t);
+            }
+        }
+        FI::template run<true>(v, buf, buf, j, twi, col);
+        float2* dst = p.S2 + (r - 1) * buf_stride + ((long)c * p.NT + tile) * H * TK;
+        if (j < NBL && valid) {
+#pragma unroll
+            for (int m = 0; m < RL; m++) dst[(j + NBL * m) * TK + col] = cscale(v[m], inv);
+        }
+        __syncthreads();                                                            // the buffer is free for the next residue
     }
 }
 

@@ -1209,8 +1209,8 @@ template <int N, int DIR, int T, int... RS> using MrFftN = MrFftNT<N, DIR, T, 1,
 #endif
 // Rows of any length UW = R0 * ... on T threads, any number of stages (MrFftN): what the run-time specialised plans
 // (jit.hpp) instantiate when no three-stage 16 * 16 * R2 plan exists, and the 8 * 8 * 4 * 15 plan of 1920x1080 on 512
-// threads (FFTUP_3840_X16=0).  R0 must be a multiple of 4 (the non-zero quarter of the spectrum fills whole first-stage
-// inputs), T >= UW/R0 and T >= UW/Rlast.
+// threads (FFTUP_3840_X16=0).  R0 must be a multiple of 2U (U = upscale factor: the non-zero 1/2U of the spectrum fills
+// whole first-stage inputs), T >= UW/R0 and T >= UW/Rlast.
 template <int UW_, int T_, int NBUF_, int WPE_, bool RR_, int... RS> struct FusedPlanN {
     using F = MrFftN<UW_, -1, T_, RS...>;
     static constexpr int UW = UW_, T = T_, R0 = F::rs(0), NB0 = UW / R0, EOUT = F::rs(F::NST - 1), SOUT = UW / EOUT, VN = F::VN;
@@ -1221,7 +1221,7 @@ template <int UW_, int T_, int NBUF_, int WPE_, bool RR_, int... RS> struct Fuse
     static constexpr int NBUF = NBUF_;
     static constexpr bool RING_REGS = RR_;                 // false: the previous pair's L rows in a second LDS buffer instead of 12 registers per pass
     static constexpr int WPE = WPE_;                       // waves per SIMD the register allocation must allow (launch bound)
-    static_assert(R0 % 4 == 0 && T >= NB0 && T >= SOUT, "first radix a multiple of 4; one butterfly per thread at both ends");
+    static_assert(T >= NB0 && T >= SOUT, "one butterfly per thread at both ends");        // (and R0 a multiple of 2U: k_c2r_sharpen_g)
     static_assert(NBUF == 2 || (F::NST - 1) % 2 == 1, "three buffers: the first exchange must go through z");
     static_assert(XB % 128 == 0, "lds_put needs 128-byte aligned buffers");
     using Tw = typename F::Tw;
@@ -1321,14 +1321,18 @@ __device__ __forceinline__ void deferred_pixel(const FusedParams& p, long of, fl
 
 // (second argument: waves per SIMD the register allocation must allow -- 4 for 512 threads = 128 VGPRs, so that two strips
 // can share a compute unit; tighter caps were tried: 80 VGPRs spill in fp32 and buy nothing in binary16)
-template <class PL, bool HALF, int TK>
+// U = the (integer) upscale factor: the spectrum rows hold kx = 0..UW/2U, output row y is row y/U of spectrum buffer y%U
+// (buffer 0 = the forward spectrum S1 itself, buffers 1..U-1 = the column kernel's residue transforms, all at U times the
+// reference's normalisation), p.odd_delta elements apart.  U = 2 for all ahead-of-time plans.
+template <class PL, bool HALF, int TK, int U = 2>
 __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
 {
-    constexpr int UW = PL::UW, T = PL::T, R0 = PL::R0, NB0 = PL::NB0, NI = R0 / 4, KH = UW / 4;
+    constexpr int UW = PL::UW, T = PL::T, R0 = PL::R0, NB0 = PL::NB0, NI = R0 / (2 * U), KH = UW / (2 * U);
+    static_assert(R0 % (2 * U) == 0, "the first radix must be a multiple of 2U");
     constexpr int EOUT = PL::EOUT, SOUT = PL::SOUT, VN = PL::VN;
     constexpr int NPASS = (UW + 4 * T - 1) / (4 * T);           // sharpen passes of 4 pixels per thread
     static_assert(KH == NB0 * NI, "the non-zero half spectrum must fill whole first-stage inputs");
-    constexpr float inv = 0.5f / (float)UW;         // 1/2: the spectrum rows carry twice the reference's scale (k_col_t)
+    constexpr float inv = (1.0f / (float)U) / (float)UW;         // 1/U: the spectrum rows carry U times the reference's scale (k_col_t)
     using L = FusedGLds<PL>;
     using LT = typename std::conditional<HALF, _Float16, float>::type;      // L rows in LDS: binary16 for -p 2
     extern __shared__ __attribute__((aligned(128))) char smem[];
@@ -1357,13 +1361,13 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
         const bool top = (y0 == 0);
         const int a0 = top ? 0 : y0 - 1;
         const int npairs = (j1 - j0) + 1;
-        const unsigned tile_stride32 = (unsigned)(uH / 2) * TK;
+        const unsigned tile_stride32 = (unsigned)(uH / U) * TK;
         const float2* base = p.S1 + (long)c * p.NT * (long)tile_stride32;
         // spectrum row `row` of the 2H-row buffer: even rows are rows of S1, odd rows live odd_delta elements further on
         auto S2at = [&](int k, int row) -> float2 {
             // (k >= 0; 24-bit multiply: full rate, v_mul_lo_u32 is quarter rate; both factors are far below 2^24)
-            const unsigned off = (__umul24((unsigned)k / TK, tile_stride32) + (unsigned)(row >> 1) * TK + ((unsigned)k % TK) +
-                                  (unsigned)(row & 1) * p.odd_delta) * (unsigned)sizeof(float2);
+            const unsigned off = (__umul24((unsigned)k / TK, tile_stride32) + ((unsigned)row / U) * TK + ((unsigned)k % TK) +
+                                  ((unsigned)row % U) * p.odd_delta) * (unsigned)sizeof(float2);
             return *(const float2*)((const char*)base + off);
         };
         const bool need_corner = !top && (y1 + 1 < uH);
