@@ -1,5 +1,7 @@
-"""GPU: seeded sweep over sizes / upscale factors / precisions / flags on the size-generic path (every
-2,3,5,7-smooth size the reference's scheduler accepts, vkFFT.h:4719-4726), each case against the oracle."""
+"""GPU: seeded sweeps over sizes / upscale factors / precisions / flags (every 2,3,5,7-smooth size the reference's
+scheduler accepts, vkFFT.h:4719-4726), each case against the oracle: small sizes with all factors (mostly the size-generic
+kernels), and larger sizes with integer factors (kernels specialised at plan time, csrc/jit.hpp: every case picks its own
+factorizations, so this is what exercises the chooser and the N-stage engines over radix combinations nobody listed)."""
 import numpy as np
 import pytest
 
@@ -34,14 +36,47 @@ def _cases():
     return out
 
 
+SMOOTH_BIG = sorted({2 ** a * 3 ** b * 5 ** c * 7 ** d for a in range(1, 12) for b in range(5) for c in range(4) for d in range(3)
+                     if 64 <= 2 ** a * 3 ** b * 5 ** c * 7 ** d <= 2048})
+
+
+def _cases_specialised():
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FFTUP_SWEEP_SEED", "20260930")) + 1)
+    out = []
+    while len(out) < int(os.environ.get("FFTUP_SWEEP_JIT_N", "24")):  # (a one-off 400-case run is logged in profiles/)
+        W, H = int(rng.choice(SMOOTH_BIG)), int(rng.choice(SMOOTH_BIG))
+        u = float(rng.choice([2.0, 2.0, 2.0, 3.0, 4.0, 5.0]))
+        if u * W > 8192 or u * u * W * H > 3 << 20:
+            continue
+        p = int(rng.choice([0, 0, 2]))
+        out.append((W, H, u, p, int(rng.choice([0, 2])), float(rng.choice([0.2, 0.2, 0.05])), len(out)))
+    return out
+
+
+@pytest.mark.parametrize("W,H,u,p,flags,sharpen,seed", _cases_specialised())
+def test_sweep_specialised_against_oracle(W, H, u, p, flags, sharpen, seed):
+    _sweep_case(W, H, u, p, flags, sharpen, seed, expect_specialised=True)
+
+
 @pytest.mark.parametrize("W,H,u,p,flags,sharpen,seed", _cases())
 def test_sweep_against_oracle(W, H, u, p, flags, sharpen, seed):
+    _sweep_case(W, H, u, p, flags, sharpen, seed)
+
+
+def _sweep_case(W, H, u, p, flags, sharpen, seed, expect_specialised=False):
     import vkresample_amd as v
     from vkresample_amd import synth
     rgb = synth.frame(1000 + seed, W, H, "N" if seed % 3 else "U")
     if O.check(W, H, u, p) != 0:
         pytest.skip("not a configuration of the reference")
     with v.Upscaler(W, H, u, p, sharpen, 0, flags) as up:
+        if expect_specialised and not up.tuned:
+            import ctypes as C
+            from vkresample_amd import _lib
+            buf = C.create_string_buffer(256)
+            # the size-generic kernels are a legitimate answer only where no factorization exists
+            assert _lib.load().fftup_jit_check(W, H, int(u), p, None, buf, 256) == 2, "plan fell back although a specialised plan exists"
         up.upload_rgb8(rgb)
         up.execute(1)
         pre = up.download_presharpen().astype(np.float64)

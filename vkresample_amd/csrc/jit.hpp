@@ -243,6 +243,7 @@ static bool choose(int W, int H, int U, bool half, const std::vector<int>& ct_ra
 {
     c.W = W; c.H = H; c.U = U; c.UW = U * W; c.half = half;
     if (W < 64 || H < 64 || W > 4096 || H > 4096 || U < 2 || c.UW > 8192) return false;
+    if (c.UW % 4) return false;        // the sharpen works on quads of pixels (-u 5 with W = 2 * odd: the size-generic kernels)
     // ---- row R2C
     if (is_pow2(W) && W >= 256) { c.row_kind = 0; c.row_block = W / 8; }
     else if (choose3(W, 1, 1024, c.rr, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 1; c.row_t = (c.row_t + 63) / 64 * 64; c.row_block = c.row_t; }

@@ -40,6 +40,7 @@ template <class PUW, bool HALF_OUT, int U = 2>
 __global__ void __launch_bounds__(PUW::T) k_row_c2r_ct(RowC2RParams p)
 {
     constexpr int UW = PUW::N, T = PUW::T, KH = UW / (2 * U);       // kx = 0..W/2 = UW/2U non-zero
+    static_assert(UW % 4 == 0, "four consecutive points per thread in the store loop");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* a = (float2*)smem;
     float2* b = a + lpad_size(UW);

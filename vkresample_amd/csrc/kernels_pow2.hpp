@@ -1329,6 +1329,7 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
 {
     constexpr int UW = PL::UW, T = PL::T, R0 = PL::R0, NB0 = PL::NB0, NI = R0 / (2 * U), KH = UW / (2 * U);
     static_assert(R0 % (2 * U) == 0, "the first radix must be a multiple of 2U");
+    static_assert(UW % 4 == 0, "the sharpen passes work on quads of pixels");
     constexpr int EOUT = PL::EOUT, SOUT = PL::SOUT, VN = PL::VN;
     constexpr int NPASS = (UW + 4 * T - 1) / (4 * T);           // sharpen passes of 4 pixels per thread
     static_assert(KH == NB0 * NI, "the non-zero half spectrum must fill whole first-stage inputs");
