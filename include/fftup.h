@@ -108,14 +108,15 @@ FFTUP_API int fftup_plan_info(const fftup_plan* plan, fftup_info* info);
 
 /* Run-time specialised plans (csrc/jit.hpp; the counterpart of VkFFT generating and compiling its shaders for the
  * requested size at plan time, VF:4707-5189 + the GLSL generator, glslang in VkResample's link line).  A plan with an
- * integer upscale factor (-u 2, 3, 4, 5, 6, 8; -p 0 / -p 2; W, H <= 4096, u*W <= 8192) whose size has no ahead-of-time
+ * integer or half-integer upscale factor (-u 1.5, 2, 2.5, 3, 4, 5, 6, 8; -p 0 / -p 2; W, H <= 4096, u*W <= 8192, 4 | u*W)
+ * whose size has no ahead-of-time
  * kernels gets its row, column and fused C2R+sharpen kernels
  * instantiated for exactly that size through hipRTC inside fftup_plan_create; fftup_info.tuned is then 2.  FFTUP_JIT=0
  * or FFTUP_FLAG_GENERIC_KERNELS keeps such plans on the size-generic kernels (as does a missing libhiprtc.so).
  * fftup_jit_check does the same WITHOUT a device: picks the factorizations, compiles for `arch` (NULL: gfx950) and
  * writes a one-line description.  FFTUP_E_UNSUPPORTED_SIZE: no specialised factorization (the generic kernels run that
  * size); FFTUP_E_HIP: hipRTC unavailable or compilation failed (fftup_last_error has the log). */
-FFTUP_API int fftup_jit_check(uint32_t width, uint32_t height, uint32_t upscale, uint32_t precision, const char* arch,
+FFTUP_API int fftup_jit_check(uint32_t width, uint32_t height, float upscale, uint32_t precision, const char* arch,
                               char* desc, size_t desclen);
 
 /* host pack loop + transferDataFromCPU (VR:1636-1688).  rgb: interleaved 8-bit RGB, H rows of

@@ -50,7 +50,7 @@ def test_specialised_plan_vs_oracle(W, H, precision, flags):
         assert so["max"] <= 8e-3 and so["p99"] <= 2.0 ** -10 and so["p99.99"] <= 4e-3
 
 
-# integer upscale factors other than 2: U - 1 residue transforms in the column kernel (k_col_u), first radix of the fused
+# upscale factors other than 2.  Integer: U - 1 residue transforms in the column kernel (k_col_u), first radix of the fused
 # kernel a multiple of 2U
 U_CASES = [
     (640, 480, 3.0),     # fused 12*10*16
@@ -61,6 +61,11 @@ U_CASES = [
     (640, 480, 5.0),     # first radix 10
     (256, 128, 8.0),     # first radix 16, NI = 1
     (2048, 1024, 3.0),   # 6144 x 3072
+    # half-integer factors: k_col_pad (forward H, zero-pad, inverse uH in one kernel), fused kernel with U = 1, D = 2u
+    (1280, 720, 1.5),    # 720p -> 1080p: fused 12*10*16, one third of the first-stage inputs non-zero
+    (1920, 1080, 1.5),
+    (2560, 1440, 1.5),   # 1440p -> 4K
+    (640, 480, 2.5),     # first radix 10, D = 5
 ]
 
 

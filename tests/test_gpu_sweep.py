@@ -1,6 +1,6 @@
 """GPU: seeded sweeps over sizes / upscale factors / precisions / flags (every 2,3,5,7-smooth size the reference's
 scheduler accepts, vkFFT.h:4719-4726), each case against the oracle: small sizes with all factors (mostly the size-generic
-kernels), and larger sizes with integer factors (kernels specialised at plan time, csrc/jit.hpp: every case picks its own
+kernels), and larger sizes with integer and half-integer factors (kernels specialised at plan time, csrc/jit.hpp: every case picks its own
 factorizations, so this is what exercises the chooser and the N-stage engines over radix combinations nobody listed)."""
 import numpy as np
 import pytest
@@ -46,8 +46,8 @@ def _cases_specialised():
     out = []
     while len(out) < int(os.environ.get("FFTUP_SWEEP_JIT_N", "24")):  # (a one-off 400-case run is logged in profiles/)
         W, H = int(rng.choice(SMOOTH_BIG)), int(rng.choice(SMOOTH_BIG))
-        u = float(rng.choice([2.0, 2.0, 2.0, 3.0, 4.0, 5.0]))
-        if u * W > 8192 or u * u * W * H > 3 << 20:
+        u = float(rng.choice([2.0, 2.0, 2.0, 3.0, 4.0, 5.0, 1.5, 1.5, 2.5]))
+        if u * W > 8192 or u * u * W * H > 3 << 20 or (2 * u * W) % 4 or (2 * u * H) % 4 or not _smooth(int(u * W)) or not _smooth(int(u * H)):
             continue
         p = int(rng.choice([0, 0, 2]))
         out.append((W, H, u, p, int(rng.choice([0, 2])), float(rng.choice([0.2, 0.2, 0.05])), len(out)))
@@ -76,7 +76,7 @@ def _sweep_case(W, H, u, p, flags, sharpen, seed, expect_specialised=False):
             from vkresample_amd import _lib
             buf = C.create_string_buffer(256)
             # the size-generic kernels are a legitimate answer only where no factorization exists
-            assert _lib.load().fftup_jit_check(W, H, int(u), p, None, buf, 256) == 2, "plan fell back although a specialised plan exists"
+            assert _lib.load().fftup_jit_check(W, H, float(u), p, None, buf, 256) == 2, "plan fell back although a specialised plan exists"
         up.upload_rgb8(rgb)
         up.execute(1)
         pre = up.download_presharpen().astype(np.float64)

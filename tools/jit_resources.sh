@@ -11,7 +11,7 @@ lib = _lib.load()
 buf = C.create_string_buffer(512)
 import os, shutil
 shutil.rmtree("/tmp/jit_res_cache", ignore_errors=True)
-rc = lib.fftup_jit_check($W, $H, $U, $P, None, buf, 512)
+rc = lib.fftup_jit_check($W, $H, float($U), $P, None, buf, 512)
 print(rc, buf.value.decode(), lib.fftup_last_error().decode()[:500] if rc else "")
 PY
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on --cuda-device-only -c -Ivkresample_amd/csrc -o /tmp/jit_res_$$.o /tmp/jit_res_$$.hip -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '

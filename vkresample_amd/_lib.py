@@ -78,6 +78,6 @@ def load():
     lib.fftup_strerror.restype = C.c_char_p
     lib.fftup_last_error.restype = C.c_char_p
     lib.fftup_version.restype = C.c_char_p
-    lib.fftup_jit_check.argtypes = [u32, u32, u32, u32, C.c_char_p, C.c_char_p, sz]
+    lib.fftup_jit_check.argtypes = [u32, u32, C.c_float, u32, C.c_char_p, C.c_char_p, sz]
     _lib = lib
     return lib

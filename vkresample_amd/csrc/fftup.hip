@@ -193,6 +193,18 @@ static bool jit_enabled()
     const char* e = getenv("FFTUP_JIT");
     return !e || atoi(e) != 0;
 }
+// 2 x the upscale factor when the specialised kernels' assumptions hold: the factor is an integer or a half-integer in
+// [1.5, 8], the output sizes are exactly u W and u H, and the reference's zero-padding guard of the column pass
+// (float arithmetic, VkResample.cpp:1494-1495) is exactly [H/2, uH - H/2).  0 otherwise.
+static int jit_factor_x2(float upscale, uint32_t W, uint32_t H, uint32_t uW, uint32_t uH, int zly, int zry)
+{
+    const float two_u = 2.0f * upscale;
+    const int D = (int)two_u;
+    if ((float)D != two_u || D < 3 || D > 16) return 0;
+    if (2 * (uint64_t)uW != (uint64_t)D * W || 2 * (uint64_t)uH != (uint64_t)D * H) return 0;
+    if (zly != (int)(H / 2) || zry != (int)(uH - H / 2)) return 0;
+    return D;
+}
 static std::vector<int> stage_radices(const StagePlan& p)
 {
     std::vector<int> r;
@@ -220,15 +232,18 @@ int fftup_device_name(int device, char* buf, size_t buflen)
     return FFTUP_OK;
 }
 
-int fftup_jit_check(uint32_t width, uint32_t height, uint32_t upscale, uint32_t precision, const char* arch, char* desc, size_t desclen)
+int fftup_jit_check(uint32_t width, uint32_t height, float upscale, uint32_t precision, const char* arch, char* desc, size_t desclen)
 {
     if (desc && desclen) desc[0] = 0;
     if (precision != 0 && precision != 2) return fail(FFTUP_E_UNSUPPORTED_PRECISION, "run-time specialised plans exist for -p 0 and -p 2");
     if (width < 2 || height < 2 || (width & 1) || (height & 1) || width > 65536 || height > 65536 || !is_smooth(width) || !is_smooth(height))
         return fail(FFTUP_E_UNSUPPORTED_SIZE, "sizes must be even and factor into 2,3,5,7");
     fftup_jit::Choice ch;
-    if (upscale < 2 || upscale > 8 || upscale * width > 8192 || !is_smooth(upscale) ||
-        !fftup_jit::choose((int)width, (int)height, (int)upscale, precision == 2, stage_radices(make_stage_plan(upscale * width)), ch))
+    if (!(upscale >= 1.0f && upscale <= 8.0f)) return fail(FFTUP_E_INVALID_ARG, "upscale out of range");
+    const uint32_t uW = (uint32_t)(upscale * (float)width), uH = (uint32_t)(upscale * (float)height);
+    const int D = (uW & 1) || (uH & 1) || !is_smooth(uW) || !is_smooth(uH) || uW > 8192 ? 0 :
+                  jit_factor_x2(upscale, width, height, uW, uH, (int)(uint32_t)((float)uH / (2 * upscale)), (int)(uint32_t)((2 * upscale - 1) * (float)uH / (2 * upscale)));
+    if (!D || !fftup_jit::choose((int)width, (int)height, D, precision == 2, stage_radices(make_stage_plan(uW)), ch))
         return fail(FFTUP_E_UNSUPPORTED_SIZE, "no specialised factorization for this size: the size-generic kernels run it");
     if (desc && desclen) snprintf(desc, desclen, "%s", fftup_jit::describe(ch).c_str());
     fftup_jit::Binary bin;
@@ -353,16 +368,16 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             if (W == MixedCfg720::W && H == MixedCfg720::H) P->mixed = 2;
         }
         if (P->mixed) { P->TK = 4; P->ldsCol = sizeof(float2) * (size_t)H * 4; }             // k_col_m: one in-place buffer
-        // any other size with an integer upscale factor: kernels specialised for it now (the counterpart of VkFFT
-        // generating its shaders at plan time)
+        // any other size with an integer or half-integer upscale factor: kernels specialised for it now (the counterpart
+        // of VkFFT generating its shaders at plan time)
         if (!P->dbl && !cplx && !P->tuned && !P->mixed && !(cfg->flags & (FFTUP_FLAG_GENERIC_KERNELS | FFTUP_FLAG_UNFUSED_SHARPEN)) && jit_enabled()) {
-            const int U = (int)(uW / W);
-            if (U >= 2 && U <= 8 && (float)U == cfg->upscale && uW == (uint32_t)U * W && uH == (uint32_t)U * H) {
+            const int D = jit_factor_x2(cfg->upscale, W, H, uW, uH, P->zly, P->zry);
+            if (D) {
                 fftup_jit::Choice ch;
                 std::string jerr;
-                if (fftup_jit::choose((int)W, (int)H, U, P->half, stage_radices(P->planUW), ch)) {
+                if (fftup_jit::choose((int)W, (int)H, D, P->half, stage_radices(P->planUW), ch)) {
                     P->jit = fftup_jit::load(ch, P->prop.gcnArchName, jerr);
-                    if (P->jit) { P->mixed = 3; P->U = U; P->TK = 4; P->ldsCol = P->jit->choice.col_lds; }
+                    if (P->jit) { P->mixed = 3; P->U = ch.U; P->TK = 4; P->ldsCol = P->jit->choice.col_lds; }
                     else if (getenv("FFTUP_JIT_VERBOSE")) fprintf(stderr, "fftup: run-time specialisation failed, size-generic kernels in use: %s\n", jerr.c_str());
                 }
             }
@@ -414,7 +429,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         // kernel addresses both with 32-bit offsets from one base)
         const size_t s1_elems = (size_t)3 * P->NT * H * P->TK;
         auto alloc_spectra = [&](float2** s1, float2** s2) -> int {
-            if (P->tuned || P->mixed) {
+            if ((P->tuned || P->mixed) && P->U >= 2) {
                 int r = dev_alloc(P, (void**)s1, P->csz * (size_t)P->U * s1_elems);       // S1 + the U-1 residue buffers
                 *s2 = r ? nullptr : *s1 + s1_elems;
                 return r;
@@ -525,7 +540,7 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
     {
         // what the launches really have to move: polyphase plans write/read only the odd half of S2; a fused strip
         // re-reads one halo pair of spectrum rows
-        const bool poly = P->tuned || P->mixed;
+        const bool poly = (P->tuned || P->mixed) && P->U >= 2;
         const double S2w = poly ? S1 * (P->U - 1) : S2;               // odd rows (residues 1..U-1) only
         const double halo = P->fused ? (double)(P->pairs_per_strip + 1) / P->pairs_per_strip : 1.0;
         info->kernel_min_bytes[0] = in + S1;
@@ -652,6 +667,7 @@ static FusedParams fused_params(fftup_plan* P, uint32_t out_slot)
 {
     FusedParams p{};
     p.S1 = P->lanes[P->cur].S1; p.odd_delta = (unsigned)(P->lanes[P->cur].S2 - P->lanes[P->cur].S1);
+    if (P->U == 1) { p.S1 = P->lanes[P->cur].S2; p.odd_delta = 0; }      // half-integer factor: one buffer with all rows (k_col_pad)
     p.out = P->out[out_slot]; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
     p.pairs_per_strip = P->pairs_per_strip; p.upsq = P->upsq; p.coef = P->coef;
     return p;
@@ -904,7 +920,10 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         p.inv_norm = 1.0f / (float)P->uW;
         dim3 grid(P->uH / 2, 3), block(P->thrUW);
         if (P->mixed) {
-            if (P->mixed == 3) jerr = fftup_jit::launch(P->jit->fn[fftup_jit::K_C2R_CT], grid, dim3(P->jit->choice.ct_t), P->ldsRowI, P->lanes[P->cur].stream, p);
+            if (P->mixed == 3) {
+                if (P->U == 1) p.S1 = p.S2;                              // half-integer factor: all rows in S2
+                jerr = fftup_jit::launch(P->jit->fn[fftup_jit::K_C2R_CT], grid, dim3(P->jit->choice.ct_t), P->ldsRowI, P->lanes[P->cur].stream, p);
+            }
             else if (P->mixed == 1) launch_c2r_ct<MixedCfg1080::CT>(P, grid, p);
             else launch_c2r_ct<MixedCfg720::CT>(P, grid, p);
         } else if (P->half) hipLaunchKernelGGL(k_row_c2r<true>, grid, block, P->ldsRowI, P->lanes[P->cur].stream, p);

@@ -49,12 +49,15 @@ static const int kRadices[] = {2, 3, 4, 5, 7, 8, 9, 10, 12, 15, 16};
 
 struct Choice {
     int W = 0, H = 0, UW = 0;
-    int U = 2;                         // integer upscale factor
+    int U = 2;                         // integer upscale factor; 1 = half-integer factor D/2 (one spectrum buffer with all rows)
+    int D = 4;                         // 2 x upscale factor: the spectrum rows hold kx = 0..UW/D
+    int UH = 0;
     bool half = false;
     int row_kind = -1;                 // 0: k_row_r2c_t<W> (power of two, 8 points per thread); 1: k_row_r2c_m (three stages); 2: k_row_r2c (not specialised); 3: k_row_r2c_n
     int rr[3] = {0, 0, 0}, row_t = 0;
     std::vector<int> rn, cn;           // kind 3: k_row_r2c_n / k_col_n (N stages)
-    int col_kind = -1;                 // 0: k_col_t<H>; 1: k_col_m (three stages); 3: k_col_n (N stages); 4: k_col_u (N stages, U - 1 residues)
+    std::vector<int> ci;               // col kind 5: the inverse transform of length UH
+    int col_kind = -1;                 // 0: k_col_t<H>; 1: k_col_m (three stages); 3: k_col_n (N stages); 4: k_col_u (N stages, U - 1 residues); 5: k_col_pad (half-integer factors)
     int cr[3] = {0, 0, 0}, col_tpc = 0;
     int fused_kind = -1;               // 0: FusedPlanPow2<UW>; 1: FusedPlanMr16<UW, UW/256>; 2: FusedPlanN<UW, T, 2, radices...>
     std::vector<int> fr;
@@ -130,14 +133,14 @@ static bool choose3(int n, int tk, int tmax, int r[3], int* threads, const char*
 // eight inputs -- beats 16 (half the threads idle in the prefetch and in the first stage) by 10-25 %, even at one stage
 // more; after that the fewest stages (every stage is an LDS exchange with two workgroup barriers), the fewest lane
 // slots, the largest smallest radix.
-static bool choose_fused_n(int n, int U, std::vector<int>& out, int* threads)
+static bool choose_fused_n(int n, int D, std::vector<int>& out, int* threads)
 {
     {
         int T = 0;
         std::vector<int> pin;
         if (env_radices("FFTUP_JIT_FUSED", pin, &T) && T >= 64 && T <= 1024 && T % 64 == 0) {
             long prod = 1;
-            bool ok = pin.size() >= 2 && pin[0] % (2 * U) == 0;
+            bool ok = pin.size() >= 2 && pin[0] % D == 0;
             for (int q : pin) { ok &= is_radix(q); prod *= q; }
             if (ok && prod == n && T >= n / pin[0] && T >= n / pin.back()) { out = pin; *threads = T; return true; }
         }
@@ -149,7 +152,7 @@ static bool choose_fused_n(int n, int U, std::vector<int>& out, int* threads)
     auto r0_rank = [](int r0) { return r0 == 8 ? 0 : r0 == 12 ? 1 : r0 == 16 ? 2 : 3; };
     auto eval = [&]() {
         const int ns = (int)cur.size();
-        if (ns < 2 || cur[0] % (2 * U)) return;
+        if (ns < 2 || cur[0] % D) return;
         const int tmin = std::max(n / cur[0], n / cur[ns - 1]);
         for (int T = (tmin + 63) / 64 * 64; T <= 1024; T += 64) {
             int vn = 0, mn = 99;
@@ -239,10 +242,12 @@ static bool choose_n(int n, int tmax, int granule, std::vector<int>& out, int* t
 
 // Factorizations for a W x H -> 2W x 2H plan.  false: some dimension has no supported factorization (the plan then
 // stays on the size-generic kernels).  ct_radices: the stage list of the size-generic plan for 2W (radices <= 8).
-static bool choose(int W, int H, int U, bool half, const std::vector<int>& ct_radices, Choice& c)
+// D = 2 x the upscale factor: even = integer factor U = D/2 (polyphase column pass), odd = half-integer factor.
+static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, Choice& c)
 {
-    c.W = W; c.H = H; c.U = U; c.UW = U * W; c.half = half;
-    if (W < 64 || H < 64 || W > 4096 || H > 4096 || U < 2 || c.UW > 8192) return false;
+    const int U = D % 2 == 0 ? D / 2 : 1;
+    c.W = W; c.H = H; c.U = U; c.D = D; c.UW = D * W / 2; c.UH = D * H / 2; c.half = half;
+    if (W < 64 || H < 64 || W > 4096 || H > 4096 || D < 3 || c.UW > 8192 || (D * W) % 2 || (D * H) % 2) return false;
     if (c.UW % 4) return false;        // the sharpen works on quads of pixels (-u 5 with W = 2 * odd: the size-generic kernels)
     // ---- row R2C
     if (is_pow2(W) && W >= 256) { c.row_kind = 0; c.row_block = W / 8; }
@@ -250,7 +255,12 @@ static bool choose(int W, int H, int U, bool half, const std::vector<int>& ct_ra
     else if (choose_n(W, 1024, 64, c.rn, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 3; c.row_block = c.row_t; }
     else c.row_kind = 2;               // no supported factorization: the size-generic row kernel (same S1 layout) stays
     // ---- column (four columns per workgroup)
-    if (U > 2) {
+    if (U == 1) {
+        int ti = 0;
+        if (c.UH > 4096 || !choose_n(H, 256, 16, c.cn, &c.col_tpc, "FFTUP_JIT_COL") || !choose_n(c.UH, 256, 16, c.ci, &ti, "FFTUP_JIT_COLI")) return false;
+        c.col_tpc = std::max(c.col_tpc, ti);
+        c.col_kind = 5; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((c.UH * 4 + 15) & ~15);
+    } else if (U > 2) {
         if (!choose_n(H, 256, 16, c.cn, &c.col_tpc, "FFTUP_JIT_COL")) return false;
         c.col_kind = 4; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * 4 + 15) & ~15);
     } else if (is_pow2(H) && H >= 128 && H <= 2048) {
@@ -264,13 +274,13 @@ static bool choose(int W, int H, int U, bool half, const std::vector<int>& ct_ra
     const int UW = c.UW;
     size_t xb = sizeof(float2) * (size_t)((UW + 15) & ~15);                    // lswz_size(UW)
     int nbuf = 2;
-    if ((UW == 1024 || UW == 2048 || UW == 4096) && 8 % (2 * U) == 0) { c.fused_kind = 0; c.fused_t = UW / 8; nbuf = 3; }
+    if ((UW == 1024 || UW == 2048 || UW == 4096) && 8 % D == 0) { c.fused_kind = 0; c.fused_t = UW / 8; nbuf = 3; }
     else {
-        const bool mr16 = UW % 256 == 0 && is_radix(UW / 256) && 16 % (2 * U) == 0 && !getenv("FFTUP_JIT_FUSED");
+        const bool mr16 = UW % 256 == 0 && is_radix(UW / 256) && 16 % D == 0 && !getenv("FFTUP_JIT_FUSED");
         if (mr16) {
             c.fused_kind = 1; c.fused_t = 256;
             xb = (sizeof(float2) * (size_t)(UW + (UW >> 4) + 1) + 15) & ~(size_t)15;                               // lpad_size(UW)
-        } else if (choose_fused_n(UW, U, c.fr, &c.fused_t)) {
+        } else if (choose_fused_n(UW, D, c.fr, &c.fused_t)) {
             c.fused_kind = 2;
             // two strips per compute unit (128 VGPRs at 512 threads) unless load() finds the kernel spilling
             if (c.fused_wpe <= 0) c.fused_wpe = std::max((c.fused_t + 255) / 256, std::min(c.fused_t * 2 / 256, 4));      // >= 128 VGPRs
@@ -304,7 +314,7 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT])
 {
     const std::string W = std::to_string(c.W), H = std::to_string(c.H), UW = std::to_string(c.UW);
     std::string s;
-    s += "// generated by fftup (jit.hpp): " + W + "x" + H + " -> " + UW + "x" + std::to_string(c.U * c.H) + (c.half ? ", binary16 storage\n" : ", fp32\n");
+    s += "// generated by fftup (jit.hpp): " + W + "x" + H + " -> " + UW + "x" + std::to_string(c.UH) + (c.half ? ", binary16 storage\n" : ", fp32\n");
     s += "#include \"kernels_mixed.hpp\"\nnamespace fftup {\n";
     s += "struct JitCfg {\n    static constexpr int W = " + W + ", H = " + H + ";\n";
     if (c.row_kind == 1)
@@ -315,7 +325,9 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT])
              ", COL_TPC = " + std::to_string(c.col_tpc) + ";\n";
     if (c.row_kind == 3)
         s += "    static constexpr int ROW_T = " + std::to_string(c.row_t) + ";\n    using RowN = MrFftNT<W, +1, ROW_T, 1, " + join(c.rn) + ">;\n";
-    if (c.col_kind == 3 || c.col_kind == 4)
+    if (c.col_kind == 5)
+        s += "    static constexpr int UH = " + std::to_string(c.UH) + ";\n    using ColIU = MrFftNT<UH, -1, " + std::to_string(c.col_tpc) + ", 4, " + join(c.ci) + ">;\n";
+    if (c.col_kind >= 3)
         s += "    static constexpr int COL_TPC = " + std::to_string(c.col_tpc) + ";\n    using ColF = MrFftNT<H, +1, COL_TPC, 4, " + join(c.cn) +
              ">;\n    using ColI = MrFftNT<H, -1, COL_TPC, 4, " + join(c.cn) + ">;\n";
     s += "};\n";
@@ -339,9 +351,9 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT])
         names[K_ROW_PLANAR] = k + "<fftup::JitCfg, " + fm + ">";
         names[K_ROW_U8] = k + "<fftup::JitCfg, " + um + ">";
     }
-    const std::string U = std::to_string(c.U);
-    names[K_COL] = c.col_kind == 0 ? "fftup::k_col_t<" + H + ", 4>" : c.col_kind == 3 ? "fftup::k_col_n<fftup::JitCfg>" :
-                   c.col_kind == 4 ? "fftup::k_col_u<fftup::JitCfg, " + U + ">" : "fftup::k_col_m<fftup::JitCfg>";
+    const std::string U = std::to_string(c.U) + ", " + std::to_string(c.D);
+    names[K_COL] = c.col_kind == 5 ? "fftup::k_col_pad<fftup::JitCfg>" : c.col_kind == 0 ? "fftup::k_col_t<" + H + ", 4>" : c.col_kind == 3 ? "fftup::k_col_n<fftup::JitCfg>" :
+                   c.col_kind == 4 ? "fftup::k_col_u<fftup::JitCfg, " + std::to_string(c.U) + ">" : "fftup::k_col_m<fftup::JitCfg>";
     names[K_FUSED] = "fftup::k_c2r_sharpen_g<fftup::JitFused, " + hb + ", 4, " + U + ">";
     names[K_C2R_CT] = "fftup::k_row_c2r_ct<fftup::JitCT, " + hb + ", " + U + ">";
     return s;
@@ -349,11 +361,11 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT])
 
 static std::string describe(const Choice& c)
 {
-    std::string s = c.U == 2 ? "row " : "u" + std::to_string(c.U) + " row ";
+    std::string s = c.D == 4 ? "row " : (c.D % 2 ? "u" + std::to_string(c.D / 2) + ".5 row " : "u" + std::to_string(c.U) + " row ");
     auto star = [](const std::vector<int>& v) { std::string t; for (size_t i = 0; i < v.size(); i++) t += (i ? "*" : "") + std::to_string(v[i]); return t; };
     s += c.row_kind == 2 ? "generic" : c.row_kind == 0 ? "pow2/8" : c.row_kind == 3 ? star(c.rn) : std::to_string(c.rr[0]) + "*" + std::to_string(c.rr[1]) + "*" + std::to_string(c.rr[2]);
     s += " x" + std::to_string(c.row_block) + ", col ";
-    s += c.col_kind == 0 ? "pow2/8" : c.col_kind >= 3 ? star(c.cn) : std::to_string(c.cr[0]) + "*" + std::to_string(c.cr[1]) + "*" + std::to_string(c.cr[2]);
+    s += c.col_kind == 0 ? "pow2/8" : c.col_kind == 5 ? star(c.cn) + " -> " + star(c.ci) : c.col_kind >= 3 ? star(c.cn) : std::to_string(c.cr[0]) + "*" + std::to_string(c.cr[1]) + "*" + std::to_string(c.cr[2]);
     s += " x" + std::to_string(c.col_block) + ", fused ";
     if (c.fused_kind == 0) s += "pow2/8";
     else if (c.fused_kind == 1) s += "16*16*" + std::to_string(c.UW / 256);

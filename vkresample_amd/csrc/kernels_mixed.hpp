@@ -36,10 +36,10 @@ __device__ __forceinline__ float2* run_plan(CtPlan<N, T, R...>, float2* a, float
 
 // ---- row C2R (see k_row_c2r), u = 2.  grid (uH/2, 3), block PUW::T, dynamic LDS 2*lpad_size(UW) float2
 // (U: integer upscale factor, see k_c2r_sharpen_g; output row y = row y/U of spectrum buffer y%U, buffers p.S2 - p.S1 apart)
-template <class PUW, bool HALF_OUT, int U = 2>
+template <class PUW, bool HALF_OUT, int U = 2, int D = 2 * U>
 __global__ void __launch_bounds__(PUW::T) k_row_c2r_ct(RowC2RParams p)
 {
-    constexpr int UW = PUW::N, T = PUW::T, KH = UW / (2 * U);       // kx = 0..W/2 = UW/2U non-zero
+    constexpr int UW = PUW::N, T = PUW::T, KH = UW / D;       // kx = 0..W/2 = UW/2u non-zero
     static_assert(UW % 4 == 0, "four consecutive points per thread in the store loop");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* a = (float2*)smem;
@@ -345,6 +345,62 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_u(ColTParams p)
             for (int m = 0; m < RL; m++) dst[(j + NBL * m) * TK + col] = cscale(v[m], inv);
         }
         __syncthreads();                                                            // the buffer is free for the next residue
+    }
+}
+
+// ---- column for a half-integer upscale factor (-u 1.5, 2.5): forward transform of length H, the reference's shift and
+// zero-padding (VkResample.cpp:514-526, read guard vkFFT.h:1670-1695) as the gather of the inverse's first stage, inverse
+// transform of length UH = u H, ALL rows written to one buffer at the reference's normalisation (no residue split: the
+// rows of the zero-padded inverse are not subsequences of equal length here).  The plan guarantees the guard
+// [H/2, UH - H/2) (fftup_plan_create checks the reference's float arithmetic gives exactly that).
+// CFG::ColF = MrFftNT<H, +1, COL_TPC, 4, ...>, CFG::ColIU = MrFftNT<UH, -1, COL_TPC, 4, ...>.  LDS lswz_size(4 UH) float2.
+template <class CFG>
+__global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_pad(ColTParams p)
+{
+    using FF = typename CFG::ColF;
+    using FI = typename CFG::ColIU;
+    constexpr int H = CFG::H, UH = CFG::UH, TK = 4, TC = CFG::COL_TPC;
+    constexpr int R0 = FF::rs(0), NB0 = H / R0, RL = FF::rs(FF::NST - 1), NBL = H / RL;
+    constexpr int Q0 = FI::rs(0), MB0 = UH / Q0, QL = FI::rs(FI::NST - 1), MBL = UH / QL;
+    static_assert(TC >= NB0 && TC >= NBL && TC >= MB0 && TC >= MBL, "one butterfly per thread in the first and the last stages");
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+    float2* buf = (float2*)smem;
+    const int tid = threadIdx.x, col = tid % TK, j = tid / TK;
+    const int tile = blockIdx.x, c = blockIdx.y;
+    const bool valid = tile * TK + col <= p.W / 2;
+    const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
+    typename FF::Tw twf;
+    typename FI::Tw twi;
+    FF::load_tw(twf, p.twH, j);
+    FI::load_tw(twi, p.twUH, j);
+    float2 v[FF::VN], w[FI::VN];
+    if (j < NB0) {
+#pragma unroll
+        for (int m = 0; m < R0; m++) v[m] = valid ? src[(j + NB0 * m) * TK + col] : make_float2(0.f, 0.f);
+    }
+    FF::template run<true>(v, buf, buf, j, twf, col);
+    if (j < NBL) {
+#pragma unroll
+        for (int m = 0; m < RL; m++) buf[lidx<TK>(j + NBL * m, col)] = v[m];       // F[k] in natural order
+    }
+    __syncthreads();
+    if (j < MB0) {
+#pragma unroll
+        for (int m = 0; m < Q0; m++) {
+            const int ky = j + MB0 * m;                                             // row of the zero-padded buffer
+            float2 g = make_float2(0.f, 0.f);
+            if (ky < H / 2) g = buf[lidx<TK>(ky, col)];
+            else if (ky >= UH - H / 2) g = buf[lidx<TK>(ky - (UH - H), col)];
+            w[m] = g;
+        }
+    }
+    __syncthreads();
+    FI::template run<true>(w, buf, buf, j, twi, col);
+    float2* dst = p.S2 + ((long)c * p.NT + tile) * UH * TK;
+    constexpr float inv = 1.0f / (float)UH;
+    if (j < MBL && valid) {
+#pragma unroll
+        for (int m = 0; m < QL; m++) dst[(j + MBL * m) * TK + col] = cscale(w[m], inv);
     }
 }
 

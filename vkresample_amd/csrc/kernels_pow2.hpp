@@ -1324,11 +1324,13 @@ __device__ __forceinline__ void deferred_pixel(const FusedParams& p, long of, fl
 // U = the (integer) upscale factor: the spectrum rows hold kx = 0..UW/2U, output row y is row y/U of spectrum buffer y%U
 // (buffer 0 = the forward spectrum S1 itself, buffers 1..U-1 = the column kernel's residue transforms, all at U times the
 // reference's normalisation), p.odd_delta elements apart.  U = 2 for all ahead-of-time plans.
-template <class PL, bool HALF, int TK, int U = 2>
+// Half-integer factors (-u 1.5, 2.5: k_col_pad writes all rows of the zero-padded inverse into ONE buffer at the
+// reference's normalisation): U = 1 and D = 2u, the spectrum rows hold kx = 0..UW/D.
+template <class PL, bool HALF, int TK, int U = 2, int D = 2 * U>
 __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
 {
-    constexpr int UW = PL::UW, T = PL::T, R0 = PL::R0, NB0 = PL::NB0, NI = R0 / (2 * U), KH = UW / (2 * U);
-    static_assert(R0 % (2 * U) == 0, "the first radix must be a multiple of 2U");
+    constexpr int UW = PL::UW, T = PL::T, R0 = PL::R0, NB0 = PL::NB0, NI = R0 / D, KH = UW / D;
+    static_assert(R0 % D == 0, "the first radix must be a multiple of 2u");
     static_assert(UW % 4 == 0, "the sharpen passes work on quads of pixels");
     constexpr int EOUT = PL::EOUT, SOUT = PL::SOUT, VN = PL::VN;
     constexpr int NPASS = (UW + 4 * T - 1) / (4 * T);           // sharpen passes of 4 pixels per thread
