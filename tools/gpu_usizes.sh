@@ -1,9 +1,9 @@
 #!/bin/bash
-# integer upscale factors: plan-time specialised vs size-generic kernels.  tools/gpu_usizes.sh <tag>
+# integer and half-integer upscale factors: plan-time specialised vs size-generic kernels.  tools/gpu_usizes.sh <tag>
 TAG=${1:-usizes}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 {
 echo "# bench.py --frames-per-step 256 --steps 3 --repeats 3 --ring 4, fp32; frac = B_alg / t / 8 TB/s; kernels(us): row / column / fused (or C2R / sharpen)"
-for cfg in "640 480 3" "640 480 4" "960 540 4" "1280 720 3" "1920 1080 3" "1920 1080 4" "2048 1024 3" "2048 1024 4" "1024 512 4" "1024 512 8" "1600 900 5"; do
+for cfg in "1280 720 1.5" "1920 1080 1.5" "2560 1440 1.5" "2048 1024 1.5" "640 480 1.5" "1280 720 2.5" "1920 1080 2.5" "640 480 3" "640 480 4" "960 540 4" "1280 720 3" "1920 1080 3" "1920 1080 4" "2048 1024 3" "2048 1024 4" "1024 512 4" "1024 512 8" "1600 900 5"; do
   set -- $cfg
   for mode in jit generic; do
     if [ $mode = generic ]; then FL="--generic"; else FL=""; fi
