@@ -49,8 +49,11 @@ enum {
                                       roadmap item); otherwise upload converts to the reference's planar
                                       float/half inputBuffer first (VR:1636-1688 semantics)               */
     FFTUP_FLAG_GENERIC_KERNELS = 4u, /* force the size-generic kernels even where a tuned plan exists    */
-    FFTUP_FLAG_UNFUSED_SHARPEN = 8u  /* keep C2R and sharpen as two launches with the pre-sharpen image in
+    FFTUP_FLAG_UNFUSED_SHARPEN = 8u, /* keep C2R and sharpen as two launches with the pre-sharpen image in
                                         HBM, like the reference (tempBuffer); default fuses them          */
+    FFTUP_FLAG_TUNE_PLAN = 16u       /* plans specialised at plan time (below): compile and time the alternatives for the fused
+                                        kernel's factorization on the device, keep the fastest, remember it in
+                                        <cache dir>/wisdom.txt (a few seconds, once per row length and device)            */
 };
 
 /* Replaces VkResampleConfiguration (VR:45-59) + the part of VkFFTConfiguration (VF:22-94) that
@@ -72,6 +75,7 @@ typedef struct fftup_config {
  *   FFTUP_G_PER_CU=n         strips (workgroups) of the fused C2R+sharpen kernel per compute unit (default 1)
  *   FFTUP_PAIRS_PER_STRIP=n  row pairs per workgroup of the fused C2R+sharpen kernel (default: pairs / compute units)
  *   FFTUP_JIT=0|1            run-time specialised plans (default 1); FFTUP_JIT_VERBOSE=1 prints why one fell back;
+ *                            FFTUP_JIT_TUNE=1 = FFTUP_FLAG_TUNE_PLAN for every plan;
  *                            FFTUP_KERNEL_DIR / FFTUP_CACHE_DIR: kernel headers / code-object cache (jit.hpp)
  *   FFTUP_3840_X16=0|1       1920x1080 -u 2: fused kernel on the 16*16*15 plan, 256 threads (1, default) or the
  *                            8*8*4*15 plan, 512 threads (0); same results up to fp32 rounding (tests) */

@@ -39,6 +39,27 @@ def test_cli_single_image_1080p(tmp_path):
     assert out.shape == (2160, 3840, 3) and d.max() <= 1 and (d != 0).mean() <= 5e-3
 
 
+@pytest.mark.parametrize("W,H,u,p", [(800, 600, "2", "0"), (1280, 720, "1.5", "0"), (960, 540, "4", "2")])
+def test_cli_sizes_specialised_at_plan_time(tmp_path, W, H, u, p):
+    """sizes and factors the CLI gets plan-time specialised kernels for (csrc/jit.hpp): 800x600 -u 2, 720p -> 1080p,
+    540p -> 2160p with -p 2"""
+    from vkresample_amd import synth
+    rgb = synth.frame(12, W, H, "N")
+    _png_write(tmp_path / "in.png", rgb)
+    r = subprocess.run([CLI, "-i", "in.png", "-o", "out.png", "-u", u, "-p", p, "-n", "2"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    uW, uH = int(float(u) * W), int(float(u) * H)
+    assert re.search(r"VkResample %.1fx upscale: %dx%d to %dx%d Time: [0-9.]+ ms" % (float(u), W, H, uW, uH), r.stdout)
+    out = _png_read(tmp_path / "out.png")
+    _, _, ou8 = O.upscale_rgb8(rgb, float(u), int(p), 0.2)
+    d = np.abs(out[:-1].astype(int) - ou8[:-1].astype(int))
+    assert out.shape == (uH, uW, 3)
+    if p == "0":
+        assert d.max() <= 1 and (d != 0).mean() <= 5e-3
+    else:
+        assert d.max() <= 2 and (d > 1).mean() <= 1e-3          # fp16 storage: a one-ulp flip can move a code by 2
+
+
 def test_cli_config1_literal_image(tmp_path):
     """BASELINE config 1 end to end: the pixels of the reference's samples/no_upscaling.png (committed as data,
     tests/golden/no_upscaling_rgb.npz; the reference decodes RGBA to 3 channels, VR:1362) -u 2 -p 0 -n 1."""

@@ -144,3 +144,28 @@ def test_ring_batch_on_specialised_plan():
         up.execute_ring(9, 0)
         for s in range(3):
             assert np.array_equal(up.download_planar(s), single[s])
+
+
+def test_plan_time_tuner(tmp_path, monkeypatch):
+    """FFTUP_FLAG_TUNE_PLAN: the alternatives for the fused kernel's factorization are compiled and timed at plan creation,
+    the decision lands in <cache dir>/wisdom.txt and the pixels stay within fp32 rounding of the untuned plan's."""
+    from vkresample_amd import FLAG_TUNE_PLAN, synth
+    monkeypatch.setenv("FFTUP_CACHE_DIR", str(tmp_path))
+    rgb = synth.frame(5, 800, 600, "N")
+
+    def run(flags):
+        with _up(800, 600, 2.0, 0, 0.2, 0, flags) as up:
+            assert up.specialised_at_plan_time
+            up.upload_rgb8(rgb)
+            up.execute(1)
+            return up.download_planar().astype(np.float64)
+    ref = run(0)
+    assert not (tmp_path / "wisdom.txt").exists()
+    tuned = run(FLAG_TUNE_PLAN)
+    lines = (tmp_path / "wisdom.txt").read_text().strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("fused v1 ") and " 1600 4 f = " in lines[0], lines
+    again = run(0)                       # reads the wisdom: same kernel as the tuned plan, bit for bit
+    assert np.array_equal(tuned, again)
+    assert np.percentile(np.abs(ref - tuned), 99.99) <= 1e-5 and np.abs(ref - tuned).max() <= 2e-4
+    run(FLAG_TUNE_PLAN)                  # already known: no second measurement, no second line
+    assert len((tmp_path / "wisdom.txt").read_text().strip().splitlines()) == 1

@@ -12,6 +12,7 @@ FLAG_U8_WRAP = 1
 FLAG_FUSE_U8_LOAD = 2
 FLAG_GENERIC_KERNELS = 4
 FLAG_UNFUSED_SHARPEN = 8
+FLAG_TUNE_PLAN = 16
 
 # every symbol include/fftup.h declares
 EXPORTS = [

@@ -205,6 +205,21 @@ static int jit_factor_x2(float upscale, uint32_t W, uint32_t H, uint32_t uW, uin
     if (zly != (int)(H / 2) || zry != (int)(uH - H / 2)) return 0;
     return D;
 }
+static void tune_fused(fftup_plan* P);
+// what the tuner's findings are filed under: the device and whether consecutive frames overlap on several streams
+// (ring > 1: what fits beside a strip decides) or run one after the other (ring = 1: the kernel's own time decides)
+static std::string wisdom_device_key(const fftup_plan* P)
+{
+    int nl = 3;
+    if (const char* e = getenv("FFTUP_STREAMS")) nl = atoi(e);
+    nl = std::max(1, std::min(nl, 4));
+    return std::string(P->prop.gcnArchName) + (std::min(nl, (int)P->ring) > 1 ? " overlapped" : " sequential");
+}
+static bool jit_tune_enabled()
+{
+    const char* e = getenv("FFTUP_JIT_TUNE");
+    return e && atoi(e) != 0;
+}
 static std::vector<int> stage_radices(const StagePlan& p)
 {
     std::vector<int> r;
@@ -375,7 +390,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             if (D) {
                 fftup_jit::Choice ch;
                 std::string jerr;
-                if (fftup_jit::choose((int)W, (int)H, D, P->half, stage_radices(P->planUW), ch)) {
+                if (fftup_jit::choose((int)W, (int)H, D, P->half, stage_radices(P->planUW), ch, wisdom_device_key(P))) {
                     P->jit = fftup_jit::load(ch, P->prop.gcnArchName, jerr);
                     if (P->jit) { P->mixed = 3; P->U = ch.U; P->TK = 4; P->ldsCol = P->jit->choice.col_lds; }
                     else if (getenv("FFTUP_JIT_VERBOSE")) fprintf(stderr, "fftup: run-time specialisation failed, size-generic kernels in use: %s\n", jerr.c_str());
@@ -502,6 +517,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         }
 #undef SET_FUSED
 #undef SET_LDS
+        if (P->mixed == 3 && ((cfg->flags & FFTUP_FLAG_TUNE_PLAN) || jit_tune_enabled())) tune_fused(P);
     }
     *out = P;
     return FFTUP_OK;
@@ -1025,6 +1041,63 @@ int fftup_execute_ring_timed(fftup_plan* P, uint32_t n_frames, uint32_t first_sl
     if (!ms_per_kernel) return fail(FFTUP_E_INVALID_ARG, "null argument");
     return execute_ring_impl(P, n_frames, first_slot, ms_total, ms_per_kernel, stride);
 }
+
+}  // extern "C"
+
+// Plan-time tuner (FFTUP_FLAG_TUNE_PLAN / FFTUP_JIT_TUNE=1) for a run-time specialised plan: the chooser's alternatives for
+// the fused C2R+sharpen kernel -- the one that takes two thirds of a frame -- are compiled and the PLAN is timed with
+// each of them on this device, the way it will run (frames overlapping on the plan's streams when it has a ring of slots,
+// else one after the other: a kernel that is faster alone but fills the compute units' registers makes overlapping
+// frames slower), with the plan's own buffers (their contents do not matter: no data-dependent control flow).
+// The fastest one is kept and remembered in <cache dir>/wisdom.txt, which later plans for the same row length, device
+// and mode read instead of measuring again.  Different factorizations give the same pixels up to fp32 rounding (tests).
+static void tune_fused(fftup_plan* P)
+{
+    const std::string arch = P->prop.gcnArchName;
+    const fftup_jit::Choice base = P->jit->choice;
+    const std::string key = fftup_jit::fused_key(base, wisdom_device_key(P));
+    std::string known;
+    if (getenv("FFTUP_JIT_FUSED") || fftup_jit::wisdom_lookup(key, known)) return;
+    const std::vector<int> kinds = P->in_kind;
+    const int executed = P->executed;
+    for (auto& k : P->in_kind) if (!k) k = 1;                                  // (uninitialised planar input: fine for timing)
+    const uint32_t frames = 4 * (uint32_t)std::max(1, std::min(P->nlanes, (int)P->ring));
+    auto time_plan = [&]() -> double {
+        double best = 1e30, ms = 0;
+        for (int rep = 0; rep < 3; rep++) {
+            if (execute_ring_impl(P, frames, 0, &ms, nullptr, 1) != FFTUP_OK) return 1e30;
+            if (rep > 0) best = std::min(best, ms / frames);                    // (the first repetition warms up)
+        }
+        return best;
+    };
+    const double t_base = time_plan();
+    double t_best = t_base;
+    fftup_jit::Module* const original = P->jit;
+    fftup_jit::Module* best = nullptr;
+    for (const auto& cand : fftup_jit::fused_candidates(base.UW, base.D, 5)) {
+        if (base.fused_kind == 2 && cand.T == base.fused_t && cand.r == base.fr) continue;
+        fftup_jit::Choice c = base;
+        fftup_jit::set_fused_n(c, cand.T, cand.r);
+        if (c.fused_lds > 160 * 1024) continue;
+        std::string err;
+        fftup_jit::Module* m = fftup_jit::load(c, arch, err);
+        if (!m) continue;
+        P->jit = m;
+        const double t = time_plan();
+        P->jit = original;
+        if (getenv("FFTUP_JIT_VERBOSE"))
+            fprintf(stderr, "fftup: tuning %s: %s %.1f us/frame (default %s %.1f)\n", key.c_str(), fftup_jit::fused_value(m->choice).c_str(), t * 1e3,
+                    fftup_jit::fused_value(base).c_str(), t_base * 1e3);
+        if (t < 0.97 * t_best) { delete best; best = m; t_best = t; }           // (3 %: do not chase noise)
+        else delete m;
+    }
+    if (best) { delete original; P->jit = best; }
+    P->in_kind = kinds;
+    P->executed = executed;
+    fftup_jit::wisdom_store(key, fftup_jit::fused_value(P->jit->choice));
+}
+
+extern "C" {
 
 int fftup_execute(fftup_plan* P, uint32_t n_iter, double* ms_per_iter)
 {

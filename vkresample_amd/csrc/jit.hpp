@@ -188,6 +188,99 @@ static bool choose_fused_n(int n, int D, std::vector<int>& out, int* threads)
     return found;
 }
 
+// The chooser's alternatives for the fused kernel, for the plan-time tuner (fftup_plan_create with FFTUP_FLAG_TUNE_PLAN /
+// FFTUP_JIT_TUNE=1): the best factorization (by the ranking above, first radix aside) of every (first radix, number of
+// stages, thread count) class, at most `max` of them, the chooser's own pick first.
+struct FusedCand { int T; std::vector<int> r; };
+static std::string cache_dir();
+static bool read_file(const std::string& path, std::string& out);
+static std::string join(const std::vector<int>& v);
+static std::vector<FusedCand> fused_candidates(int n, int D, size_t max)
+{
+    struct Best { int r0, ns, T, mn; double cost; std::vector<int> r; };
+    std::vector<Best> classes;
+    std::vector<int> cur;
+    auto eval = [&]() {
+        const int ns = (int)cur.size();
+        if (ns < 2 || ns > 4 || cur[0] % D) return;
+        const int tmin = std::max(n / cur[0], n / cur[ns - 1]);
+        for (int T = (tmin + 63) / 64 * 64, tries = 0; T <= 1024 && tries < 2; T += 64) {
+            int vn = 0, mn = 99;
+            double cost = 0;
+            for (int s = 0; s < ns; s++) {
+                const int bpt = (n / cur[s] + T - 1) / T;
+                vn = std::max(vn, bpt * cur[s]);
+                mn = std::min(mn, cur[s]);
+                cost += (double)bpt * T * cur[s];
+            }
+            if (vn > 16) continue;
+            tries++;
+            mn = std::min(mn, 4);
+            bool placed = false;
+            for (auto& b : classes)
+                if (b.r0 == cur[0] && b.ns == ns && b.T == T) {
+                    if (mn > b.mn || (mn == b.mn && cost < b.cost)) { b.mn = mn; b.cost = cost; b.r = cur; }
+                    placed = true;
+                }
+            if (!placed) classes.push_back({cur[0], ns, T, mn, cost, cur});
+            if (T % 256 == 0) break;                                           // (also try the next multiple of 256 threads)
+            T = T / 256 * 256 + 256 - 64;
+        }
+    };
+    struct Rec {
+        static void go(int m, std::vector<int>& cur, const std::function<void()>& leaf)
+        {
+            if (m == 1) { leaf(); return; }
+            if (cur.size() >= 4) return;
+            for (int r : kRadices)
+                if (m % r == 0) { cur.push_back(r); go(m / r, cur, leaf); cur.pop_back(); }
+        }
+    };
+    Rec::go(n, cur, eval);
+    auto r0_rank = [](int r0) { return r0 == 8 ? 0 : r0 == 12 ? 1 : r0 == 16 ? 2 : 3; };
+    std::sort(classes.begin(), classes.end(), [&](const Best& a, const Best& b) {
+        if (a.ns != b.ns) return a.ns < b.ns;
+        if (r0_rank(a.r0) != r0_rank(b.r0)) return r0_rank(a.r0) < r0_rank(b.r0);
+        if (a.mn != b.mn) return a.mn > b.mn;
+        return a.cost < b.cost;
+    });
+    // variety before depth: at most two candidates per (first radix, number of stages)
+    std::vector<FusedCand> out;
+    for (const auto& b : classes) {
+        if (out.size() >= max) break;
+        int same = 0;
+        for (const auto& o : out) same += (o.r[0] == b.r0 && (int)o.r.size() == b.ns);
+        if (same < 2) out.push_back({b.T, b.r});
+    }
+    return out;
+}
+
+// plan-time tuner's memory: <cache dir>/wisdom.txt, one "key = value" per line, last one wins
+static std::string wisdom_path() { const std::string d = cache_dir(); return d.empty() ? "" : d + "/wisdom.txt"; }
+static bool wisdom_lookup(const std::string& key, std::string& value)
+{
+    std::string text;
+    const std::string path = wisdom_path();
+    if (path.empty() || !read_file(path, text)) return false;
+    bool found = false;
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t eol = text.find('\n', pos);
+        if (eol == std::string::npos) eol = text.size();
+        const std::string line = text.substr(pos, eol - pos);
+        const size_t eq = line.find(" = ");
+        if (eq != std::string::npos && line.compare(0, eq, key) == 0) { value = line.substr(eq + 3); found = true; }
+        pos = eol + 1;
+    }
+    return found;
+}
+static void wisdom_store(const std::string& key, const std::string& value)
+{
+    const std::string path = wisdom_path();
+    if (path.empty()) return;
+    if (FILE* f = fopen(path.c_str(), "a")) { fprintf(f, "%s = %s\n", key.c_str(), value.c_str()); fclose(f); }
+}
+
 // any number of stages for the row and column kernels (MrFftNT, XOR index map: no preference for odd first radices):
 // one butterfly per thread in the first and the last stage, at most 16 points per thread, T a multiple of `granule`.
 static bool choose_n(int n, int tmax, int granule, std::vector<int>& out, int* threads, const char* env)
@@ -242,8 +335,28 @@ static bool choose_n(int n, int tmax, int granule, std::vector<int>& out, int* t
 
 // Factorizations for a W x H -> 2W x 2H plan.  false: some dimension has no supported factorization (the plan then
 // stays on the size-generic kernels).  ct_radices: the stage list of the size-generic plan for 2W (radices <= 8).
+// the fused kernel of `c` := FusedPlanN<UW, T, 2, wpe, rr, radices...>
+static void set_fused_n(Choice& c, int T, const std::vector<int>& radices)
+{
+    c.fused_kind = 2; c.fr = radices; c.fused_t = T; c.fused_rr = true;
+    c.fused_wpe = std::max((T + 255) / 256, std::min(T * 2 / 256, 4));         // >= 128 VGPRs; load() relaxes it when the kernel spills
+    const size_t xb = sizeof(float2) * (size_t)((c.UW + 15) & ~15);
+    const int npass = (c.UW + 4 * T - 1) / (4 * T);
+    c.fused_lds = (npass <= 4 ? 1 : 2) * xb + 32 * sizeof(float);
+}
+static std::string fused_key(const Choice& c, const std::string& arch)
+{
+    return "fused v1 " + arch + " " + std::to_string(c.UW) + " " + std::to_string(c.D) + (c.half ? " h" : " f");
+}
+static std::string fused_value(const Choice& c)
+{
+    if (c.fused_kind == 0) return "pow2";
+    if (c.fused_kind == 1) return "mr16";
+    return std::to_string(c.fused_t) + ":" + join(c.fr);
+}
+
 // D = 2 x the upscale factor: even = integer factor U = D/2 (polyphase column pass), odd = half-integer factor.
-static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, Choice& c)
+static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, Choice& c, const std::string& arch = "")
 {
     const int U = D % 2 == 0 ? D / 2 : 1;
     c.W = W; c.H = H; c.U = U; c.D = D; c.UW = D * W / 2; c.UH = D * H / 2; c.half = half;
@@ -282,6 +395,7 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
             xb = (sizeof(float2) * (size_t)(UW + (UW >> 4) + 1) + 15) & ~(size_t)15;                               // lpad_size(UW)
         } else if (choose_fused_n(UW, D, c.fr, &c.fused_t)) {
             c.fused_kind = 2;
+            c.fused_wpe = 0;
             // two strips per compute unit (128 VGPRs at 512 threads) unless load() finds the kernel spilling
             if (c.fused_wpe <= 0) c.fused_wpe = std::max((c.fused_t + 255) / 256, std::min(c.fused_t * 2 / 256, 4));      // >= 128 VGPRs
             if (const char* e = getenv("FFTUP_JIT_FUSED_OPT")) { int w = 0, r = 1; if (sscanf(e, "%d,%d", &w, &r) == 2) { c.fused_wpe = std::max(1, w); c.fused_rr = r != 0; } }
@@ -292,6 +406,24 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
         const size_t nx = (npass <= 4 && (c.fused_kind != 2 || c.fused_rr)) ? 1 : 2;    // FusedGLds::RR
         c.fused_lds = (nx + (nbuf == 3 ? 1 : 0)) * xb + (nbuf == 3 ? 0 : 32 * sizeof(float));
         if (c.fused_lds > 160 * 1024) return false;
+    }
+    // what the plan-time tuner found best on this device for rows of this length (wisdom.txt)
+    if (!arch.empty() && !getenv("FFTUP_JIT_FUSED")) {
+        std::string w;
+        if (wisdom_lookup(fused_key(c, arch), w) && w != fused_value(c) && w != "pow2" && w != "mr16") {
+            int T = 0;
+            std::vector<int> r;
+            const size_t colon = w.find(':');
+            if (colon != std::string::npos) {
+                T = atoi(w.c_str());
+                size_t pos = colon + 1;
+                while (pos < w.size()) { r.push_back(atoi(w.c_str() + pos)); const size_t cm = w.find(',', pos); if (cm == std::string::npos) break; pos = cm + 1; }
+            }
+            long prod = 1;
+            bool ok = r.size() >= 2 && T >= 64 && T <= 1024 && T % 64 == 0 && r[0] % D == 0;
+            for (int q : r) { ok &= is_radix(q); prod *= q; }
+            if (ok && prod == UW && T >= UW / r[0] && T >= UW / r.back()) set_fused_n(c, T, r);
+        }
     }
     // ---- stand-alone C2R for the pre-sharpen tap (LDS ping-pong, compile-time radices)
     c.ct = ct_radices;
