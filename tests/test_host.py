@@ -156,12 +156,14 @@ def test_jit_check_compiles_without_a_device(tmp_path, monkeypatch):
     monkeypatch.setenv("FFTUP_CACHE_DIR", str(tmp_path / "cache"))
     lib = _lib.load()
     buf = C.create_string_buffer(256)
-    for (W, H, p, expect) in [(640, 480, 0, "fused 16*16*5"), (1000, 1000, 2, "fused 8*5*5*10"), (1024, 768, 0, "row pow2/8")]:
+    cases = [(640, 480, 0, "fused 8*10*16"),          # (the built-in wisdom table's pick for rows of 1280; the chooser's is 16*16*5)
+             (896, 504, 0, "fused 16*16*7"), (1000, 1000, 2, "fused 8*5*5*10"), (1024, 768, 0, "row pow2/8")]
+    for (W, H, p, expect) in cases:
         rc = lib.fftup_jit_check(W, H, 2, p, None, buf, 256)
         assert rc == 0, lib.fftup_last_error().decode()
         assert expect in buf.value.decode(), buf.value
     files = list((tmp_path / "cache").glob("*.fjit"))
-    assert len(files) == 3 and all(f.stat().st_size > 10000 for f in files)
+    assert len(files) == len(cases) and all(f.stat().st_size > 10000 for f in files)
     assert lib.fftup_jit_check(2000, 1250, 2, 0, None, buf, 256) == 0 and "row 8*5*5*10" in buf.value.decode()       # N-stage kernels
     assert lib.fftup_jit_check(4000, 3000, 2, 0, None, buf, 256) == 2          # FFTUP_E_UNSUPPORTED_SIZE: the generic kernels run it
     assert lib.fftup_jit_check(640, 480, 2, 1, None, buf, 256) == 3            # FFTUP_E_UNSUPPORTED_PRECISION

@@ -154,7 +154,10 @@ static bool choose_fused_n(int n, int D, std::vector<int>& out, int* threads)
         const int ns = (int)cur.size();
         if (ns < 2 || cur[0] % D) return;
         const int tmin = std::max(n / cur[0], n / cur[ns - 1]);
-        for (int T = (tmin + 63) / 64 * 64; T <= 1024; T += 64) {
+        // whole multiples of 256 threads (the waves spread evenly over the four SIMDs, fewer sharpen passes) beat the
+        // minimum in 30 of 43 tuner decisions; small workgroups take one wave more than they need
+        const int t0 = tmin > 128 ? (tmin + 255) / 256 * 256 : (tmin + 63) / 64 * 64 + 64;
+        for (int T = t0; T <= 1024; T += 64) {
             int vn = 0, mn = 99;
             double cost = 0;
             for (int s = 0; s < ns; s++) {
@@ -164,7 +167,7 @@ static bool choose_fused_n(int n, int D, std::vector<int>& out, int* threads)
                 cost += (double)bpt * T * cur[s];
             }
             if (vn > 16) continue;
-            if (T > 512) cost *= 1.5;                                          // 64-VGPR territory
+            if (T > 768) cost *= 1.5;                                          // 64-VGPR territory
             if ((n + 4 * T - 1) / (4 * T) > 4) cost *= 1.3;                    // ring rows no longer fit the registers
             const int rk = r0_rank(cur[0]);
             mn = std::min(mn, 4);                                              // radix-2/3 stages: all exchange, hardly any arithmetic
@@ -254,6 +257,55 @@ static std::vector<FusedCand> fused_candidates(int n, int D, size_t max)
     }
     return out;
 }
+
+// What the plan-time tuner found on an MI355X (tools/gpu_wisdom.py, profiles/r02_o_wisdom_mi355x.txt: 107 row lengths x
+// factors, frames overlapping on three streams) where it differed from the chooser's pick by more than 3 %: row length,
+// D = 2 x upscale factor, "threads:radices".  Consulted after the user's wisdom.txt, for both precisions.
+static const struct { int uw, d; const char* plan; } kBuiltinWisdom[] = {
+    {768, 3, "128:12,8,8"},
+    {1080, 3, "256:12,9,10"},
+    {1200, 3, "256:12,10,10"},
+    {1280, 4, "256:8,10,16"},
+    {1280, 5, "192:10,16,8"},
+    {1344, 3, "192:12,16,7"},
+    {1440, 3, "192:12,10,12"},
+    {1500, 3, "192:15,10,10"},
+    {1536, 3, "192:12,16,8"},
+    {1536, 6, "192:12,16,8"},
+    {1600, 4, "256:16,10,10"},
+    {1600, 5, "256:10,10,16"},
+    {1728, 3, "256:12,12,12"},
+    {1800, 5, "256:10,12,15"},
+    {1920, 3, "256:12,10,16"},
+    {1920, 4, "256:12,10,16"},
+    {1920, 6, "256:12,10,16"},
+    {2240, 5, "448:5,7,8,8"},
+    {2688, 3, "512:12,4,7,8"},
+    {2688, 6, "512:12,4,7,8"},
+    {2880, 4, "256:12,15,16"},
+    {2880, 8, "256:16,12,15"},
+    {3200, 5, "448:10,4,10,8"},
+    {3200, 8, "512:8,4,10,10"},
+    {3200, 10, "448:10,4,10,8"},
+    {3600, 10, "512:10,4,9,10"},
+    {3840, 3, "256:15,16,16"},
+    {3840, 6, "384:12,4,8,10"},
+    {4000, 5, "512:10,4,10,10"},
+    {4000, 10, "512:10,4,10,10"},
+    {4480, 5, "640:10,8,8,7"},
+    {4480, 10, "640:10,8,8,7"},
+    {4608, 8, "768:8,8,8,9"},
+    {4800, 5, "512:10,4,10,12"},
+    {5040, 6, "512:12,5,7,12"},
+    {5120, 5, "768:10,8,8,8"},
+    {5120, 8, "768:8,8,8,10"},
+    {5120, 10, "768:10,8,8,8"},
+    {5376, 6, "768:12,7,8,8"},
+    {5760, 10, "768:10,8,8,9"},
+    {6000, 6, "768:12,5,10,10"},
+    {6144, 6, "768:12,8,8,8"},
+    {8000, 10, "1024:10,8,10,10"},
+};
 
 // plan-time tuner's memory: <cache dir>/wisdom.txt, one "key = value" per line, last one wins
 static std::string wisdom_path() { const std::string d = cache_dir(); return d.empty() ? "" : d + "/wisdom.txt"; }
@@ -408,9 +460,13 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
         if (c.fused_lds > 160 * 1024) return false;
     }
     // what the plan-time tuner found best on this device for rows of this length (wisdom.txt)
-    if (!arch.empty() && !getenv("FFTUP_JIT_FUSED")) {
+    if (!getenv("FFTUP_JIT_FUSED")) {
         std::string w;
-        if (wisdom_lookup(fused_key(c, arch), w) && w != fused_value(c) && w != "pow2" && w != "mr16") {
+        bool have = !arch.empty() && wisdom_lookup(fused_key(c, arch), w);
+        if (!have && !getenv("FFTUP_JIT_NO_BUILTIN_WISDOM"))
+            for (const auto& e : kBuiltinWisdom)
+                if (e.uw == UW && e.d == D) { w = e.plan; have = true; }
+        if (have && w != fused_value(c) && w != "pow2" && w != "mr16") {
             int T = 0;
             std::vector<int> r;
             const size_t colon = w.find(':');
