@@ -247,7 +247,7 @@ def main():
                                       "uint8 RGB (fused load)" if args.fuse_u8 and args.precision != 1 else "planar fp%d" % {0: 32, 1: 64, 2: 16}[args.precision]),
                        "preset": args.preset or "config2", "frames_per_step": args.frames_per_step,
                        "sharding": "independent frames, no collective",
-                       "kernels": ("plan-time" if up.specialised_at_plan_time else "tuned") if up.tuned else "generic", "streams": args.streams, "device": up.device_name},
+                       "kernels": ("plan-time" if up.specialised_at_plan_time else "tuned") if up.tuned else "generic", "plan": up.description, "streams": args.streams, "device": up.device_name},
             "repeats": len(region_s), "region_s": region_s, "timed_region_s_median": dt,
             "ms_per_frame": wall_frame_ms, "ms_per_frame_device_events": frame_ms,
             "frame_alg_bytes": up.alg_bytes_per_frame, "B_min": b_min,

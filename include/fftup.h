@@ -109,6 +109,8 @@ FFTUP_API int fftup_plan_create(fftup_plan** out, const fftup_config* cfg);
 /* deleteVulkanFFT x2, deleteShiftApp x2, buffer frees (VR:1759-1771) */
 FFTUP_API void fftup_plan_destroy(fftup_plan* plan);
 FFTUP_API int fftup_plan_info(const fftup_plan* plan, fftup_info* info);
+/* one line saying which kernels the plan runs (for a plan specialised at plan time: the chosen factorizations) */
+FFTUP_API int fftup_plan_describe(const fftup_plan* plan, char* buf, size_t buflen);
 
 /* Run-time specialised plans (csrc/jit.hpp; the counterpart of VkFFT generating and compiling its shaders for the
  * requested size at plan time, VF:4707-5189 + the GLSL generator, glslang in VkResample's link line).  A plan with an

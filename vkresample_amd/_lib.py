@@ -20,7 +20,7 @@ EXPORTS = [
     "fftup_upload_rgb8", "fftup_upload_rgb8_slot", "fftup_upload_planar", "fftup_execute", "fftup_execute_ring", "fftup_execute_ring_timed",
     "fftup_profile_kernels", "fftup_download_rgb8", "fftup_download_planar", "fftup_download_presharpen",
     "fftup_download_input_planar", "fftup_host_alloc", "fftup_host_free", "fftup_submit_rgb8", "fftup_wait",
-    "fftup_drain", "fftup_strerror", "fftup_last_error", "fftup_version", "fftup_jit_check",
+    "fftup_drain", "fftup_strerror", "fftup_last_error", "fftup_version", "fftup_jit_check", "fftup_plan_describe",
 ]
 
 
@@ -79,6 +79,7 @@ def load():
     lib.fftup_strerror.restype = C.c_char_p
     lib.fftup_last_error.restype = C.c_char_p
     lib.fftup_version.restype = C.c_char_p
+    lib.fftup_plan_describe.argtypes = [vp, C.c_char_p, sz]
     lib.fftup_jit_check.argtypes = [u32, u32, C.c_float, u32, C.c_char_p, C.c_char_p, sz]
     _lib = lib
     return lib

@@ -57,6 +57,9 @@ class Upscaler:
         self.device_name = info.device_name.decode()
         self.device_bytes = info.device_bytes
         self.tuned = bool(info.tuned)
+        _buf = C.create_string_buffer(512)
+        _check(self._lib.fftup_plan_describe(self._h, _buf, 512), "fftup_plan_describe")
+        self.description = _buf.value.decode()
         self.specialised_at_plan_time = info.tuned == 2      # kernels instantiated for this size through hipRTC (csrc/jit.hpp)
         self._dtype = {0: np.float32, 1: np.float64, 2: np.float16}[precision]
 

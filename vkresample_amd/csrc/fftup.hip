@@ -364,7 +364,9 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
 
         const size_t lds_max = P->prop.sharedMemPerBlock ? P->prop.sharedMemPerBlock : 65536;
         // size-specialised kernels: u == 2 and power-of-two sizes with instantiated plans
-        P->tuned = !P->dbl && !cplx && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && uW == 2 * W && uH == 2 * H &&
+        // (FFTUP_AOT=0: experiments -- the sizes with ahead-of-time kernels go through the plan-time compiler as well)
+        const bool aot = !(getenv("FFTUP_AOT") && atoi(getenv("FFTUP_AOT")) == 0);
+        P->tuned = aot && !P->dbl && !cplx && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && uW == 2 * W && uH == 2 * H &&
                    (W == 512 || W == 1024 || W == 2048) && (H == 256 || H == 512 || H == 1024);
         P->TK = 0;
         if (P->tuned) {
@@ -378,7 +380,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             }
         }
         if (!P->TK) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled height too large for LDS"); goto bad; }
-        if (!P->dbl && !cplx && !P->tuned && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && uW == 2 * W && uH == 2 * H && P->TK >= 4) {
+        if (aot && !P->dbl && !cplx && !P->tuned && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && uW == 2 * W && uH == 2 * H && P->TK >= 4) {
             if (W == MixedCfg1080::W && H == MixedCfg1080::H) P->mixed = 1;
             if (W == MixedCfg720::W && H == MixedCfg720::H) P->mixed = 2;
         }
@@ -526,6 +528,19 @@ bad:
     return rc;
 #undef PLAN_TRY
 #undef PLAN_RC
+}
+
+int fftup_plan_describe(const fftup_plan* P, char* buf, size_t buflen)
+{
+    if (!P || !buf || !buflen) return fail(FFTUP_E_INVALID_ARG, "null argument");
+    std::string s;
+    if (P->mixed == 3) s = "specialised at plan time: " + fftup_jit::describe(P->jit->choice);
+    else if (P->tuned) s = "ahead-of-time power-of-two kernels (radix 8, 8 points per thread; fused C2R+sharpen " + std::string(P->fused ? "on" : "off") + ")";
+    else if (P->mixed) s = std::string("ahead-of-time mixed-radix kernels: ") + (P->mixed == 1 ? "row 15*8*16, col 9*10*12, fused 16*16*15" : "row 5*16*16, col 9*8*10, fused 16*16*10");
+    else if (P->cplx) s = "size-generic kernels, non-R2C path (full complex transforms)";
+    else s = std::string("size-generic kernels (LDS ping-pong, run-time radix lists)") + (P->dbl ? ", double" : "");
+    snprintf(buf, buflen, "%s", s.c_str());
+    return FFTUP_OK;
 }
 
 int fftup_plan_info(const fftup_plan* P, fftup_info* info)
