@@ -119,8 +119,8 @@ FFTUP_API int fftup_plan_describe(const fftup_plan* plan, char* buf, size_t bufl
  * kernels gets its row, column and fused C2R+sharpen kernels
  * instantiated for exactly that size through hipRTC inside fftup_plan_create; fftup_info.tuned is then 2.  FFTUP_JIT=0
  * or FFTUP_FLAG_GENERIC_KERNELS keeps such plans on the size-generic kernels (as does a missing libhiprtc.so).
- * fftup_jit_check does the same WITHOUT a device: picks the factorizations, compiles for `arch` (NULL: gfx950) and
- * writes a one-line description.  FFTUP_E_UNSUPPORTED_SIZE: no specialised factorization (the generic kernels run that
+ * fftup_jit_check does the same WITHOUT a device: picks the factorizations, compiles for `arch` (NULL: gfx950; "": does not
+ * compile) and writes a one-line description.  FFTUP_E_UNSUPPORTED_SIZE: no specialised factorization (the generic kernels run that
  * size); FFTUP_E_HIP: hipRTC unavailable or compilation failed (fftup_last_error has the log). */
 FFTUP_API int fftup_jit_check(uint32_t width, uint32_t height, float upscale, uint32_t precision, const char* arch,
                               char* desc, size_t desclen);

@@ -169,3 +169,12 @@ def test_plan_time_tuner(tmp_path, monkeypatch):
     assert np.percentile(np.abs(ref - tuned), 99.99) <= 1e-5 and np.abs(ref - tuned).max() <= 2e-4
     run(FLAG_TUNE_PLAN)                  # already known: no second measurement, no second line
     assert len((tmp_path / "wisdom.txt").read_text().strip().splitlines()) == 1
+
+
+def test_plan_describe():
+    with _up(1000, 1000, 2.0, 0) as up:
+        assert up.description.startswith("specialised at plan time: row 10*10*10") and "fused 8*5*5*10" in up.description
+    with _up(2048, 1024, 2.0, 0) as up:
+        assert up.description.startswith("ahead-of-time power-of-two")
+    with _up(240, 126, 1.25, 0) as up:
+        assert up.description.startswith("size-generic")

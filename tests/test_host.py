@@ -172,3 +172,63 @@ def test_jit_check_compiles_without_a_device(tmp_path, monkeypatch):
     assert lib.fftup_jit_check(640, 480, 2, 0, None, buf, 256) == 0 and "row 5*8*16" in buf.value.decode()
     monkeypatch.setenv("FFTUP_JIT_ROW", "5,8,8")
     assert lib.fftup_jit_check(640, 480, 2, 0, None, buf, 256) == 0 and "row 10*8*8" in buf.value.decode()
+
+
+def test_jit_chooser_invariants_over_all_sizes():
+    """Every factorization the plan-time chooser (csrc/jit.hpp) can hand out, for all even 2,3,5,7-smooth widths and a
+    spread of heights up to 4096 and the factors 1.5 ... 8: radices multiply to the length, the workgroup holds the first
+    and the last stage, at most 16 points per thread, the fused kernel's first radix is a multiple of 2u, LDS within
+    160 KB, at most 1024 threads.  (No compilation: arch = "".)"""
+    import ctypes as C
+    import re
+    from vkresample_amd import _lib
+    lib = _lib.load()
+    buf = C.create_string_buffer(512)
+    smooth = sorted({2 ** a * 3 ** b * 5 ** c * 7 ** d for a in range(1, 13) for b in range(6) for c in range(5) for d in range(4)
+                     if 64 <= 2 ** a * 3 ** b * 5 ** c * 7 ** d <= 4096})
+    radices = {2, 3, 4, 5, 7, 8, 9, 10, 12, 15, 16}
+
+    def prod(xs):
+        p = 1
+        for x in xs:
+            p *= x
+        return p
+
+    def parse(part):       # "8*5*5*10 x256" -> ([8,5,5,10], 256)
+        m = re.match(r"([\d*]+) x(\d+)", part)
+        return [int(x) for x in m.group(1).split("*")], int(m.group(2))
+    seen = 0
+    for i, W in enumerate(smooth):
+        H = smooth[(i * 7 + 3) % len(smooth)]
+        for u in (1.5, 2.0, 2.5, 3.0, 4.0, 5.0, 8.0):
+            rc = lib.fftup_jit_check(W, H, u, 0, b"", buf, 512)
+            assert rc in (0, 2, 1), (W, H, u, rc)
+            if rc != 0:
+                continue
+            seen += 1
+            d = buf.value.decode()
+            UW, UH, D = int(u * W), int(u * H), int(2 * u)
+            assert UW % 4 == 0 and UW <= 8192
+            m = re.search(r"row (.*?), col (.*?), fused (.*?) \((\d+) B LDS", d)
+            assert m, d
+            row, col, fused, lds = m.group(1), m.group(2), m.group(3), int(m.group(4))
+            assert lds <= 160 * 1024
+            if not row.startswith(("pow2", "generic")):
+                r, t = parse(row)
+                assert prod(r) == W and set(r) <= radices and t <= 1024 and t >= W // r[0] and t >= W // r[-1], d
+            if not col.startswith("pow2"):
+                if "->" in col:                                     # half-integer factor: forward H, inverse uH
+                    f, rest = col.split(" -> ")
+                    fr = [int(x) for x in f.split("*")]
+                    ir, t = parse(rest)
+                    assert prod(fr) == H and prod(ir) == UH and set(fr) | set(ir) <= radices, d
+                    assert t <= 1024 and t >= 4 * max(H // fr[0], H // fr[-1], UH // ir[0], UH // ir[-1]), d
+                else:
+                    r, t = parse(col)
+                    assert prod(r) == H and set(r) <= radices and t <= 1024 and t >= 4 * max(H // r[0], H // r[-1]), d
+            if not fused.startswith("pow2"):
+                r, t = parse(fused)
+                assert prod(r) == UW and set(r) <= radices and r[0] % D == 0 and t <= 1024 and t % 64 == 0, d
+                assert t >= UW // r[0] and t >= UW // r[-1], d
+                assert max(-(-(UW // q) // t) * q for q in r) <= 16, d          # points per thread
+    assert seen > 400
