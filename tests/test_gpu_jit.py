@@ -176,5 +176,5 @@ def test_plan_describe():
         assert up.description.startswith("specialised at plan time: row 10*10*10") and "fused 8*5*5*10" in up.description
     with _up(2048, 1024, 2.0, 0) as up:
         assert up.description.startswith("ahead-of-time power-of-two")
-    with _up(240, 126, 1.25, 0) as up:
+    with _up(240, 128, 1.25, 0) as up:
         assert up.description.startswith("size-generic")

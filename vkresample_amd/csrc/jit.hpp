@@ -385,8 +385,6 @@ static bool choose_n(int n, int tmax, int granule, std::vector<int>& out, int* t
     return found;
 }
 
-// Factorizations for a W x H -> 2W x 2H plan.  false: some dimension has no supported factorization (the plan then
-// stays on the size-generic kernels).  ct_radices: the stage list of the size-generic plan for 2W (radices <= 8).
 // the fused kernel of `c` := FusedPlanN<UW, T, 2, wpe, rr, radices...>
 static void set_fused_n(Choice& c, int T, const std::vector<int>& radices)
 {
@@ -407,7 +405,10 @@ static std::string fused_value(const Choice& c)
     return std::to_string(c.fused_t) + ":" + join(c.fr);
 }
 
-// D = 2 x the upscale factor: even = integer factor U = D/2 (polyphase column pass), odd = half-integer factor.
+// Factorizations for a W x H -> (D/2) W x (D/2) H plan.  D = 2 x the upscale factor: even = integer factor U = D/2
+// (polyphase column pass), odd = half-integer factor.  false: some dimension has no supported factorization (the plan
+// then stays on the size-generic kernels).  ct_radices: the stage list of the size-generic plan for the output width
+// (radices <= 8); arch: device + mode key of the tuner's wisdom file ("" = built-in wisdom only).
 static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, Choice& c, const std::string& arch = "")
 {
     const int U = D % 2 == 0 ? D / 2 : 1;
@@ -446,10 +447,7 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
             c.fused_kind = 1; c.fused_t = 256;
             xb = (sizeof(float2) * (size_t)(UW + (UW >> 4) + 1) + 15) & ~(size_t)15;                               // lpad_size(UW)
         } else if (choose_fused_n(UW, D, c.fr, &c.fused_t)) {
-            c.fused_kind = 2;
-            c.fused_wpe = 0;
-            // two strips per compute unit (128 VGPRs at 512 threads) unless load() finds the kernel spilling
-            if (c.fused_wpe <= 0) c.fused_wpe = std::max((c.fused_t + 255) / 256, std::min(c.fused_t * 2 / 256, 4));      // >= 128 VGPRs
+            set_fused_n(c, c.fused_t, std::vector<int>(c.fr));
             if (const char* e = getenv("FFTUP_JIT_FUSED_OPT")) { int w = 0, r = 1; if (sscanf(e, "%d,%d", &w, &r) == 2) { c.fused_wpe = std::max(1, w); c.fused_rr = r != 0; } }
         } else return false;
     }
@@ -478,7 +476,7 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
             long prod = 1;
             bool ok = r.size() >= 2 && T >= 64 && T <= 1024 && T % 64 == 0 && r[0] % D == 0;
             for (int q : r) { ok &= is_radix(q); prod *= q; }
-            if (ok && prod == UW && T >= UW / r[0] && T >= UW / r.back()) set_fused_n(c, T, r);
+            if (ok && prod == UW && T >= UW / r[0] && T >= UW / r.back() && sizeof(float2) * (size_t)UW * 2 + 1024 <= 160 * 1024) set_fused_n(c, T, r);
         }
     }
     // ---- stand-alone C2R for the pre-sharpen tap (LDS ping-pong, compile-time radices)
