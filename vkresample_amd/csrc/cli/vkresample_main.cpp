@@ -9,6 +9,7 @@
 //   -alldevices   batched mode: thread t uses device (d + t) % device_count instead of all threads on -d
 //   -fuseu8       the row kernel reads the uint8 image directly (README.md:31 roadmap item)
 //   -wrapu8       u8 store wraps like the reference's C cast instead of saturating
+//   -tune         FFTUP_FLAG_TUNE_PLAN: time the alternatives for a size specialised at plan time, keep the fastest (wisdom file)
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -223,6 +224,7 @@ int main(int argc, char* argv[])
         printf("	-alldevices: thread t runs on GPU (d + t) %% count\n");
         printf("	-fuseu8: FFT kernel reads the 8-bit image directly\n");
         printf("	-wrapu8: 8-bit store wraps like the original's C cast instead of saturating\n");
+        printf("	-tune: sizes whose kernels are specialised at plan time: measure the alternatives once, remember the fastest\n");
         return 0;
     }
     if (findFlag(B, E, "-devices")) return devices_list();
@@ -257,6 +259,7 @@ int main(int argc, char* argv[])
     config.allDevices = findFlag(B, E, "-alldevices");
     if (findFlag(B, E, "-fuseu8")) config.flags |= FFTUP_FLAG_FUSE_U8_LOAD;
     if (findFlag(B, E, "-wrapu8")) config.flags |= FFTUP_FLAG_U8_WRAP;
+    if (findFlag(B, E, "-tune")) config.flags |= FFTUP_FLAG_TUNE_PLAN;
 
     if (!findFlag(B, E, "-ifolder")) {
         config.fileUpload = 0;
