@@ -33,6 +33,8 @@ JIT_SIZES = [
 @pytest.mark.parametrize("W,H", JIT_SIZES)
 @pytest.mark.parametrize("precision,flags", [(0, 0), (0, 2), (2, 2)])
 def test_specialised_plan_vs_oracle(W, H, precision, flags):
+    if W > 3000 and (precision, flags) == (0, 2):
+        pytest.skip("8K outputs: the fused u8 load runs with -p 2 only (the oracle takes 10 s per case)")
     with _up(W, H, 2.0, precision, 0.2, 0, flags) as up:
         assert up.tuned and up.specialised_at_plan_time, "plan fell back to the size-generic kernels"
     (pre, out, u8), (opre, oout, ou8) = _run(W, H, 2.0, precision, "N", flags=flags, seed=W + H)
