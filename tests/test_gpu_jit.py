@@ -25,6 +25,7 @@ JIT_SIZES = [
     (128, 64),      # smallest sizes that are specialised
     (2000, 1250),   # no three-stage factorization: N-stage row 8*5*5*10, column 5*5*5*10 on 1024 threads, fused 8*5*10*10
     (486, 294),     # 9*2*3*9 / 7*2*3*7 / 12*9*9
+    (640, 3000),    # a column length whose first and last stage need 300 threads: two columns per workgroup (10*3*10*10)
     (3584, 2016),   # 16*2*7*16 / 12*2*7*12 / 8*8*16*7 on 1024 threads
     (3840, 2160),   # 4K -> 8K: 15*16*16 / 15*12*12 on 720 threads / 8*8*10*12 on 960 threads, 61 KB of LDS
 ]
@@ -68,6 +69,8 @@ U_CASES = [
     (1920, 1080, 1.5),
     (2560, 1440, 1.5),   # 1440p -> 4K
     (640, 480, 2.5),     # first radix 10, D = 5
+    (1280, 2160, 1.5),   # uH = 3240: k_col_pad with two columns per workgroup
+    (640, 3000, 3.0),    # k_col_u with two columns per workgroup
 ]
 
 

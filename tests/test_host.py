@@ -165,7 +165,8 @@ def test_jit_check_compiles_without_a_device(tmp_path, monkeypatch):
     files = list((tmp_path / "cache").glob("*.fjit"))
     assert len(files) == len(cases) and all(f.stat().st_size > 10000 for f in files)
     assert lib.fftup_jit_check(2000, 1250, 2, 0, None, buf, 256) == 0 and "row 8*5*5*10" in buf.value.decode()       # N-stage kernels
-    assert lib.fftup_jit_check(4000, 3000, 2, 0, None, buf, 256) == 2          # FFTUP_E_UNSUPPORTED_SIZE: the generic kernels run it
+    assert lib.fftup_jit_check(4000, 3000, 2, 0, None, buf, 256) == 0 and "(2 columns)" in buf.value.decode()      # long columns
+    assert lib.fftup_jit_check(2450, 1080, 2, 0, None, buf, 256) == 2          # FFTUP_E_UNSUPPORTED_SIZE: the generic kernels run it
     assert lib.fftup_jit_check(640, 480, 2, 1, None, buf, 256) == 3            # FFTUP_E_UNSUPPORTED_PRECISION
     # a pinned factorization that does not multiply to the size is ignored; a valid one is used
     monkeypatch.setenv("FFTUP_JIT_ROW", "5,8,16")
@@ -216,16 +217,18 @@ def test_jit_chooser_invariants_over_all_sizes():
             if not row.startswith(("pow2", "generic")):
                 r, t = parse(row)
                 assert prod(r) == W and set(r) <= radices and t <= 1024 and t >= W // r[0] and t >= W // r[-1], d
+            cols = 2 if "(2 columns)" in col else 4
+            col = col.replace(" (2 columns)", "")
             if not col.startswith("pow2"):
                 if "->" in col:                                     # half-integer factor: forward H, inverse uH
                     f, rest = col.split(" -> ")
                     fr = [int(x) for x in f.split("*")]
                     ir, t = parse(rest)
                     assert prod(fr) == H and prod(ir) == UH and set(fr) | set(ir) <= radices, d
-                    assert t <= 1024 and t >= 4 * max(H // fr[0], H // fr[-1], UH // ir[0], UH // ir[-1]), d
+                    assert t <= 1024 and t >= cols * max(H // fr[0], H // fr[-1], UH // ir[0], UH // ir[-1]), d
                 else:
                     r, t = parse(col)
-                    assert prod(r) == H and set(r) <= radices and t <= 1024 and t >= 4 * max(H // r[0], H // r[-1]), d
+                    assert prod(r) == H and set(r) <= radices and t <= 1024 and t >= cols * max(H // r[0], H // r[-1]), d
             if not fused.startswith("pow2"):
                 r, t = parse(fused)
                 assert prod(r) == UW and set(r) <= radices and r[0] % D == 0 and t <= 1024 and t % 64 == 0, d

@@ -925,7 +925,11 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         if (P->mixed) {
             ColTParams q{};
             q.S1 = P->lanes[P->cur].S1; q.S2 = P->lanes[P->cur].S2; q.twH = P->twH; q.twUH = P->twUH; q.W = (int)P->W; q.NT = P->NT;
-            if (P->mixed == 3) jerr = fftup_jit::launch(P->jit->fn[fftup_jit::K_COL], grid, dim3(P->jit->choice.col_block), P->ldsCol, P->lanes[P->cur].stream, q);
+            if (P->mixed == 3) {
+                const auto& ch = P->jit->choice;
+                const dim3 jgrid(P->NT * (ch.col_kind >= 3 ? 4 / ch.col_cols : 1), 3);        // (long columns: two per workgroup)
+                jerr = fftup_jit::launch(P->jit->fn[fftup_jit::K_COL], jgrid, dim3(ch.col_block), P->ldsCol, P->lanes[P->cur].stream, q);
+            }
             else if (P->mixed == 1) hipLaunchKernelGGL(k_col_m<MixedCfg1080>, grid, dim3(4 * MixedCfg1080::COL_TPC), P->ldsCol, P->lanes[P->cur].stream, q);
             else hipLaunchKernelGGL(k_col_m<MixedCfg720>, grid, dim3(4 * MixedCfg720::COL_TPC), P->ldsCol, P->lanes[P->cur].stream, q);
         } else switch (P->TK) {

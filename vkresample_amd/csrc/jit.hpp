@@ -57,6 +57,7 @@ struct Choice {
     int rr[3] = {0, 0, 0}, row_t = 0;
     std::vector<int> rn, cn;           // kind 3: k_row_r2c_n / k_col_n (N stages)
     std::vector<int> ci;               // col kind 5: the inverse transform of length UH
+    int col_cols = 4;                  // col kinds 3-5: columns of a 4-wide spectrum tile per workgroup (4, or 2 for long columns)
     int col_kind = -1;                 // 0: k_col_t<H>; 1: k_col_m (three stages); 3: k_col_n (N stages); 4: k_col_u (N stages, U - 1 residues); 5: k_col_pad (half-integer factors)
     int cr[3] = {0, 0, 0}, col_tpc = 0;
     int fused_kind = -1;               // 0: FusedPlanPow2<UW>; 1: FusedPlanMr16<UW, UW/256>; 2: FusedPlanN<UW, T, 2, radices...>
@@ -420,21 +421,30 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
     else if (choose3(W, 1, 1024, c.rr, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 1; c.row_t = (c.row_t + 63) / 64 * 64; c.row_block = c.row_t; }
     else if (choose_n(W, 1024, 64, c.rn, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 3; c.row_block = c.row_t; }
     else c.row_kind = 2;               // no supported factorization: the size-generic row kernel (same S1 layout) stays
-    // ---- column (four columns per workgroup)
+    // ---- column (four columns of a spectrum tile per workgroup; two when a stage of a long column needs more than 256 threads)
+    auto col_n = [&](int len, std::vector<int>& r, int* tpc, const char* env) {
+        if (choose_n(len, 256, 16, r, tpc, env)) return 4;
+        if (choose_n(len, 512, 32, r, tpc, env)) return 2;
+        return 0;
+    };
     if (U == 1) {
         int ti = 0;
-        if (c.UH > 4096 || !choose_n(H, 256, 16, c.cn, &c.col_tpc, "FFTUP_JIT_COL") || !choose_n(c.UH, 256, 16, c.ci, &ti, "FFTUP_JIT_COLI")) return false;
+        if (c.UH > 4096) return false;
+        const int cf = col_n(H, c.cn, &c.col_tpc, "FFTUP_JIT_COL"), ci = col_n(c.UH, c.ci, &ti, "FFTUP_JIT_COLI");
+        if (!cf || !ci) return false;
+        c.col_cols = std::min(cf, ci);
         c.col_tpc = std::max(c.col_tpc, ti);
-        c.col_kind = 5; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((c.UH * 4 + 15) & ~15);
+        if (c.col_cols * c.col_tpc > 1024) return false;
+        c.col_kind = 5; c.col_block = c.col_cols * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((c.UH * c.col_cols + 15) & ~15);
     } else if (U > 2) {
-        if (!choose_n(H, 256, 16, c.cn, &c.col_tpc, "FFTUP_JIT_COL")) return false;
-        c.col_kind = 4; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * 4 + 15) & ~15);
+        if (!(c.col_cols = col_n(H, c.cn, &c.col_tpc, "FFTUP_JIT_COL"))) return false;
+        c.col_kind = 4; c.col_block = c.col_cols * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * c.col_cols + 15) & ~15);
     } else if (is_pow2(H) && H >= 128 && H <= 2048) {
         c.col_kind = 0; c.col_block = 4 * H / 8; c.col_lds = sizeof(float2) * (size_t)((H * 4 + 15) & ~15);      // lswz_size
     } else if (choose3(H, 4, 256, c.cr, &c.col_tpc, "FFTUP_JIT_COL")) {
         c.col_kind = 1; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)H * 4;
-    } else if (choose_n(H, 256, 16, c.cn, &c.col_tpc, "FFTUP_JIT_COL")) {
-        c.col_kind = 3; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * 4 + 15) & ~15);
+    } else if ((c.col_cols = col_n(H, c.cn, &c.col_tpc, "FFTUP_JIT_COL"))) {
+        c.col_kind = 3; c.col_block = c.col_cols * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * c.col_cols + 15) & ~15);
     } else return false;
     // ---- fused C2R + sharpen
     const int UW = c.UW;
@@ -511,11 +521,12 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT])
              ", COL_TPC = " + std::to_string(c.col_tpc) + ";\n";
     if (c.row_kind == 3)
         s += "    static constexpr int ROW_T = " + std::to_string(c.row_t) + ";\n    using RowN = MrFftNT<W, +1, ROW_T, 1, " + join(c.rn) + ">;\n";
+    const std::string cc = std::to_string(c.col_cols);
     if (c.col_kind == 5)
-        s += "    static constexpr int UH = " + std::to_string(c.UH) + ";\n    using ColIU = MrFftNT<UH, -1, " + std::to_string(c.col_tpc) + ", 4, " + join(c.ci) + ">;\n";
+        s += "    static constexpr int UH = " + std::to_string(c.UH) + ";\n    using ColIU = MrFftNT<UH, -1, " + std::to_string(c.col_tpc) + ", " + cc + ", " + join(c.ci) + ">;\n";
     if (c.col_kind >= 3)
-        s += "    static constexpr int COL_TPC = " + std::to_string(c.col_tpc) + ";\n    using ColF = MrFftNT<H, +1, COL_TPC, 4, " + join(c.cn) +
-             ">;\n    using ColI = MrFftNT<H, -1, COL_TPC, 4, " + join(c.cn) + ">;\n";
+        s += "    static constexpr int COL_TPC = " + std::to_string(c.col_tpc) + ", COL_COLS = " + cc + ";\n    using ColF = MrFftNT<H, +1, COL_TPC, COL_COLS, " + join(c.cn) +
+             ">;\n    using ColI = MrFftNT<H, -1, COL_TPC, COL_COLS, " + join(c.cn) + ">;\n";
     s += "};\n";
     if (c.fused_kind == 0) s += "using JitFused = FusedPlanPow2<" + UW + ">;\n";
     else if (c.fused_kind == 1) s += "using JitFused = FusedPlanMr16<" + UW + ", " + std::to_string(c.UW / 256) + ">;\n";
@@ -552,7 +563,7 @@ static std::string describe(const Choice& c)
     s += c.row_kind == 2 ? "generic" : c.row_kind == 0 ? "pow2/8" : c.row_kind == 3 ? star(c.rn) : std::to_string(c.rr[0]) + "*" + std::to_string(c.rr[1]) + "*" + std::to_string(c.rr[2]);
     s += " x" + std::to_string(c.row_block) + ", col ";
     s += c.col_kind == 0 ? "pow2/8" : c.col_kind == 5 ? star(c.cn) + " -> " + star(c.ci) : c.col_kind >= 3 ? star(c.cn) : std::to_string(c.cr[0]) + "*" + std::to_string(c.cr[1]) + "*" + std::to_string(c.cr[2]);
-    s += " x" + std::to_string(c.col_block) + ", fused ";
+    s += " x" + std::to_string(c.col_block) + (c.col_kind >= 3 && c.col_cols == 2 ? " (2 columns)" : "") + ", fused ";
     if (c.fused_kind == 0) s += "pow2/8";
     else if (c.fused_kind == 1) s += "16*16*" + std::to_string(c.UW / 256);
     else for (size_t i = 0; i < c.fr.size(); i++) s += (i ? "*" : "") + std::to_string(c.fr[i]);

@@ -236,19 +236,21 @@ __global__ void __launch_bounds__(CFG::ROW_T) k_row_r2c_n(RowR2CTParams p)
     }
 }
 
-// ---- column, polyphase form (k_col_t).  grid (NT, 3), block 4 * CFG::COL_TPC, LDS lswz_size(4 H) float2.
+// ---- column, polyphase form (k_col_t).  A workgroup transforms CC = CFG::COL_COLS columns of a 4-wide spectrum tile (4, or 2
+// for lengths whose first and last stage need more than 256 threads per column).  grid (NT * 4/CC, 3), block CC * CFG::COL_TPC,
+// LDS lswz_size(CC H) float2.
 template <class CFG>
-__global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_n(ColTParams p)
+__global__ void __launch_bounds__(CFG::COL_COLS * CFG::COL_TPC) k_col_n(ColTParams p)
 {
     using FF = typename CFG::ColF;
     using FI = typename CFG::ColI;
-    constexpr int H = CFG::H, TK = 4, TC = CFG::COL_TPC, R0 = FF::rs(0), NB0 = H / R0, RL = FF::rs(FF::NST - 1), NBL = H / RL;
+    constexpr int H = CFG::H, TK = 4, CC = CFG::COL_COLS, TC = CFG::COL_TPC, R0 = FF::rs(0), NB0 = H / R0, RL = FF::rs(FF::NST - 1), NBL = H / RL;
     static_assert(TC >= NB0 && TC >= NBL, "one butterfly per thread in the first and the last stage");
     extern __shared__ __attribute__((aligned(128))) char smem[];
     float2* buf = (float2*)smem;
-    const int tid = threadIdx.x, col = tid % TK, j = tid / TK;
-    const int tile = blockIdx.x, c = blockIdx.y;
-    const bool valid = tile * TK + col <= p.W / 2;
+    const int tid = threadIdx.x, col = tid % CC, j = tid / CC;
+    const int tile = blockIdx.x / (TK / CC), gcol = (blockIdx.x % (TK / CC)) * CC + col, c = blockIdx.y;
+    const bool valid = tile * TK + gcol <= p.W / 2;
     const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
     typename FF::Tw twf;
     typename FI::Tw twi;
@@ -257,12 +259,12 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_n(ColTParams p)
     float2 v[FF::VN];
     if (j < NB0) {
 #pragma unroll
-        for (int m = 0; m < R0; m++) v[m] = valid ? src[(j + NB0 * m) * TK + col] : make_float2(0.f, 0.f);
+        for (int m = 0; m < R0; m++) v[m] = valid ? src[(j + NB0 * m) * TK + gcol] : make_float2(0.f, 0.f);
     }
     FF::template run<true>(v, buf, buf, j, twf, col);
     if (j < NBL) {
 #pragma unroll
-        for (int m = 0; m < RL; m++) buf[lidx<TK>(j + NBL * m, col)] = v[m];       // F[k] in natural order
+        for (int m = 0; m < RL; m++) buf[lidx<CC>(j + NBL * m, col)] = v[m];       // F[k] in natural order
     }
     __syncthreads();
     if (j < NB0) {
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_n(ColTParams p)
             const int k = j + NB0 * m;
             float2 t = twid<-1>(p.twUH[k]);
             if (k >= H / 2) t = make_float2(-t.x, -t.y);
-            v[m] = cmul(buf[lidx<TK>(k, col)], t);
+            v[m] = cmul(buf[lidx<CC>(k, col)], t);
         }
     }
     __syncthreads();
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_n(ColTParams p)
     constexpr float inv = 1.0f / (float)H;
     if (j < NBL && valid) {
 #pragma unroll
-        for (int m = 0; m < RL; m++) dst[(j + NBL * m) * TK + col] = cscale(v[m], inv);
+        for (int m = 0; m < RL; m++) dst[(j + NBL * m) * TK + gcol] = cscale(v[m], inv);
     }
 }
 
@@ -292,17 +294,17 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_n(ColTParams p)
 // (the upper half of the spectrum sits (U-1) H rows higher).  U = 2 is the odd-row transform of k_col_t.  Residue buffer
 // r lives (r-1) * buf_stride elements behind p.S2, all at U times the reference's normalisation (D / H).
 template <class CFG, int U>
-__global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_u(ColTParams p)
+__global__ void __launch_bounds__(CFG::COL_COLS * CFG::COL_TPC) k_col_u(ColTParams p)
 {
     using FF = typename CFG::ColF;
     using FI = typename CFG::ColI;
-    constexpr int H = CFG::H, TK = 4, TC = CFG::COL_TPC, R0 = FF::rs(0), NB0 = H / R0, RL = FF::rs(FF::NST - 1), NBL = H / RL;
+    constexpr int H = CFG::H, TK = 4, CC = CFG::COL_COLS, TC = CFG::COL_TPC, R0 = FF::rs(0), NB0 = H / R0, RL = FF::rs(FF::NST - 1), NBL = H / RL;
     static_assert(TC >= NB0 && TC >= NBL, "one butterfly per thread in the first and the last stage");
     extern __shared__ __attribute__((aligned(128))) char smem[];
     float2* buf = (float2*)smem;
-    const int tid = threadIdx.x, col = tid % TK, j = tid / TK;
-    const int tile = blockIdx.x, c = blockIdx.y;
-    const bool valid = tile * TK + col <= p.W / 2;
+    const int tid = threadIdx.x, col = tid % CC, j = tid / CC;
+    const int tile = blockIdx.x / (TK / CC), gcol = (blockIdx.x % (TK / CC)) * CC + col, c = blockIdx.y;
+    const bool valid = tile * TK + gcol <= p.W / 2;
     const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
     typename FF::Tw twf;
     typename FI::Tw twi;
@@ -311,17 +313,17 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_u(ColTParams p)
     float2 v[FF::VN], f[R0];
     if (j < NB0) {
 #pragma unroll
-        for (int m = 0; m < R0; m++) v[m] = valid ? src[(j + NB0 * m) * TK + col] : make_float2(0.f, 0.f);
+        for (int m = 0; m < R0; m++) v[m] = valid ? src[(j + NB0 * m) * TK + gcol] : make_float2(0.f, 0.f);
     }
     FF::template run<true>(v, buf, buf, j, twf, col);
     if (j < NBL) {
 #pragma unroll
-        for (int m = 0; m < RL; m++) buf[lidx<TK>(j + NBL * m, col)] = v[m];       // F[k] in natural order
+        for (int m = 0; m < RL; m++) buf[lidx<CC>(j + NBL * m, col)] = v[m];       // F[k] in natural order
     }
     __syncthreads();
     if (j < NB0) {
 #pragma unroll
-        for (int m = 0; m < R0; m++) f[m] = buf[lidx<TK>(j + NB0 * m, col)];       // kept in registers over the residues
+        for (int m = 0; m < R0; m++) f[m] = buf[lidx<CC>(j + NB0 * m, col)];       // kept in registers over the residues
     }
     __syncthreads();
     const long buf_stride = (long)3 * p.NT * H * TK;
@@ -342,7 +344,7 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_u(ColTParams p)
         float2* dst = p.S2 + (r - 1) * buf_stride + ((long)c * p.NT + tile) * H * TK;
         if (j < NBL && valid) {
 #pragma unroll
-            for (int m = 0; m < RL; m++) dst[(j + NBL * m) * TK + col] = cscale(v[m], inv);
+            for (int m = 0; m < RL; m++) dst[(j + NBL * m) * TK + gcol] = cscale(v[m], inv);
         }
         __syncthreads();                                                            // the buffer is free for the next residue
     }
@@ -355,19 +357,19 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_u(ColTParams p)
 // [H/2, UH - H/2) (fftup_plan_create checks the reference's float arithmetic gives exactly that).
 // CFG::ColF = MrFftNT<H, +1, COL_TPC, 4, ...>, CFG::ColIU = MrFftNT<UH, -1, COL_TPC, 4, ...>.  LDS lswz_size(4 UH) float2.
 template <class CFG>
-__global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_pad(ColTParams p)
+__global__ void __launch_bounds__(CFG::COL_COLS * CFG::COL_TPC) k_col_pad(ColTParams p)
 {
     using FF = typename CFG::ColF;
     using FI = typename CFG::ColIU;
-    constexpr int H = CFG::H, UH = CFG::UH, TK = 4, TC = CFG::COL_TPC;
+    constexpr int H = CFG::H, UH = CFG::UH, TK = 4, CC = CFG::COL_COLS, TC = CFG::COL_TPC;
     constexpr int R0 = FF::rs(0), NB0 = H / R0, RL = FF::rs(FF::NST - 1), NBL = H / RL;
     constexpr int Q0 = FI::rs(0), MB0 = UH / Q0, QL = FI::rs(FI::NST - 1), MBL = UH / QL;
     static_assert(TC >= NB0 && TC >= NBL && TC >= MB0 && TC >= MBL, "one butterfly per thread in the first and the last stages");
     extern __shared__ __attribute__((aligned(128))) char smem[];
     float2* buf = (float2*)smem;
-    const int tid = threadIdx.x, col = tid % TK, j = tid / TK;
-    const int tile = blockIdx.x, c = blockIdx.y;
-    const bool valid = tile * TK + col <= p.W / 2;
+    const int tid = threadIdx.x, col = tid % CC, j = tid / CC;
+    const int tile = blockIdx.x / (TK / CC), gcol = (blockIdx.x % (TK / CC)) * CC + col, c = blockIdx.y;
+    const bool valid = tile * TK + gcol <= p.W / 2;
     const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
     typename FF::Tw twf;
     typename FI::Tw twi;
@@ -376,12 +378,12 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_pad(ColTParams p)
     float2 v[FF::VN], w[FI::VN];
     if (j < NB0) {
 #pragma unroll
-        for (int m = 0; m < R0; m++) v[m] = valid ? src[(j + NB0 * m) * TK + col] : make_float2(0.f, 0.f);
+        for (int m = 0; m < R0; m++) v[m] = valid ? src[(j + NB0 * m) * TK + gcol] : make_float2(0.f, 0.f);
     }
     FF::template run<true>(v, buf, buf, j, twf, col);
     if (j < NBL) {
 #pragma unroll
-        for (int m = 0; m < RL; m++) buf[lidx<TK>(j + NBL * m, col)] = v[m];       // F[k] in natural order
+        for (int m = 0; m < RL; m++) buf[lidx<CC>(j + NBL * m, col)] = v[m];       // F[k] in natural order
     }
     __syncthreads();
     if (j < MB0) {
@@ -389,8 +391,8 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_pad(ColTParams p)
         for (int m = 0; m < Q0; m++) {
             const int ky = j + MB0 * m;                                             // row of the zero-padded buffer
             float2 g = make_float2(0.f, 0.f);
-            if (ky < H / 2) g = buf[lidx<TK>(ky, col)];
-            else if (ky >= UH - H / 2) g = buf[lidx<TK>(ky - (UH - H), col)];
+            if (ky < H / 2) g = buf[lidx<CC>(ky, col)];
+            else if (ky >= UH - H / 2) g = buf[lidx<CC>(ky - (UH - H), col)];
             w[m] = g;
         }
     }
@@ -400,7 +402,7 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_pad(ColTParams p)
     constexpr float inv = 1.0f / (float)UH;
     if (j < MBL && valid) {
 #pragma unroll
-        for (int m = 0; m < QL; m++) dst[(j + MBL * m) * TK + col] = cscale(w[m], inv);
+        for (int m = 0; m < QL; m++) dst[(j + MBL * m) * TK + gcol] = cscale(w[m], inv);
     }
 }
 
