@@ -235,3 +235,17 @@ def test_jit_chooser_invariants_over_all_sizes():
                 assert t >= UW // r[0] and t >= UW // r[-1], d
                 assert max(-(-(UW // q) // t) * q for q in r) <= 16, d          # points per thread
     assert seen > 400
+
+
+def test_without_the_runtime_compiler_the_library_says_so(tmp_path):
+    """libhiprtc.so is dlopen'ed: a machine without it keeps working on the size-generic kernels; fftup_jit_check reports
+    it (FFTUP_E_HIP, 'hipRTC ... not available') instead of failing to load the library."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from vkresample_amd import _lib; lib = _lib.load(); "
+            "buf = C.create_string_buffer(256); rc = lib.fftup_jit_check(640, 480, 2.0, 0, None, buf, 256); "
+            "print(rc, lib.fftup_last_error().decode())" % ROOT)
+    env = dict(os.environ, FFTUP_HIPRTC_LIB=str(tmp_path / "no_such_libhiprtc.so"), FFTUP_CACHE_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("5 ") and "not available" in r.stdout, r.stdout

@@ -594,10 +594,12 @@ static const Rtc& rtc()
     static Rtc r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r.lib) break;
-        }
+        if (const char* e = getenv("FFTUP_HIPRTC_LIB")) r.lib = dlopen(e, RTLD_NOW | RTLD_LOCAL);       // (this one or none)
+        else
+            for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+                r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (r.lib) break;
+            }
         if (!r.lib) return;
         bool all = true;
 #define FFTUP_RTC_SYM(field, sym) all &= ((*(void**)&r.field = dlsym(r.lib, sym)) != nullptr)
