@@ -71,12 +71,15 @@ U_CASES = [
     (640, 480, 2.5),     # first radix 10, D = 5
     (1280, 2160, 1.5),   # uH = 3240: k_col_pad with two columns per workgroup
     (640, 3000, 3.0),    # k_col_u with two columns per workgroup
+    (5120, 2880, 1.5),   # 5K -> 8K: the widest input (7680 output columns), uH = 4320
 ]
 
 
 @pytest.mark.parametrize("W,H,u", U_CASES)
 @pytest.mark.parametrize("precision,flags", [(0, 0), (2, 2)])
 def test_specialised_integer_factor_vs_oracle(W, H, u, precision, flags):
+    if W > 5000 and precision == 0 and os.environ.get("FFTUP_BIG_TESTS", "1") == "0":
+        pytest.skip("FFTUP_BIG_TESTS=0")
     with _up(W, H, u, precision, 0.2, 0, flags) as up:
         assert up.tuned and up.specialised_at_plan_time, "plan fell back to the size-generic kernels"
     (pre, out, u8), (opre, oout, ou8) = _run(W, H, u, precision, "N", flags=flags, seed=W + H)

@@ -414,7 +414,7 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
 {
     const int U = D % 2 == 0 ? D / 2 : 1;
     c.W = W; c.H = H; c.U = U; c.D = D; c.UW = D * W / 2; c.UH = D * H / 2; c.half = half;
-    if (W < 64 || H < 64 || W > 4096 || H > 4096 || D < 3 || c.UW > 8192 || (D * W) % 2 || (D * H) % 2) return false;
+    if (W < 64 || H < 64 || W > 8192 || H > 4096 || D < 3 || c.UW > 8192 || (D * W) % 2 || (D * H) % 2) return false;
     if (c.UW % 4) return false;        // the sharpen works on quads of pixels (-u 5 with W = 2 * odd: the size-generic kernels)
     // ---- row R2C
     if (is_pow2(W) && W >= 256) { c.row_kind = 0; c.row_block = W / 8; }
@@ -429,13 +429,13 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
     };
     if (U == 1) {
         int ti = 0;
-        if (c.UH > 4096) return false;
+        if (c.UH > 8192) return false;
         const int cf = col_n(H, c.cn, &c.col_tpc, "FFTUP_JIT_COL"), ci = col_n(c.UH, c.ci, &ti, "FFTUP_JIT_COLI");
         if (!cf || !ci) return false;
         c.col_cols = std::min(cf, ci);
         c.col_tpc = std::max(c.col_tpc, ti);
-        if (c.col_cols * c.col_tpc > 1024) return false;
         c.col_kind = 5; c.col_block = c.col_cols * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((c.UH * c.col_cols + 15) & ~15);
+        if (c.col_block > 1024 || c.col_lds > 160 * 1024) return false;
     } else if (U > 2) {
         if (!(c.col_cols = col_n(H, c.cn, &c.col_tpc, "FFTUP_JIT_COL"))) return false;
         c.col_kind = 4; c.col_block = c.col_cols * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * c.col_cols + 15) & ~15);
