@@ -44,7 +44,7 @@ def _cases_specialised():
     import os
     rng = np.random.default_rng(int(os.environ.get("FFTUP_SWEEP_SEED", "20260930")) + 1)
     out = []
-    while len(out) < int(os.environ.get("FFTUP_SWEEP_JIT_N", "24")):  # (a one-off 400-case run is logged in profiles/)
+    while len(out) < int(os.environ.get("FFTUP_SWEEP_JIT_N", "16")):  # (a one-off 400-case run is logged in profiles/)
         W, H = int(rng.choice(SMOOTH_BIG)), int(rng.choice(SMOOTH_BIG))
         u = float(rng.choice([2.0, 2.0, 2.0, 3.0, 4.0, 5.0, 1.5, 1.5, 2.5]))
         if u * W > 8192 or u * u * W * H > 3 << 20 or (2 * u * W) % 4 or (2 * u * H) % 4 or not _smooth(int(u * W)) or not _smooth(int(u * H)):
