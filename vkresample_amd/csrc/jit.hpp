@@ -3,18 +3,29 @@
 // The reference treats every 2*3*5*7-smooth size as first class because VkFFT GENERATES its shaders for the requested
 // size at plan time and compiles them with glslang (vkFFT.h:4707-5189 scheduler, :6200-7700 generator, VkResample.cpp
 // links glslang for it).  The MI355X-native counterpart: the register-resident kernels of kernels_pow2.hpp /
-// kernels_mixed.hpp are C++ templates over the size and its radix factorisation; for a -u 2 plan whose size has no
-// ahead-of-time instantiation, fftup_plan_create picks factorizations (choose()), writes a ten-line translation unit
-// that names the instantiations, compiles it for the plan's device with hipRTC (the ROCm run-time compiler, loaded with
-// dlopen -- no link-time dependency, and without it the plan silently stays on the size-generic kernels), and launches
-// the kernels from the loaded code object.  Code objects are cached in memory and on disk
-// ($FFTUP_CACHE_DIR, else $XDG_CACHE_HOME/fftup, else ~/.cache/fftup), keyed by a hash of the translation unit, the
-// compiler options, the hipRTC version and the kernel headers' text.
+// kernels_mixed.hpp are C++ templates over the size, its radix factorisation and the upscale factor; for a plan with an
+// integer or half-integer factor whose size has no ahead-of-time instantiation, fftup_plan_create
+//   * picks factorizations (choose(): measured rules, a built-in table of tuner results for the MI355X, the user's
+//     wisdom file),
+//   * writes a ten-line translation unit that names the instantiations (make_source()),
+//   * compiles it for the plan's device with hipRTC (the ROCm run-time compiler, loaded with dlopen -- no link-time
+//     dependency, and without it the plan silently stays on the size-generic kernels),
+//   * loads the code object, relaxes the fused kernel's register bound if it spills (load()), and launches the kernels
+//     from it (launch()).
+// Code objects are cached in memory and on disk ($FFTUP_CACHE_DIR, else $XDG_CACHE_HOME/fftup, else ~/.cache/fftup),
+// keyed by a hash of the translation unit, the compiler options, the hipRTC version and the kernel headers' text.
+// With FFTUP_FLAG_TUNE_PLAN the plan is also timed with the alternative factorizations of its dominant kernel
+// (fused_candidates(), tune_fused() in fftup.hip) and the decision kept in <cache dir>/wisdom.txt.
 //
 // The kernel headers' text is embedded in the library at build time (kernel_sources.inc, written by
 // __graft_entry__.build() from the very files the ahead-of-time kernels are compiled from) and handed to hipRTC as
 // in-memory headers; $FFTUP_KERNEL_DIR overrides it with a directory (development), and a library built without the
 // generated file reads csrc/ next to libfftup.so.
+//
+// Environment (experiments, tests): FFTUP_JIT=0 off; FFTUP_JIT_VERBOSE=1 says why a plan fell back and what the tuner
+// measured; FFTUP_JIT_ROW / _COL / _COLI / _FUSED ("r0,r1,.." resp. "threads:r0,r1,..") pin a factorization;
+// FFTUP_JIT_FUSED_OPT="waves,ring" pins the fused kernel's register bound and ring-row placement;
+// FFTUP_JIT_NO_BUILTIN_WISDOM=1; FFTUP_JIT_DUMP=<file> writes the translation unit; FFTUP_HIPRTC_LIB=<libhiprtc.so>.
 #pragma once
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
