@@ -136,7 +136,9 @@ def test_pinned_factorizations(monkeypatch):
 
 
 def test_ring_batch_on_specialised_plan():
-    """batched mode (three streams, ring of slots) on a specialised plan: every slot equals the single-frame result"""
+    """batched mode (three streams, ring of slots) on a specialised plan: every slot equals the single-frame result -- up to
+    fp32 rounding: a plan without a ring cuts the frame into shorter strips (two per compute unit), and the first strip of a
+    plane pairs the rows of its transforms differently (test_fused_output_independent_of_strip_length)"""
     from vkresample_amd import synth
     W, H = 720, 576
     frames = [synth.frame(20 + s, W, H, "N") for s in range(3)]
@@ -151,7 +153,7 @@ def test_ring_batch_on_specialised_plan():
             up.upload_rgb8(f, slot=s)
         up.execute_ring(9, 0)
         for s in range(3):
-            assert np.array_equal(up.download_planar(s), single[s])
+            assert np.abs(up.download_planar(s).astype(np.float64) - single[s]).max() <= 5e-6
 
 
 def test_plan_time_tuner(tmp_path, monkeypatch):

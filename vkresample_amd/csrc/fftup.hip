@@ -206,6 +206,26 @@ static int jit_factor_x2(float upscale, uint32_t W, uint32_t H, uint32_t uW, uin
     return D;
 }
 static void tune_fused(fftup_plan* P);
+static std::string wisdom_device_key(const fftup_plan* P);
+
+// Row pairs per workgroup (strip) of the fused C2R+sharpen kernel.
+// Plans whose frames overlap on several streams (ring > 1): ONE strip per compute unit -- the rest of every unit is left
+// to the row and column kernels of the frames on the other streams, and the frame time is what counts.
+// Plans that run one frame after the other (ring = 1: the CLI's single-image mode, the reference's -n timing): nothing
+// runs beside a strip, and a workgroup of at most 256 threads (one wave per SIMD) cannot hide its own latencies: two
+// strips per unit (1080p 98 -> 90 us per frame, 1000x1000 76 -> 62; no gain at 512 threads and beyond).
+// FFTUP_G_PER_CU / FFTUP_PAIRS_PER_STRIP override; how many workgroups are resident is the hardware's business.
+static void set_strip_length(fftup_plan* P)
+{
+    const int fused_threads = P->tuned ? (int)P->uW / 8 : P->mixed == 3 ? P->jit->choice.fused_t : P->mixed == 2 ? 256 : (P->plan3840_x16 ? 256 : 512);
+    const std::string mode = wisdom_device_key(P);
+    const bool sequential = mode.size() >= 10 && mode.compare(mode.size() - 10, 10, "sequential") == 0;
+    int per_cu = (sequential && fused_threads <= 256) ? 2 : 1;
+    if (const char* e = getenv("FFTUP_G_PER_CU")) per_cu = std::max(1, std::min(4, atoi(e)));
+    const int total_pairs = 3 * (int)P->uH / 2, slots = std::max(1, P->prop.multiProcessorCount) * per_cu;
+    P->pairs_per_strip = std::max(2, (total_pairs + slots - 1) / slots);
+    if (const char* e = getenv("FFTUP_PAIRS_PER_STRIP")) P->pairs_per_strip = std::max(1, atoi(e));
+}
 // what the tuner's findings are filed under: the device and whether consecutive frames overlap on several streams
 // (ring > 1: what fits beside a strip decides) or run one after the other (ring = 1: the kernel's own time decides)
 static std::string wisdom_device_key(const fftup_plan* P)
@@ -401,18 +421,8 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             }
         }
         P->fused = (P->tuned || P->mixed) && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
-        {
-            // One strip (workgroup of uW/8 threads) per compute unit: the rest of every compute unit is left to the row and
-            // column kernels of the frames on the other streams, and the frame time is what counts.
-            // FFTUP_G_PER_CU only sets the strip length (strips = units * per_cu); how many workgroups are resident is
-            // the hardware's business (the power-of-two plans take 64 KB of LDS and 96 VGPRs x 8 waves).
-            if (const char* e = getenv("FFTUP_3840_X16")) P->plan3840_x16 = atoi(e) != 0;
-            int per_cu = 1;
-            if (const char* e = getenv("FFTUP_G_PER_CU")) per_cu = std::max(1, std::min(4, atoi(e)));
-            const int total_pairs = 3 * (int)uH / 2, slots = std::max(1, P->prop.multiProcessorCount) * per_cu;
-            P->pairs_per_strip = std::max(2, (total_pairs + slots - 1) / slots);
-        }
-        if (const char* e = getenv("FFTUP_PAIRS_PER_STRIP")) P->pairs_per_strip = std::max(1, atoi(e));
+        if (const char* e = getenv("FFTUP_3840_X16")) P->plan3840_x16 = atoi(e) != 0;
+        set_strip_length(P);
         P->NT = (P->ncols + P->TK - 1) / P->TK;
         P->ldsRowF = 2 * P->csz * (size_t)lpad_size((int)W);
         P->ldsRowI = 2 * P->csz * (size_t)lpad_size((int)uW);
@@ -1103,15 +1113,17 @@ static void tune_fused(fftup_plan* P)
         fftup_jit::Module* m = fftup_jit::load(c, arch, err);
         if (!m) continue;
         P->jit = m;
+        set_strip_length(P);
         const double t = time_plan();
         P->jit = original;
+        set_strip_length(P);
         if (getenv("FFTUP_JIT_VERBOSE"))
             fprintf(stderr, "fftup: tuning %s: %s %.1f us/frame (default %s %.1f)\n", key.c_str(), fftup_jit::fused_value(m->choice).c_str(), t * 1e3,
                     fftup_jit::fused_value(base).c_str(), t_base * 1e3);
         if (t < 0.97 * t_best) { delete best; best = m; t_best = t; }           // (3 %: do not chase noise)
         else delete m;
     }
-    if (best) { delete original; P->jit = best; }
+    if (best) { delete original; P->jit = best; set_strip_length(P); }
     P->in_kind = kinds;
     P->executed = executed;
     fftup_jit::wisdom_store(key, fftup_jit::fused_value(P->jit->choice));
