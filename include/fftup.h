@@ -72,12 +72,15 @@ typedef struct fftup_config {
 /* Environment read once by fftup_plan_create (tuning and test knobs, not part of the reference's surface):
  *   FFTUP_STREAMS=n          HIP streams consecutive frames of fftup_execute_ring / fftup_submit_rgb8 alternate on
  *                            (default 3, 1..4); fftup_execute always uses one
- *   FFTUP_G_PER_CU=n         strips (workgroups) of the fused C2R+sharpen kernel per compute unit (default 1)
+ *   FFTUP_G_PER_CU=n         strips (workgroups) of the fused C2R+sharpen kernel per compute unit (default: 1 for plans with a
+ *                            ring of slots, whose frames overlap on the streams; 2 for plans without one when the fused
+ *                            kernel's workgroup has at most 256 threads)
  *   FFTUP_PAIRS_PER_STRIP=n  row pairs per workgroup of the fused C2R+sharpen kernel (default: pairs / compute units)
  *   FFTUP_JIT=0|1            run-time specialised plans (default 1); FFTUP_JIT_VERBOSE=1 prints why one fell back;
  *                            FFTUP_JIT_TUNE=1 = FFTUP_FLAG_TUNE_PLAN for every plan;
  *                            FFTUP_KERNEL_DIR / FFTUP_CACHE_DIR: kernel headers / code-object cache (jit.hpp);
  *                            FFTUP_HIPRTC_LIB: the run-time compiler's shared object (default: libhiprtc.so of the ROCm install)
+ *   FFTUP_AOT=0              experiments: sizes with ahead-of-time kernels go through the plan-time compiler as well
  *   FFTUP_3840_X16=0|1       1920x1080 -u 2: fused kernel on the 16*16*15 plan, 256 threads (1, default) or the
  *                            8*8*4*15 plan, 512 threads (0); same results up to fp32 rounding (tests) */
 
