@@ -429,7 +429,7 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
     if (c.UW % 4) return false;        // the sharpen works on quads of pixels (-u 5 with W = 2 * odd: the size-generic kernels)
     // ---- row R2C
     if (is_pow2(W) && W >= 256) { c.row_kind = 0; c.row_block = W / 8; }
-    else if (choose3(W, 1, 1024, c.rr, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 1; c.row_t = (c.row_t + 63) / 64 * 64; c.row_block = c.row_t; }
+    else if (!getenv("FFTUP_JIT_ROW_NSTAGE") && choose3(W, 1, 1024, c.rr, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 1; c.row_t = (c.row_t + 63) / 64 * 64; c.row_block = c.row_t; }
     else if (choose_n(W, 1024, 64, c.rn, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 3; c.row_block = c.row_t; }
     else c.row_kind = 2;               // no supported factorization: the size-generic row kernel (same S1 layout) stays
     // ---- column (four columns of a spectrum tile per workgroup; two when a stage of a long column needs more than 256 threads)
@@ -452,7 +452,7 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
         c.col_kind = 4; c.col_block = c.col_cols * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * c.col_cols + 15) & ~15);
     } else if (is_pow2(H) && H >= 128 && H <= 2048) {
         c.col_kind = 0; c.col_block = 4 * H / 8; c.col_lds = sizeof(float2) * (size_t)((H * 4 + 15) & ~15);      // lswz_size
-    } else if (choose3(H, 4, 256, c.cr, &c.col_tpc, "FFTUP_JIT_COL")) {
+    } else if (!getenv("FFTUP_JIT_COL_NSTAGE") && choose3(H, 4, 256, c.cr, &c.col_tpc, "FFTUP_JIT_COL")) {
         c.col_kind = 1; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)H * 4;
     } else if ((c.col_cols = col_n(H, c.cn, &c.col_tpc, "FFTUP_JIT_COL"))) {
         c.col_kind = 3; c.col_block = c.col_cols * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * c.col_cols + 15) & ~15);
