@@ -163,7 +163,11 @@ def test_jit_check_compiles_without_a_device(tmp_path, monkeypatch):
         assert rc == 0, lib.fftup_last_error().decode()
         assert expect in buf.value.decode(), buf.value
     files = list((tmp_path / "cache").glob("*.fjit"))
-    assert len(files) == len(cases) and all(f.stat().st_size > 10000 for f in files)
+    # two code objects per plan: row + column kernels, fused C2R+sharpen + stand-alone C2R
+    assert len(files) == 2 * len(cases) and all(f.stat().st_size > 10000 for f in files)
+    # a plan of another height shares the second one (it depends on the output row length only)
+    assert lib.fftup_jit_check(896, 648, 2, 0, None, buf, 256) == 0
+    assert len(list((tmp_path / "cache").glob("*.fjit"))) == 2 * len(cases) + 1
     assert lib.fftup_jit_check(2000, 1250, 2, 0, None, buf, 256) == 0 and "row 8*5*5*10" in buf.value.decode()       # N-stage kernels
     assert lib.fftup_jit_check(4000, 3000, 2, 0, None, buf, 256) == 0 and "(2 columns)" in buf.value.decode()      # long columns
     assert lib.fftup_jit_check(2450, 1080, 2, 0, None, buf, 256) == 2          # FFTUP_E_UNSUPPORTED_SIZE: the generic kernels run it

@@ -14,7 +14,7 @@ shutil.rmtree("/tmp/jit_res_cache", ignore_errors=True)
 rc = lib.fftup_jit_check($W, $H, float($U), $P, None, buf, 512)
 print(rc, buf.value.decode(), lib.fftup_last_error().decode()[:500] if rc else "")
 PY
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on --cuda-device-only -c -Ivkresample_amd/csrc -o /tmp/jit_res_$$.o /tmp/jit_res_$$.hip -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
+for part in rowcol fused; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on --cuda-device-only -c -Ivkresample_amd/csrc -o /tmp/jit_res_$$.o /tmp/jit_res_$$.hip.$part.hip -Rpass-analysis=kernel-resource-usage 2>&1; done | python3 -c '
 import sys,re,subprocess
 cur=None; rows=[]
 for l in sys.stdin:

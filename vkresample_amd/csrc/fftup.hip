@@ -282,9 +282,9 @@ int fftup_jit_check(uint32_t width, uint32_t height, float upscale, uint32_t pre
         return fail(FFTUP_E_UNSUPPORTED_SIZE, "no specialised factorization for this size: the size-generic kernels run it");
     if (desc && desclen) snprintf(desc, desclen, "%s", fftup_jit::describe(ch).c_str());
     if (arch && !*arch) return FFTUP_OK;                     // "": the factorizations only, nothing is compiled
-    fftup_jit::Binary bin;
+    fftup_jit::Binary bin[2];
     std::string err;
-    if (!fftup_jit::compile(ch, arch ? arch : "gfx950", bin, err)) return fail(FFTUP_E_HIP, err);
+    if (!fftup_jit::compile_both(ch, arch ? arch : "gfx950", bin, err)) return fail(FFTUP_E_HIP, err);
     return FFTUP_OK;
 }
 

@@ -42,6 +42,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #if __has_include("kernel_sources.inc")
@@ -516,29 +517,49 @@ static std::string join(const std::vector<int>& v)
 
 enum { K_ROW_PLANAR = 0, K_ROW_U8, K_COL, K_FUSED, K_C2R_CT, K_COUNT };
 
-// the translation unit and the name expressions of its five kernels
-static std::string make_source(const Choice& c, std::string names[K_COUNT])
+// A plan's kernels come from two translation units: part 0 holds the row and column kernels (they depend on W, H and the
+// factor), part 1 the fused C2R+sharpen kernel and the stand-alone C2R (they depend on the output row length only), so
+// that plans of different heights share part 1's code object, and the register-bound relaxation and the tuner recompile
+// part 1 alone.  Returns the source of `part` and the name expressions of its kernels (others "").
+static std::string make_source(const Choice& c, std::string names[K_COUNT], int part)
 {
     const std::string W = std::to_string(c.W), H = std::to_string(c.H), UW = std::to_string(c.UW);
+    for (int k = 0; k < K_COUNT; k++) names[k] = "";
     std::string s;
-    s += "// generated by fftup (jit.hpp): " + W + "x" + H + " -> " + UW + "x" + std::to_string(c.UH) + (c.half ? ", binary16 storage\n" : ", fp32\n");
+    if (part == 0) {
+        s += "// generated by fftup (jit.hpp): row and column kernels, " + W + "x" + H + " -> " + UW + "x" + std::to_string(c.UH) + (c.half ? ", binary16 storage\n" : ", fp32\n");
+        s += "#include \"kernels_mixed.hpp\"\nnamespace fftup {\n";
+        s += "struct JitCfg {\n    static constexpr int W = " + W + ", H = " + H + ";\n";
+        if (c.row_kind == 1)
+            s += "    static constexpr int RR0 = " + std::to_string(c.rr[0]) + ", RR1 = " + std::to_string(c.rr[1]) + ", RR2 = " + std::to_string(c.rr[2]) +
+                 ", ROW_T = " + std::to_string(c.row_t) + ";\n";
+        if (c.col_kind == 1)
+            s += "    static constexpr int CR0 = " + std::to_string(c.cr[0]) + ", CR1 = " + std::to_string(c.cr[1]) + ", CR2 = " + std::to_string(c.cr[2]) +
+                 ", COL_TPC = " + std::to_string(c.col_tpc) + ";\n";
+        if (c.row_kind == 3)
+            s += "    static constexpr int ROW_T = " + std::to_string(c.row_t) + ";\n    using RowN = MrFftNT<W, +1, ROW_T, 1, " + join(c.rn) + ">;\n";
+        const std::string cc = std::to_string(c.col_cols);
+        if (c.col_kind == 5)
+            s += "    static constexpr int UH = " + std::to_string(c.UH) + ";\n    using ColIU = MrFftNT<UH, -1, " + std::to_string(c.col_tpc) + ", " + cc + ", " + join(c.ci) + ">;\n";
+        if (c.col_kind >= 3)
+            s += "    static constexpr int COL_TPC = " + std::to_string(c.col_tpc) + ", COL_COLS = " + cc + ";\n    using ColF = MrFftNT<H, +1, COL_TPC, COL_COLS, " + join(c.cn) +
+                 ">;\n    using ColI = MrFftNT<H, -1, COL_TPC, COL_COLS, " + join(c.cn) + ">;\n";
+        s += "};\n}\n";
+        const std::string fm = c.half ? "fftup::IN_F16" : "fftup::IN_F32", um = c.half ? "fftup::IN_U8_F16" : "fftup::IN_U8_F32";
+        if (c.row_kind == 0) {
+            names[K_ROW_PLANAR] = "fftup::k_row_r2c_t<" + W + ", " + fm + ", 4>";
+            names[K_ROW_U8] = "fftup::k_row_r2c_t<" + W + ", " + um + ", 4>";
+        } else if (c.row_kind != 2) {
+            const std::string k = c.row_kind == 3 ? "fftup::k_row_r2c_n" : "fftup::k_row_r2c_m";
+            names[K_ROW_PLANAR] = k + "<fftup::JitCfg, " + fm + ">";
+            names[K_ROW_U8] = k + "<fftup::JitCfg, " + um + ">";
+        }
+        names[K_COL] = c.col_kind == 5 ? "fftup::k_col_pad<fftup::JitCfg>" : c.col_kind == 0 ? "fftup::k_col_t<" + H + ", 4>" : c.col_kind == 3 ? "fftup::k_col_n<fftup::JitCfg>" :
+                       c.col_kind == 4 ? "fftup::k_col_u<fftup::JitCfg, " + std::to_string(c.U) + ">" : "fftup::k_col_m<fftup::JitCfg>";
+        return s;
+    }
+    s += "// generated by fftup (jit.hpp): fused C2R + sharpen and stand-alone C2R for rows of " + UW + (c.half ? ", binary16 storage\n" : ", fp32\n");
     s += "#include \"kernels_mixed.hpp\"\nnamespace fftup {\n";
-    s += "struct JitCfg {\n    static constexpr int W = " + W + ", H = " + H + ";\n";
-    if (c.row_kind == 1)
-        s += "    static constexpr int RR0 = " + std::to_string(c.rr[0]) + ", RR1 = " + std::to_string(c.rr[1]) + ", RR2 = " + std::to_string(c.rr[2]) +
-             ", ROW_T = " + std::to_string(c.row_t) + ";\n";
-    if (c.col_kind == 1)
-        s += "    static constexpr int CR0 = " + std::to_string(c.cr[0]) + ", CR1 = " + std::to_string(c.cr[1]) + ", CR2 = " + std::to_string(c.cr[2]) +
-             ", COL_TPC = " + std::to_string(c.col_tpc) + ";\n";
-    if (c.row_kind == 3)
-        s += "    static constexpr int ROW_T = " + std::to_string(c.row_t) + ";\n    using RowN = MrFftNT<W, +1, ROW_T, 1, " + join(c.rn) + ">;\n";
-    const std::string cc = std::to_string(c.col_cols);
-    if (c.col_kind == 5)
-        s += "    static constexpr int UH = " + std::to_string(c.UH) + ";\n    using ColIU = MrFftNT<UH, -1, " + std::to_string(c.col_tpc) + ", " + cc + ", " + join(c.ci) + ">;\n";
-    if (c.col_kind >= 3)
-        s += "    static constexpr int COL_TPC = " + std::to_string(c.col_tpc) + ", COL_COLS = " + cc + ";\n    using ColF = MrFftNT<H, +1, COL_TPC, COL_COLS, " + join(c.cn) +
-             ">;\n    using ColI = MrFftNT<H, -1, COL_TPC, COL_COLS, " + join(c.cn) + ">;\n";
-    s += "};\n";
     if (c.fused_kind == 0) s += "using JitFused = FusedPlanPow2<" + UW + ">;\n";
     else if (c.fused_kind == 1) s += "using JitFused = FusedPlanMr16<" + UW + ", " + std::to_string(c.UW / 256) + ">;\n";
     else s += "using JitFused = FusedPlanN<" + UW + ", " + std::to_string(c.fused_t) + ", 2, " + std::to_string(c.fused_wpe) + ", " + (c.fused_rr ? "true" : "false") +
@@ -547,21 +568,8 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT])
     s += "static_assert(FusedGLds<JitFused>::TOTAL == " + std::to_string(c.fused_lds) + " && JitFused::T == " + std::to_string(c.fused_t) +
          ", \"host and device disagree on the fused kernel's geometry\");\n";
     s += "}\n";
-    const std::string fm = c.half ? "fftup::IN_F16" : "fftup::IN_F32", um = c.half ? "fftup::IN_U8_F16" : "fftup::IN_U8_F32";
     const std::string hb = c.half ? "true" : "false";
-    if (c.row_kind == 2) {
-        names[K_ROW_PLANAR] = names[K_ROW_U8] = "";
-    } else if (c.row_kind == 0) {
-        names[K_ROW_PLANAR] = "fftup::k_row_r2c_t<" + W + ", " + fm + ", 4>";
-        names[K_ROW_U8] = "fftup::k_row_r2c_t<" + W + ", " + um + ", 4>";
-    } else {
-        const std::string k = c.row_kind == 3 ? "fftup::k_row_r2c_n" : "fftup::k_row_r2c_m";
-        names[K_ROW_PLANAR] = k + "<fftup::JitCfg, " + fm + ">";
-        names[K_ROW_U8] = k + "<fftup::JitCfg, " + um + ">";
-    }
     const std::string U = std::to_string(c.U) + ", " + std::to_string(c.D);
-    names[K_COL] = c.col_kind == 5 ? "fftup::k_col_pad<fftup::JitCfg>" : c.col_kind == 0 ? "fftup::k_col_t<" + H + ", 4>" : c.col_kind == 3 ? "fftup::k_col_n<fftup::JitCfg>" :
-                   c.col_kind == 4 ? "fftup::k_col_u<fftup::JitCfg, " + std::to_string(c.U) + ">" : "fftup::k_col_m<fftup::JitCfg>";
     names[K_FUSED] = "fftup::k_c2r_sharpen_g<fftup::JitFused, " + hb + ", 4, " + U + ">";
     names[K_C2R_CT] = "fftup::k_row_c2r_ct<fftup::JitCT, " + hb + ", " + U + ">";
     return s;
@@ -716,7 +724,7 @@ static void store_cached(const std::string& path, const Binary& b)
 }
 
 // compile (or fetch) the translation unit of `c` for `arch` ("gfx950:sramecc+:xnack-").  No device needed.
-static bool compile(const Choice& c, const std::string& arch, Binary& out, std::string& err)
+static bool compile(const Choice& c, const std::string& arch, int part, Binary& out, std::string& err)
 {
     const Rtc& R = rtc();
     if (!R.ok) { err = "hipRTC (libhiprtc.so) not available"; return false; }
@@ -739,9 +747,9 @@ static bool compile(const Choice& c, const std::string& arch, Binary& out, std::
     std::string hdr_text;
     for (const auto& h : hdr) hdr_text += h;
     std::string names[K_COUNT];
-    const std::string src = make_source(c, names);
+    const std::string src = make_source(c, names, part);
     if (const char* dump = getenv("FFTUP_JIT_DUMP")) {       // the generated translation unit, for inspection (tools/jit_resources.sh)
-        if (FILE* f = fopen(dump, "w")) {
+        if (FILE* f = fopen((std::string(dump) + (part ? ".fused.hip" : ".rowcol.hip")).c_str(), "w")) {
             fputs(src.c_str(), f);
             for (int k = 0; k < K_COUNT; k++) if (!names[k].empty()) fprintf(f, "template __global__ decltype(%s) %s;\n", names[k].c_str(), names[k].c_str());
             fclose(f);
@@ -761,14 +769,17 @@ static bool compile(const Choice& c, const std::string& arch, Binary& out, std::
     char keyhex[32];
     snprintf(keyhex, sizeof keyhex, "%016llx", (unsigned long long)key);
 
+    // (the lock guards the in-memory table only: the two parts of a plan compile side by side, compile_both())
     static std::mutex mu;
     static std::map<uint64_t, Binary> memo;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = memo.find(key);
-    if (it != memo.end()) { out = it->second; return true; }
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = memo.find(key);
+        if (it != memo.end()) { out = it->second; return true; }
+    }
     const std::string cdir = cache_dir();
     const std::string cpath = cdir.empty() ? "" : cdir + "/" + keyhex + ".fjit";
-    if (!cpath.empty() && load_cached(cpath, out)) { memo[key] = out; return true; }
+    if (!cpath.empty() && load_cached(cpath, out)) { std::lock_guard<std::mutex> lock(mu); memo[key] = out; return true; }
 
     hiprtcProgram prog = nullptr;
     const char* hdr_ptr[4] = {hdr[0].c_str(), hdr[1].c_str(), hdr[2].c_str(), hdr[3].c_str()};
@@ -791,6 +802,7 @@ static bool compile(const Choice& c, const std::string& arch, Binary& out, std::
     R.GetCode(prog, &out.code[0]);
     bool ok = cs > 0;
     for (int k = 0; k < K_COUNT; k++) {
+        out.lowered[k].clear();
         if (names[k].empty()) continue;
         const char* low = nullptr;
         ok &= R.GetLoweredName(prog, names[k].c_str(), &low) == HIPRTC_SUCCESS && low;
@@ -798,17 +810,32 @@ static bool compile(const Choice& c, const std::string& arch, Binary& out, std::
     }
     R.DestroyProgram(&prog);
     if (!ok) { err = "hipRTC returned no code / no lowered names"; return false; }
-    memo[key] = out;
+    { std::lock_guard<std::mutex> lock(mu); memo[key] = out; }
     if (!cpath.empty()) store_cached(cpath, out);
     return true;
 }
 
+// both parts of a plan.  (FFTUP_JIT_THREADS=1 compiles the second one on a thread of its own: measured, no gain --
+// hipRTC serialises its compilations internally, 48 plans take 54 s either way -- so one after the other is the default.)
+static bool compile_both(const Choice& c, const std::string& arch, Binary b[2], std::string& err)
+{
+    const char* e = getenv("FFTUP_JIT_THREADS");
+    if (!e || atoi(e) == 0) return compile(c, arch, 0, b[0], err) && compile(c, arch, 1, b[1], err);
+    std::string err1;
+    bool ok1 = false;
+    std::thread t([&] { ok1 = compile(c, arch, 1, b[1], err1); });
+    const bool ok0 = compile(c, arch, 0, b[0], err);
+    t.join();
+    if (ok0 && !ok1) err = err1;
+    return ok0 && ok1;
+}
+
 // a code object loaded on one device
 struct Module {
-    hipModule_t mod = nullptr;
+    hipModule_t mod[2] = {nullptr, nullptr};       // part 0: row + column kernels, part 1: fused C2R+sharpen + stand-alone C2R
     hipFunction_t fn[K_COUNT] = {};
     Choice choice;
-    ~Module() { if (mod) (void)hipModuleUnload(mod); }
+    ~Module() { for (hipModule_t m : mod) if (m) (void)hipModuleUnload(m); }
 };
 
 static Module* load_once(const Choice& c, const std::string& arch, std::string& err);
@@ -837,16 +864,19 @@ static Module* load(Choice c, const std::string& arch, std::string& err)
 
 static Module* load_once(const Choice& c, const std::string& arch, std::string& err)
 {
-    Binary b;
-    if (!compile(c, arch, b, err)) return nullptr;
+    Binary bin[2];
+    if (!compile_both(c, arch, bin, err)) return nullptr;
     Module* m = new Module();
     m->choice = c;
-    hipError_t e = hipModuleLoadData(&m->mod, b.code.data());
-    if (e != hipSuccess) { err = std::string("hipModuleLoadData: ") + hipGetErrorString(e); m->mod = nullptr; delete m; return nullptr; }
-    for (int k = 0; k < K_COUNT; k++) {
-        if (b.lowered[k].empty()) continue;
-        e = hipModuleGetFunction(&m->fn[k], m->mod, b.lowered[k].c_str());
-        if (e != hipSuccess) { err = "hipModuleGetFunction(" + b.lowered[k] + "): " + hipGetErrorString(e); delete m; return nullptr; }
+    for (int part = 0; part < 2; part++) {
+        const Binary& b = bin[part];
+        hipError_t e = hipModuleLoadData(&m->mod[part], b.code.data());
+        if (e != hipSuccess) { err = std::string("hipModuleLoadData: ") + hipGetErrorString(e); m->mod[part] = nullptr; delete m; return nullptr; }
+        for (int k = 0; k < K_COUNT; k++) {
+            if (b.lowered[k].empty()) continue;
+            e = hipModuleGetFunction(&m->fn[k], m->mod[part], b.lowered[k].c_str());
+            if (e != hipSuccess) { err = "hipModuleGetFunction(" + b.lowered[k] + "): " + hipGetErrorString(e); delete m; return nullptr; }
+        }
     }
     return m;
 }
