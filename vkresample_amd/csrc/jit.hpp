@@ -763,6 +763,7 @@ static bool compile(const Choice& c, const std::string& arch, int part, Binary& 
     int vmaj = 0, vmin = 0;
     R.Version(&vmaj, &vmin);
     uint64_t key = fnv1a(src);
+    for (int k = 0; k < K_COUNT; k++) key = fnv1a(names[k] + ";", key);      // (the instantiations: factor and precision live here)
     for (const char* o : opts) key = fnv1a(o, key);
     key = fnv1a(std::to_string(vmaj) + "." + std::to_string(vmin), key);
     key = fnv1a(hdr_text, key);
