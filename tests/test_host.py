@@ -168,6 +168,10 @@ def test_jit_check_compiles_without_a_device(tmp_path, monkeypatch):
     # a plan of another height shares the second one (it depends on the output row length only)
     assert lib.fftup_jit_check(896, 648, 2, 0, None, buf, 256) == 0
     assert len(list((tmp_path / "cache").glob("*.fjit"))) == 2 * len(cases) + 1
+    # ... but not with a plan of the same row length and another factor (960 x 2 = 640 x 3 = 1920: the instantiations differ)
+    n0 = len(list((tmp_path / "cache").glob("*.fjit")))
+    assert lib.fftup_jit_check(960, 540, 2, 0, None, buf, 256) == 0 and lib.fftup_jit_check(640, 360, 3, 0, None, buf, 256) == 0
+    assert len(list((tmp_path / "cache").glob("*.fjit"))) == n0 + 4
     assert lib.fftup_jit_check(2000, 1250, 2, 0, None, buf, 256) == 0 and "row 8*5*5*10" in buf.value.decode()       # N-stage kernels
     assert lib.fftup_jit_check(4000, 3000, 2, 0, None, buf, 256) == 0 and "(2 columns)" in buf.value.decode()      # long columns
     assert lib.fftup_jit_check(2450, 1080, 2, 0, None, buf, 256) == 2          # FFTUP_E_UNSUPPORTED_SIZE: the generic kernels run it
