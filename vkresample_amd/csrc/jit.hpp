@@ -7,13 +7,15 @@
 // integer or half-integer factor whose size has no ahead-of-time instantiation, fftup_plan_create
 //   * picks factorizations (choose(): measured rules, a built-in table of tuner results for the MI355X, the user's
 //     wisdom file),
-//   * writes a ten-line translation unit that names the instantiations (make_source()),
+//   * writes two ten-line translation units that name the instantiations (make_source(): row + column kernels, and
+//     fused C2R+sharpen + stand-alone C2R, which depend on the output row length only and are shared between heights),
 //   * compiles it for the plan's device with hipRTC (the ROCm run-time compiler, loaded with dlopen -- no link-time
 //     dependency, and without it the plan silently stays on the size-generic kernels),
 //   * loads the code object, relaxes the fused kernel's register bound if it spills (load()), and launches the kernels
 //     from it (launch()).
 // Code objects are cached in memory and on disk ($FFTUP_CACHE_DIR, else $XDG_CACHE_HOME/fftup, else ~/.cache/fftup),
-// keyed by a hash of the translation unit, the compiler options, the hipRTC version and the kernel headers' text.
+// keyed by a hash of the translation unit, the instantiated names, the compiler options, the hipRTC version and the
+// kernel headers' text.
 // With FFTUP_FLAG_TUNE_PLAN the plan is also timed with the alternative factorizations of its dominant kernel
 // (fused_candidates(), tune_fused() in fftup.hip) and the decision kept in <cache dir>/wisdom.txt.
 //
