@@ -33,7 +33,7 @@ for (W, H) in SIZES:
         if (int(uW), u) in done:
             continue
         try:
-            with v.Upscaler(W, H, u, 0, 0.2, 0, v.FLAG_TUNE_PLAN, int(os.environ.get("WISDOM_RING", "4"))) as up:
+            with v.Upscaler(W, H, u, int(os.environ.get("WISDOM_PRECISION", "0")), 0.2, 0, v.FLAG_TUNE_PLAN, int(os.environ.get("WISDOM_RING", "4"))) as up:
                 if up.specialised_at_plan_time:
                     done.add((int(uW), u))
         except Exception as e:       # noqa: BLE001
