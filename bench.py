@@ -11,12 +11,19 @@ frames per GPU).  The default step is 1024 frames, i.e. the reference's `-n 1000
 Frames are independent, so N GPUs = N independent shards, no data-path collective ("weak" scaling: per-GPU work
 fixed).  The K-step timed region (barrier + synchronize on both sides, MAX over ranks) is repeated --repeats times
 and the MEDIAN region gives `value`.  Rank 0 prints ONE JSON line.
+
+At N = 1 the same invocation also times, briefly, the other single-GPU BASELINE configurations and the reference's own
+`-n 1000` figure (`others`: config3 = -p 2 with the fused uint8 load, config4 = 1920x1080, execute_n1000 =
+fftup_execute(plan, 1000) on a plan without a ring of slots, i.e. performVulkanUpscale(..., 1000), VkResample.cpp:1260-1278).
+`--preset config5` (BASELINE's 512-frame batch over 8 GPUs) carries the job accounting: every rank processes the frames
+shard.frames_for_rank() gives it (the reference's -numthreads stripe, VkResample.cpp:1622-1629), each frame distinct and
+resident, and one RCCL all-reduce of {frames, checksum of the outputs, max time} closes the job (`job` in the JSON line).
 """
 import argparse
 import json
 import os
-import statistics
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,7 +36,8 @@ PRESETS = {
     "config4": dict(width=1920, height=1080, precision=0, fuse_u8=False),
     "720p": dict(width=1280, height=720, precision=0, fuse_u8=False),          # not a BASELINE config: second mixed-radix plan
     # 512 synthetic 2048x1024 frames, -u 2 -p 2, sharded over 8 GPUs: 64 frames per rank and step
-    "config5": dict(width=2048, height=1024, precision=2, fuse_u8=True, frames_per_step=64),
+    # (64 distinct resident frames per rank: frame f * world + rank of the job goes to slot f)
+    "config5": dict(width=2048, height=1024, precision=2, fuse_u8=True, frames_per_step=64, ring=64, job=True),
 }
 
 
@@ -51,7 +59,11 @@ def parse_args():
     ap.add_argument("--generic", action="store_true", help="size-generic kernels (FFTUP_FLAG_GENERIC_KERNELS): no tuned, no plan-time specialised plan")
     ap.add_argument("--tune", action="store_true", help="FFTUP_FLAG_TUNE_PLAN: plan-time tuner for sizes specialised at plan time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the bounded CPU-baseline sample (~15 s on 128 threads)")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-baseline sample (~8 s on 128 threads)")
+    ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other BASELINE configurations (`others`)")
+    ap.add_argument("--job", action="store_true",
+                    help="job accounting: rank r processes frames shard.frames_for_rank(frames_per_step * world, world, r), all distinct "
+                         "(needs --ring >= --frames-per-step), output checksums reduced over the ranks (implied by --preset config5)")
     ap.add_argument("--profile-iters", type=int, default=50)
     ap.add_argument("--event-stride", type=int, default=32, help="kernel-timing events on every n-th frame of the first timed region")
     ap.add_argument("--streams", type=int, default=3,
@@ -65,6 +77,8 @@ def parse_args():
     if a.preset:
         for k, v in PRESETS[a.preset].items():
             setattr(a, k, v)
+    if a.job and a.ring < a.frames_per_step:
+        ap.error("--job needs --ring >= --frames-per-step (every frame of a step resident and distinct)")
     return a
 
 
@@ -113,6 +127,41 @@ def reference_vulkan_baseline(args):
         return {"available": True, "ms_per_frame": float(m.group(1)), "frames_per_s": 1e3 / float(m.group(1)), "command": "-u 2 -n 1000"}
 
 
+def other_configs(v, synth, dev, ring=8):
+    """Short runs of the other single-GPU BASELINE configurations on the same GPU, same method as the headline (ring of
+    resident frames, three streams, HIP events per kernel), and the reference's -n 1000 figure on ring-less plans."""
+    out = {}
+    for name in ("config3", "config4"):
+        c = PRESETS[name]
+        flags = v.FLAG_FUSE_U8_LOAD if c["fuse_u8"] else 0
+        with v.Upscaler(c["width"], c["height"], 2.0, c["precision"], 0.2, dev, flags, ring) as up:
+            for s in range(ring):
+                up.upload_rgb8(synth.frame(s, c["width"], c["height"], "U"), slot=s)
+            up.execute_ring(256, 0)
+            t = sorted(up.execute_ring(1024, 0) / 1024 for _ in range(3))[1]          # device ms per frame, median of three
+            iso = up.profile_kernels(30)
+            dom = max(range(len(iso)), key=lambda i: iso[i])
+            out[name] = {"workload": "%dx%d -u 2 -p %d%s" % (c["width"], c["height"], c["precision"], ", fused uint8 load" if c["fuse_u8"] else ""),
+                         "ms_per_frame": t, "frames_per_s": 1e3 / t,
+                         "frame_frac": up.alg_bytes_per_frame / (t * 1e-3) / 8e12,
+                         "kernel_ms": dict(zip(up.kernel_names, iso)),
+                         "kernel_frac": up.kernel_alg_bytes[dom] / (iso[dom] * 1e-3) / 8e12,
+                         "kernel_frac_real_bytes": up.kernel_min_bytes[dom] / (iso[dom] * 1e-3) / 8e12,
+                         "plan": up.description}
+    n1000 = {}
+    for name in ("config2", "config3", "config4"):
+        c = PRESETS[name]
+        flags = v.FLAG_FUSE_U8_LOAD if c["fuse_u8"] else 0
+        with v.Upscaler(c["width"], c["height"], 2.0, c["precision"], 0.2, dev, flags, 1) as up:      # no ring: the CLI's single-image plan
+            up.upload_rgb8(synth.frame(0, c["width"], c["height"], "U"))
+            up.execute(100)
+            ms = sorted(up.execute(1000) for _ in range(3))[1]
+            n1000[name] = {"ms_per_iter": ms, "frame_frac": up.alg_bytes_per_frame / (ms * 1e-3) / 8e12}
+    out["execute_n1000"] = dict(n1000, note="fftup_execute(plan, 1000) on a plan without a ring = performVulkanUpscale(.., 1000), "
+                                            "VkResample.cpp:1260-1278: one stream, nothing overlaps; the CLI prints this as Time:")
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -130,16 +179,29 @@ def main():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     os.environ["FFTUP_STREAMS"] = str(args.streams)
+    # plan-time tuner findings of earlier runs on this machine (<cache dir>/wisdom.txt) must not steer a measurement
+    wisdom = "user cache (%s)" % os.environ["FFTUP_CACHE_DIR"] if "FFTUP_CACHE_DIR" in os.environ else "built-in only (private cache dir)"
+    tmp_cache = None
+    if "FFTUP_CACHE_DIR" not in os.environ and not args.tune:
+        tmp_cache = tempfile.TemporaryDirectory(prefix="fftup_bench_")
+        os.environ["FFTUP_CACHE_DIR"] = tmp_cache.name
     import vkresample_amd as v
-    from vkresample_amd import synth
+    from vkresample_amd import shard, synth
     if v.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
     dev = local_rank % v.device_count()
     flags = (v.FLAG_FUSE_U8_LOAD if args.fuse_u8 else 0) | (v.FLAG_GENERIC_KERNELS if args.generic else 0) | (v.FLAG_TUNE_PLAN if args.tune else 0)
     up = v.Upscaler(args.width, args.height, args.upscale, args.precision, 0.2, dev, flags, args.ring)
-    # distinct frames per rank and slot: rank r owns frames r*ring .. r*ring+ring-1 of the job
-    for s in range(args.ring):
-        up.upload_rgb8(synth.frame(rank * args.ring + s, args.width, args.height, "U"), slot=s)
+    if args.job:
+        # the reference's stripe (VR:1622-1629): thread/rank t of T takes files f*T + t; slot f holds this rank's f-th frame
+        my_frames = shard.frames_for_rank(args.frames_per_step * world, world, rank)
+        assert len(my_frames) == args.frames_per_step
+        for s, g in enumerate(my_frames):
+            up.upload_rgb8(synth.frame(g, args.width, args.height, "U"), slot=s)
+    else:
+        # distinct frames per rank and slot: rank r owns frames r*ring .. r*ring+ring-1 of the job
+        for s in range(args.ring):
+            up.upload_rgb8(synth.frame(rank * args.ring + s, args.width, args.height, "U"), slot=s)
 
     def barrier():
         if torch.cuda.is_available():
@@ -204,6 +266,25 @@ def main():
 
     frames_per_region = world * args.steps * args.frames_per_step
     fps = frames_per_region / dt
+    job = None
+    if args.job:
+        # every output slot holds the result of one distinct frame of the job: fingerprint them on the device, reduce
+        sums = [up.output_checksum(s) for s in range(args.frames_per_step)]
+        checksum = sum(sums) % (1 << 52)
+        frames_done, total, tmax = shard.reduce_summary(dist, args.frames_per_step, checksum, dt)
+        me = {"rank": rank, "device": dev, "pci_bus_id": v.device_pci_bus_id(dev), "name": up.device_name,
+              "first_frames": my_frames[:3], "frames": len(my_frames)}
+        ranks, nranks = [me], 1
+        if dist is not None:
+            ranks = [None] * world
+            dist.all_gather_object(ranks, me)
+            one = torch.ones(1, dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(one)                         # how many ranks the communicator really has
+            nranks = int(one.item())
+        job = {"frames_per_step_total": args.frames_per_step * world, "frames_done": frames_done, "checksum": total % (1 << 52),
+               "elapsed_max_s": tmax, "collective_ranks": nranks, "backend": dist.get_backend() if dist is not None else None,
+               "ranks": ranks, "distinct_devices": len({(r["pci_bus_id"]) for r in ranks}),
+               "stripe": "frame f*world + rank (VkResample.cpp:1622-1629)"}
     line = None
     if rank == 0:
         # kms: average kernel durations inside the first timed region (consecutive frames overlap on --streams lanes, so a
@@ -248,7 +329,8 @@ def main():
                                       "uint8 RGB (fused load)" if args.fuse_u8 and args.precision != 1 else "planar fp%d" % {0: 32, 1: 64, 2: 16}[args.precision]),
                        "preset": args.preset or "config2", "frames_per_step": args.frames_per_step,
                        "sharding": "independent frames, no collective",
-                       "kernels": ("plan-time" if up.specialised_at_plan_time else "tuned") if up.tuned else "generic", "plan": up.description, "streams": args.streams, "device": up.device_name},
+                       "kernels": ("plan-time" if up.specialised_at_plan_time else "tuned") if up.tuned else "generic", "plan": up.description, "streams": args.streams, "device": up.device_name,
+                       "wisdom": wisdom},
             "repeats": len(region_s), "region_s": region_s, "timed_region_s_median": dt,
             "ms_per_frame": wall_frame_ms, "ms_per_frame_device_events": frame_ms,
             "frame_alg_bytes": up.alg_bytes_per_frame, "B_min": b_min,
@@ -272,10 +354,18 @@ def main():
             line["config"]["workload"] += ", HOST-STREAMED: uint8 RGB frames from/to pinned host memory"
             line["pcie_bytes_per_frame"] = pcie
             line["pcie_GBps"] = pcie / (wall_frame_ms * 1e-3) / 1e9
+        if job is not None:
+            line["job"] = job
+            line["rccl_ranks"] = job["collective_ranks"]
+            line["frames_done"] = job["frames_done"]
+            line["checksum"] = job["checksum"]
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args)
             line["reference_vulkan_baseline"] = reference_vulkan_baseline(args)
     up.close()
+    if rank == 0 and world == 1 and not args.no_others and not args.host_streamed and (args.preset or "config2") == "config2" \
+            and (args.width, args.height, args.precision) == (2048, 1024, 0):
+        line["others"] = other_configs(v, synth, dev)
     if pins:
         pins[0].close()
         pins[1].close()

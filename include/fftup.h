@@ -89,23 +89,33 @@ typedef struct fftup_plan fftup_plan;   /* opaque; replaces VkGPU + 2x VkFFTAppl
 
 enum { FFTUP_NUM_KERNELS = 4 };          /* row R2C, column fwd+pad+inv, row C2R, sharpen        */
 
+/* ABI: fields are only ever APPENDED to this struct; `abi_version` (== FFTUP_ABI_VERSION of the library that filled it) says
+ * how far it is valid: 1 = up to kernel_names, 2 = + kernel_min_bytes, tuned may be 2, abi_version itself.
+ * (0.2.x builds had kernel_min_bytes in front of device_bytes: callers built against those must be rebuilt.) */
+enum { FFTUP_ABI_VERSION = 2 };
 typedef struct fftup_info {
     uint32_t out_width, out_height;      /* uW, uH                                                */
     uint32_t num_kernels;                /* launches per frame                                    */
-    uint32_t tuned;                      /* 1: ahead-of-time size-specialised kernels, 2: specialised at plan time (hipRTC), 0: size-generic */
+    uint32_t tuned;                      /* 0: size-generic kernels, non-zero: size-specialised (1: ahead-of-time, 2: at plan time through hipRTC) */
     double   alg_bytes_per_frame;        /* B_alg of SURVEY 8(d) for this plan's I/O types        */
     double   kernel_alg_bytes[FFTUP_NUM_KERNELS]; /* algorithmic bytes of each kernel: a fused C2R+sharpen
                                                      launch keeps S2 + 2R + out although R never reaches HBM          */
-    double   kernel_min_bytes[FFTUP_NUM_KERNELS]; /* bytes each kernel has to move through HBM as implemented
-                                                     (e.g. fused: spectrum rows incl. strip halos + out)               */
     uint64_t device_bytes;               /* device memory owned by the plan ("VRAM per thread")   */
     char     device_name[256];
     char     kernel_names[FFTUP_NUM_KERNELS][64];
+    /* ---- appended in ABI version 2 ---- */
+    double   kernel_min_bytes[FFTUP_NUM_KERNELS]; /* bytes each kernel has to move through HBM as implemented
+                                                     (e.g. fused: spectrum rows incl. strip halos + out)               */
+    uint32_t abi_version;                /* FFTUP_ABI_VERSION of the library                      */
+    uint32_t reserved_;
 } fftup_info;
 
 /* devices_list() VR:239-268 */
 FFTUP_API int fftup_device_count(void);
 FFTUP_API int fftup_device_name(int device, char* buf, size_t buflen);
+/* PCI bus id ("0000:c1:00.0") of a device: job accounting of multi-GPU runs (one process / thread per GPU: the ids of a
+ * job's ranks must all differ) */
+FFTUP_API int fftup_device_pci_bus_id(int device, char* buf, size_t buflen);
 
 /* initializeVulkanFFT x2 + createShiftApp + createSharpenApp + 3x allocateFFTBuffer
  * (VR:1437-1448, 1506-1509, 1562, 1617) */
@@ -168,6 +178,10 @@ FFTUP_API int fftup_download_planar(fftup_plan* plan, uint32_t slot, void* plane
  * part of the complex image -- and the converted input planes [3][H][W]. */
 FFTUP_API int fftup_download_presharpen(fftup_plan* plan, void* planes);
 FFTUP_API int fftup_download_input_planar(fftup_plan* plan, uint32_t slot, void* planes);
+/* job accounting (batched / multi-GPU runs): 64-bit wrapping sum of the 32-bit words of output slot `slot` (the dense
+ * [3][uH][uW] planes), computed on the device -- a frame's fingerprint without moving the frame over PCIe.  Sums over
+ * the frames of a job do not depend on which rank or thread processed which frame. */
+FFTUP_API int fftup_output_checksum(fftup_plan* plan, uint32_t slot, uint64_t* sum);
 
 /* Host-streamed batches (replaces the blocking transferDataFromCPU / transferDataToCPU + the two CPU
  * conversion loops of VR:1636-1748 for the batched mode, VR:1621-1760).  fftup_submit_rgb8 enqueues one whole

@@ -21,7 +21,9 @@ EXPORTS = [
     "fftup_profile_kernels", "fftup_download_rgb8", "fftup_download_planar", "fftup_download_presharpen",
     "fftup_download_input_planar", "fftup_host_alloc", "fftup_host_free", "fftup_submit_rgb8", "fftup_wait",
     "fftup_drain", "fftup_strerror", "fftup_last_error", "fftup_version", "fftup_jit_check", "fftup_plan_describe",
+    "fftup_device_pci_bus_id", "fftup_output_checksum",
 ]
+ABI_VERSION = 2
 
 
 class Config(C.Structure):
@@ -33,9 +35,10 @@ class Config(C.Structure):
 class Info(C.Structure):
     _fields_ = [("out_width", C.c_uint32), ("out_height", C.c_uint32), ("num_kernels", C.c_uint32),
                 ("tuned", C.c_uint32), ("alg_bytes_per_frame", C.c_double),
-                ("kernel_alg_bytes", C.c_double * FFTUP_NUM_KERNELS),
-                ("kernel_min_bytes", C.c_double * FFTUP_NUM_KERNELS), ("device_bytes", C.c_uint64),
-                ("device_name", C.c_char * 256), ("kernel_names", (C.c_char * 64) * FFTUP_NUM_KERNELS)]
+                ("kernel_alg_bytes", C.c_double * FFTUP_NUM_KERNELS), ("device_bytes", C.c_uint64),
+                ("device_name", C.c_char * 256), ("kernel_names", (C.c_char * 64) * FFTUP_NUM_KERNELS),
+                # appended in ABI version 2
+                ("kernel_min_bytes", C.c_double * FFTUP_NUM_KERNELS), ("abi_version", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 _lib = None
@@ -81,5 +84,7 @@ def load():
     lib.fftup_version.restype = C.c_char_p
     lib.fftup_plan_describe.argtypes = [vp, C.c_char_p, sz]
     lib.fftup_jit_check.argtypes = [u32, u32, C.c_float, u32, C.c_char_p, C.c_char_p, sz]
+    lib.fftup_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, sz]
+    lib.fftup_output_checksum.argtypes = [vp, u32, C.POINTER(C.c_uint64)]
     _lib = lib
     return lib

@@ -36,6 +36,12 @@ def device_name(device=0):
     return buf.value.decode()
 
 
+def device_pci_bus_id(device=0):
+    buf = C.create_string_buffer(64)
+    _check(_lib.load().fftup_device_pci_bus_id(device, buf, 64), "fftup_device_pci_bus_id")
+    return buf.value.decode()
+
+
 class Upscaler:
     """One plan = one (width, height, upscale, precision, sharpen, device) configuration."""
 
@@ -46,6 +52,9 @@ class Upscaler:
         _check(self._lib.fftup_plan_create(C.byref(self._h), C.byref(cfg)), "fftup_plan_create")
         info = _lib.Info()
         _check(self._lib.fftup_plan_info(self._h, C.byref(info)), "fftup_plan_info")
+        if info.abi_version != _lib.ABI_VERSION:
+            raise RuntimeError("libfftup.so speaks ABI version %d, this binding %d: rebuild (python -c 'import __graft_entry__ as g; g.build()')"
+                               % (info.abi_version, _lib.ABI_VERSION))
         self.width, self.height = width, height
         self.out_width, self.out_height = info.out_width, info.out_height
         self.precision = precision
@@ -148,6 +157,12 @@ class Upscaler:
 
     def drain(self):
         _check(self._lib.fftup_drain(self._h), "fftup_drain")
+
+    def output_checksum(self, slot=0):
+        """64-bit wrapping sum of the 32-bit words of output slot `slot`, computed on the device (job accounting)."""
+        v = C.c_uint64()
+        _check(self._lib.fftup_output_checksum(self._h, slot, C.byref(v)), "fftup_output_checksum")
+        return v.value
 
     def download_rgb8(self, slot=0):
         out = np.empty((self.out_height, self.out_width, 3), dtype=np.uint8)

@@ -102,6 +102,8 @@ struct fftup_plan {
     uint64_t q_next = 0;
     float2 *twW = nullptr, *twH = nullptr, *twUW = nullptr, *twUH = nullptr;
     uint64_t device_bytes = 0;
+    size_t r_bytes = 0;               // bytes of one pre-sharpen image
+    uint64_t* d_sum = nullptr;        // fftup_output_checksum accumulator (created on first use)
     size_t in_plane_stride = 0;
     int executed = 0;
 
@@ -264,6 +266,14 @@ int fftup_device_name(int device, char* buf, size_t buflen)
     if (device < 0 || device >= fftup_device_count()) return fail(FFTUP_E_NO_DEVICE, "bad device id");
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     snprintf(buf, buflen, "%s", prop.name);
+    return FFTUP_OK;
+}
+
+int fftup_device_pci_bus_id(int device, char* buf, size_t buflen)
+{
+    if (!buf || buflen < 16) return fail(FFTUP_E_INVALID_ARG, "buffer of at least 16 bytes needed");
+    if (device < 0 || device >= fftup_device_count()) return fail(FFTUP_E_NO_DEVICE, "bad device id");
+    HIP_TRY(hipDeviceGetPCIBusId(buf, (int)buflen, device));
     return FFTUP_OK;
 }
 
@@ -466,8 +476,10 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             return r ? r : dev_alloc(P, (void**)s2, P->csz * 3 * (size_t)P->NT * uH * P->TK);
         };
         PLAN_RC(alloc_spectra(&P->S1, &P->S2));
-        const size_t r_bytes = (size_t)3 * uW * uH * (cplx ? P->csz : esz);        // non-R2C path: complex pre-sharpen image
-        PLAN_RC(dev_alloc(P, &P->R, r_bytes));
+        // the pre-sharpen image (the reference's tempBuffer): every frame of an unfused plan goes through it; a fused plan
+        // only needs one for the fftup_download_presharpen tap, which allocates it on first use (ensure_R)
+        P->r_bytes = (size_t)3 * uW * uH * (cplx ? P->csz : esz);                  // non-R2C path: complex pre-sharpen image
+        if (!P->fused) PLAN_RC(dev_alloc(P, &P->R, P->r_bytes));
         PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH));
         {
             int nl = 3;
@@ -479,22 +491,25 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
                 PLAN_TRY(hipStreamCreateWithFlags(&P->lanes[l].stream, hipStreamNonBlocking));
                 PLAN_TRY(hipEventCreateWithFlags(&P->lanes[l].done, hipEventDisableTiming));
                 PLAN_RC(alloc_spectra(&P->lanes[l].S1, &P->lanes[l].S2));
-                PLAN_RC(dev_alloc(P, &P->lanes[l].R, r_bytes));
+                if (!P->fused) PLAN_RC(dev_alloc(P, &P->lanes[l].R, P->r_bytes));
             }
         }
 
-        // allow > 64 KB dynamic LDS
+        // allow > 64 KB dynamic LDS -- for the kernels THIS plan launches, nothing else
 #define SET_LDS(kern, bytes) PLAN_TRY(hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
-        SET_LDS(k_row_r2c<IN_F32>, P->ldsRowF);
-        SET_LDS(k_row_r2c<IN_F16>, P->ldsRowF);
-        SET_LDS(k_row_r2c<IN_U8_F32>, P->ldsRowF);
-        SET_LDS(k_row_r2c<IN_U8_F16>, P->ldsRowF);
-        SET_LDS(k_col<8>, P->ldsCol);
-        SET_LDS(k_col<4>, P->ldsCol);
-        SET_LDS(k_col<2>, P->ldsCol);
-        SET_LDS(k_col<1>, P->ldsCol);
-        SET_LDS(k_row_c2r<false>, P->ldsRowI);
-        SET_LDS(k_row_c2r<true>, P->ldsRowI);
+        const bool generic = !P->tuned && !P->mixed;
+        if (generic && !cplx && !P->dbl) {
+            if (P->half) { SET_LDS(k_row_r2c<IN_F16>, P->ldsRowF); SET_LDS(k_row_r2c<IN_U8_F16>, P->ldsRowF); SET_LDS(k_row_c2r<true>, P->ldsRowI); }
+            else { SET_LDS(k_row_r2c<IN_F32>, P->ldsRowF); SET_LDS(k_row_r2c<IN_U8_F32>, P->ldsRowF); SET_LDS(k_row_c2r<false>, P->ldsRowI); }
+        }
+        if (generic && !P->dbl) {
+            switch (P->TK) {
+            case 8: SET_LDS(k_col<8>, P->ldsCol); break;
+            case 4: SET_LDS(k_col<4>, P->ldsCol); break;
+            case 2: SET_LDS(k_col<2>, P->ldsCol); break;
+            default: SET_LDS(k_col<1>, P->ldsCol); break;
+            }
+        }
         if (cplx) {
             if (P->dbl) { SET_LDS((k_row_c2c_fwd<IN_F64, double2>), P->ldsRowF); SET_LDS((k_row_c2c_inv<double2>), P->ldsRowI); }
             else {
@@ -503,17 +518,20 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             }
         }
         if (P->dbl) {
-            SET_LDS((k_row_r2c<IN_F64, double2>), P->ldsRowF);
-            SET_LDS((k_col<8, double2>), P->ldsCol);
-            SET_LDS((k_col<4, double2>), P->ldsCol);
-            SET_LDS((k_col<2, double2>), P->ldsCol);
-            SET_LDS((k_col<1, double2>), P->ldsCol);
-            SET_LDS((k_row_c2r<false, double2>), P->ldsRowI);
+            if (!cplx) { SET_LDS((k_row_r2c<IN_F64, double2>), P->ldsRowF); SET_LDS((k_row_c2r<false, double2>), P->ldsRowI); }
+            switch (P->TK) {
+            case 8: SET_LDS((k_col<8, double2>), P->ldsCol); break;
+            case 4: SET_LDS((k_col<4, double2>), P->ldsCol); break;
+            case 2: SET_LDS((k_col<2, double2>), P->ldsCol); break;
+            default: SET_LDS((k_col<1, double2>), P->ldsCol); break;
+            }
         }
-#define SET_FUSED(PL, TKK) SET_LDS((k_c2r_sharpen_g<PL, false, TKK>), FusedGLds<PL>::TOTAL); SET_LDS((k_c2r_sharpen_g<PL, true, TKK>), FusedGLds<PL>::TOTAL)
-#define SET_MIXED(CFG) SET_LDS(k_col_m<CFG>, P->ldsCol); SET_LDS((k_row_c2r_ct<CFG::CT, false>), P->ldsRowI); \
-        SET_LDS((k_row_c2r_ct<CFG::CT, true>), P->ldsRowI); SET_FUSED(CFG::FUSED, 4)
-        if (P->mixed == 1) { SET_MIXED(MixedCfg1080); SET_FUSED(FusedPlan3840, 4); }
+#define SET_FUSED(PL, TKK) do { if (P->half) SET_LDS((k_c2r_sharpen_g<PL, true, TKK>), FusedGLds<PL>::TOTAL); \
+                                else SET_LDS((k_c2r_sharpen_g<PL, false, TKK>), FusedGLds<PL>::TOTAL); } while (0)
+#define SET_MIXED(CFG) do { SET_LDS(k_col_m<CFG>, P->ldsCol); \
+        if (P->half) SET_LDS((k_row_c2r_ct<CFG::CT, true>), P->ldsRowI); else SET_LDS((k_row_c2r_ct<CFG::CT, false>), P->ldsRowI); \
+        SET_FUSED(CFG::FUSED, 4); } while (0)
+        if (P->mixed == 1) { SET_MIXED(MixedCfg1080); if (!P->plan3840_x16) SET_FUSED(FusedPlan3840, 4); }
         if (P->mixed == 2) { SET_MIXED(MixedCfg720); }
 #undef SET_MIXED
         if (P->tuned) {
@@ -591,6 +609,7 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
         info->kernel_min_bytes[3] = P->fused ? 0.0 : R + o;
     }
     info->device_bytes = P->device_bytes;
+    info->abi_version = FFTUP_ABI_VERSION;
     snprintf(info->device_name, sizeof info->device_name, "%s", P->prop.name);
     snprintf(info->kernel_names[0], 64, P->cplx ? "row_c2c" : "row_r2c");
     snprintf(info->kernel_names[1], 64, "col_fwd_pad_inv");
@@ -888,6 +907,9 @@ template <class CT> static void launch_c2r_ct(fftup_plan* P, dim3 grid, const Ro
     else hipLaunchKernelGGL((k_row_c2r_ct<CT, false>), grid, dim3(CT::T), P->ldsRowI, P->lanes[P->cur].stream, p);
 }
 
+// (a frame's later launches must not mask the failure of an earlier one)
+static void keep_first(hipError_t& first, hipError_t e) { if (first == hipSuccess) first = e; }
+
 static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
 {
     const int kind = P->in_kind[in_slot];
@@ -912,8 +934,8 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
             q.S1 = P->lanes[P->cur].S1; q.tw = P->twW; q.H = (int)P->H; q.NT = P->NT;
             if (kind == 2) { q.in = P->in_u8[in_slot]; q.in_row_stride = 3l * P->W; q.in_plane_stride = 0; }
             else { q.in = P->in_planar[in_slot]; q.in_row_stride = P->W; q.in_plane_stride = (long)P->in_plane_stride; }
-            jerr = fftup_jit::launch(P->jit->fn[kind == 2 ? fftup_jit::K_ROW_U8 : fftup_jit::K_ROW_PLANAR], grid, dim3(P->jit->choice.row_block), 0,
-                                     P->lanes[P->cur].stream, q);
+            keep_first(jerr, fftup_jit::launch(P->jit->fn[kind == 2 ? fftup_jit::K_ROW_U8 : fftup_jit::K_ROW_PLANAR], grid, dim3(P->jit->choice.row_block), 0,
+                                     P->lanes[P->cur].stream, q));
         } else if (P->mixed == 1 || P->mixed == 2) {
             if (P->mixed == 1) launch_row_mixed<MixedCfg1080>(P, in_slot, kind); else launch_row_mixed<MixedCfg720>(P, in_slot, kind);
         } else if (kind == 2) {
@@ -938,7 +960,7 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
             if (P->mixed == 3) {
                 const auto& ch = P->jit->choice;
                 const dim3 jgrid(P->NT * (ch.col_kind >= 3 ? 4 / ch.col_cols : 1), 3);        // (long columns: two per workgroup)
-                jerr = fftup_jit::launch(P->jit->fn[fftup_jit::K_COL], jgrid, dim3(ch.col_block), P->ldsCol, P->lanes[P->cur].stream, q);
+                keep_first(jerr, fftup_jit::launch(P->jit->fn[fftup_jit::K_COL], jgrid, dim3(ch.col_block), P->ldsCol, P->lanes[P->cur].stream, q));
             }
             else if (P->mixed == 1) hipLaunchKernelGGL(k_col_m<MixedCfg1080>, grid, dim3(4 * MixedCfg1080::COL_TPC), P->ldsCol, P->lanes[P->cur].stream, q);
             else hipLaunchKernelGGL(k_col_m<MixedCfg720>, grid, dim3(4 * MixedCfg720::COL_TPC), P->ldsCol, P->lanes[P->cur].stream, q);
@@ -953,8 +975,8 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         if (P->mixed == 3) {
             const FusedParams fp = fused_params(P, out_slot);
             const int total_pairs = 3 * (int)P->uH / 2;
-            jerr = fftup_jit::launch(P->jit->fn[fftup_jit::K_FUSED], dim3((total_pairs + fp.pairs_per_strip - 1) / fp.pairs_per_strip),
-                                     dim3(P->jit->choice.fused_t), P->jit->choice.fused_lds, P->lanes[P->cur].stream, fp);
+            keep_first(jerr, fftup_jit::launch(P->jit->fn[fftup_jit::K_FUSED], dim3((total_pairs + fp.pairs_per_strip - 1) / fp.pairs_per_strip),
+                                     dim3(P->jit->choice.fused_t), P->jit->choice.fused_lds, P->lanes[P->cur].stream, fp));
         } else if (P->mixed == 2) launch_fused_t<MixedCfg720::FUSED>(P, fused_params(P, out_slot));
         else if (P->plan3840_x16) launch_fused_t<MixedCfg1080::FUSED>(P, fused_params(P, out_slot));
         else launch_fused_t<FusedPlan3840>(P, fused_params(P, out_slot));       // (only the mixed plans are fused on this path)
@@ -968,7 +990,7 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
         if (P->mixed) {
             if (P->mixed == 3) {
                 if (P->U == 1) p.S1 = p.S2;                              // half-integer factor: all rows in S2
-                jerr = fftup_jit::launch(P->jit->fn[fftup_jit::K_C2R_CT], grid, dim3(P->jit->choice.ct_t), P->ldsRowI, P->lanes[P->cur].stream, p);
+                keep_first(jerr, fftup_jit::launch(P->jit->fn[fftup_jit::K_C2R_CT], grid, dim3(P->jit->choice.ct_t), P->ldsRowI, P->lanes[P->cur].stream, p));
             }
             else if (P->mixed == 1) launch_c2r_ct<MixedCfg1080::CT>(P, grid, p);
             else launch_c2r_ct<MixedCfg720::CT>(P, grid, p);
@@ -1221,11 +1243,15 @@ int fftup_download_presharpen(fftup_plan* P, void* planes)
     if (P->fused && !P->R_valid) {
         // the fused kernel never writes the pre-sharpen image; rebuild it from the spectrum of the last
         // frame (still in S2) with the stand-alone C2R kernel
+        if (!P->lanes[P->last_lane].R) {
+            int rc = dev_alloc(P, &P->lanes[P->last_lane].R, P->r_bytes);
+            if (rc) return rc;
+            if (P->last_lane == 0) P->R = P->lanes[0].R;
+        }
         P->cur = P->last_lane;
-        if (P->tuned) launch_frame_tuned(P, 0, 0, 22);
-        else launch_frame(P, 0, 0, 22);
+        const int rc = launch_frame(P, 0, 0, 22);
         P->cur = 0;
-        HIP_TRY(hipGetLastError());
+        if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(P->lanes[P->last_lane].stream));
     }
     if (P->cplx)        // non-R2C path: the pre-sharpen image is complex; this tap returns its real parts
@@ -1233,6 +1259,40 @@ int fftup_download_presharpen(fftup_plan* P, void* planes)
                                  hipMemcpyDeviceToHost, P->stream));
     else
         HIP_TRY(hipMemcpyAsync(planes, P->lanes[P->last_lane].R, (size_t)3 * P->uW * P->uH * P->esz, hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    return FFTUP_OK;
+}
+
+}  // extern "C"
+
+// 64-bit wrapping sum of 32-bit words (fftup_output_checksum): per-thread partial sums, wave reduction, one atomic per wave
+__global__ void __launch_bounds__(256) k_checksum(const uint32_t* __restrict__ w, size_t n, unsigned long long* sum)
+{
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += w[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
+}
+
+extern "C" {
+
+int fftup_output_checksum(fftup_plan* P, uint32_t slot, uint64_t* sum)
+{
+    int rc = check_slot(P, slot);
+    if (rc) return rc;
+    if (!sum) return fail(FFTUP_E_INVALID_ARG, "null destination");
+    if (!P->executed) return fail(FFTUP_E_NO_INPUT, "nothing executed yet");
+    HIP_TRY(hipSetDevice(P->device));
+    if (!P->d_sum) {
+        rc = dev_alloc(P, (void**)&P->d_sum, sizeof(uint64_t));
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemsetAsync(P->d_sum, 0, sizeof(uint64_t), P->stream));
+    const size_t nwords = (size_t)3 * P->uW * P->uH * P->esz / 4;          // (uW even: whole words for binary16 too)
+    hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, P->stream, (const uint32_t*)P->out[slot], nwords, (unsigned long long*)P->d_sum);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(sum, P->d_sum, sizeof(uint64_t), hipMemcpyDeviceToHost, P->stream));
     HIP_TRY(hipStreamSynchronize(P->stream));
     return FFTUP_OK;
 }
@@ -1388,6 +1448,6 @@ const char* fftup_strerror(int code)
 }
 
 const char* fftup_last_error(void) { return g_last_error.c_str(); }
-const char* fftup_version(void) { return "fftup 0.1.0 (gfx950)"; }
+const char* fftup_version(void) { return "fftup 0.3.0 (gfx950, ABI 2)"; }
 
 }  // extern "C"

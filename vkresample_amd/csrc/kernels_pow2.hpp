@@ -21,17 +21,8 @@
 
 
 
-#ifndef FFTUP_OPQ
-#define FFTUP_OPQ 1
-#endif
 #ifndef FFTUP_COL_WAVES
 #define FFTUP_COL_WAVES 8     // k_col_t: 8 waves per SIMD = 64 VGPRs: four 512-thread workgroups per CU, all 771 of a frame resident at once
-#endif
-#ifndef FFTUP_PK_BFLY
-#define FFTUP_PK_BFLY 1
-#endif
-#ifndef FFTUP_KO
-#define FFTUP_KO 0          // timing experiments only (results invalid): 1 no sharpen arithmetic, 2 no transform, 4 no output stores, 8 no tap loads
 #endif
 
 namespace fftup {
@@ -148,6 +139,19 @@ __device__ __forceinline__ float2 cmul_tw(float2 z, float2 w)
     return make_float2(r.x, r.y);
 }
 
+// a + i b and conj(a) + i conj(b) in one packed addition each (the C2R kernels' input formation, vkFFT.h:2096-2131)
+__device__ __forceinline__ float2 cadd_i(float2 a, float2 b)
+{
+    const pk2 r = pk_addi<1>(pk2{a.x, a.y}, pk2{b.x, b.y});
+    return make_float2(r.x, r.y);
+}
+__device__ __forceinline__ float2 cadd_conj_i(float2 a, float2 b)
+{
+    const pk2 av = {a.x, a.y}, bv = {b.x, b.y};
+    pk2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(av), "v"(bv));
+    return make_float2(r.x, r.y);
+}
 // ---- radix-4 / radix-8 butterflies written on register pairs: every complex addition is ONE v_pk_add_f32, a +- i b
 // included (op_sel swaps b's halves, neg_lo / neg_hi puts the sign), the 1/sqrt2 rotations are two v_pk_fma_f32 each.
 // Same operations and roundings as bfly4 / bfly8 of fft_engine.hpp; the compiler, given those, builds the operands of
@@ -229,9 +233,9 @@ template <int DIR> __device__ __forceinline__ void bfly16_pk(float2* v)
 // butterflies of the register-resident kernels
 template <int R, int DIR> __device__ __forceinline__ void bfly_reg(float2* v)
 {
-    if constexpr (R == 8 && FFTUP_PK_BFLY) bfly8_pk<DIR>(v);
-    else if constexpr (R == 16 && FFTUP_PK_BFLY) bfly16_pk<DIR>(v);
-    else if constexpr ((R == 2 || R == 3 || R == 4 || R == 5 || R == 9 || R == 10 || R == 12 || R == 15) && FFTUP_PK_BFLY) {
+    if constexpr (R == 8) bfly8_pk<DIR>(v);
+    else if constexpr (R == 16) bfly16_pk<DIR>(v);
+    else if constexpr (R == 2 || R == 3 || R == 4 || R == 5 || R == 9 || R == 10 || R == 12 || R == 15) {
         pk2 z[R];                                            // the generic composites on register pairs (fft_engine.hpp)
 #pragma unroll
         for (int m = 0; m < R; m++) z[m] = pk2{v[m].x, v[m].y};
@@ -243,10 +247,6 @@ template <int R, int DIR> __device__ __forceinline__ void bfly_reg(float2* v)
 
 template <int R> __device__ __forceinline__ void twiddle_powers(float2* v, float2 w1)
 {
-    if constexpr ((FFTUP_KO & 128) != 0) {          // timing experiment: all powers = w1 (no power chain)
-#pragma unroll
-        for (int m = 1; m < R; m++) v[m] = cmul_tw(v[m], w1);
-    } else
     if constexpr (R == 2) {
         v[1] = cmul_tw(v[1], w1);
     } else if constexpr (R == 4) {
@@ -831,6 +831,14 @@ struct FusedParams {
 
 __host__ __device__ constexpr size_t fused_buf_bytes(int uw) { return (sizeof(float2) * lswz_size(uw) + 15) & ~(size_t)15; }
 
+// min(|x|, 1) in one instruction.  (Written with fminf(fabsf(x), 1.0f) the compiler first canonicalises -- v_max x, x -- an
+// x that comes out of the inline-asm butterflies, since it cannot know that it is not a signalling NaN.)
+__device__ __forceinline__ float absmin1(float x)
+{
+    float r;
+    asm("v_min_f32_e64 %0, |%1|, 1.0" : "=v"(r) : "v"(x));
+    return r;
+}
 template <bool HALF> __device__ __forceinline__ float to_L(float g, float upsq)
 {
     using A = Arith<HALF>;
@@ -976,6 +984,7 @@ __device__ __forceinline__ void sharpen_quad_half(const H2Row& r0, const H2Row& 
 // thread j < NB0 = UW/R0 on registers (inputs Z[j + NB0*m]); on return thread lt < SOUT owns X[lt + SOUT*q], q < EOUT.
 template <int UW_> struct FusedPlanPow2 {                   // radix-8 Stockham, 8 points per thread (reg_fft)
     static constexpr int UW = UW_, T = UW / 8, R0 = 8, NB0 = T, EOUT = 8, SOUT = T, VN = 8;
+
     static constexpr size_t XB = sizeof(float2) * lswz_size(UW);
     // NBUF = 3: an LDS buffer z used by the transform only.  The exchanges alternate z, c, z (c = the buffer that
     // receives this pair's L rows), one barrier each; the first one writes z, which nobody has read since the last
@@ -1340,13 +1349,8 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
     using LT = typename std::conditional<HALF, _Float16, float>::type;      // L rows in LDS: binary16 for -p 2
     extern __shared__ __attribute__((aligned(128))) char smem[];
     float* red = (float*)(smem + L::RED);      // [0..15] corner partial sums, [16] corner DC term (strip start only)
-    int lt = threadIdx.x;                       // (made opaque at the phase entries, see FFTUP_OPQ)
-#ifndef FFTUP_G_PRIO
-#define FFTUP_G_PRIO 0
-#endif
-    // (-DFFTUP_G_PRIO=1..3: issue priority for this kernel's waves over the row and column kernels that run beside it.
-    // Measured at 0, 1 and 3 in all three configurations: no difference beyond +-0.5 %.)
-    if constexpr (FFTUP_G_PRIO != 0) __builtin_amdgcn_s_setprio(FFTUP_G_PRIO);
+    int lt = threadIdx.x;                       // (made opaque at the entry of the transform phase: addresses derived from it are
+                                                // formed per step instead of being hoisted and kept in registers)
     const int uH = p.uH;
     const int pairs_per_plane = uH / 2;
     const long plane = (long)UW * uH;
@@ -1366,13 +1370,27 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
         const int npairs = (j1 - j0) + 1;
         const unsigned tile_stride32 = (unsigned)(uH / U) * TK;
         const float2* base = p.S1 + (long)c * p.NT * (long)tile_stride32;
-        // spectrum row `row` of the 2H-row buffer: even rows are rows of S1, odd rows live odd_delta elements further on
-        auto S2at = [&](int k, int row) -> float2 {
+        // spectrum row `row` of the 2H-row buffer: even rows are rows of S1, odd rows live odd_delta elements further on.
+        // An element's address = [plane base + row part] (wave-uniform: a scalar register pair) + [column part] (per thread,
+        // the same for every row: computed once per segment and kept) -- the prefetch of a step costs no vector
+        // instructions for addresses.
+        auto koff = [&](int k) -> unsigned {
             // (k >= 0; 24-bit multiply: full rate, v_mul_lo_u32 is quarter rate; both factors are far below 2^24)
-            const unsigned off = (__umul24((unsigned)k / TK, tile_stride32) + ((unsigned)row / U) * TK + ((unsigned)k % TK) +
-                                  ((unsigned)row % U) * p.odd_delta) * (unsigned)sizeof(float2);
-            return *(const float2*)((const char*)base + off);
+            return (__umul24((unsigned)k / TK, tile_stride32) + ((unsigned)k % TK)) * (unsigned)sizeof(float2);
         };
+        typedef const __attribute__((address_space(1))) char* gptr_t;            // (global address space: global_load, not flat_load)
+        auto rowbase = [&](int row) -> gptr_t {
+            const unsigned off = (((unsigned)row / U) * TK + ((unsigned)row % U) * p.odd_delta) * (unsigned)sizeof(float2);
+            gptr_t r = (gptr_t)base + __builtin_amdgcn_readfirstlane(off);
+            asm("" : "+s"(r));                      // (a scalar pair as it stands: not re-associated into per-thread 64-bit sums)
+            return r;
+        };
+        auto gload = [](gptr_t r, unsigned off) -> float2 {
+            asm("" : "+v"(off));                    // (the 32-bit offset is re-defined here: base + zero-extended offset is then selected as global_load v, s[..])
+            const lds_f2raw t = *(const __attribute__((address_space(1))) lds_f2raw*)(r + off);
+            return make_float2(t.x, t.y);
+        };
+        auto S2at = [&](int k, int row) -> float2 { return gload(rowbase(row), koff(k)); };
         const bool need_corner = !top && (y1 + 1 < uH);
         const int rs = y1 + 1;
 
@@ -1380,15 +1398,21 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
         // m < NI, and at the mirror partners KH - lt - NB0*m (vkFFT.h:2096-2106); thread 0 also needs Im of the DC column
         // of the two reference partners (leak).  Threads beyond the first stage (lt >= NB0) re-read valid elements.
         struct In { float2 a[NI], am[NI], b[NI], bm[NI]; float lka, lkb; };
+        unsigned ko[NI], kom[NI];                   // column parts of the 2 * NI elements this thread prefetches per row
+        {
+            const int jj = PL::first_index(lt);
+#pragma unroll
+            for (int m = 0; m < NI; m++) { ko[m] = koff(jj + NB0 * m); kom[m] = koff(KH - jj - NB0 * m); }
+        }
         auto load_pair = [&](int i) -> In {
             In in;
             const int a = a0 + 2 * i;
             const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);       // rows past the plane: duplicate of the last row
-            const int jj = PL::first_index(lt);
+            const gptr_t ra = rowbase(ya), rb = rowbase(yb);
 #pragma unroll
             for (int m = 0; m < NI; m++) {
-                in.a[m] = S2at(jj + NB0 * m, ya); in.am[m] = S2at(KH - jj - NB0 * m, ya);
-                in.b[m] = S2at(jj + NB0 * m, yb); in.bm[m] = S2at(KH - jj - NB0 * m, yb);
+                in.a[m] = gload(ra, ko[m]); in.am[m] = gload(ra, kom[m]);
+                in.b[m] = gload(rb, ko[m]); in.bm[m] = gload(rb, kom[m]);
             }
             // (loaded by every lane, raw, so that no lane-dependent branch and no arithmetic -- hence no wait -- follows the loads)
             in.lka = S2at(0, ya ^ 1).y;
@@ -1445,14 +1469,14 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
             LT* cur = (LT*)buf;                                                     // rows a, a+1 after the transform
             const LT* ring = (const LT*)(smem + ((s + 1) & 1) * L::XB);             // rows a-2, a-1 (not RR)
             // ================= transform of pair s
-            if constexpr ((FFTUP_OPQ & 1) != 0) asm volatile("" : "+v"(lt));
+            asm volatile("" : "+v"(lt));
             float2 v[VN];
 #pragma unroll
             for (int m = 0; m < VN; m++) v[m] = make_float2(0.f, 0.f);
 #pragma unroll
             for (int m = 0; m < NI; m++) {
-                v[m] = make_float2(in.a[m].x - in.b[m].y, in.a[m].y + in.b[m].x);
-                v[R0 - NI + m] = make_float2(in.am[m].x + in.bm[m].y, -in.am[m].y + in.bm[m].x);
+                v[m] = cadd_i(in.a[m], in.b[m]);                       // A + i B          (a.x - b.y, a.y + b.x)
+                v[R0 - NI + m] = cadd_conj_i(in.am[m], in.bm[m]);      // conj(A) + i conj(B)   (am.x + bm.y, -am.y + bm.x)
             }
             if (lt == 0) {
                 v[NI] = make_float2(in.am[0].x - in.bm[0].y, in.am[0].y + in.bm[0].x);       // k = KH = W/2
@@ -1460,9 +1484,8 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                 const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);
                 v[0] = make_float2(in.a[0].x + ((ya & 1) ? in.lka : -in.lka), in.b[0].x + ((yb & 1) ? in.lkb : -in.lkb));
             }
-            if constexpr ((FFTUP_KO & 32) == 0)
             in = load_pair(min(s + 1, npairs - 1));                                 // lands during this step (last step: a harmless re-read)
-            if constexpr ((FFTUP_KO & 2) == 0) PL::fft(v, buf, (float2*)(smem + L::ZOFF), lt, tws);
+            PL::fft(v, buf, (float2*)(smem + L::ZOFF), lt, tws);
             settle(in);
             if constexpr (HALF) {
                 // C2R output stored as binary16 (vkFFT.h:7289-7290), then |u^2 g| clamped, each step rounded like the shader's
@@ -1477,8 +1500,6 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                         cur[UW + lt + SOUT * i] = Lv.y;
                     }
                 }
-            } else if constexpr ((FFTUP_KO & 16) != 0) {
-                if (v[0].x + v[1].y + v[6].x + v[7].y + v[2].x == 12345.f) cur[lt] = v[0].x;
             } else {
                 // one packed multiply: (v / UW) * u^2 == v * (u^2 / UW), bit for bit when UW is a power of two
                 const float ks = inv * p.upsq;
@@ -1486,14 +1507,13 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
 #pragma unroll
                     for (int i = 0; i < EOUT; i++) {
                         const f2v sv = mk2(v[i].x, v[i].y) * mk2(ks, ks);
-                        cur[lt + SOUT * i] = fminf(fabsf(sv.x), 1.0f);
-                        cur[UW + lt + SOUT * i] = fminf(fabsf(sv.y), 1.0f);
+                        cur[lt + SOUT * i] = absmin1(sv.x);
+                        cur[UW + lt + SOUT * i] = absmin1(sv.y);
                     }
                 }
             }
             __syncthreads();                                                        // L rows a, a+1 visible
             // ================= sharpen rows a-1 and a
-            if constexpr ((FFTUP_OPQ & 2) != 0) asm volatile("" : "+v"(lt));
             auto rowp = [&](int r) -> const LT* { return r < 0 ? ring + (r + 2) * UW : cur + r * UW; };      // (r < 0: not RR)
             const bool out0 = (a - 1) >= y0 && (a - 1) < y1;                        // row y = a-1
             const bool out1 = a >= y0 && a < y1;                                    // row y = a
@@ -1617,19 +1637,13 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                         // one IS x = 0 of the second (quirk B5); x0 == 0 reads 16 bytes in front of the row (at worst out of
                         // range: LDS returns 0) and is replaced below.
                         const float* rp = rows[r] + x0;
-                        if constexpr ((FFTUP_KO & 8) != 0) {
-                            for (int k = 0; k < 4; k++) t[r].q[k] = p.coef * (float)(x0 + k + 1 + r);
-                            t[r].l = p.coef * (float)(x0 + r);
-                            t[r].r = p.coef * (float)(x0 + 5 + r);
-                        } else {
-                            // (whole tuples are pinned: left alone the compiler narrows the neighbour loads to the one dword
-                            // that is used, and single-dword reads 16 bytes apart are a 4-way bank conflict)
-                            f4t q = *(const f4t*)rp, ql = *(const f4t*)(rp - 4), qr = *(const f4t*)(rp + 4);
-                            asm volatile("" : "+v"(q), "+v"(ql), "+v"(qr));
-                            t[r].q = q;
-                            t[r].l = ql.w;
-                            t[r].r = qr.x;
-                        }
+                        // (whole tuples are pinned: left alone the compiler narrows the neighbour loads to the one dword
+                        // that is used, and single-dword reads 16 bytes apart are a 4-way bank conflict)
+                        f4t q = *(const f4t*)rp, ql = *(const f4t*)(rp - 4), qr = *(const f4t*)(rp + 4);
+                        asm volatile("" : "+v"(q), "+v"(ql), "+v"(qr));
+                        t[r].q = q;
+                        t[r].l = ql.w;
+                        t[r].r = qr.x;
                         if (x0 == 0) t[r].l = t[r].q.x;            // id_x_m clamp (VkResample.cpp:889)
                     }
                     if (x0 + 4 == UW) {
@@ -1648,20 +1662,11 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
 #pragma unroll
                     for (int w = 0; w < 2; w++) {
                         if (w == 0 ? !out0 : !out1) continue;
-                        f4t o;
-                        if constexpr ((FFTUP_KO & 1) != 0) {
-                            for (int k = 0; k < 4; k++) o[k] = t[w][k + 1] + t[w + 1][k] + t[w + 1][k + 2] + t[w + 2][k + 1] + t[w + 1][k + 1];
-                        } else {
-                            float vmn[6], vmx[6];
-                            sharpen_vminmax(t, w, vmn, vmx);
-                            o = sharpen_quad_packed(t, w, vmn, vmx, p.coef);
-                        }
+                        float vmn[6], vmx[6];
+                        sharpen_vminmax(t, w, vmn, vmx);
+                        const f4t o = sharpen_quad_packed(t, w, vmn, vmx, p.coef);
                         const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
-                        if constexpr ((FFTUP_KO & 4) != 0) {
-                            if (o[0] + o[1] + o[2] + o[3] == 12345.f) ((float*)p.out)[row_of + x0] = o[0];
-                        } else {
-                            __builtin_nontemporal_store(o, (f4t*)((char*)((float*)p.out + row_of) + (unsigned)x0 * 4u));
-                        }
+                        __builtin_nontemporal_store(o, (f4t*)((char*)((float*)p.out + row_of) + (unsigned)x0 * 4u));
                     }
                 };
                 if constexpr (RR) {
