@@ -35,6 +35,18 @@ def test_bench_single_rank_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["kernel_ms"]["-"] < 0.01                       # empty slot: event overhead is netted out (5 iterations: noisy)
+    assert "built-in" in d["config"]["wisdom"]               # no tuner findings of earlier runs on this machine steer the run
+    # the other single-GPU BASELINE configurations and the reference's -n 1000 figure, in the same line
+    o = d["others"]
+    for k in ("config3", "config4"):
+        assert 0.01 < o[k]["ms_per_frame"] < 1.0 and 0.1 < o[k]["frame_frac"] < 1.5 and "row_c2r_sharpen" in o[k]["kernel_ms"]
+        assert abs(o[k]["frames_per_s"] - 1e3 / o[k]["ms_per_frame"]) < 1e-6 * o[k]["frames_per_s"]
+    assert "-p 2" in o["config3"]["workload"] and "1920x1080" in o["config4"]["workload"]
+    n = o["execute_n1000"]
+    for k in ("config2", "config3", "config4"):
+        assert 0.01 < n[k]["ms_per_iter"] < 1.0
+    # one stream, nothing overlaps: never faster than the overlapped figure of the same configuration
+    assert n["config2"]["ms_per_iter"] >= 0.9 * d["ms_per_frame"] and n["config4"]["ms_per_iter"] >= 0.9 * o["config4"]["ms_per_frame"]
 
 
 def test_bench_two_ranks_config5_over_gloo():
@@ -47,4 +59,33 @@ def test_bench_two_ranks_config5_over_gloo():
     assert d["n_gpus"] == 2 and d["config"]["preset"] == "config5" and d["config"]["frames_per_step"] == 64
     assert d["dtype"] == "f16-memory/f32-math" and "uint8 RGB (fused load)" in d["config"]["workload"]
     assert abs(d["value"] - 2 * 2 * 64 / d["timed_region_s_median"]) < 1e-6 * d["value"]
-    assert "cpu_baseline" not in d                           # rank 0 at N = 1 only
+    assert "cpu_baseline" not in d and "others" not in d     # rank 0 at N = 1 only
+    # job accounting: the collective really had two ranks, every frame of the 128-frame job was processed once
+    j = d["job"]
+    assert d["rccl_ranks"] == 2 and j["collective_ranks"] == 2 and j["backend"] == "gloo"
+    assert d["frames_done"] == 128 and j["frames_per_step_total"] == 128
+    assert [r["rank"] for r in j["ranks"]] == [0, 1] and [r["first_frames"] for r in j["ranks"]] == [[0, 2, 4], [1, 3, 5]]
+    assert all(len(r["pci_bus_id"]) >= 7 for r in j["ranks"]) and j["distinct_devices"] == 1      # (two ranks share this box's one GPU)
+    assert d["checksum"] > 0
+
+
+def _job(nproc, frames_per_step, port):
+    env = dict(os.environ, FFTUP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    args = ["bench.py", "--gpus", str(nproc), "--steps", "1", "--warmup", "1", "--repeats", "1", "--precision", "2", "--fuse-u8", "--job",
+            "--frames-per-step", str(frames_per_step), "--ring", str(frames_per_step), "--profile-iters", "2", "--no-cpu-baseline", "--no-others",
+            "--width", "512", "--height", "256"]
+    cmd = [sys.executable] + args if nproc == 1 else \
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return _line(r.stdout)
+
+
+def test_job_checksum_is_independent_of_the_sharding():
+    """The same 16-frame job on one rank and striped over two (frame f*2 + r on rank r, VkResample.cpp:1622-1629): same
+    number of frames done, same checksum of the outputs -- each frame was processed exactly once, whoever did it."""
+    one = _job(1, 16, 0)
+    two = _job(2, 8, 29519)
+    assert one["frames_done"] == two["frames_done"] == 16
+    assert one["checksum"] == two["checksum"] and one["checksum"] > 0
+    assert two["rccl_ranks"] == 2 and one["rccl_ranks"] == 1

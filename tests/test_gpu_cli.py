@@ -94,6 +94,30 @@ def test_cli_batched_two_threads(tmp_path):
         assert d.max() <= 2 and (d > 1).mean() <= 1e-3          # fp16 storage: a one-ulp flip can move a code by 2
 
 
+@pytest.mark.parametrize("threads,extra", [(3, ["-workqueue"]), (3, ["-workqueue", "-n", "2"]), (9, ["-workqueue", "-alldevices"])])
+def test_cli_batched_work_queue(tmp_path, threads, extra):
+    """-workqueue: the threads share ONE file counter instead of the static stripe (VR:1622-1629); every file is processed
+    exactly once whatever the thread count (more threads than files: the idle ones end at once), same pixels as the stripe."""
+    from vkresample_amd import synth
+    for d in ("inp", "oq", "os"):
+        os.makedirs(tmp_path / d)
+    frames = [synth.frame(60 + k, 128, 64, "N") for k in range(7)]
+    for k, f in enumerate(frames):
+        _png_write(tmp_path / "inp" / ("%06d.png" % (k + 1)), f)
+    base = [CLI, "-ifolder", "inp", "-numfiles", "7", "-u", "2", "-p", "0"]
+    r = subprocess.run(base + ["-ofolder", "oq", "-numthreads", str(threads)] + extra, capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and r.stdout.count("finished.") == threads, r.stdout + r.stderr
+    r = subprocess.run(base + ["-ofolder", "os", "-numthreads", "2"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert sorted(os.listdir(tmp_path / "oq")) == ["%06d.png" % (k + 1) for k in range(7)]
+    for k, f in enumerate(frames):
+        a = _png_read(tmp_path / "oq" / ("%06d.png" % (k + 1)))
+        assert np.array_equal(a, _png_read(tmp_path / "os" / ("%06d.png" % (k + 1)))), k
+        _, _, ou8 = O.upscale_rgb8(f, 2.0, 0, 0.2)
+        d = np.abs(a[:-1].astype(int) - ou8[:-1].astype(int))
+        assert d.max() <= 1 and (d != 0).mean() <= 5e-3
+
+
 def test_cli_batched_queue_one_thread_and_missing_file(tmp_path):
     """one thread, 7 files: the double-buffered queue (fftup_submit_rgb8) writes every frame; -n 3 takes the
     blocking path with identical files; a missing file ends the thread like the reference (VR:1631-1634)."""

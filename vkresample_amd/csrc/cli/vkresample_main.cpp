@@ -9,8 +9,11 @@
 //   -alldevices   batched mode: thread t uses device (d + t) % device_count instead of all threads on -d
 //   -fuseu8       the row kernel reads the uint8 image directly (README.md:31 roadmap item)
 //   -wrapu8       u8 store wraps like the reference's C cast instead of saturating
+//   -workqueue    batched mode: threads take the next unprocessed file from ONE shared counter (dynamic balancing over
+//                 threads / GPUs of unequal speed) instead of the static stripe t+1, t+1+T, .. of VR:1622-1629
 //   -tune         FFTUP_FLAG_TUNE_PLAN: time the alternatives for a size specialised at plan time, keep the fastest (wisdom file)
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -39,6 +42,7 @@ struct ResampleConfiguration {           // VkResampleConfiguration, VR:45-59
     float sharpenConst = 0.2f;
     bool allDevices = false;
     uint32_t flags = 0;
+    std::atomic<int>* workQueue = nullptr;   // -workqueue: next file number - 1, shared by all threads
 };
 
 static bool findFlag(char** start, char** end, const std::string& flag)      // VR:1782-1784: exact token match
@@ -67,8 +71,31 @@ static int devices_list()                                                     //
 static int launchResample(ResampleConfiguration config)                      // VR:1280-1780
 {
     if (config.threadId == 0) printf("VkResample - FFT based upscaling\n");
+    // which file (1-based number) is this thread's f-th one, 0 = none left.  Static stripe of the reference: f*T + t + 1 for
+    // f < numLocalFiles (VR:1622-1629); -workqueue: whatever the shared counter hands out next.
+    int numLocalFiles = 1;
+    if (config.fileUpload) {                                                   // VR:1622-1625
+        numLocalFiles = (int)std::ceil(config.numFiles / (float)config.numThreads);
+        if ((numLocalFiles - 1) * config.numThreads + config.threadId > config.numFiles - 1) numLocalFiles--;
+    }
+    std::vector<int> claimed;
+    auto fileAt = [&](int f) -> int {
+        while ((int)claimed.size() <= f) {
+            int n;
+            if (config.workQueue) { n = config.workQueue->fetch_add(1) + 1; if (n > config.numFiles) n = 0; }
+            else n = ((int)claimed.size() < numLocalFiles || claimed.empty()) ? (int)claimed.size() * config.numThreads + config.threadId + 1 : 0;
+            claimed.push_back(n);
+        }
+        return claimed[(size_t)f];
+    };
     char fileName[1024];
-    if (config.fileUpload) snprintf(fileName, sizeof fileName, "%s/%06d.png", config.ifolder_prefix, config.threadId + 1);   // VR:1357
+    if (config.fileUpload) {
+        if (fileAt(0) == 0) {                                                  // -workqueue with more threads than files
+            printf("Thread %d finished. No files left in the queue\n", config.threadId);
+            return FFTUP_OK;
+        }
+        snprintf(fileName, sizeof fileName, "%s/%06d.png", config.ifolder_prefix, fileAt(0));   // VR:1357
+    }
     else snprintf(fileName, sizeof fileName, "%s", config.png_input_name);
 
     std::vector<uint8_t> png_input;
@@ -101,12 +128,8 @@ static int launchResample(ResampleConfiguration config)                      // 
     const uint32_t uW = info.out_width, uH = info.out_height;
     std::vector<uint8_t> png_output((size_t)uW * uH * 3);
 
-    int numLocalFiles = 1;
-    if (config.fileUpload) {                                                   // VR:1622-1625
-        numLocalFiles = (int)std::ceil(config.numFiles / (float)config.numThreads);
-        if ((numLocalFiles - 1) * config.numThreads + config.threadId > config.numFiles - 1) numLocalFiles--;
-    }
-    if (config.fileUpload && config.numIter == 1 && numLocalFiles > 1) {
+    const bool more = config.fileUpload && (config.workQueue ? config.numFiles > 1 : numLocalFiles > 1);
+    if (more && config.numIter == 1) {
         // batched mode, double-buffered: frame f is on the device (fftup_submit_rgb8: H2D, kernels,
         // D2H asynchronously from/to page-locked memory) while this thread encodes frame f-1 and decodes frame f+1
         const size_t inBytes = (size_t)width * height * 3, outBytes = (size_t)uW * uH * 3;
@@ -122,7 +145,7 @@ static int launchResample(ResampleConfiguration config)                      // 
             release();
             return FFTUP_E_OUT_OF_MEMORY;
         }
-        auto fileIndex = [&](int f) { return f * config.numThreads + config.threadId + 1; };
+        auto fileIndex = [&](int f) { return fileAt(f); };
         auto writeFrame = [&](int f, uint64_t ticket) -> int {
             int r = fftup_wait(plan, ticket);
             if (r != FFTUP_OK) { printf("Download failed: %s (%s)\n", fftup_strerror(r), fftup_last_error()); return r; }
@@ -133,7 +156,8 @@ static int launchResample(ResampleConfiguration config)                      // 
             return FFTUP_OK;
         };
         uint64_t tickets[2] = {0, 0};
-        for (int f = 0; f < numLocalFiles; f++) {
+        int f = 0;
+        for (; fileAt(f) > 0; f++) {
             if (f > 0) {
                 snprintf(fileName, sizeof fileName, "%s/%06d.png", config.ifolder_prefix, fileIndex(f));
                 int w2 = 0, h2 = 0;
@@ -153,15 +177,15 @@ static int launchResample(ResampleConfiguration config)                      // 
             }
             if (f > 0 && (res = writeFrame(f - 1, tickets[(f - 1) & 1])) != FFTUP_OK) { release(); return res; }
         }
-        res = writeFrame(numLocalFiles - 1, tickets[(numLocalFiles - 1) & 1]);
+        res = writeFrame(f - 1, tickets[(f - 1) & 1]);
         release();
         if (res != FFTUP_OK) return res;
         printf("Thread %d finished. Device name: %s API:HIP\n", config.threadId, info.device_name);   // VR:1773
         return FFTUP_OK;
     }
-    for (int f = 0; f < numLocalFiles; f++) {
+    for (int f = 0; config.fileUpload ? fileAt(f) > 0 : f < 1; f++) {
         if (f > 0) {
-            snprintf(fileName, sizeof fileName, "%s/%06d.png", config.ifolder_prefix, f * config.numThreads + config.threadId + 1);
+            snprintf(fileName, sizeof fileName, "%s/%06d.png", config.ifolder_prefix, fileAt(f));
             int w2 = 0, h2 = 0;
             if (!pngio::load_rgb8(fileName, png_input, w2, h2, channels, err) || w2 != width || h2 != height) {
                 printf("Image not found\n");                                   // VR:1631-1634 (all files share one size)
@@ -186,7 +210,7 @@ static int launchResample(ResampleConfiguration config)                      // 
             return res;
         }
         char outName[1024];
-        if (config.fileUpload) snprintf(outName, sizeof outName, "%s/%06d.png", config.ofolder_prefix, f * config.numThreads + config.threadId + 1);
+        if (config.fileUpload) snprintf(outName, sizeof outName, "%s/%06d.png", config.ofolder_prefix, fileAt(f));
         else if (config.png_output_name) snprintf(outName, sizeof outName, "%s", config.png_output_name);
         else snprintf(outName, sizeof outName, "%d_%d_upscaled.png", width, (int)uW);   // VR:1706
         if (!pngio::write_rgb8(outName, png_output.data(), (int)uW, (int)uH, (size_t)uW * 3, err))
@@ -224,6 +248,7 @@ int main(int argc, char* argv[])
         printf("	-alldevices: thread t runs on GPU (d + t) %% count\n");
         printf("	-fuseu8: FFT kernel reads the 8-bit image directly\n");
         printf("	-wrapu8: 8-bit store wraps like the original's C cast instead of saturating\n");
+        printf("	-workqueue: batched mode: threads take the next unprocessed file from one shared counter instead of the fixed stripe\n");
         printf("	-tune: sizes whose kernels are specialised at plan time: measure the alternatives once, remember the fastest\n");
         return 0;
     }
@@ -286,6 +311,8 @@ int main(int argc, char* argv[])
         if (config.numThreads < 1) config.numThreads = 1;
         if (config.numFiles < 1) { printf("No numFiles is selected with -numfiles flag\n"); return 1; }
     }
+    std::atomic<int> queue{0};
+    if (config.fileUpload && findFlag(B, E, "-workqueue")) config.workQueue = &queue;
     auto timeSubmit = std::chrono::system_clock::now();
     std::vector<std::thread> threads;
     std::vector<int> results((size_t)config.numThreads, 0);

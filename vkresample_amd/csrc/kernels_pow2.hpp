@@ -324,6 +324,10 @@ __device__ __forceinline__ void reg_gather(float2 (&v)[E], const float2* __restr
     const unsigned a0 = lds_addr(buf) + 8u * (unsigned)lidx<TK>(p, col);    // p < Tc: bits of i*Tc*TK are clear
 #pragma unroll
     for (int i = 0; i < E; i++) v[i] = lds_get(a0, lswz_c(i * Tc * TK));
+    // All reads in flight together, ONE wait: left alone the scheduler issues a read, waits, multiplies by the twiddle, issues
+    // the next read .. -- E/2 LDS round trips in a row (350 cycles per gather, s_memtime marks) where one suffices.
+#pragma unroll
+    for (int i = 0; i < E; i += 2) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i + 1].x), "+v"(v[i + 1].y));
 }
 
 // ---- all stages.  On entry v[i] = x[p + Tc*i].  If FINAL_TO_LDS the result X is left in LDS in
@@ -1391,6 +1395,9 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
             return make_float2(t.x, t.y);
         };
         auto S2at = [&](int k, int row) -> float2 { return gload(rowbase(row), koff(k)); };
+        // Im of the DC element of row `row` -- one dword: a register of a wider load that is never read would be re-used by
+        // the compiler while the load is still in flight (and waited for)
+        auto dc_im = [&](int row) -> float { return *(const __attribute__((address_space(1))) float*)(rowbase(row) + 4); };
         const bool need_corner = !top && (y1 + 1 < uH);
         const int rs = y1 + 1;
 
@@ -1415,13 +1422,16 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                 in.b[m] = gload(rb, ko[m]); in.bm[m] = gload(rb, kom[m]);
             }
             // (loaded by every lane, raw, so that no lane-dependent branch and no arithmetic -- hence no wait -- follows the loads)
-            in.lka = S2at(0, ya ^ 1).y;
-            in.lkb = S2at(0, yb ^ 1).y;
+            in.lka = dc_im(ya ^ 1);
+            in.lkb = dc_im(yb ^ 1);
             return in;
         };
         // Loads and stores retire through ONE in-order counter (vmcnt).  settle() is called where the prefetch is a whole
-        // transform old and the previous step's stores even older: the wait costs nothing, and re-defining the values
-        // keeps the compiler from copying the just-issued loads' registers (and waiting for them) right behind the loads.
+        // transform old and the previous step's stores even older, and re-defining the values keeps the compiler from copying
+        // the just-issued loads' registers (and waiting for them) right behind the loads.  (Round 3 tried the wait at the end
+        // of the step instead -- a constant number of stores per wave and step, rows that are not output rows stored through a
+        // buffer resource with an out-of-range offset, which the hardware drops, then vmcnt(that number): correct, and not a
+        // microsecond faster; the prefetch is not what the kernel waits for.  DESIGN.md section 4.)
         auto settle = [](In& in) {
             __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0), nothing else
 #pragma unroll
@@ -1514,28 +1524,44 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
             }
             __syncthreads();                                                        // L rows a, a+1 visible
             // ================= sharpen rows a-1 and a
+            // L(a, 0) and L(a + 1, 0): the wrapped right neighbours of the row ends (quirk B5) -- read by EVERY lane (two broadcast
+            // reads issued with the first taps) and put in place with selects.  (They used to be read by the one lane that
+            // needs them, inside lane-dependent branches, each read a round trip through an LDS pipe busy with the other waves'
+            // taps: that wave finished its sharpen 1700 cycles after the others -- in-kernel s_memtime marks -- and the whole
+            // workgroup waited for it at the next barrier, every step.)
+            const float la0 = (float)cur[0], la1 = (float)cur[UW];
+            constexpr int LT_LAST = (UW / 4 - 1) % T, H_LAST = (UW / 4 - 1) / T;
+            // The pixel deferred by the previous step, (a-2, UW-1): by the thread that owns the last four pixels of a row, from
+            // registers only (it needs the ring rows as the previous step left them: called inside pass H_LAST, behind the
+            // issue of that pass's tap reads and before it replaces the saved rows).
+            auto finish_deferred = [&]() __attribute__((always_inline)) {
+                if constexpr (RR) {
+                    if (lt == LT_LAST) {
+                        const SavedRow& R2 = sv[H_LAST][0];         // row a-2, pixels UW-4 .. UW-1 and L(a-1, 0)
+                        const SavedRow& R1 = sv[H_LAST][1];         // row a-1
+                        float r2a, r2b, r1a, r1b, r10;
+                        if constexpr (HALF) { r2a = (float)R2.h23.x; r2b = (float)R2.h23.y; r1a = (float)R1.h23.x; r1b = (float)R1.h23.y; r10 = (float)R2.sc.y; }
+                        else { r2a = R2.q.z; r2b = R2.q.w; r1a = R1.q.z; r1b = R1.q.w; r10 = R2.r; }
+                        if (s > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1)
+                            deferred_pixel<HALF>(p, c * plane + (long)(a - 2) * UW + (UW - 1), pn0, pn1, (a - 2 == 0) ? r10 : lprev0,
+                                                 r2a, r2b, r10, r1a, r1b, la0);
+                        if (a == 0) { pn0 = (float)cur[UW - 2]; pn1 = (float)cur[UW - 1]; }       // (top strip, first step only)
+                        else { pn0 = r1a; pn1 = r1b; }
+                        lprev0 = la0;
+                    }
+                }
+            };
+            // the SE tap of pixel (a, UW-1) is L(a+2, 0): past the plane it clamps to row uH-1; in the last step it is the
+            // corner sample; otherwise the pixel is finished next step (placeholder now)
+            float lse = la1;
+            {
+                const int r2 = min(a + 2, uH - 1) - a;
+                if (r2 == 0) lse = la0;
+                else if (r2 > 1 && s == npairs - 1) lse = to_L<HALF>(corner, p.upsq);
+            }
             auto rowp = [&](int r) -> const LT* { return r < 0 ? ring + (r + 2) * UW : cur + r * UW; };      // (r < 0: not RR)
             const bool out0 = (a - 1) >= y0 && (a - 1) < y1;                        // row y = a-1
             const bool out1 = a >= y0 && a < y1;                                    // row y = a
-            if constexpr (RR) {
-                // the deferred pixel first: it needs the ring rows as the previous step left them; by the thread that owns
-                // the last four pixels of a row
-                constexpr int LT_LAST = (UW / 4 - 1) % T, H_LAST = (UW / 4 - 1) / T;
-                if (lt == LT_LAST) {
-                    const float r00 = (float)rowp(0)[0];
-                    const SavedRow& R2 = sv[H_LAST][0];         // row a-2, pixels UW-4 .. UW-1 and L(a-1, 0)
-                    const SavedRow& R1 = sv[H_LAST][1];         // row a-1
-                    float r2a, r2b, r1a, r1b, r10;
-                    if constexpr (HALF) { r2a = (float)R2.h23.x; r2b = (float)R2.h23.y; r1a = (float)R1.h23.x; r1b = (float)R1.h23.y; r10 = (float)R2.sc.y; }
-                    else { r2a = R2.q.z; r2b = R2.q.w; r1a = R1.q.z; r1b = R1.q.w; r10 = R2.r; }
-                    if (s > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1)
-                        deferred_pixel<HALF>(p, c * plane + (long)(a - 2) * UW + (UW - 1), pn0, pn1, (a - 2 == 0) ? r10 : lprev0,
-                                             r2a, r2b, r10, r1a, r1b, r00);
-                    if (a == 0) { pn0 = (float)rowp(0)[UW - 2]; pn1 = (float)rowp(0)[UW - 1]; }
-                    else { pn0 = r1a; pn1 = r1b; }
-                    lprev0 = r00;
-                }
-            }
             if constexpr (HALF) {
                 if (out0 || out1 || RR) {
                     const h2v ncoef = h2_splat(-p.coef);
@@ -1545,6 +1571,15 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                         if (UW % (4 * T) != 0 && x0 >= UW) return;        // (wave-uniform: UW/4 is a multiple of 64)
                         // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
                         const LT* rows[4] = {RR ? nullptr : rowp(-2), RR ? nullptr : ((a == 0) ? rowp(0) : rowp(-1)), rowp(0), rowp(1)};
+                        // own four pixels (8 bytes) and the quads of both neighbours of every row that comes from LDS: all reads
+                        // of the pass in flight together (one wait, not one per row); the shifted pairs by v_alignbit
+                        uint2 q[4], ql[4], qr[4];
+#pragma unroll
+                        for (int r = 3; r >= (RR ? 2 : 0); r--) {
+                            const LT* rp = rows[r] + x0;
+                            q[r] = *(const uint2*)rp; ql[r] = *(const uint2*)(rp - 4); qr[r] = *(const uint2*)(rp + 4);
+                        }
+                        if constexpr (RR) { if (h == H_LAST) finish_deferred(); }
                         H2Row R[4];
 #pragma unroll
                         for (int r = 3; r >= 0; r--) {
@@ -1562,28 +1597,18 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                                 R[0].sa = R[0].h01 = R[0].sb = R[0].h23 = R[0].sc = h2_splat(0.f);
                                 continue;
                             }
-                            // own four pixels (8 bytes) and the quads of both neighbours; the shifted pairs by v_alignbit
-                            const LT* rp = rows[r] + x0;
-                            uint2 q = *(const uint2*)rp, ql = *(const uint2*)(rp - 4), qr = *(const uint2*)(rp + 4);
-                            asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(ql.x), "+v"(ql.y), "+v"(qr.x), "+v"(qr.y));   // keep them 8-byte reads
-                            R[r].h01 = h2_bits(q.x);
-                            R[r].h23 = h2_bits(q.y);
-                            R[r].sa = h2_bits(__builtin_amdgcn_alignbit(q.x, ql.y, 16));        // (x0-1, x0)
-                            R[r].sb = h2_bits(__builtin_amdgcn_alignbit(q.y, q.x, 16));         // (x0+1, x0+2)
-                            R[r].sc = h2_bits(__builtin_amdgcn_alignbit(qr.x, q.y, 16));        // (x0+3, x0+4)
+                            asm volatile("" : "+v"(q[r].x), "+v"(q[r].y), "+v"(ql[r].x), "+v"(ql[r].y), "+v"(qr[r].x), "+v"(qr[r].y));   // keep them 8-byte reads
+                            R[r].h01 = h2_bits(q[r].x);
+                            R[r].h23 = h2_bits(q[r].y);
+                            R[r].sa = h2_bits(__builtin_amdgcn_alignbit(q[r].x, ql[r].y, 16));        // (x0-1, x0)
+                            R[r].sb = h2_bits(__builtin_amdgcn_alignbit(q[r].y, q[r].x, 16));         // (x0+1, x0+2)
+                            R[r].sc = h2_bits(__builtin_amdgcn_alignbit(qr[r].x, q[r].y, 16));        // (x0+3, x0+4)
                             if (x0 == 0) R[r].sa = h2_bits((bits_h2(R[r].h01) & 0xffffu) * 0x10001u);      // id_x_m clamp (VkResample.cpp:889)
                         }
                         if (x0 + 4 == UW) {
-                            auto set_hi = [](h2v& d, LT v) { d.y = v; };
-                            // row a-1 wraps into row a, which lives in the other buffer
-                            if (a != 0) set_hi(R[1].sc, rowp(0)[0]);
-                            // SE tap of pixel (a, UW-1) is L(a+2, 0): see the fp32 pass
-                            set_hi(R[3].sc, rowp(1)[0]);
-                            const int r2 = min(a + 2, uH - 1) - a;
-                            if (r2 <= 1) set_hi(R[3].sc, rowp(r2)[0]);
-                            else if (s == npairs - 1) {
-                                set_hi(R[3].sc, (LT)to_L<HALF>(corner, p.upsq));
-                            }
+                            auto set_hi = [](h2v& d, float v) { d.y = (_Float16)v; };      // (exact: binary16 values)
+                            if (a != 0) set_hi(R[1].sc, la0);       // row a-1 wraps into row a
+                            set_hi(R[3].sc, lse);
                         }
                         if constexpr (RR) { sv[h][0] = R[2]; sv[h][1] = R[3]; }
 #pragma unroll
@@ -1614,6 +1639,19 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                     if (UW % (4 * T) != 0 && x0 >= UW) return;            // (wave-uniform: UW/4 is a multiple of 64)
                     // row -1 clamps to row 0: for a == 0 the "a-1" slot aliases row a
                     const float* rows[4] = {RR ? nullptr : rowp(-2), RR ? nullptr : ((a == 0) ? rowp(0) : rowp(-1)), rowp(0), rowp(1)};
+                    // own four pixels and the quads of both neighbours of every row that comes from LDS: conflict-free 16-byte
+                    // reads, no cross-lane moves, no wave-edge branches -- all reads of the pass in flight together (one wait,
+                    // not one per row).  The two rows of a pair are contiguous in LDS, so x = UW of the first one IS x = 0 of the
+                    // second (quirk B5); x0 == 0 reads 16 bytes in front of the row (at worst out of range: LDS returns 0) and is
+                    // replaced below.  (Whole tuples are pinned: left alone the compiler narrows the neighbour loads to the
+                    // one dword that is used, and single-dword reads 16 bytes apart are a 4-way bank conflict.)
+                    f4t q[4], ql[4], qr[4];
+#pragma unroll
+                    for (int r = 3; r >= (RR ? 2 : 0); r--) {
+                        const float* rp = rows[r] + x0;
+                        q[r] = *(const f4t*)rp; ql[r] = *(const f4t*)(rp - 4); qr[r] = *(const f4t*)(rp + 4);
+                    }
+                    if constexpr (RR) { if (h == H_LAST) finish_deferred(); }
                     TapRow t[4];
 #pragma unroll
                     for (int r = 3; r >= 0; r--) {
@@ -1632,31 +1670,15 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                             t[0].l = t[0].r = 0.f;
                             continue;
                         }
-                        // own four pixels and the quads of both neighbours: three conflict-free 16-byte reads, no cross-lane
-                        // moves, no wave-edge branches.  The two rows of a pair are contiguous in LDS, so x = UW of the first
-                        // one IS x = 0 of the second (quirk B5); x0 == 0 reads 16 bytes in front of the row (at worst out of
-                        // range: LDS returns 0) and is replaced below.
-                        const float* rp = rows[r] + x0;
-                        // (whole tuples are pinned: left alone the compiler narrows the neighbour loads to the one dword
-                        // that is used, and single-dword reads 16 bytes apart are a 4-way bank conflict)
-                        f4t q = *(const f4t*)rp, ql = *(const f4t*)(rp - 4), qr = *(const f4t*)(rp + 4);
-                        asm volatile("" : "+v"(q), "+v"(ql), "+v"(qr));
-                        t[r].q = q;
-                        t[r].l = ql.w;
-                        t[r].r = qr.x;
+                        asm volatile("" : "+v"(q[r]), "+v"(ql[r]), "+v"(qr[r]));
+                        t[r].q = q[r];
+                        t[r].l = ql[r].w;
+                        t[r].r = qr[r].x;
                         if (x0 == 0) t[r].l = t[r].q.x;            // id_x_m clamp (VkResample.cpp:889)
                     }
                     if (x0 + 4 == UW) {
-                        // row a-1 wraps into row a, which lives in the other buffer
-                        if (a != 0) t[1].r = rowp(0)[0];
-                        // SE tap of pixel (a, UW-1) is L(a+2, 0): past the plane it clamps to row uH-1; in the last step
-                        // it is the corner sample; otherwise the pixel is finished next step (placeholder now)
-                        t[3].r = rowp(1)[0];
-                        const int r2 = min(a + 2, uH - 1) - a;
-                        if (r2 <= 1) t[3].r = rowp(r2)[0];
-                        else if (s == npairs - 1) {
-                            t[3].r = to_L<HALF>(corner, p.upsq);
-                        }
+                        if (a != 0) t[1].r = la0;                  // row a-1 wraps into row a
+                        t[3].r = lse;
                     }
                     if constexpr (RR) { sv[h][0] = t[2]; sv[h][1] = t[3]; }
 #pragma unroll
