@@ -42,15 +42,16 @@ def test_specialised_plan_vs_oracle(W, H, precision, flags):
     tag = "jit %dx%d p%d flags%d" % (W, H, precision, flags)
     if precision == 0:
         so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 1e-4)
-        assert _rel_l2(pre, opre) <= 1e-5 and np.abs(pre - opre).max() * 4 <= 1e-4
-        assert so["p99.99"] <= 1e-4 and so["max"] <= 1e-3 and so["count_above"] <= 1e-4 * so["n"]
+        # (about ten times the measured distributions, profiles/r02_q_pytest_gpu.txt: max 1.2e-6 .. 2.1e-6, p99.99 1.2e-6)
+        assert _rel_l2(pre, opre) <= 2e-6 and np.abs(pre - opre).max() * 4 <= 1e-5
+        assert so["p99.99"] <= 1.2e-5 and so["max"] <= 2e-5 and so["count_above"] == 0
         d = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
-        assert d.max() <= 1 and (d != 0).mean() <= 5e-3
+        assert d.max() <= 1 and (d != 0).mean() <= 5e-4
     else:
         ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
         assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
         so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 2.0 ** -10)
-        assert so["max"] <= 8e-3 and so["p99"] <= 2.0 ** -10 and so["p99.99"] <= 4e-3
+        assert so["max"] <= 8e-3 and so["p99"] == 0 and so["p99.99"] <= 3e-3 and so["count_above"] <= 5e-4 * so["n"]      # (measured: max <= 4.6e-3, p99.99 <= 1.5e-3, <= 1.5e-4 n)
 
 
 # upscale factors other than 2.  Integer: U - 1 residue transforms in the column kernel (k_col_u), first radix of the fused
@@ -86,15 +87,15 @@ def test_specialised_integer_factor_vs_oracle(W, H, u, precision, flags):
     tag = "jit %dx%d u%g p%d flags%d" % (W, H, u, precision, flags)
     if precision == 0:
         so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 1e-4)
-        assert _rel_l2(pre, opre) <= 1e-5 and np.abs(pre - opre).max() * u * u <= 1e-4
-        assert so["p99.99"] <= 1e-4 and so["max"] <= 1e-3 and so["count_above"] <= 1e-4 * so["n"]
+        assert _rel_l2(pre, opre) <= 2e-6 and np.abs(pre - opre).max() * u * u <= 1e-5
+        assert so["p99.99"] <= 1.2e-5 and so["max"] <= 2e-5 and so["count_above"] == 0
         d = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
-        assert d.max() <= 1 and (d != 0).mean() <= 5e-3
+        assert d.max() <= 1 and (d != 0).mean() <= 5e-4
     else:
         ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
         assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
         so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 2.0 ** -10)
-        assert so["max"] <= 8e-3 and so["p99"] <= 2.0 ** -10 and so["p99.99"] <= 4e-3
+        assert so["max"] <= 8e-3 and so["p99"] == 0 and so["p99.99"] <= 3e-3 and so["count_above"] <= 5e-4 * so["n"]      # (measured: max <= 4.6e-3, p99.99 <= 1.5e-3, <= 1.5e-4 n)
 
 
 @pytest.mark.parametrize("W,H", [(640, 480), (1000, 1000), (1600, 900)])

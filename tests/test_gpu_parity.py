@@ -242,26 +242,32 @@ FULL_SIZE = [(2048, 1024, 0, 0), (2048, 1024, 0, 2), (1920, 1080, 0, 0), (1920, 
 def test_full_size_vs_oracle(W, H, precision, flags, dist):
     """BASELINE configs 2-4 at full size against the (multi-threaded) oracle; flags = 2 is FFTUP_FLAG_FUSE_U8_LOAD,
     i.e. config 3 exactly as BASELINE states it (-p 2, uint8 load fused) and the same for fp32.
-    fp32: sharpened output p99.99 <= 1e-4 (north_star's tolerance), max <= 1e-3 (the filter's sqrt has unbounded
-    slope at 0: a handful of pixels whose 3x3 minimum is exactly 0 in fp64 amplify fp32 noise)."""
+    Thresholds = about ten times the measured distributions (profiles/r02_q_pytest_gpu.txt, r03_*_pytest_gpu.txt), far inside
+    north_star's 1e-4: fp32 pre-sharpen max 6e-7 .. 1e-6 measured -> 1e-5; sharpened "N" frames max 2e-6, p99.99 1.2e-6 ->
+    2e-5 / 1.2e-5 and NO pixel above 1e-4; uniform noise max 8.5e-5 (the filter's sqrt has unbounded slope at 0: a handful
+    of pixels whose 3x3 minimum is exactly 0 in fp64 amplify fp32 noise) -> 2e-4, p99.99 2.1e-6 -> 2.5e-5."""
     (pre, out, u8), (opre, oout, ou8) = _run(W, H, 2.0, precision, dist, flags=flags)
     tag = "%dx%d p%d flags%d %s" % (W, H, precision, flags, dist)
     if precision == 0:
         sp = _report(tag + " pre*u^2", (pre - opre) * 4, 1e-5)
         so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 1e-4)
-        assert _rel_l2(pre, opre) <= 1e-5
-        assert sp["max"] <= 1e-4 and sp["p99.99"] <= 1e-5
-        assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-4
-        assert so["p99.99"] <= 1e-4 and so["max"] <= 1e-3 and so["count_above"] <= 1e-4 * so["n"]
+        assert _rel_l2(pre, opre) <= 2e-6
+        assert sp["max"] <= 1e-5 and sp["p99.99"] <= 5e-6 and sp["count_above"] == 0
+        assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-5
+        if dist == "N":
+            assert so["max"] <= 2e-5 and so["p99.99"] <= 1.2e-5 and so["count_above"] == 0
+        else:
+            assert so["max"] <= 2e-4 and so["p99.99"] <= 2.5e-5 and so["count_above"] <= 3
         d = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
-        assert d.max() <= 1 and (d != 0).mean() <= 5e-3
+        assert d.max() <= 1 and (d != 0).mean() <= 5e-4
     else:
         ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
         assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
         # in binary16 ulps of the output (ulp at 0.5..1 = 4.9e-4): the sharpen amplifies one-ulp input flips
+        # (measured: p99 0, p99.99 one ulp = 9.8e-4, max 2e-3 .. 3.4e-3, 4e-6 .. 8e-5 of the pixels above one ulp)
         so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 2.0 ** -10)
-        assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-3
-        assert so["max"] <= 8e-3 and so["p99"] <= 2.0 ** -10 and so["p99.99"] <= 4e-3
+        assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 3e-4
+        assert so["max"] <= 6e-3 and so["p99"] == 0 and so["p99.99"] <= 2e-3 and so["count_above"] <= 4e-4 * so["n"]
 
 
 def _config1_rgb():
@@ -277,11 +283,11 @@ def test_config1_literal_image_api(flags):
     (pre, out, u8), (opre, oout, ou8) = _run_rgb(d["rgb"], 2.0, 0, flags=flags)
     assert np.abs(oout[:, 1000:1064, 1800:1864] - d["out_crop"]).max() <= 1e-12       # the oracle build is sane
     so = _report("config1 no_upscaling.png flags%d out" % flags, out[:, :-1] - oout[:, :-1], 1e-4)
-    assert np.abs(pre - opre).max() * 4 <= 1e-4 and _rel_l2(pre, opre) <= 1e-5
-    assert so["p99.99"] <= 1e-4 and so["max"] <= 1e-3
+    assert np.abs(pre - opre).max() * 4 <= 1e-5 and _rel_l2(pre, opre) <= 2e-6
+    assert so["p99.99"] <= 1.5e-5 and so["max"] <= 1e-4 and so["count_above"] == 0        # (measured 1.4e-6 / 9e-6)
     dd = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
     print("PARITY config1 u8: differing codes %.2e, max %d" % ((dd != 0).mean(), dd.max()))
-    assert dd.max() <= 1 and (dd != 0).mean() <= 5e-3
+    assert dd.max() <= 1 and (dd != 0).mean() <= 5e-4                                      # (measured 5e-5)
 
 
 def test_full_size_properties():
@@ -565,10 +571,10 @@ def test_hip_path_reproduces_reference_output_crops(name, flags):
         up.upload_rgb8(d["rgb"])
         up.execute(1)
         u8 = up.download_rgb8()
-    r0, r1, c0, c1 = [int(v) for v in d["inner"]]
-    Yo, Xo = int(d["Yo"]), int(d["Xo"])
-    diff = np.abs(u8[Yo:Yo + 300, Xo:Xo + 300].astype(np.int64) - d["fft_panel"].astype(np.int64))[r0:r1, c0:c1]
-    assert diff.mean() <= 0.35 and np.percentile(diff, 99) <= 1 and diff.max() <= 3
+    # every panel pixel outside the label corner and a 12-pixel border (O.readme_panel_mask), same bounds as the oracle's test
+    st = O.readme_panel_stats(u8, d)
+    print("README %s flags%d HIP: %s" % (name, flags, st))
+    assert st["mean"] <= 0.35 and st["p99"] <= 2 and st["p99.9"] <= 3 and st["max"] <= 5, st
 
 
 def test_plans_in_concurrent_host_threads():

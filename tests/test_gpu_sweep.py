@@ -87,9 +87,10 @@ def _sweep_case(W, H, u, p, flags, sharpen, seed, expect_specialised=False):
         assert np.abs(pre - opre).max() <= 1e-12
         assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1e-7      # sqrt(min) has unbounded slope at 0 (see the fp32 test)
     elif p == 0:
-        assert np.abs(pre - opre).max() <= 1e-4 * scale * 4 and np.linalg.norm(pre - opre) <= 1e-5 * np.linalg.norm(opre)
-        assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 2e-3
-        assert np.linalg.norm(out[:, :-1] - oout[:, :-1]) <= 2e-4 * np.linalg.norm(oout[:, :-1])
+        # (ten times what the full-size tests measure; uniform-noise frames and small sharpen factors: the filter's sqrt slope)
+        assert np.abs(pre - opre).max() <= 1e-5 * scale * 4 and np.linalg.norm(pre - opre) <= 3e-6 * np.linalg.norm(opre)
+        assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 5e-4
+        assert np.linalg.norm(out[:, :-1] - oout[:, :-1]) <= 2e-5 * np.linalg.norm(oout[:, :-1])
     else:
         ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
         assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()

@@ -183,6 +183,54 @@ def test_jit_check_compiles_without_a_device(tmp_path, monkeypatch):
     assert lib.fftup_jit_check(640, 480, 2, 0, None, buf, 256) == 0 and "row 10*8*8" in buf.value.decode()
 
 
+def test_jit_cache_rejects_torn_files_and_coalesces_concurrent_compiles(tmp_path):
+    """(a) a cache file with damaged bytes (a torn write, another process still writing) must not load -- the
+    header carries a checksum; the plan is compiled again and the file replaced; (b) threads that ask for the same
+    translation unit at the same moment (the CLI's -numthreads mode) get ONE compilation, not one each, and no two writers
+    share a temporary file.  Each part in a process of its own (the in-memory table must not answer)."""
+    import subprocess
+    import sys
+    cache = tmp_path / "cache"
+    # (AMD_COMGR_CACHE=0: hipRTC's own code cache would make a compilation as quick as a load, and the timings below blind)
+    env = dict(os.environ, FFTUP_CACHE_DIR=str(cache), AMD_COMGR_CACHE="0")
+    check = ("import ctypes as C, sys, time; sys.path.insert(0, %r); from vkresample_amd import _lib; lib = _lib.load(); "
+             "buf = C.create_string_buffer(256); t = time.time(); rc = lib.fftup_jit_check(720, 576, 2, 0, None, buf, 256); "
+             "print(rc, '%%.2f' %% (time.time() - t))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", check], env=env, capture_output=True, text=True, timeout=300)
+    assert r.stdout.split()[0] == "0", r.stdout + r.stderr
+    files = sorted(cache.glob("*.fjit"))
+    assert len(files) == 2 and not list(cache.glob("*.fjit.*"))                   # no temporaries left behind
+    good = [f.read_bytes() for f in files]
+    assert all(g[:6] == b"FJIT2\n" for g in good)
+    # (a) flip one byte in the middle of each code object
+    for f, g in zip(files, good):
+        f.write_bytes(g[:len(g) // 2] + bytes([g[len(g) // 2] ^ 0x55]) + g[len(g) // 2 + 1:])
+    r = subprocess.run([sys.executable, "-c", check], env=env, capture_output=True, text=True, timeout=300)
+    rc, secs = r.stdout.split()
+    assert rc == "0" and float(secs) > 0.3, r.stdout + r.stderr                   # compiled again, not loaded
+    def whole(raw):                                                                # FJIT2: magic, fnv1a-64 of the rest, payload
+        h = 1469598103934665603
+        for ch in raw[14:]:
+            h = ((h ^ ch) * 1099511628211) & (2 ** 64 - 1)
+        return raw[:6] == b"FJIT2\n" and int.from_bytes(raw[6:14], "little") == h
+    assert all(whole(g) for g in good) and all(whole(f.read_bytes()) for f in files)       # and the files are whole again
+    r = subprocess.run([sys.executable, "-c", check], env=env, capture_output=True, text=True, timeout=300)
+    assert r.stdout.split()[0] == "0" and float(r.stdout.split()[1]) < 0.3, r.stdout         # now served from the cache
+    # (b) four threads, same plan, cold cache: about the time of one compilation
+    for f in files:
+        f.unlink()
+    conc = ("import ctypes as C, sys, time, threading; sys.path.insert(0, %r); from vkresample_amd import _lib; lib = _lib.load();\n"
+            "def one():\n    buf = C.create_string_buffer(256); assert lib.fftup_jit_check(720, 576, 2, 0, None, buf, 256) == 0\n"
+            "t = time.time(); ths = [threading.Thread(target=one) for _ in range(4)]; [x.start() for x in ths]; [x.join() for x in ths]; "
+            "print('%%.2f' %% (time.time() - t))" % ROOT)
+    r1 = subprocess.run([sys.executable, "-c", check], env=dict(env, FFTUP_CACHE_DIR=str(tmp_path / "c2")), capture_output=True, text=True, timeout=300)
+    single = float(r1.stdout.split()[1])
+    r = subprocess.run([sys.executable, "-c", conc], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert float(r.stdout.split()[0]) < 2.2 * single + 0.5, (r.stdout, single)     # (four compilations in a row would be 4 x)
+    assert len(list(cache.glob("*.fjit"))) == 2 and not list(cache.glob("*.fjit.*"))
+
+
 def test_jit_chooser_invariants_over_all_sizes():
     """Every factorization the plan-time chooser (csrc/jit.hpp) can hand out, for all even 2,3,5,7-smooth widths and a
     spread of heights up to 4096 and the factors 1.5 ... 8: radices multiply to the length, the workgroup holds the first

@@ -300,25 +300,22 @@ def test_config1_fixture_digests():
 README_STRIPS = ["car", "close_people", "distant_people", "skyscraper", "trees"]
 
 
-def _panel_diff(u8, d):
-    r0, r1, c0, c1 = [int(v) for v in d["inner"]]
-    Yo, Xo = int(d["Yo"]), int(d["Xo"])
-    diff = np.abs(u8[Yo:Yo + 300, Xo:Xo + 300].astype(np.int64) - d["fft_panel"].astype(np.int64))[r0:r1, c0:c1]
-    return float(diff.mean()), float(np.percentile(diff, 99)), int(diff.max())
-
-
 @pytest.mark.parametrize("name", README_STRIPS)
 def test_oracle_reproduces_reference_output_crops(name):
     """tests/golden/make_readme_crops.py: the FFT panels of the README's comparison strips are crops of images the
     reference itself produced; their NN panels give the exact input pixels of the same window.  The oracle run on
     that input reproduces the reference's pixels to the 8-bit grid (the residue comes from the input outside the
-    window, known only to ~2 grey levels), and only with the reference's default sharpen strength."""
+    window, known only to ~2 grey levels), and only with the reference's default sharpen strength.  Compared: every
+    panel pixel outside the label corner and a 12-pixel border (O.readme_panel_mask: 68 476 pixels x 3 channels per strip;
+    measured mean 0.19-0.30 grey levels, p99 <= 2, max <= 4 -- profiles/r03_b_readme_crops_histograms.txt)."""
     d = np.load(os.path.join(GOLDEN, "readme_%s.npz" % name))
     _, _, u8 = O.upscale_rgb8(d["rgb"], float(d["upscale"]), int(d["precision"]), float(d["sharpen"]))
-    mean, p99, mx = _panel_diff(u8, d)
-    assert mean <= 0.35 and p99 <= 1 and mx <= 3, (mean, p99, mx)
+    st = O.readme_panel_stats(u8, d)
+    print("README %s oracle: %s" % (name, st))
+    assert st["mean"] <= 0.35 and st["p99"] <= 2 and st["p99.9"] <= 3 and st["max"] <= 5, st
     _, _, weak = O.upscale_rgb8(d["rgb"], 2.0, 0, 0.1)          # discriminating power: -s 0.1 is visibly off
-    assert _panel_diff(weak, d)[0] > 2 * mean and _panel_diff(weak, d)[2] >= 10
+    sw = O.readme_panel_stats(weak, d)
+    assert sw["mean"] > 2 * st["mean"] and sw["max"] >= 20 and sw["p99"] >= 5, sw
 
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/samples/car.png"), reason="needs the reference's samples")

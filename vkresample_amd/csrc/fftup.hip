@@ -1123,13 +1123,30 @@ static void tune_fused(fftup_plan* P)
         return best;
     };
     const double t_base = time_plan();
+    if (t_base >= 1e30) {                                                       // the plan does not even run: nothing to learn, nothing to file
+        P->in_kind = kinds;
+        P->executed = executed;
+        return;
+    }
     double t_best = t_base;
     fftup_jit::Module* const original = P->jit;
     fftup_jit::Module* best = nullptr;
+    // candidates: the chooser's alternatives -- and the structural default (pow2 / 16*16*R), when built-in wisdom made the
+    // plan start from something else
+    std::vector<fftup_jit::Choice> cands;
+    {
+        fftup_jit::Choice d;
+        if (fftup_jit::choose(base.W, base.H, base.D, base.half, stage_radices(P->planUW), d, "", false) &&
+            fftup_jit::fused_value(d) != fftup_jit::fused_value(base))
+            cands.push_back(d);
+    }
     for (const auto& cand : fftup_jit::fused_candidates(base.UW, base.D, 5)) {
         if (base.fused_kind == 2 && cand.T == base.fused_t && cand.r == base.fr) continue;
         fftup_jit::Choice c = base;
         fftup_jit::set_fused_n(c, cand.T, cand.r);
+        cands.push_back(c);
+    }
+    for (const fftup_jit::Choice& c : cands) {
         if (c.fused_lds > 160 * 1024) continue;
         std::string err;
         fftup_jit::Module* m = fftup_jit::load(c, arch, err);

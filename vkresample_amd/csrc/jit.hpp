@@ -37,12 +37,14 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -423,8 +425,9 @@ static std::string fused_value(const Choice& c)
 // Factorizations for a W x H -> (D/2) W x (D/2) H plan.  D = 2 x the upscale factor: even = integer factor U = D/2
 // (polyphase column pass), odd = half-integer factor.  false: some dimension has no supported factorization (the plan
 // then stays on the size-generic kernels).  ct_radices: the stage list of the size-generic plan for the output width
-// (radices <= 8); arch: device + mode key of the tuner's wisdom file ("" = built-in wisdom only).
-static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, Choice& c, const std::string& arch = "")
+// (radices <= 8); arch: device + mode key of the tuner's wisdom file ("" = built-in wisdom only); use_wisdom = false: the
+// structural default (pow2 / 16*16*R / the chooser's pick), whatever the wisdom says -- the tuner times it as a candidate.
+static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, Choice& c, const std::string& arch = "", bool use_wisdom = true)
 {
     const int U = D % 2 == 0 ? D / 2 : 1;
     c.W = W; c.H = H; c.U = U; c.D = D; c.UW = D * W / 2; c.UH = D * H / 2; c.half = half;
@@ -482,7 +485,7 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
         if (c.fused_lds > 160 * 1024) return false;
     }
     // what the plan-time tuner found best on this device for rows of this length (wisdom.txt)
-    if (!getenv("FFTUP_JIT_FUSED")) {
+    if (use_wisdom && !getenv("FFTUP_JIT_FUSED")) {
         std::string w;
         bool have = !arch.empty() && wisdom_lookup(fused_key(c, arch), w);
         if (!have && !getenv("FFTUP_JIT_NO_BUILTIN_WISDOM"))
@@ -500,6 +503,10 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
             long prod = 1;
             bool ok = r.size() >= 2 && T >= 64 && T <= 1024 && T % 64 == 0 && r[0] % D == 0;
             for (int q : r) { ok &= is_radix(q); prod *= q; }
+            // (a hand-edited or stale entry must pass the chooser's own bound: at most 16 points per thread in every stage --
+            // 16,3,16 on UW/16 threads needs 18 and would not compile, leaving the plan on the size-generic kernels for good)
+            if (ok && prod == UW)
+                for (int q : r) ok &= ((UW / q + T - 1) / T) * q <= 16;
             if (ok && prod == UW && T >= UW / r[0] && T >= UW / r.back() && sizeof(float2) * (size_t)UW * 2 + 1024 <= 160 * 1024) set_fused_n(c, T, r);
         }
     }
@@ -694,8 +701,13 @@ struct Binary {
 static bool load_cached(const std::string& path, Binary& b)
 {
     std::string raw;
-    if (!read_file(path, raw) || raw.size() < 16 || raw.compare(0, 6, "FJIT1\n") != 0) return false;
-    size_t off = 6;
+    if (!read_file(path, raw) || raw.size() < 24 || raw.compare(0, 6, "FJIT2\n") != 0) return false;
+    // FJIT2: magic, fnv1a of everything behind the checksum, lowered names, code -- a file that another process or thread
+    // is still writing, or a torn one, does not load
+    uint64_t sum;
+    memcpy(&sum, raw.data() + 6, 8);
+    if (sum != fnv1a(raw.substr(14))) return false;
+    size_t off = 14;
     auto rd = [&](void* dst, size_t n) { if (off + n > raw.size()) return false; memcpy(dst, raw.data() + off, n); off += n; return true; };
     for (int k = 0; k < K_COUNT; k++) {
         uint32_t len;
@@ -711,16 +723,23 @@ static bool load_cached(const std::string& path, Binary& b)
 
 static void store_cached(const std::string& path, const Binary& b)
 {
-    const std::string tmp = path + "." + std::to_string((long)getpid()) + ".tmp";
-    FILE* f = fopen(tmp.c_str(), "wb");
-    if (!f) return;
-    bool ok = fwrite("FJIT1\n", 1, 6, f) == 6;
+    std::string body;
     for (int k = 0; k < K_COUNT; k++) {
         const uint32_t len = (uint32_t)b.lowered[k].size();
-        ok &= fwrite(&len, 4, 1, f) == 1 && fwrite(b.lowered[k].data(), 1, len, f) == len;
+        body.append((const char*)&len, 4);
+        body += b.lowered[k];
     }
     const uint64_t cs = b.code.size();
-    ok &= fwrite(&cs, 8, 1, f) == 1 && fwrite(b.code.data(), 1, cs, f) == cs;
+    body.append((const char*)&cs, 8);
+    body += b.code;
+    const uint64_t sum = fnv1a(body);
+    // a temporary of its own per writer (mkstemp: threads of one process share the pid), published by rename
+    std::string tmp = path + ".XXXXXX";
+    const int fd = mkstemp(&tmp[0]);
+    if (fd < 0) return;
+    FILE* f = fdopen(fd, "wb");
+    if (!f) { (void)close(fd); (void)unlink(tmp.c_str()); return; }
+    bool ok = fwrite("FJIT2\n", 1, 6, f) == 6 && fwrite(&sum, 8, 1, f) == 1 && fwrite(body.data(), 1, body.size(), f) == body.size();
     ok &= fclose(f) == 0;
     if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
 }
@@ -772,14 +791,27 @@ static bool compile(const Choice& c, const std::string& arch, int part, Binary& 
     char keyhex[32];
     snprintf(keyhex, sizeof keyhex, "%016llx", (unsigned long long)key);
 
-    // (the lock guards the in-memory table only: the two parts of a plan compile side by side, compile_both())
+    // The lock guards the tables only (the two parts of a plan compile side by side, compile_both()).  Threads that ask for
+    // a translation unit another thread is compiling right now wait for it instead of compiling it again (the CLI's
+    // -numthreads mode: N threads create plans of one size at the same moment).
     static std::mutex mu;
+    static std::condition_variable cv;
     static std::map<uint64_t, Binary> memo;
+    static std::set<uint64_t> in_flight;
     {
-        std::lock_guard<std::mutex> lock(mu);
-        auto it = memo.find(key);
-        if (it != memo.end()) { out = it->second; return true; }
+        std::unique_lock<std::mutex> lock(mu);
+        for (;;) {
+            auto it = memo.find(key);
+            if (it != memo.end()) { out = it->second; return true; }
+            if (!in_flight.count(key)) break;
+            cv.wait(lock);
+        }
+        in_flight.insert(key);
     }
+    struct Done {                                   // whatever way this call ends: let the waiters look again
+        uint64_t key;
+        ~Done() { { std::lock_guard<std::mutex> lock(mu); in_flight.erase(key); } cv.notify_all(); }
+    } done{key};
     const std::string cdir = cache_dir();
     const std::string cpath = cdir.empty() ? "" : cdir + "/" + keyhex + ".fjit";
     if (!cpath.empty() && load_cached(cpath, out)) { std::lock_guard<std::mutex> lock(mu); memo[key] = out; return true; }
