@@ -51,9 +51,15 @@ enum {
     FFTUP_FLAG_GENERIC_KERNELS = 4u, /* force the size-generic kernels even where a tuned plan exists    */
     FFTUP_FLAG_UNFUSED_SHARPEN = 8u, /* keep C2R and sharpen as two launches with the pre-sharpen image in
                                         HBM, like the reference (tempBuffer); default fuses them          */
-    FFTUP_FLAG_TUNE_PLAN = 16u       /* plans specialised at plan time (below): compile and time the alternatives for the fused
+    FFTUP_FLAG_TUNE_PLAN = 16u,      /* plans specialised at plan time (below): compile and time the alternatives for the fused
                                         kernel's factorization on the device, keep the fastest, remember it in
                                         <cache dir>/wisdom.txt (a few seconds, once per row length and device)            */
+    FFTUP_FLAG_FUSE_U8_STORE = 32u   /* 8-bit pipelines (the reference's own: PNG in, PNG out): the fused C2R+sharpen kernel stores
+                                        the interleaved 8-bit RGB image itself (the conversion of VR:1708-1748 in registers); the
+                                        float / half planes are never written, fftup_download_rgb8 / fftup_submit_rgb8 need no
+                                        conversion launch, fftup_download_planar fails with FFTUP_E_INVALID_ARG.  Plans without a
+                                        fused kernel (size-generic, -p 1, non-R2C, FFTUP_FLAG_UNFUSED_SHARPEN) ignore the flag:
+                                        fftup_info.u8_store says which it is                                               */
 };
 
 /* Replaces VkResampleConfiguration (VR:45-59) + the part of VkFFTConfiguration (VF:22-94) that
@@ -107,7 +113,7 @@ typedef struct fftup_info {
     double   kernel_min_bytes[FFTUP_NUM_KERNELS]; /* bytes each kernel has to move through HBM as implemented
                                                      (e.g. fused: spectrum rows incl. strip halos + out)               */
     uint32_t abi_version;                /* FFTUP_ABI_VERSION of the library                      */
-    uint32_t reserved_;
+    uint32_t u8_store;                   /* 1: the plan's output slots hold 8-bit RGB (FFTUP_FLAG_FUSE_U8_STORE in effect)     */
 } fftup_info;
 
 /* devices_list() VR:239-268 */

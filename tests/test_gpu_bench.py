@@ -19,8 +19,9 @@ def _line(out):
 
 
 def test_bench_single_rank_line():
+    env = {k: v for k, v in os.environ.items() if k != "FFTUP_CACHE_DIR"}        # (as the driver runs it: no cache dir pinned)
     r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--repeats", "3", "--frames-per-step", "64",
-                        "--cpu-frames", "1", "--profile-iters", "5"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "--cpu-frames", "1", "--profile-iters", "5"], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _line(r.stdout)
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "frames/s" and d["higher_is_better"] is True

@@ -577,6 +577,60 @@ def test_hip_path_reproduces_reference_output_crops(name, flags):
     assert st["mean"] <= 0.35 and st["p99"] <= 2 and st["p99.9"] <= 3 and st["max"] <= 5, st
 
 
+U8_STORE_CASES = [(2048, 1024, 0, 0), (2048, 1024, 2, 2), (1920, 1080, 0, 2), (1280, 720, 2, 2), (512, 256, 0, 1), (1000, 1000, 0, 0),
+                  (640, 480, 2, 2), (1024, 512, 0, 0)]
+
+
+@pytest.mark.parametrize("W,H,precision,flags", U8_STORE_CASES)
+def test_fused_u8_store_equals_planes_plus_conversion(W, H, precision, flags):
+    """FFTUP_FLAG_FUSE_U8_STORE (SURVEY 8 f3 as written): the fused C2R+sharpen kernel stores the interleaved 8-bit image
+    itself.  Same bytes, all of them, as the float / half planes followed by the conversion launch (k_pack_u8) -- for the
+    ahead-of-time plans (2048x1024, 1920x1080, 1280x720, 512x256), plans specialised at plan time (1000x1000, 640x480), the
+    wrapping store (flag 1) -- and within one code of the oracle (BASELINE configs 2, 3, 4); no float planes exist."""
+    import vkresample_amd as v
+    from vkresample_amd import FLAG_FUSE_U8_STORE, synth
+    rgb = synth.frame(31, W, H, "U" if flags & 1 else "N")
+    with _up(W, H, 2.0, precision, 0.2, 0, flags) as up:
+        up.upload_rgb8(rgb)
+        up.execute(1)
+        ref = up.download_rgb8()
+        assert not up.u8_store
+    with _up(W, H, 2.0, precision, 0.2, 0, flags | FLAG_FUSE_U8_STORE) as up:
+        assert up.u8_store and "8-bit RGB store" in up.description
+        up.upload_rgb8(rgb)
+        up.execute(2)
+        got = up.download_rgb8()
+        with pytest.raises(v.FftupError):
+            up.download_planar()
+        assert up.output_checksum(0) == int(np.frombuffer(got.tobytes(), dtype=np.uint32).astype(np.uint64).sum())
+    assert np.array_equal(got, ref), (np.argwhere(got != ref)[:5], (got != ref).sum())
+    if W * H <= 2048 * 1024 and not (flags & 1):
+        _, _, ou8 = O.upscale_rgb8(rgb, 2.0, precision, 0.2)
+        d = np.abs(got[:-1].astype(int) - ou8[:-1].astype(int))
+        assert d.max() <= (1 if precision == 0 else 2)
+
+
+def test_fused_u8_store_host_streamed_and_unfused_fallback():
+    """the host-streamed queue with the fused 8-bit store (no conversion launch between the kernels and the D2H copy), and a
+    plan without a fused kernel: the flag is ignored, fftup_info says so, the bytes are the same"""
+    import vkresample_amd as v
+    from vkresample_amd import FLAG_FUSE_U8_LOAD, FLAG_FUSE_U8_STORE, FLAG_GENERIC_KERNELS, synth
+    W, H, n = 1024, 512, 6
+    frames = [synth.frame(80 + k, W, H) for k in range(n)]
+    outs = []
+    for fl in (FLAG_FUSE_U8_LOAD, FLAG_FUSE_U8_LOAD | FLAG_FUSE_U8_STORE, FLAG_GENERIC_KERNELS | FLAG_FUSE_U8_STORE):
+        with v.Upscaler(W, H, 2.0, 0, 0.2, 0, fl, ring=3) as up, v.PinnedArray((n, H, W, 3)) as pi, v.PinnedArray((n, 2 * H, 2 * W, 3)) as po:
+            assert up.u8_store == (fl == (FLAG_FUSE_U8_LOAD | FLAG_FUSE_U8_STORE))
+            for k in range(n):
+                pi.array[k] = frames[k]
+                up.submit_rgb8(pi.array[k], po.array[k])
+            up.drain()
+            outs.append(po.array.copy())
+    assert np.array_equal(outs[0], outs[1])
+    d = np.abs(outs[2][:, :-1].astype(int) - outs[0][:, :-1].astype(int))
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-3          # size-generic kernels: other fp32 roundings, same pixels
+
+
 def test_plans_in_concurrent_host_threads():
     """one plan per host thread, no shared mutable state (the reference's -numthreads model, VR:1282-1320, 1959-1969):
     four threads with different configurations run interleaved on one device and reproduce their single-threaded

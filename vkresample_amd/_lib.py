@@ -13,6 +13,7 @@ FLAG_FUSE_U8_LOAD = 2
 FLAG_GENERIC_KERNELS = 4
 FLAG_UNFUSED_SHARPEN = 8
 FLAG_TUNE_PLAN = 16
+FLAG_FUSE_U8_STORE = 32
 
 # every symbol include/fftup.h declares
 EXPORTS = [
@@ -38,7 +39,7 @@ class Info(C.Structure):
                 ("kernel_alg_bytes", C.c_double * FFTUP_NUM_KERNELS), ("device_bytes", C.c_uint64),
                 ("device_name", C.c_char * 256), ("kernel_names", (C.c_char * 64) * FFTUP_NUM_KERNELS),
                 # appended in ABI version 2
-                ("kernel_min_bytes", C.c_double * FFTUP_NUM_KERNELS), ("abi_version", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("kernel_min_bytes", C.c_double * FFTUP_NUM_KERNELS), ("abi_version", C.c_uint32), ("u8_store", C.c_uint32)]
 
 
 _lib = None

@@ -66,6 +66,7 @@ class Upscaler:
         self.device_name = info.device_name.decode()
         self.device_bytes = info.device_bytes
         self.tuned = bool(info.tuned)
+        self.u8_store = bool(info.u8_store)             # output slots hold 8-bit RGB (FLAG_FUSE_U8_STORE in effect)
         _buf = C.create_string_buffer(512)
         _check(self._lib.fftup_plan_describe(self._h, _buf, 512), "fftup_plan_describe")
         self.description = _buf.value.decode()

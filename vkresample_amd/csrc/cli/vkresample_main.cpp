@@ -8,6 +8,7 @@
 // Extensions (do not change the reference behaviour when absent):
 //   -alldevices   batched mode: thread t uses device (d + t) % device_count instead of all threads on -d
 //   -fuseu8       the row kernel reads the uint8 image directly (README.md:31 roadmap item)
+//   -fuseu8out    the last kernel stores the 8-bit image itself (FFTUP_FLAG_FUSE_U8_STORE): no float planes, no conversion launch
 //   -wrapu8       u8 store wraps like the reference's C cast instead of saturating
 //   -workqueue    batched mode: threads take the next unprocessed file from ONE shared counter (dynamic balancing over
 //                 threads / GPUs of unequal speed) instead of the static stripe t+1, t+1+T, .. of VR:1622-1629
@@ -247,6 +248,7 @@ int main(int argc, char* argv[])
         printf("Extensions:\n");
         printf("	-alldevices: thread t runs on GPU (d + t) %% count\n");
         printf("	-fuseu8: FFT kernel reads the 8-bit image directly\n");
+        printf("	-fuseu8out: the last kernel writes the 8-bit image directly (no float planes, no conversion pass)\n");
         printf("	-wrapu8: 8-bit store wraps like the original's C cast instead of saturating\n");
         printf("	-workqueue: batched mode: threads take the next unprocessed file from one shared counter instead of the fixed stripe\n");
         printf("	-tune: sizes whose kernels are specialised at plan time: measure the alternatives once, remember the fastest\n");
@@ -283,6 +285,7 @@ int main(int argc, char* argv[])
     }
     config.allDevices = findFlag(B, E, "-alldevices");
     if (findFlag(B, E, "-fuseu8")) config.flags |= FFTUP_FLAG_FUSE_U8_LOAD;
+    if (findFlag(B, E, "-fuseu8out")) config.flags |= FFTUP_FLAG_FUSE_U8_STORE;
     if (findFlag(B, E, "-wrapu8")) config.flags |= FFTUP_FLAG_U8_WRAP;
     if (findFlag(B, E, "-tune")) config.flags |= FFTUP_FLAG_TUNE_PLAN;
 

@@ -73,6 +73,7 @@ struct fftup_plan {
     float upsq = 0, coef = 0;
     bool tuned = false;
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
+    bool u8out = false;               // FFTUP_FLAG_FUSE_U8_STORE in effect: the fused kernel stores 8-bit RGB, `out` slots hold [uH][uW][3] bytes
     int mixed = 0;                    // compile-time mixed-radix plans: 1 = 1920x1080 -> 3840x2160, 2 = 1280x720 -> 2560x1440,
                                       // 3 = specialised at plan time for this size (jit.hpp), kernels in `jit`
     fftup_jit::Module* jit = nullptr;
@@ -424,6 +425,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
                 fftup_jit::Choice ch;
                 std::string jerr;
                 if (fftup_jit::choose((int)W, (int)H, D, P->half, stage_radices(P->planUW), ch, wisdom_device_key(P))) {
+                    ch.u8out = (cfg->flags & FFTUP_FLAG_FUSE_U8_STORE) != 0;         // (such a plan is always fused)
                     P->jit = fftup_jit::load(ch, P->prop.gcnArchName, jerr);
                     if (P->jit) { P->mixed = 3; P->U = ch.U; P->TK = 4; P->ldsCol = P->jit->choice.col_lds; }
                     else if (getenv("FFTUP_JIT_VERBOSE")) fprintf(stderr, "fftup: run-time specialisation failed, size-generic kernels in use: %s\n", jerr.c_str());
@@ -431,6 +433,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             }
         }
         P->fused = (P->tuned || P->mixed) && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
+        P->u8out = P->fused && (cfg->flags & FFTUP_FLAG_FUSE_U8_STORE);
         if (const char* e = getenv("FFTUP_3840_X16")) P->plan3840_x16 = atoi(e) != 0;
         set_strip_length(P);
         P->NT = (P->ncols + P->TK - 1) / P->TK;
@@ -461,7 +464,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         for (uint32_t s = 0; s < P->ring; s++) {
             PLAN_RC(dev_alloc(P, &P->in_planar[s], 3 * P->in_plane_stride * esz));
             PLAN_RC(dev_alloc(P, (void**)&P->in_u8[s], (size_t)3 * W * H));
-            PLAN_RC(dev_alloc(P, &P->out[s], (size_t)3 * uW * uH * esz));
+            PLAN_RC(dev_alloc(P, &P->out[s], (size_t)3 * uW * uH * (P->u8out ? 1 : esz)));
         }
         // tuned plans (k_col_t): S2 holds the odd rows only and sits right behind S1 in ONE allocation (the fused
         // kernel addresses both with 32-bit offsets from one base)
@@ -480,7 +483,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         // only needs one for the fftup_download_presharpen tap, which allocates it on first use (ensure_R)
         P->r_bytes = (size_t)3 * uW * uH * (cplx ? P->csz : esz);                  // non-R2C path: complex pre-sharpen image
         if (!P->fused) PLAN_RC(dev_alloc(P, &P->R, P->r_bytes));
-        PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH));
+        if (!P->u8out) PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH));       // staging of the conversion launch
         {
             int nl = 3;
             if (const char* e = getenv("FFTUP_STREAMS")) nl = atoi(e);
@@ -526,7 +529,9 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             default: SET_LDS((k_col<1, double2>), P->ldsCol); break;
             }
         }
-#define SET_FUSED(PL, TKK) do { if (P->half) SET_LDS((k_c2r_sharpen_g<PL, true, TKK>), FusedGLds<PL>::TOTAL); \
+#define SET_FUSED(PL, TKK) do { if (P->u8out) { if (P->half) SET_LDS((k_c2r_sharpen_g<PL, true, TKK, 2, 4, true>), FusedGLds<PL>::TOTAL); \
+                                                else SET_LDS((k_c2r_sharpen_g<PL, false, TKK, 2, 4, true>), FusedGLds<PL>::TOTAL); } \
+                                else if (P->half) SET_LDS((k_c2r_sharpen_g<PL, true, TKK>), FusedGLds<PL>::TOTAL); \
                                 else SET_LDS((k_c2r_sharpen_g<PL, false, TKK>), FusedGLds<PL>::TOTAL); } while (0)
 #define SET_MIXED(CFG) do { SET_LDS(k_col_m<CFG>, P->ldsCol); \
         if (P->half) SET_LDS((k_row_c2r_ct<CFG::CT, true>), P->ldsRowI); else SET_LDS((k_row_c2r_ct<CFG::CT, false>), P->ldsRowI); \
@@ -568,6 +573,7 @@ int fftup_plan_describe(const fftup_plan* P, char* buf, size_t buflen)
     else if (P->mixed) s = std::string("ahead-of-time mixed-radix kernels: ") + (P->mixed == 1 ? "row 15*8*16, col 9*10*12, fused 16*16*15" : "row 5*16*16, col 9*8*10, fused 16*16*10");
     else if (P->cplx) s = "size-generic kernels, non-R2C path (full complex transforms)";
     else s = std::string("size-generic kernels (LDS ping-pong, run-time radix lists)") + (P->dbl ? ", double" : "");
+    if (P->u8out) s += "; fused 8-bit RGB store";
     snprintf(buf, buflen, "%s", s.c_str());
     return FFTUP_OK;
 }
@@ -584,7 +590,7 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
     const double C = 3.0, W = P->W, H = P->H, uW = P->uW, uH = P->uH;
     const bool fused_u8 = fuse_u8(P);
     const double b_in = fused_u8 ? 1.0 : (double)P->esz;
-    const double b_r = (double)P->esz, b_out = b_r, b_c = (double)P->csz;
+    const double b_r = (double)P->esz, b_out = P->u8out ? 1.0 : b_r, b_c = (double)P->csz;
     const double in = C * W * H * b_in;
     const double S1 = C * P->ncols * H * b_c;
     const double S2 = C * P->ncols * uH * b_c;
@@ -610,6 +616,7 @@ int fftup_plan_info(const fftup_plan* P, fftup_info* info)
     }
     info->device_bytes = P->device_bytes;
     info->abi_version = FFTUP_ABI_VERSION;
+    info->u8_store = P->u8out ? 1 : 0;
     snprintf(info->device_name, sizeof info->device_name, "%s", P->prop.name);
     snprintf(info->kernel_names[0], 64, P->cplx ? "row_c2c" : "row_r2c");
     snprintf(info->kernel_names[1], 64, "col_fwd_pad_inv");
@@ -721,8 +728,13 @@ template <class PL> static void launch_fused_t(fftup_plan* P, const FusedParams&
 {
     const int total_pairs = 3 * (int)P->uH / 2;
     dim3 grid((total_pairs + p.pairs_per_strip - 1) / p.pairs_per_strip), block(PL::T);
-    if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_g<PL, true, TUNED_TK>), grid, block, FusedGLds<PL>::TOTAL, P->lanes[P->cur].stream, p);
-    else hipLaunchKernelGGL((k_c2r_sharpen_g<PL, false, TUNED_TK>), grid, block, FusedGLds<PL>::TOTAL, P->lanes[P->cur].stream, p);
+    hipStream_t st = P->lanes[P->cur].stream;
+    if (P->u8out) {
+        if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_g<PL, true, TUNED_TK, 2, 4, true>), grid, block, FusedGLds<PL>::TOTAL, st, p);
+        else hipLaunchKernelGGL((k_c2r_sharpen_g<PL, false, TUNED_TK, 2, 4, true>), grid, block, FusedGLds<PL>::TOTAL, st, p);
+    }
+    else if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_g<PL, true, TUNED_TK>), grid, block, FusedGLds<PL>::TOTAL, st, p);
+    else hipLaunchKernelGGL((k_c2r_sharpen_g<PL, false, TUNED_TK>), grid, block, FusedGLds<PL>::TOTAL, st, p);
 }
 static FusedParams fused_params(fftup_plan* P, uint32_t out_slot)
 {
@@ -731,6 +743,7 @@ static FusedParams fused_params(fftup_plan* P, uint32_t out_slot)
     if (P->U == 1) { p.S1 = P->lanes[P->cur].S2; p.odd_delta = 0; }      // half-integer factor: one buffer with all rows (k_col_pad)
     p.out = P->out[out_slot]; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
     p.pairs_per_strip = P->pairs_per_strip; p.upsq = P->upsq; p.coef = P->coef;
+    p.u8_wrap = (P->cfg.flags & FFTUP_FLAG_U8_WRAP) ? 1 : 0;
     return p;
 }
 
@@ -1137,8 +1150,10 @@ static void tune_fused(fftup_plan* P)
     {
         fftup_jit::Choice d;
         if (fftup_jit::choose(base.W, base.H, base.D, base.half, stage_radices(P->planUW), d, "", false) &&
-            fftup_jit::fused_value(d) != fftup_jit::fused_value(base))
+            fftup_jit::fused_value(d) != fftup_jit::fused_value(base)) {
+            d.u8out = base.u8out;
             cands.push_back(d);
+        }
     }
     for (const auto& cand : fftup_jit::fused_candidates(base.UW, base.D, 5)) {
         if (base.fused_kind == 2 && cand.T == base.fused_t && cand.r == base.fr) continue;
@@ -1246,6 +1261,7 @@ int fftup_download_planar(fftup_plan* P, uint32_t slot, void* planes)
     if (rc) return rc;
     if (!planes) return fail(FFTUP_E_INVALID_ARG, "null destination");
     if (!P->executed) return fail(FFTUP_E_NO_INPUT, "nothing executed yet");
+    if (P->u8out) return fail(FFTUP_E_INVALID_ARG, "the plan stores 8-bit RGB only (FFTUP_FLAG_FUSE_U8_STORE): use fftup_download_rgb8");
     HIP_TRY(hipSetDevice(P->device));
     HIP_TRY(hipMemcpyAsync(planes, P->out[slot], (size_t)3 * P->uW * P->uH * P->esz, hipMemcpyDeviceToHost, P->stream));
     HIP_TRY(hipStreamSynchronize(P->stream));
@@ -1306,7 +1322,7 @@ int fftup_output_checksum(fftup_plan* P, uint32_t slot, uint64_t* sum)
         if (rc) return rc;
     }
     HIP_TRY(hipMemsetAsync(P->d_sum, 0, sizeof(uint64_t), P->stream));
-    const size_t nwords = (size_t)3 * P->uW * P->uH * P->esz / 4;          // (uW even: whole words for binary16 too)
+    const size_t nwords = (size_t)3 * P->uW * P->uH * (P->u8out ? 1 : P->esz) / 4;       // (uW, uH even: whole words for binary16 and bytes too)
     hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, P->stream, (const uint32_t*)P->out[slot], nwords, (unsigned long long*)P->d_sum);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(sum, P->d_sum, sizeof(uint64_t), hipMemcpyDeviceToHost, P->stream));
@@ -1336,9 +1352,13 @@ int fftup_download_rgb8(fftup_plan* P, uint32_t slot, uint8_t* rgb, size_t row_s
     if (!rgb || row_stride_bytes < (size_t)3 * P->uW) return fail(FFTUP_E_INVALID_ARG, "bad rgb pointer/stride");
     if (!P->executed) return fail(FFTUP_E_NO_INPUT, "nothing executed yet");
     HIP_TRY(hipSetDevice(P->device));
-    launch_pack(P, slot, P->out_u8, P->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy2DAsync(rgb, row_stride_bytes, P->out_u8, (size_t)3 * P->uW, (size_t)3 * P->uW, P->uH, hipMemcpyDeviceToHost, P->stream));
+    const uint8_t* src = (const uint8_t*)P->out[slot];                      // (FFTUP_FLAG_FUSE_U8_STORE: the slot holds the bytes already)
+    if (!P->u8out) {
+        launch_pack(P, slot, P->out_u8, P->stream);
+        HIP_TRY(hipGetLastError());
+        src = P->out_u8;
+    }
+    HIP_TRY(hipMemcpy2DAsync(rgb, row_stride_bytes, src, (size_t)3 * P->uW, (size_t)3 * P->uW, P->uH, hipMemcpyDeviceToHost, P->stream));
     HIP_TRY(hipStreamSynchronize(P->stream));
     return FFTUP_OK;
 }
@@ -1369,7 +1389,8 @@ static int queue_init(fftup_plan* P)
     std::vector<fftup_plan::QSlot> q(P->ring);
     int rc = FFTUP_OK;
     for (uint32_t s = 0; s < P->ring && !rc; s++) {
-        if (s == 0) q[s].out_u8 = P->out_u8;
+        if (P->u8out) q[s].out_u8 = (uint8_t*)P->out[s];                            // the output slot holds the bytes
+        else if (s == 0) q[s].out_u8 = P->out_u8;
         else rc = dev_alloc(P, (void**)&q[s].out_u8, (size_t)3 * P->uW * P->uH);     // owned by P->allocs either way
         if (!rc) {
             hipError_t e = hipEventCreateWithFlags(&q[s].done, hipEventDisableTiming);
@@ -1418,7 +1439,7 @@ int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, ui
     P->last_lane = lane;
     P->cur = 0;
     if (rc) return rc;
-    launch_pack(P, s, Q.out_u8, cs);
+    if (!P->u8out) launch_pack(P, s, Q.out_u8, cs);
     HIP_TRY(hipGetLastError());
     if (out_stride == out_row) HIP_TRY(hipMemcpyAsync(rgb_out, Q.out_u8, out_row * P->uH, hipMemcpyDeviceToHost, cs));
     else HIP_TRY(hipMemcpy2DAsync(rgb_out, out_stride, Q.out_u8, out_row, out_row, P->uH, hipMemcpyDeviceToHost, cs));

@@ -86,6 +86,7 @@ struct Choice {
     // launch geometry derived from the above (what the device-side templates compute for themselves)
     int row_block = 0, col_block = 0;
     size_t col_lds = 0, fused_lds = 0, ct_lds = 0;
+    bool u8out = false;                // fused kernel stores interleaved 8-bit RGB (FFTUP_FLAG_FUSE_U8_STORE)
 };
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
@@ -579,7 +580,7 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT], int 
     s += "}\n";
     const std::string hb = c.half ? "true" : "false";
     const std::string U = std::to_string(c.U) + ", " + std::to_string(c.D);
-    names[K_FUSED] = "fftup::k_c2r_sharpen_g<fftup::JitFused, " + hb + ", 4, " + U + ">";
+    names[K_FUSED] = "fftup::k_c2r_sharpen_g<fftup::JitFused, " + hb + ", 4, " + U + (c.u8out ? ", true>" : ">");
     names[K_C2R_CT] = "fftup::k_row_c2r_ct<fftup::JitCT, " + hb + ", " + U + ">";
     return s;
 }

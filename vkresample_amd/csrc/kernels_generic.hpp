@@ -357,6 +357,33 @@ __global__ void __launch_bounds__(256) k_unpack_u8(const uint8_t* rgb, long row_
     }
 }
 
+// u8 = (unsigned char)(255.0 * x) of VkResample.cpp:1715: the product in double (exact for a float x), the C cast = truncation;
+// out of range (undefined in the reference): saturating, or wrapping like the x86 cast (FFTUP_FLAG_U8_WRAP)
+__device__ __forceinline__ uint8_t cvt_f_u8(float v, int wrap)
+{
+    const double d = 255.0 * (double)v;
+    if (wrap) return (d > -2147483648.0 && d < 2147483648.0) ? (uint8_t)(((int)d) & 0xFF) : 0;
+    return !(d > 0.0) ? 0 : (d >= 255.0 ? 255 : (uint8_t)d);
+}
+
+// The same for four pixels in registers (the fused kernel's 8-bit store): saturating form without double arithmetic.
+// trunc(255 x) of the EXACT product = trunc of the product rounded TOWARD ZERO (an integer n <= 255 x is representable, so the
+// rounded product cannot fall below it): four v_mul_f32 between two changes of the rounding mode -- one asm statement, the
+// compiler cannot move anything affected in between -- then v_cvt_u32_f32 (truncates; negative and NaN -> 0) and a minimum.
+// Bit for bit cvt_f_u8 (tests: the fused store against planes + k_pack_u8 on whole frames).
+__device__ __forceinline__ void cvt4_f_u8(float a, float b, float c, float d, int wrap, uint8_t (&o)[4])
+{
+    if (wrap) { o[0] = cvt_f_u8(a, 1); o[1] = cvt_f_u8(b, 1); o[2] = cvt_f_u8(c, 1); o[3] = cvt_f_u8(d, 1); return; }      // (wave-uniform)
+    float ta, tb, tc, td;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_mul_f32 %0, 0x437f0000, %4\n\tv_mul_f32 %1, 0x437f0000, %5\n\tv_mul_f32 %2, 0x437f0000, %6\n\tv_mul_f32 %3, 0x437f0000, %7\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(ta), "=&v"(tb), "=&v"(tc), "=&v"(td) : "v"(a), "v"(b), "v"(c), "v"(d));
+    // (the instruction, not a C++ cast: out-of-range float -> unsigned is undefined in the language, saturating in the hardware)
+    auto cvt = [](float t) { unsigned k; asm("v_cvt_u32_f32 %0, %1" : "=v"(k) : "v"(t)); return (uint8_t)min(k, 255u); };
+    o[0] = cvt(ta); o[1] = cvt(tb); o[2] = cvt(tc); o[3] = cvt(td);
+}
+
 // VkResample.cpp:1708-1748: planar float/half -> u8 interleaved, u8 = (unsigned char)(255.0*x)
 template <bool HALF>
 __global__ void __launch_bounds__(256) k_pack_u8(const void* planes, uint8_t* rgb, int uW, int uH, int wrap)
@@ -370,14 +397,7 @@ __global__ void __launch_bounds__(256) k_pack_u8(const void* planes, uint8_t* rg
         float v;
         if constexpr (HALF) v = __half2float(((const __half*)planes)[c * plane + (long)y * uW + x]);
         else v = ((const float*)planes)[c * plane + (long)y * uW + x];
-        double d = 255.0 * (double)v;            // the reference multiplies in double
-        uint8_t o;
-        if (wrap) {
-            o = (d > -2147483648.0 && d < 2147483648.0) ? (uint8_t)(((int)d) & 0xFF) : 0;
-        } else {
-            o = !(d > 0.0) ? 0 : (d >= 255.0 ? 255 : (uint8_t)d);
-        }
-        rgb[((long)y * uW + x) * 3 + c] = o;
+        rgb[((long)y * uW + x) * 3 + c] = cvt_f_u8(v, wrap);
     }
 }
 

@@ -831,6 +831,7 @@ struct FusedParams {
     int uH, NT;
     int pairs_per_strip;
     float upsq, coef;
+    int u8_wrap;             // OUT_U8 kernels: `out` is the interleaved 8-bit RGB image [uH][uW][3]; FFTUP_FLAG_U8_WRAP
 };
 
 __host__ __device__ constexpr size_t fused_buf_bytes(int uw) { return (sizeof(float2) * lswz_size(uw) + 15) & ~(size_t)15; }
@@ -1311,7 +1312,8 @@ template <class PL> struct FusedGLds {
 
 // The one pixel per row pair that has to wait for the next pair, (y, UW-1): its SE tap is L(y+2, 0).  Taps: row y-1
 // (n0, n1 | ne), row y (m0, m1 | me), row y+1 (s0, s1 | se) at x = UW-2, UW-1 | the wrapped right neighbour.
-template <bool HALF>
+// `of` = index of the pixel in the dense planes; OUT_U8: (row * UW + x) * 3 + c in the interleaved 8-bit image
+template <bool HALF, bool OUT_U8 = false>
 __device__ __forceinline__ void deferred_pixel(const FusedParams& p, long of, float n0, float n1, float ne, float m0, float m1, float me,
                                                float s0, float s1, float se)
 {
@@ -1323,12 +1325,14 @@ __device__ __forceinline__ void deferred_pixel(const FusedParams& p, long of, fl
         const h2v mx0 = pk_max3(a0, b0, c0), mx1 = pk_max3(a1, b1, c1), mx2 = pk_max3(a2, b2, c2);
         const h2v o = sharpen_eval_pair_half(a1, c1, b0, b2, b1, pk_min3(mn1, b0, b2), pk_min3(mn0, mn1, mn2),
                                              pk_max3(mx1, b0, b2), pk_max3(mx0, mx1, mx2), h2_splat(-p.coef));
-        ((_Float16*)p.out)[of] = o.x;
+        if constexpr (OUT_U8) ((uint8_t*)p.out)[of] = cvt_f_u8((float)o.x, p.u8_wrap);
+        else ((_Float16*)p.out)[of] = o.x;
     } else {
         const float tt[3][6] = {{n0, n0, n1, ne, ne, ne}, {m0, m0, m1, me, me, me}, {s0, s0, s1, se, se, se}};
         float o[4];
         sharpen_quad<false>(tt, p.coef, o);
-        ((float*)p.out)[of] = o[1];
+        if constexpr (OUT_U8) ((uint8_t*)p.out)[of] = cvt_f_u8(o[1], p.u8_wrap);
+        else ((float*)p.out)[of] = o[1];
     }
 }
 
@@ -1339,7 +1343,11 @@ __device__ __forceinline__ void deferred_pixel(const FusedParams& p, long of, fl
 // reference's normalisation), p.odd_delta elements apart.  U = 2 for all ahead-of-time plans.
 // Half-integer factors (-u 1.5, 2.5: k_col_pad writes all rows of the zero-padded inverse into ONE buffer at the
 // reference's normalisation): U = 1 and D = 2u, the spectrum rows hold kx = 0..UW/D.
-template <class PL, bool HALF, int TK, int U = 2, int D = 2 * U>
+// OUT_U8 (FFTUP_FLAG_FUSE_U8_STORE): the kernel stores the interleaved 8-bit RGB image itself -- the conversion
+// of VkResample.cpp:1708-1748 on the sharpened values in registers, bit for bit what k_pack_u8 makes of the stored planes
+// (cvt_f_u8) -- four byte stores per quad, one base register + immediate offsets; the float / half planes are never
+// written (100 MB less HBM traffic per 4096x2048 frame than planes + k_pack_u8).
+template <class PL, bool HALF, int TK, int U = 2, int D = 2 * U, bool OUT_U8 = false>
 __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
 {
     constexpr int UW = PL::UW, T = PL::T, R0 = PL::R0, NB0 = PL::NB0, NI = R0 / D, KH = UW / D;
@@ -1543,8 +1551,8 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                         if constexpr (HALF) { r2a = (float)R2.h23.x; r2b = (float)R2.h23.y; r1a = (float)R1.h23.x; r1b = (float)R1.h23.y; r10 = (float)R2.sc.y; }
                         else { r2a = R2.q.z; r2b = R2.q.w; r1a = R1.q.z; r1b = R1.q.w; r10 = R2.r; }
                         if (s > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1)
-                            deferred_pixel<HALF>(p, c * plane + (long)(a - 2) * UW + (UW - 1), pn0, pn1, (a - 2 == 0) ? r10 : lprev0,
-                                                 r2a, r2b, r10, r1a, r1b, la0);
+                            deferred_pixel<HALF, OUT_U8>(p, OUT_U8 ? ((long)(a - 2) * UW + (UW - 1)) * 3 + c : c * plane + (long)(a - 2) * UW + (UW - 1),
+                                                         pn0, pn1, (a - 2 == 0) ? r10 : lprev0, r2a, r2b, r10, r1a, r1b, la0);
                         if (a == 0) { pn0 = (float)cur[UW - 2]; pn1 = (float)cur[UW - 1]; }       // (top strip, first step only)
                         else { pn0 = r1a; pn1 = r1b; }
                         lprev0 = la0;
@@ -1616,6 +1624,13 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                             if (w == 0 ? !out0 : !out1) continue;
                             h2v o01, o23;
                             sharpen_quad_half(R[w], R[w + 1], R[w + 2], ncoef, o01, o23);
+                            if constexpr (OUT_U8) {
+                                uint8_t* d8 = (uint8_t*)p.out + ((long)(a - 1 + w) * UW * 3 + c) + (unsigned)x0 * 3u;    // (uniform base + x0 * 3)
+                                uint8_t b8[4];
+                                cvt4_f_u8((float)o01.x, (float)o01.y, (float)o23.x, (float)o23.y, p.u8_wrap, b8);
+                                d8[0] = b8[0]; d8[3] = b8[1]; d8[6] = b8[2]; d8[9] = b8[3];
+                                continue;
+                            }
                             const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
                             f2v val = {__builtin_bit_cast(float, o01), __builtin_bit_cast(float, o23)};
                             __builtin_nontemporal_store(val, (f2v*)((char*)((__half*)p.out + row_of) + (unsigned)x0 * 2u));
@@ -1687,6 +1702,13 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                         float vmn[6], vmx[6];
                         sharpen_vminmax(t, w, vmn, vmx);
                         const f4t o = sharpen_quad_packed(t, w, vmn, vmx, p.coef);
+                        if constexpr (OUT_U8) {
+                            uint8_t* d8 = (uint8_t*)p.out + ((long)(a - 1 + w) * UW * 3 + c) + (unsigned)x0 * 3u;        // (uniform base + x0 * 3)
+                            uint8_t b8[4];
+                            cvt4_f_u8(o.x, o.y, o.z, o.w, p.u8_wrap, b8);
+                            d8[0] = b8[0]; d8[3] = b8[1]; d8[6] = b8[2]; d8[9] = b8[3];
+                            continue;
+                        }
                         const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
                         __builtin_nontemporal_store(o, (f4t*)((char*)((float*)p.out + row_of) + (unsigned)x0 * 4u));
                     }
@@ -1709,7 +1731,7 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                     const LT* r1 = rowp(-1);
                     const float r10 = (float)r1[0], r00 = (float)rowp(0)[0];
                     if (s > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1)
-                        deferred_pixel<HALF>(p, c * plane + (long)(a - 2) * UW + (UW - 1), pn0, pn1, (a - 2 == 0) ? r10 : (float)r2[0],
+                        deferred_pixel<HALF, OUT_U8>(p, OUT_U8 ? ((long)(a - 2) * UW + (UW - 1)) * 3 + c : c * plane + (long)(a - 2) * UW + (UW - 1), pn0, pn1, (a - 2 == 0) ? r10 : (float)r2[0],
                                              (float)r2[UW - 2], (float)r2[UW - 1], r10, (float)r1[UW - 2], (float)r1[UW - 1], r00);
                     const LT* rn = (a == 0) ? rowp(0) : rowp(-1);
                     pn0 = (float)rn[UW - 2];
