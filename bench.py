@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--upscale", type=float, default=2.0)
     ap.add_argument("--precision", type=int, default=0, help="0 = fp32 (headline), 1 = fp64, 2 = fp16 memory")
     ap.add_argument("--fuse-u8", action="store_true", help="row kernel reads uint8 RGB directly")
+    ap.add_argument("--fuse-u8-store", action="store_true", help="the fused C2R+sharpen kernel stores 8-bit RGB (FFTUP_FLAG_FUSE_U8_STORE): 8-bit in, 8-bit out")
     ap.add_argument("--generic", action="store_true", help="size-generic kernels (FFTUP_FLAG_GENERIC_KERNELS): no tuned, no plan-time specialised plan")
     ap.add_argument("--tune", action="store_true", help="FFTUP_FLAG_TUNE_PLAN: plan-time tuner for sizes specialised at plan time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -131,9 +132,9 @@ def other_configs(v, synth, dev, ring=8):
     """Short runs of the other single-GPU BASELINE configurations on the same GPU, same method as the headline (ring of
     resident frames, three streams, HIP events per kernel), and the reference's -n 1000 figure on ring-less plans."""
     out = {}
-    for name in ("config3", "config4"):
-        c = PRESETS[name]
-        flags = v.FLAG_FUSE_U8_LOAD if c["fuse_u8"] else 0
+    for name in ("config3", "config4", "config3_u8_store"):
+        c = PRESETS[name.replace("_u8_store", "")]
+        flags = (v.FLAG_FUSE_U8_LOAD if c["fuse_u8"] else 0) | (v.FLAG_FUSE_U8_STORE if name.endswith("_u8_store") else 0)
         with v.Upscaler(c["width"], c["height"], 2.0, c["precision"], 0.2, dev, flags, ring) as up:
             for s in range(ring):
                 up.upload_rgb8(synth.frame(s, c["width"], c["height"], "U"), slot=s)
@@ -141,7 +142,8 @@ def other_configs(v, synth, dev, ring=8):
             t = sorted(up.execute_ring(1024, 0) / 1024 for _ in range(3))[1]          # device ms per frame, median of three
             iso = up.profile_kernels(30)
             dom = max(range(len(iso)), key=lambda i: iso[i])
-            out[name] = {"workload": "%dx%d -u 2 -p %d%s" % (c["width"], c["height"], c["precision"], ", fused uint8 load" if c["fuse_u8"] else ""),
+            out[name] = {"workload": "%dx%d -u 2 -p %d%s%s" % (c["width"], c["height"], c["precision"], ", fused uint8 load" if c["fuse_u8"] else "",
+                                                                  ", fused 8-bit RGB store (8-bit in, 8-bit out)" if up.u8_store else ""),
                          "ms_per_frame": t, "frames_per_s": 1e3 / t,
                          "frame_frac": up.alg_bytes_per_frame / (t * 1e-3) / 8e12,
                          "kernel_ms": dict(zip(up.kernel_names, iso)),
@@ -190,7 +192,8 @@ def main():
     if v.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
     dev = local_rank % v.device_count()
-    flags = (v.FLAG_FUSE_U8_LOAD if args.fuse_u8 else 0) | (v.FLAG_GENERIC_KERNELS if args.generic else 0) | (v.FLAG_TUNE_PLAN if args.tune else 0)
+    flags = (v.FLAG_FUSE_U8_LOAD if args.fuse_u8 else 0) | (v.FLAG_GENERIC_KERNELS if args.generic else 0) | (v.FLAG_TUNE_PLAN if args.tune else 0) | \
+            (v.FLAG_FUSE_U8_STORE if args.fuse_u8_store else 0)
     up = v.Upscaler(args.width, args.height, args.upscale, args.precision, 0.2, dev, flags, args.ring)
     if args.job:
         # the reference's stripe (VR:1622-1629): thread/rank t of T takes files f*T + t; slot f holds this rank's f-th frame
@@ -301,7 +304,7 @@ def main():
         wall_frame_ms = dt / (args.steps * args.frames_per_step) * 1e3
         # measured HBM bytes (rocprofv3 --pmc, corrected as profiles/hbm_traffic.json documents) -- static: taken from the
         # committed profile of THIS configuration, not re-measured by this run
-        key = config_key(args)
+        key = config_key(args) + ("_u8out" if up.u8_store else "")
         traffic, frame_hbm, tsrc = None, None, None
         if os.path.exists(args.traffic_json):
             try:
@@ -315,7 +318,7 @@ def main():
                 traffic = None
         esz = {0: 4, 1: 8, 2: 2}[args.precision]
         b_in = 1 if (args.fuse_u8 and args.precision != 1) else esz
-        b_min = 3.0 * (args.width * args.height * b_in + up.out_width * up.out_height * esz)
+        b_min = 3.0 * (args.width * args.height * b_in + up.out_width * up.out_height * (1 if up.u8_store else esz))
         line = {
             "metric": "frames/s, %dx%d->%dx%d %s FFT upscale (R2C+zero-pad+C2R+sharpen)"
                       % (args.width, args.height, up.out_width, up.out_height, {0: "fp32", 1: "fp64", 2: "fp16-memory"}[args.precision]),
@@ -326,7 +329,8 @@ def main():
             "config": {"workload": "%dx%d->%dx%d -u %g -p %d, %d frames/step/GPU, ring of %d resident %s frames/GPU"
                                    % (args.width, args.height, up.out_width, up.out_height, args.upscale,
                                       args.precision, args.frames_per_step, args.ring,
-                                      "uint8 RGB (fused load)" if args.fuse_u8 and args.precision != 1 else "planar fp%d" % {0: 32, 1: 64, 2: 16}[args.precision]),
+                                      "uint8 RGB (fused load)" if args.fuse_u8 and args.precision != 1 else "planar fp%d" % {0: 32, 1: 64, 2: 16}[args.precision])
+                                   + (", 8-bit RGB out (fused store)" if up.u8_store else ""),
                        "preset": args.preset or "config2", "frames_per_step": args.frames_per_step,
                        "sharding": "independent frames, no collective",
                        "kernels": ("plan-time" if up.specialised_at_plan_time else "tuned") if up.tuned else "generic", "plan": up.description, "streams": args.streams, "device": up.device_name,

@@ -243,7 +243,9 @@ static void sharpen_plane(const double* R, const double* Rim, double* out, uint3
                     while (f >= plane) f -= uW;
                     double t = RQ(upsq * R[f]);            /* tex = upscale * inputs[...]      */
                     double l = fabs(t);                     /* length(scalar)                   */
-                    if (Rim) { double ti = RQ(upsq * Rim[f]); l = sqrt(t * t + ti * ti); }   /* length(vec2) */
+                    /* length(vec2) = sqrt(x*x + y*y); with float16_t operands (-p 2 on the non-R2C path, f16vec2 tex[]) every
+                     * operation is a binary16 operation like the rest of that shader */
+                    if (Rim) { double ti = RQ(upsq * Rim[f]); l = RQ(sqrt(RQ(RQ(t * t) + RQ(ti * ti)))); }
                     if (l > 1.0) l = 1.0;
                     if (l < 0.0) l = 0.0;
                     len[a * 3 + b] = l;
@@ -369,8 +371,12 @@ static int upscale_planes_complex(const orc_config* c, const double* in_planes, 
                 }
                 fft1d(&puW, z, w, -1);
                 for (uint32_t n = 0; n < uW; n++) {
-                    re[(uint64_t)ch * plane + (uint64_t)y * uW + n] = z[n].re / uW;
-                    im[(uint64_t)ch * plane + (uint64_t)y * uW + n] = z[n].im / uW;
+                    double r0 = z[n].re / uW, r1 = z[n].im / uW;
+                    /* -p 2 = half MEMORY only (VR:1420-1421 set independently of performR2C, VR:1424): the spectrum buffers
+                     * stay float, the last write of the inverse -- this one, axis 0 -- stores binary16 (VF:7289-7290) */
+                    if (c->precision == 2) { r0 = round_half(r0); r1 = round_half(r1); }
+                    re[(uint64_t)ch * plane + (uint64_t)y * uW + n] = r0;
+                    im[(uint64_t)ch * plane + (uint64_t)y * uW + n] = r1;
                 }
             }
             free(z); free(w);
@@ -383,7 +389,7 @@ static int upscale_planes_complex(const orc_config* c, const double* in_planes, 
         double upsq = const_via_percent_f((double)(c->upscale * c->upscale), c->precision);
         double coef = const_via_percent_f((double)c->sharpen, c->precision);
         for (int ch = 0; ch < 3; ch++)
-            sharpen_plane(re + ch * plane, im + ch * plane, out + ch * plane, uW, uH, upsq, coef, 0);
+            sharpen_plane(re + ch * plane, im + ch * plane, out + ch * plane, uW, uH, upsq, coef, c->precision == 2);
     }
     if (!pre_re) free(re);
     if (!pre_im) free(im);
@@ -397,7 +403,6 @@ ORC_API int orc_upscale_planes_complex(const orc_config* c, const double* in_pla
 {
     int rc = orc_check(c);
     if (rc) return rc;
-    if (c->precision == 2) return 3;         /* half-memory buffers of the complex path are not restated */
     return upscale_planes_complex(c, in_planes, pre_re, pre_im, out, poison_reads);
 }
 

@@ -71,7 +71,7 @@ def test_error_paths_without_device():
     assert lib.fftup_version().startswith(b"fftup")
     for kwargs, code in ((dict(width=2 * 11 * 64, height=64), 2), (dict(width=63, height=64), 1),
                          (dict(width=64, height=64, precision=3), 3), (dict(width=4096, height=64, precision=1), 2), (dict(width=64, height=64, upscale=0.5), 1),
-                         (dict(width=8192, height=64), 2)):
+                         (dict(width=9216, height=64), 2), (dict(width=8064, height=64), 2)):          # 18432-point rows; 16128 = 2^8 * 63: radix 7 beyond 14336
         with pytest.raises(v.FftupError) as e:
             v.Upscaler(**kwargs)
         assert e.value.code == code, kwargs

@@ -256,6 +256,28 @@ def test_complex_path_oracle_equals_layout_emulation_and_closed_form(W, H, u):
     assert np.abs(out[:, 1:-1, 1:-1] - ref[:, 1:-1, 1:-1]).max() <= 1e-12      # (_sharpen_ref: interior pixels)
 
 
+def test_complex_path_half_memory():
+    """-p 2 beyond the R2C limit (VR:1420-1424): the complex pre-sharpen image is stored as binary16 pairs (the inverse's last
+    write, VF:7282-7292), the shader works on f16vec2 in float16_t.  KAT1: a constant image stays constant; the pre-sharpen
+    values are binary16 numbers; against the fp32-memory run of the same (binary16-rounded) input the image differs by the
+    storage rounding only."""
+    rng = np.random.default_rng(5)
+    W, H = 4608, 8
+    assert O.uses_complex_path(W, H, 2.0, 2)
+    const = np.full((H, W, 3), 77, np.uint8)
+    pre, out, u8 = O.upscale_rgb8(const, 2.0, 2, 0.2)
+    cval = float(np.float16(np.float64(np.float32(np.float16(77))) / 255.0))
+    assert np.abs(pre * 4 - cval).max() <= 2.0 ** -11 and np.ptp(out[:, :-1]) == 0.0 and np.all(u8[:-1] == u8[0, 0])
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    pre, out, _ = O.upscale_rgb8(rgb, 2.0, 2, 0.2)
+    assert np.array_equal(pre, pre.astype(np.float16).astype(np.float64)) and np.array_equal(out, out.astype(np.float16).astype(np.float64))
+    planes = np.ascontiguousarray(rgb.transpose(2, 0, 1)).astype(np.float16)
+    planes = (planes.astype(np.float32).astype(np.float64) / 255.0).astype(np.float16).astype(np.float64)     # the -p 2 load conversion
+    z, _, _ = O.upscale_planes_complex(planes, 2.0, 0)
+    ulp = np.maximum(np.abs(z.real), 2.0 ** -14) * 2.0 ** -11
+    assert (np.abs(pre - z.real) <= ulp * 1.0001).all()
+
+
 def test_complex_path_selection_and_kat():
     assert not O.uses_complex_path(4096, 64) and O.uses_complex_path(4608, 64)
     assert not O.uses_complex_path(2048, 64, precision=1) and O.uses_complex_path(2304, 64, precision=1)

@@ -461,4 +461,64 @@ __device__ __forceinline__ C* fft_lds(C* a, C* b, const StagePlan& P,
     return a;
 }
 
+// ---------------------------------------------------------------- the same IN PLACE, one LDS buffer
+// For sequences too long for two buffers (complex rows of 10 240 .. 16 384 points on the non-R2C path: 139 KB of the
+// 160 KB for ONE; the reference splits such axes into several uploads with a transposition through a temporary buffer,
+// vkFFT.h:4773-4992, 2290-2388, 6562-6576).  A Stockham stage writes every output to another place than it read its inputs
+// from, so a stage cannot run in place element by element -- but it can thread by thread: everybody takes the inputs of all
+// his butterflies into registers (at most PT points), the workgroup synchronises, everybody writes his outputs to their
+// autosort positions.  Needs N / R <= (PT / R) * T for every radix R of the plan (stage_fits_inplace: checked by the host).
+template <int R, int DIR, int PT, typename C>
+__device__ __forceinline__ void stage_lds_inplace(C* __restrict__ buf, int N, int Ns, const C* __restrict__ tw, int tid, int T)
+{
+    constexpr int NBT = PT / R;
+    const int nb = N / R;
+    const int tstep = nb / Ns;
+    const bool ns_pow2 = (Ns & (Ns - 1)) == 0;
+    C v[NBT][R];
+#pragma unroll
+    for (int b = 0; b < NBT; b++) {
+        const int j = tid + b * T;
+        if (j < nb) {
+#pragma unroll
+            for (int m = 0; m < R; m++) v[b][m] = buf[lpad(j + m * nb)];
+        }
+    }
+    __syncthreads();                            // every input of the stage is in somebody's registers
+#pragma unroll
+    for (int b = 0; b < NBT; b++) {
+        const int j = tid + b * T;
+        if (j < nb) {
+            const int k = ns_pow2 ? (j & (Ns - 1)) : (j % Ns);
+            if (Ns > 1) apply_twiddles<R, DIR>(v[b], tw, k * tstep);
+            bfly<R, DIR>(v[b]);
+            const int j0 = (j - k) * R + k;
+#pragma unroll
+            for (int m = 0; m < R; m++) buf[lpad(j0 + m * Ns)] = v[b][m];
+        }
+    }
+    __syncthreads();
+}
+__host__ __device__ constexpr bool stage_fits_inplace(int N, int R, int T, int PT) { return N / R <= (PT / R) * T; }
+
+// Data in `a` (valid after a barrier executed by the caller); the result is left in `a` (synced).
+template <int DIR, int PT, typename C>
+__device__ __forceinline__ void fft_lds_inplace(C* a, const StagePlan& P, const C* __restrict__ tw, int tid, int T)
+{
+    const int N = P.n;
+    int Ns = 1;
+    for (int s = 0; s < P.nstages; s++) {
+        const int R = P.radix[s];
+        switch (R) {
+        case 8: stage_lds_inplace<8, DIR, PT>(a, N, Ns, tw, tid, T); break;
+        case 4: stage_lds_inplace<4, DIR, PT>(a, N, Ns, tw, tid, T); break;
+        case 2: stage_lds_inplace<2, DIR, PT>(a, N, Ns, tw, tid, T); break;
+        case 3: stage_lds_inplace<3, DIR, PT>(a, N, Ns, tw, tid, T); break;
+        case 5: stage_lds_inplace<5, DIR, PT>(a, N, Ns, tw, tid, T); break;
+        default: stage_lds_inplace<7, DIR, PT>(a, N, Ns, tw, tid, T); break;
+        }
+        Ns *= R;
+    }
+}
+
 }  // namespace fftup

@@ -80,6 +80,7 @@ struct fftup_plan {
     int U = 2;                        // integer upscale factor of a polyphase plan (tuned / mixed): S1 + U-1 residue buffers
     bool plan3840_x16 = true;         // 1080p: fused kernel on the 16*16*15 plan (256 threads, 120 VGPRs); false: 8*8*4*15 on 512 threads
     bool cplx = false;                // non-R2C path (VR:1424 false): full complex transforms, uW beyond the R2C limit
+    bool inplaceF = false, inplaceI = false;   // ... whose forward / inverse rows are too long for two LDS buffers: fft_lds_inplace
     int ncols = 0;                    // spectrum columns kept: W/2 + 1, or W on the non-R2C path
     int pairs_per_strip = 6;
     bool R_valid = false;             // pre-sharpen buffer holds the last frame (unfused path only)
@@ -339,11 +340,20 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
     // R2C rule of the reference: uW <= maxComputeSharedMemorySize/8 with 64 KB (VkResample.cpp:1424; complexSizeCalc = 16
     // for -p 1, VkResample.cpp:1334-1336, halves the limit); beyond it the full complex path runs
     const bool cplx = uW > (cfg->precision == 1 ? 4096u : 8192u);
-    if (cplx && cfg->precision == 2)
-        return fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width beyond the R2C limit (8192) with -p 2: the non-R2C path is implemented for -p 0 and -p 1");
-    // (checked here, before any device access: gfx950 has 160 KB of LDS per workgroup)
-    if (cplx && 2 * (size_t)(cfg->precision == 1 ? 16 : 8) * (size_t)lpad_size((int)uW) > (size_t)160 * 1024)
-        return fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width too large: the two row buffers of the non-R2C path exceed the LDS");
+    // (checked here, before any device access: gfx950 has 160 KB of LDS per workgroup.)  Non-R2C rows whose two Stockham
+    // buffers do not fit run in ONE buffer (fft_lds_inplace: up to 16 384 complex fp32 points, 1024 threads, every stage
+    // N/R <= (16/R) * 1024: radix 7 up to 14336 points, 3 and 5 up to 15360); the reference switches to multi-upload plans there (vkFFT.h:4773-4992)
+    auto rows_fit = [&](uint32_t n) -> int {             // 2: two buffers, 1: one buffer (in place), 0: not at all
+        const size_t el = cfg->precision == 1 ? 16 : 8, lds = (size_t)160 * 1024;
+        if (2 * el * (size_t)lpad_size((int)n) <= lds) return 2;
+        if (cfg->precision == 1 || el * (size_t)lpad_size((int)n) > lds) return 0;
+        const StagePlan sp = make_stage_plan(n);
+        for (int st = 0; st < sp.nstages; st++)
+            if (!stage_fits_inplace((int)n, sp.radix[st], 1024, 16)) return 0;
+        return 1;
+    };
+    if (cplx && (!rows_fit(uW) || !rows_fit(W)))
+        return fail(FFTUP_E_UNSUPPORTED_SIZE, "row too long for the LDS: non-R2C rows go up to 16384 points (-p 0 / -p 2), ~4800 for -p 1");
 
     int ndev = fftup_device_count();
     if (ndev <= 0) return fail(FFTUP_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
@@ -439,6 +449,11 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         P->NT = (P->ncols + P->TK - 1) / P->TK;
         P->ldsRowF = 2 * P->csz * (size_t)lpad_size((int)W);
         P->ldsRowI = 2 * P->csz * (size_t)lpad_size((int)uW);
+        if (cplx) {                                          // long non-R2C rows: one buffer, in place (rows_fit above)
+            P->inplaceF = rows_fit(W) == 1; P->inplaceI = rows_fit(uW) == 1;
+            if (P->inplaceF) P->ldsRowF /= 2;
+            if (P->inplaceI) P->ldsRowI /= 2;
+        }
         if (P->ldsRowI > lds_max) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width too large for LDS"); goto bad; }
         {
             const int tmax = P->dbl ? GenericMaxThreads<double2>::value : GenericMaxThreads<float2>::value;
@@ -481,7 +496,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         PLAN_RC(alloc_spectra(&P->S1, &P->S2));
         // the pre-sharpen image (the reference's tempBuffer): every frame of an unfused plan goes through it; a fused plan
         // only needs one for the fftup_download_presharpen tap, which allocates it on first use (ensure_R)
-        P->r_bytes = (size_t)3 * uW * uH * (cplx ? P->csz : esz);                  // non-R2C path: complex pre-sharpen image
+        P->r_bytes = (size_t)3 * uW * uH * (cplx ? (P->half ? 4 : P->csz) : esz);  // non-R2C path: complex pre-sharpen image (binary16 pairs for -p 2)
         if (!P->fused) PLAN_RC(dev_alloc(P, &P->R, P->r_bytes));
         if (!P->u8out) PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH));       // staging of the conversion launch
         {
@@ -514,10 +529,18 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             }
         }
         if (cplx) {
+            // (one instantiation per input type / output type / one-or-two-buffer form: only this plan's)
             if (P->dbl) { SET_LDS((k_row_c2c_fwd<IN_F64, double2>), P->ldsRowF); SET_LDS((k_row_c2c_inv<double2>), P->ldsRowI); }
-            else {
-                SET_LDS((k_row_c2c_fwd<IN_F32, float2>), P->ldsRowF); SET_LDS((k_row_c2c_fwd<IN_U8_F32, float2>), P->ldsRowF);
-                SET_LDS((k_row_c2c_inv<float2>), P->ldsRowI);
+            else if (P->half) {
+                if (P->inplaceF) { SET_LDS((k_row_c2c_fwd<IN_F16, float2, true>), P->ldsRowF); SET_LDS((k_row_c2c_fwd<IN_U8_F16, float2, true>), P->ldsRowF); }
+                else { SET_LDS((k_row_c2c_fwd<IN_F16, float2>), P->ldsRowF); SET_LDS((k_row_c2c_fwd<IN_U8_F16, float2>), P->ldsRowF); }
+                if (P->inplaceI) SET_LDS((k_row_c2c_inv<float2, true, true>), P->ldsRowI);
+                else SET_LDS((k_row_c2c_inv<float2, true, false>), P->ldsRowI);
+            } else {
+                if (P->inplaceF) { SET_LDS((k_row_c2c_fwd<IN_F32, float2, true>), P->ldsRowF); SET_LDS((k_row_c2c_fwd<IN_U8_F32, float2, true>), P->ldsRowF); }
+                else { SET_LDS((k_row_c2c_fwd<IN_F32, float2>), P->ldsRowF); SET_LDS((k_row_c2c_fwd<IN_U8_F32, float2>), P->ldsRowF); }
+                if (P->inplaceI) SET_LDS((k_row_c2c_inv<float2, false, true>), P->ldsRowI);
+                else SET_LDS((k_row_c2c_inv<float2, false, false>), P->ldsRowI);
             }
         }
         if (P->dbl) {
@@ -846,6 +869,22 @@ static int launch_frame_f64(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, 
 }
 
 // non-R2C path: four launches of size-generic kernels on complex data
+template <typename C, int MODE> static void launch_c2c_fwd(fftup_plan* P, const RowR2CParamsT<C>& p, hipStream_t st)
+{
+    const dim3 grid(P->H, 3);
+    if constexpr (sizeof(scalar_t<C>) == 4) {
+        if (P->inplaceF) { hipLaunchKernelGGL((k_row_c2c_fwd<MODE, C, true>), grid, dim3(1024), P->ldsRowF, st, p); return; }
+    }
+    hipLaunchKernelGGL((k_row_c2c_fwd<MODE, C, false>), grid, dim3(P->thrW), P->ldsRowF, st, p);
+}
+template <typename C, bool HALF_OUT> static void launch_c2c_inv(fftup_plan* P, const RowC2RParamsT<C>& p, hipStream_t st)
+{
+    const dim3 grid(P->uH, 3);
+    if constexpr (sizeof(scalar_t<C>) == 4) {
+        if (P->inplaceI) { hipLaunchKernelGGL((k_row_c2c_inv<C, HALF_OUT, true>), grid, dim3(1024), P->ldsRowI, st, p); return; }
+    }
+    hipLaunchKernelGGL((k_row_c2c_inv<C, HALF_OUT, false>), grid, dim3(P->thrUW), P->ldsRowI, st, p);
+}
 template <typename C> static int launch_frame_cplx(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
 {
     hipStream_t st = P->lanes[P->cur].stream;
@@ -855,14 +894,17 @@ template <typename C> static int launch_frame_cplx(fftup_plan* P, uint32_t in_sl
         RowR2CParamsT<C> p{};
         p.S1 = (C*)P->lanes[P->cur].S1; p.tw = (const C*)P->twW; p.plan = P->planW; p.W = (int)P->W; p.H = (int)P->H;
         p.TK = P->TK; p.NT = P->NT;
-        dim3 grid(P->H, 3), block(P->thrW);
         if (kind == 2) {
             p.in = P->in_u8[in_slot]; p.in_row_stride = 3l * P->W; p.in_plane_stride = 0;
-            if constexpr (sizeof(S) == 4) hipLaunchKernelGGL((k_row_c2c_fwd<IN_U8_F32, C>), grid, block, P->ldsRowF, st, p);
+            if constexpr (sizeof(S) == 4) {
+                if (P->half) launch_c2c_fwd<C, IN_U8_F16>(P, p, st);
+                else launch_c2c_fwd<C, IN_U8_F32>(P, p, st);
+            }
         } else {
             p.in = P->in_planar[in_slot]; p.in_row_stride = P->W; p.in_plane_stride = (long)P->in_plane_stride;
-            if constexpr (sizeof(S) == 8) hipLaunchKernelGGL((k_row_c2c_fwd<IN_F64, C>), grid, block, P->ldsRowF, st, p);
-            else hipLaunchKernelGGL((k_row_c2c_fwd<IN_F32, C>), grid, block, P->ldsRowF, st, p);
+            if constexpr (sizeof(S) == 8) launch_c2c_fwd<C, IN_F64>(P, p, st);
+            else if (P->half) launch_c2c_fwd<C, IN_F16>(P, p, st);
+            else launch_c2c_fwd<C, IN_F32>(P, p, st);
         }
     }
     if (which < 0 || which == 1) {
@@ -884,13 +926,21 @@ template <typename C> static int launch_frame_cplx(fftup_plan* P, uint32_t in_sl
         p.S2 = (const C*)P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = (const C*)P->twUW; p.plan = P->planUW;
         p.W = (int)P->W; p.uW = (int)P->uW; p.uH = (int)P->uH; p.TK = P->TK; p.NT = P->NT; p.zlx = P->zlx; p.zrx = P->zrx;
         p.inv_norm = (S)(1.0 / (double)P->uW);
-        hipLaunchKernelGGL((k_row_c2c_inv<C>), dim3(P->uH, 3), dim3(P->thrUW), P->ldsRowI, st, p);
+        bool done = false;
+        if constexpr (sizeof(S) == 4) {
+            if (P->half) { launch_c2c_inv<C, true>(P, p, st); done = true; }
+        }
+        if (!done) launch_c2c_inv<C, false>(P, p, st);
         P->R_valid = true;
     }
     if (which < 0 || which == 3) {
         SharpenParams p{};
         p.R = P->lanes[P->cur].R; p.out = P->out[out_slot]; p.uW = (int)P->uW; p.uH = (int)P->uH; p.upsq = P->upsq; p.coef = P->coef;
-        hipLaunchKernelGGL((k_sharpen_c<C>), dim3((P->uW + 255) / 256, P->uH, 3), dim3(256), 0, st, p);
+        bool done = false;
+        if constexpr (sizeof(S) == 4) {
+            if (P->half) { hipLaunchKernelGGL((k_sharpen_c<C, true>), dim3((P->uW + 255) / 256, P->uH, 3), dim3(256), 0, st, p); done = true; }
+        }
+        if (!done) hipLaunchKernelGGL((k_sharpen_c<C>), dim3((P->uW + 255) / 256, P->uH, 3), dim3(256), 0, st, p);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FFTUP_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));

@@ -44,6 +44,7 @@ template <typename C> struct RowR2CParamsT {
     StagePlan plan;          // n = W
     int W, H;
     long in_row_stride, in_plane_stride;
+    int inplace;             // non-R2C rows too long for two LDS buffers: one buffer, fft_lds_inplace
     int TK, NT;              // tile width (complex), number of tiles = ceil((W/2+1)/TK)
 };
 using RowR2CParams = RowR2CParamsT<float2>;
@@ -154,6 +155,7 @@ template <typename C> struct RowC2RParamsT {
     int TK, NT;
     int zlx, zrx;            // column-index read guard [zlx,zrx) (VkResample.cpp:1492-1493)
     scalar_t<C> inv_norm;    // 1/uW
+    int inplace;             // non-R2C rows too long for two LDS buffers: one buffer, fft_lds_inplace
 };
 using RowC2RParams = RowC2RParamsT<float2>;
 
@@ -210,7 +212,7 @@ __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_c2r(RowC2RP
 // VR:527-546), the x half happens in the gather of the inverse row kernel together with the read guard
 // [W/2, (2u-1) uW / 2u) of VR:1497-1498.
 // grid (H, 3); dynamic LDS = 2 * lpad_size(W) complex
-template <int MODE, typename C = float2>
+template <int MODE, typename C = float2, bool INPLACE = false>
 __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_c2c_fwd(RowR2CParamsT<C> p)
 {
     using S = scalar_t<C>;
@@ -222,14 +224,18 @@ __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_c2c_fwd(Row
     const int W = p.W;
     for (int n = tid; n < W; n += T) a[lpad(n)] = mk<C>((S)load_px<MODE>(p, c, y, n), S(0));
     __syncthreads();
-    const C* Z = fft_lds<+1, 1>(a, b, p.plan, p.tw, tid, T);
+    const C* Z = a;
+    if constexpr (INPLACE) fft_lds_inplace<+1, 16>(a, p.plan, p.tw, tid, T);       // rows beyond ~9600 points: one buffer (float plans; host-checked)
+    else Z = fft_lds<+1, 1>(a, b, p.plan, p.tw, tid, T);
     const long tile_stride = (long)p.H * p.TK;
     C* base = p.S1 + (long)c * p.NT * tile_stride + (long)y * p.TK;
     for (int k = tid; k < W; k += T) base[(long)(k / p.TK) * tile_stride + (k % p.TK)] = Z[lpad(k)];
 }
 
-// grid (uH, 3); dynamic LDS = 2 * lpad_size(uW) complex.  R: complex [3][uH][uW].
-template <typename C = float2>
+// grid (uH, 3); dynamic LDS = 2 * lpad_size(uW) complex.  R: complex [3][uH][uW]; HALF_OUT (-p 2 = half MEMORY only, VR:1420-1421
+// set independently of performR2C): binary16 pairs -- the last write of the inverse is the one the reference's plan stores as
+// half (VF:7282-7292: axis 0 of the inverse), the spectrum buffers stay float.
+template <typename C = float2, bool HALF_OUT = false, bool INPLACE = false>
 __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_c2c_inv(RowC2RParamsT<C> p)
 {
     using S = scalar_t<C>;
@@ -253,9 +259,19 @@ __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_c2c_inv(Row
         a[lpad(kx)] = v;
     }
     __syncthreads();
-    const C* z = fft_lds<-1, 1>(a, b, p.plan, p.tw, tid, T);
-    C* R = (C*)p.R + ((long)c * p.uH + y) * uW;
-    for (int n = tid; n < uW; n += T) R[n] = cscale(z[lpad(n)], p.inv_norm);
+    const C* z = a;
+    if constexpr (INPLACE) fft_lds_inplace<-1, 16>(a, p.plan, p.tw, tid, T);
+    else z = fft_lds<-1, 1>(a, b, p.plan, p.tw, tid, T);
+    if constexpr (HALF_OUT) {
+        __half2* R = (__half2*)p.R + ((long)c * p.uH + y) * uW;
+        for (int n = tid; n < uW; n += T) {
+            const C v = cscale(z[lpad(n)], p.inv_norm);
+            R[n] = __floats2half2_rn((float)v.x, (float)v.y);
+        }
+    } else {
+        C* R = (C*)p.R + ((long)c * p.uH + y) * uW;
+        for (int n = tid; n < uW; n += T) R[n] = cscale(z[lpad(n)], p.inv_norm);
+    }
 }
 
 // ---------------------------------------------------------------- sharpen (VkResample.cpp:819-925)
@@ -473,8 +489,9 @@ __global__ void __launch_bounds__(256) k_pack_u8_f64(const double* planes, uint8
 }
 
 // sharpen on the complex image of the non-R2C path: len = length(u^2 z) (VkResample.cpp:865-907 with vec2 inputs);
-// one thread = one pixel
-template <typename C = float2>
+// one thread = one pixel.  HALF (-p 2): f16vec2 inputs, float16_t arithmetic -- every operation of tex = u^2 * z,
+// length() = sqrt(x*x + y*y) and of the filter rounded to binary16 like the oracle's -- binary16 output.
+template <typename C = float2, bool HALF = false>
 __global__ void __launch_bounds__(256) k_sharpen_c(SharpenParams p)
 {
     using S = scalar_t<C>;
@@ -486,6 +503,24 @@ __global__ void __launch_bounds__(256) k_sharpen_c(SharpenParams p)
     const C* R = (const C*)p.R + c * plane;
     const int xs[3] = {x > 0 ? x - 1 : x, x, x + 1};
     const int ys[3] = {y > 0 ? y - 1 : y, y, y + 1};
+    if constexpr (HALF) {
+        using A = Arith<true>;
+        const __half2* Rh = (const __half2*)p.R + c * plane;
+        float len[9];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                long f = (long)ys[a] * uW + xs[b];
+                while (f >= plane) f -= uW;
+                const float2 z = __half22float2(Rh[f]);
+                const float tr = A::r(p.upsq * z.x), ti = A::r(p.upsq * z.y);
+                const float l = A::r(__fsqrt_rn(A::r(A::r(tr * tr) + A::r(ti * ti))));
+                len[a * 3 + b] = l > 1.0f ? 1.0f : (l < 0.0f ? 0.0f : l);
+            }
+        ((__half*)p.out)[c * plane + (long)y * uW + x] = __float2half_rn(sharpen_px<true>(len, p.coef));
+        return;
+    }
     S len[9];
 #pragma unroll
     for (int a = 0; a < 3; a++)
