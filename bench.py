@@ -270,6 +270,20 @@ def main():
     frames_per_region = world * args.steps * args.frames_per_step
     fps = frames_per_region / dt
     job = None
+    if not args.job and dist is not None:
+        # any multi-rank run says what the collective and the devices really were (the driver's scaling runs use the default
+        # preset): ranks seen by an all-reduce, one device per rank, a fingerprint of every rank's distinct resident frames
+        sums = [up.output_checksum(s) for s in range(args.ring)]
+        me = {"rank": rank, "device": dev, "pci_bus_id": v.device_pci_bus_id(dev), "name": up.device_name,
+              "frames": [rank * args.ring, rank * args.ring + args.ring - 1], "checksum": sum(sums) % (1 << 52)}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        one = torch.ones(1, dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(one)
+        job = {"collective_ranks": int(one.item()), "backend": dist.get_backend(), "ranks": ranks,
+               "distinct_devices": len({r["pci_bus_id"] for r in ranks}), "distinct_resident_frames": world * args.ring,
+               "frames_done": frames_per_region, "checksum": sum(r["checksum"] for r in ranks) % (1 << 52),
+               "sharding": "rank r owns resident frames r*ring .. r*ring+ring-1; no data-path collective"}
     if args.job:
         # every output slot holds the result of one distinct frame of the job: fingerprint them on the device, reduce
         sums = [up.output_checksum(s) for s in range(args.frames_per_step)]

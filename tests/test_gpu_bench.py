@@ -70,6 +70,21 @@ def test_bench_two_ranks_config5_over_gloo():
     assert d["checksum"] > 0
 
 
+def test_bench_two_ranks_default_preset_says_what_ran():
+    """the driver's scaling runs use the default preset: such a line, too, carries the ranks the collective really had and one
+    device (PCI bus id) per rank"""
+    env = dict(os.environ, FFTUP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29521", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--repeats", "1",
+                        "--frames-per-step", "32", "--profile-iters", "2"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["preset"] == "config2" and d["rccl_ranks"] == 2 and d["frames_done"] == 2 * 32
+    j = d["job"]
+    assert [x["rank"] for x in j["ranks"]] == [0, 1] and [x["frames"] for x in j["ranks"]] == [[0, 7], [8, 15]]
+    assert j["distinct_resident_frames"] == 16 and j["checksum"] > 0 and j["ranks"][0]["checksum"] != j["ranks"][1]["checksum"]
+
+
 def _job(nproc, frames_per_step, port):
     env = dict(os.environ, FFTUP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     args = ["bench.py", "--gpus", str(nproc), "--steps", "1", "--warmup", "1", "--repeats", "1", "--precision", "2", "--fuse-u8", "--job",

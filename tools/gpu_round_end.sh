@@ -1,17 +1,41 @@
 #!/bin/bash
-# end-of-round evidence: full gpu tests, PMC traffic, bench lines for the BASELINE configs, rocprof kernel stats
-TAG=${1:-r01final}
+# end-of-round evidence on the GPU box:  gpurun --timeout 3000 -- tools/gpu_round_end.sh <tag>   -> gpurun_out/<tag>/
+# full GPU suite + smoke, the bench line (with `others`), bench lines of the other configurations, rocprofv3 kernel stats
+# (sequential and overlapped), PMC passes per configuration -> hbm_traffic.json.  tools/collect_profiles.sh copies the summaries.
+TAG=${1:-rXXfinal}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-bash tools/gpu_pmc.sh $TAG/pmc > /dev/null 2>&1
-python tools/make_traffic_json.py gpurun_out/$TAG/pmc/summary.txt $OUT/hbm_traffic.json > /dev/null && cp $OUT/hbm_traffic.json profiles/hbm_traffic.json
-timeout 1200 python -m pytest tests -m gpu -q --timeout=900 > $OUT/pytest_gpu.txt 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu.txt | tail -8
-python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -3 $OUT/smoke.txt
+R=$GRAFT_REPO_ROOT
+timeout 2400 python -m pytest tests -m gpu -q -s --timeout=900 > $OUT/pytest_gpu.txt 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu.txt | tail -8
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -4 $OUT/smoke.txt
 python bench.py > $OUT/bench_fp32.json 2> $OUT/bench.err; cat $OUT/bench_fp32.json
-python bench.py --precision 2 --fuse-u8 --no-cpu-baseline > $OUT/bench_fp16_u8.json 2>> $OUT/bench.err; cat $OUT/bench_fp16_u8.json
-python bench.py --width 1920 --height 1080 --no-cpu-baseline --frames-per-step 16 --steps 5 > $OUT/bench_1080p.json 2>> $OUT/bench.err; cat $OUT/bench_1080p.json
-python bench.py --fuse-u8 --no-cpu-baseline > $OUT/bench_fp32_u8.json 2>> $OUT/bench.err; cat $OUT/bench_fp32_u8.json
-python bench.py --precision 1 --no-cpu-baseline --frames-per-step 16 --steps 5 --ring 4 > $OUT/bench_fp64.json 2>> $OUT/bench.err; cat $OUT/bench_fp64.json
-python bench.py --host-streamed --no-cpu-baseline --ring 4 > $OUT/bench_host_streamed_fp32.json 2>> $OUT/bench.err; cat $OUT/bench_host_streamed_fp32.json
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof1 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1 > $GRAFT_REPO_ROOT/$OUT/rocprof_bench_streams1.log 2>&1; rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1)
-cat $(find $OUT/prof -name "*kernel_stats.csv" | head -1) | head -8
+python bench.py --preset config3 --no-cpu-baseline > $OUT/bench_fp16_u8.json 2>> $OUT/bench.err
+python bench.py --preset config4 --no-cpu-baseline > $OUT/bench_1080p.json 2>> $OUT/bench.err
+python bench.py --preset config3 --fuse-u8-store --no-cpu-baseline > $OUT/bench_fp16_u8_u8store.json 2>> $OUT/bench.err
+python bench.py --fuse-u8 --fuse-u8-store --no-cpu-baseline > $OUT/bench_fp32_u8_u8store.json 2>> $OUT/bench.err
+python bench.py --preset config5 --no-cpu-baseline > $OUT/bench_config5_1gpu.json 2>> $OUT/bench.err
+python bench.py --streams 1 --no-cpu-baseline --no-others > $OUT/bench_fp32_streams1.json 2>> $OUT/bench.err
+python bench.py --host-streamed --no-cpu-baseline --ring 4 > $OUT/bench_host_streamed_fp32.json 2>> $OUT/bench.err
+python bench.py --host-streamed --fuse-u8 --fuse-u8-store --no-cpu-baseline --ring 4 > $OUT/bench_host_streamed_u8store.json 2>> $OUT/bench.err
+for f in fp16_u8 1080p fp16_u8_u8store fp32_u8_u8store config5_1gpu fp32_streams1 host_streamed_fp32 host_streamed_u8store; do
+  python -c "import json,sys; d=json.load(open('$OUT/bench_$f.json')); print('%-24s %9.0f frames/s %.2f us/frame frac %.3f' % ('$f', d['value'], d['ms_per_frame']*1e3, d['frame_roofline_frac']), {k: round(v*1e3,1) for k,v in d['kernel_ms'].items()})"
+done
+prof() {  # tag, bench args
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_$1 -o bench -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-others ${@:2} > $R/$OUT/rocprof_$1.log 2>&1)
+}
+prof fp32_s1 --streams 1
+prof fp32_s3
+prof fp16_u8_s1 --preset config3 --streams 1
+prof 1080p_s1 --preset config4 --streams 1
+prof fp16_u8_u8store_s1 --preset config3 --fuse-u8-store --streams 1
+head -5 $(find $OUT/prof_fp32_s1 -name "*kernel_stats.csv" | head -1)
+bash tools/gpu_pmc.sh $TAG/pmc_fp32 > /dev/null 2>&1
+bash tools/gpu_pmc.sh $TAG/pmc_fp16u8 --preset config3 > /dev/null 2>&1
+bash tools/gpu_pmc.sh $TAG/pmc_1080p --preset config4 > /dev/null 2>&1
+bash tools/gpu_pmc.sh $TAG/pmc_fp16u8_u8store --preset config3 --fuse-u8-store > /dev/null 2>&1
+cp profiles/hbm_traffic.json $OUT/hbm_traffic.json
+python tools/make_traffic_json.py $OUT/pmc_fp32/summary.txt $OUT/hbm_traffic.json 2048x1024_p0_planar > /dev/null
+python tools/make_traffic_json.py $OUT/pmc_fp16u8/summary.txt $OUT/hbm_traffic.json 2048x1024_p2_u8 > /dev/null
+python tools/make_traffic_json.py $OUT/pmc_1080p/summary.txt $OUT/hbm_traffic.json 1920x1080_p0_planar > /dev/null
+python tools/make_traffic_json.py $OUT/pmc_fp16u8_u8store/summary.txt $OUT/hbm_traffic.json 2048x1024_p2_u8_u8out > /dev/null
+grep -A12 "k_c2r_sharpen_g" $OUT/pmc_fp32/summary.txt | grep -E "==|SQ_INSTS_VALU|FETCH_SIZE|WRITE_SIZE" | head -8
