@@ -246,8 +246,12 @@ def test_full_size_vs_oracle(W, H, precision, flags, dist):
     north_star's 1e-4: fp32 pre-sharpen max 6e-7 .. 1e-6 measured -> 1e-5; sharpened "N" frames max 2e-6, p99.99 1.2e-6 ->
     2e-5 / 1.2e-5 and NO pixel above 1e-4; uniform noise max 8.5e-5 (the filter's sqrt has unbounded slope at 0: a handful
     of pixels whose 3x3 minimum is exactly 0 in fp64 amplify fp32 noise) -> 2e-4, p99.99 2.1e-6 -> 2.5e-5."""
+    _check_full_size(W, H, precision, flags, dist)
+
+
+def _check_full_size(W, H, precision, flags, dist, tagx=""):
     (pre, out, u8), (opre, oout, ou8) = _run(W, H, 2.0, precision, dist, flags=flags)
-    tag = "%dx%d p%d flags%d %s" % (W, H, precision, flags, dist)
+    tag = "%dx%d p%d flags%d %s%s" % (W, H, precision, flags, dist, tagx)
     if precision == 0:
         sp = _report(tag + " pre*u^2", (pre - opre) * 4, 1e-5)
         so = _report(tag + " out", out[:, :-1] - oout[:, :-1], 1e-4)
@@ -740,3 +744,50 @@ def test_1080p_fused_plans_agree(precision):
     d = np.abs(a[:, :, :-1] - b[:, :, :-1]) if a.ndim == 3 else np.abs(a - b)
     tol = 2e-4 if precision == 0 else 4e-3
     assert d.max() <= tol and (d > (1e-5 if precision == 0 else 1e-3)).mean() <= 1e-3
+
+
+# ---- k_c2r_sharpen_v (csrc/kernels_vpair.hpp): the opt-in fused kernel for output rows of 4096 points (FFTUP_VPAIR=1) --
+# digit-swap transform (one workgroup-wide exchange, one inside the wave's LDS block, one by v_permlane swaps), L rows as
+# vertical pairs, sharpen on vertical pairs.  Same bars as the default kernel.
+@pytest.mark.parametrize("precision,flags", [(0, 0), (0, 2), (2, 0), (2, 2)])
+@pytest.mark.parametrize("dist", ["N", "U"])
+def test_vpair_kernel_full_size_vs_oracle(precision, flags, dist, monkeypatch):
+    monkeypatch.setenv("FFTUP_VPAIR", "1")
+    _check_full_size(2048, 1024, precision, flags, dist, " vpair")
+
+
+@pytest.mark.parametrize("precision", [0, 2])
+def test_vpair_kernel_strips_and_default_kernel(precision):
+    """strips of 3, 5, 7, 50 pairs (the last one crossing plane boundaries) agree with one strip per compute unit, and the
+    kernel agrees with the default one (k_c2r_sharpen_g) to rounding: same butterflies, another order of operations"""
+    ref = _run_env({"FFTUP_VPAIR": "1"}, 2048, 1024, precision).astype(np.float64)
+    for pairs in (3, 5, 7, 50):
+        got = _run_env({"FFTUP_VPAIR": "1", "FFTUP_PAIRS_PER_STRIP": str(pairs)}, 2048, 1024, precision).astype(np.float64)
+        d = np.abs(ref - got)
+        if precision == 0:
+            assert d.max() <= 5e-6, "pairs_per_strip = %d: %g" % (pairs, d.max())
+        else:
+            assert d.max() <= 4e-3 and (d != 0).mean() <= 2e-4, "pairs_per_strip = %d: %g, %g" % (pairs, d.max(), (d != 0).mean())
+    dflt = _run_env({"FFTUP_VPAIR": "0"}, 2048, 1024, precision).astype(np.float64)
+    d = np.abs(ref - dflt)
+    if precision == 0:
+        assert d.max() <= 1e-5, d.max()
+    else:
+        assert d.max() <= 4e-3 and (d != 0).mean() <= 5e-4, (d.max(), (d != 0).mean())
+
+
+@pytest.mark.parametrize("precision,flags", [(0, 0), (2, 2)])
+def test_vpair_kernel_fused_u8_store(precision, flags, monkeypatch):
+    """its 8-bit RGB store against planes + conversion launch of the same kernel: the same bytes"""
+    from vkresample_amd import FLAG_FUSE_U8_STORE, synth
+    monkeypatch.setenv("FFTUP_VPAIR", "1")
+    rgb = synth.frame(31, 2048, 1024, "N")
+    with _up(2048, 1024, 2.0, precision, 0.2, 0, flags) as up:
+        up.upload_rgb8(rgb)
+        up.execute(1)
+        ref = up.download_rgb8()
+    with _up(2048, 1024, 2.0, precision, 0.2, 0, flags | FLAG_FUSE_U8_STORE) as up:
+        up.upload_rgb8(rgb)
+        up.execute(2)
+        got = up.download_rgb8()
+    assert np.array_equal(got, ref), (np.argwhere(got != ref)[:5], (got != ref).sum())

@@ -11,6 +11,7 @@ seg = list(zip(ids[i0:n], t[i0:n]))
 print("marks in strip:", len(seg)); print("HW_ID words:", [hex(int(x)) for x in d[4000:4008]])
 names = {0: "step0", 1: "step", 2: "pre-fft(v formed, prefetch issued)", 3: "fft done", 4: "L rows written", 5: "after L barrier", 6: "sharpen done", 7: "after settle"}
 names[8] = "chunk(1,1) done"
+names[13] = "  lane transpose done"; names[9] = "taps landed"
 for k in range(3): names[50 + k] = "  st%d chunk done" % k
 for k in range(3): names[10 + k] = "  st%d bfly done" % k; names[20 + k] = "  st%d scatter issued" % k; names[30 + k] = "  st%d barrier passed" % k; names[40 + k] = "  st%d gather landed" % (k)
 # per step table for steps 3..5

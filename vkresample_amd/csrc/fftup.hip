@@ -14,6 +14,7 @@
 #include "kernels_generic.hpp"
 #include "kernels_pow2.hpp"
 #include "kernels_mixed.hpp"
+#include "kernels_vpair.hpp"
 #include "jit.hpp"
 
 using namespace fftup;
@@ -73,6 +74,7 @@ struct fftup_plan {
     float upsq = 0, coef = 0;
     bool tuned = false;
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
+    bool vpair = false;               // uW = 4096: the fused kernel is k_c2r_sharpen_v (kernels_vpair.hpp); FFTUP_VPAIR=0: k_c2r_sharpen_g
     bool u8out = false;               // FFTUP_FLAG_FUSE_U8_STORE in effect: the fused kernel stores 8-bit RGB, `out` slots hold [uH][uW][3] bytes
     int mixed = 0;                    // compile-time mixed-radix plans: 1 = 1920x1080 -> 3840x2160, 2 = 1280x720 -> 2560x1440,
                                       // 3 = specialised at plan time for this size (jit.hpp), kernels in `jit`
@@ -83,6 +85,7 @@ struct fftup_plan {
     bool inplaceF = false, inplaceI = false;   // ... whose forward / inverse rows are too long for two LDS buffers: fft_lds_inplace
     int ncols = 0;                    // spectrum columns kept: W/2 + 1, or W on the non-R2C path
     int pairs_per_strip = 6;
+    int phase_q = 0;                  // fused kernel: start offset between workgroup groups, in units of 512 cycles (fused_phase_delay)
     bool R_valid = false;             // pre-sharpen buffer holds the last frame (unfused path only)
 
     // device memory
@@ -229,6 +232,7 @@ static void set_strip_length(fftup_plan* P)
     const int total_pairs = 3 * (int)P->uH / 2, slots = std::max(1, P->prop.multiProcessorCount) * per_cu;
     P->pairs_per_strip = std::max(2, (total_pairs + slots - 1) / slots);
     if (const char* e = getenv("FFTUP_PAIRS_PER_STRIP")) P->pairs_per_strip = std::max(1, atoi(e));
+    if (const char* e = getenv("FFTUP_PHASE_Q")) P->phase_q = std::max(0, std::min(64, atoi(e)));
 }
 // what the tuner's findings are filed under: the device and whether consecutive frames overlap on several streams
 // (ring > 1: what fits beside a strip decides) or run one after the other (ring = 1: the kernel's own time decides)
@@ -566,7 +570,13 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             switch (uW) {
             case 1024: SET_FUSED(FusedPlanPow2<1024>, TUNED_TK); break;
             case 2048: SET_FUSED(FusedPlanPow2<2048>, TUNED_TK); break;
-            default: SET_FUSED(FusedPlanPow2<4096>, TUNED_TK); break;
+            default:
+                if (const char* e = getenv("FFTUP_VPAIR")) P->vpair = atoi(e) != 0;     // (opt-in: same speed for -p 2, slower for -p 0)
+                if (!P->vpair) SET_FUSED(FusedPlanPow2<4096>, TUNED_TK);
+                else if (P->u8out) { if (P->half) SET_LDS((k_c2r_sharpen_v<true, TUNED_TK, true>), VPlan4096::lds(P->half)); else SET_LDS((k_c2r_sharpen_v<false, TUNED_TK, true>), VPlan4096::lds(P->half)); }
+                else if (P->half) SET_LDS((k_c2r_sharpen_v<true, TUNED_TK>), VPlan4096::lds(P->half));
+                else SET_LDS((k_c2r_sharpen_v<false, TUNED_TK>), VPlan4096::lds(P->half));
+                break;
             }
             switch (H) {
             case 256: SET_LDS((k_col_t<256, TUNED_TK>), P->ldsCol); break;
@@ -592,7 +602,7 @@ int fftup_plan_describe(const fftup_plan* P, char* buf, size_t buflen)
     if (!P || !buf || !buflen) return fail(FFTUP_E_INVALID_ARG, "null argument");
     std::string s;
     if (P->mixed == 3) s = "specialised at plan time: " + fftup_jit::describe(P->jit->choice);
-    else if (P->tuned) s = "ahead-of-time power-of-two kernels (radix 8, 8 points per thread; fused C2R+sharpen " + std::string(P->fused ? "on" : "off") + ")";
+    else if (P->tuned) s = "ahead-of-time power-of-two kernels (radix 8, 8 points per thread; fused C2R+sharpen " + std::string(P->fused ? (P->vpair ? "on: k_c2r_sharpen_v" : "on") : "off") + ")";
     else if (P->mixed) s = std::string("ahead-of-time mixed-radix kernels: ") + (P->mixed == 1 ? "row 15*8*16, col 9*10*12, fused 16*16*15" : "row 5*16*16, col 9*8*10, fused 16*16*10");
     else if (P->cplx) s = "size-generic kernels, non-R2C path (full complex transforms)";
     else s = std::string("size-generic kernels (LDS ping-pong, run-time radix lists)") + (P->dbl ? ", double" : "");
@@ -759,6 +769,18 @@ template <class PL> static void launch_fused_t(fftup_plan* P, const FusedParams&
     else if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_g<PL, true, TUNED_TK>), grid, block, FusedGLds<PL>::TOTAL, st, p);
     else hipLaunchKernelGGL((k_c2r_sharpen_g<PL, false, TUNED_TK>), grid, block, FusedGLds<PL>::TOTAL, st, p);
 }
+static void launch_fused_v(fftup_plan* P, const FusedParams& p)
+{
+    const int total_pairs = 3 * (int)P->uH / 2;
+    dim3 grid((total_pairs + p.pairs_per_strip - 1) / p.pairs_per_strip), block(VPlan4096::T);
+    hipStream_t st = P->lanes[P->cur].stream;
+    if (P->u8out) {
+        if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_v<true, TUNED_TK, true>), grid, block, VPlan4096::lds(P->half), st, p);
+        else hipLaunchKernelGGL((k_c2r_sharpen_v<false, TUNED_TK, true>), grid, block, VPlan4096::lds(P->half), st, p);
+    }
+    else if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_v<true, TUNED_TK>), grid, block, VPlan4096::lds(P->half), st, p);
+    else hipLaunchKernelGGL((k_c2r_sharpen_v<false, TUNED_TK>), grid, block, VPlan4096::lds(P->half), st, p);
+}
 static FusedParams fused_params(fftup_plan* P, uint32_t out_slot)
 {
     FusedParams p{};
@@ -767,6 +789,7 @@ static FusedParams fused_params(fftup_plan* P, uint32_t out_slot)
     p.out = P->out[out_slot]; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
     p.pairs_per_strip = P->pairs_per_strip; p.upsq = P->upsq; p.coef = P->coef;
     p.u8_wrap = (P->cfg.flags & FFTUP_FLAG_U8_WRAP) ? 1 : 0;
+    p.phase_q = P->phase_q;
     return p;
 }
 
@@ -801,7 +824,9 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
         switch (P->uW) {
         case 1024: launch_fused_t<FusedPlanPow2<1024>>(P, p); break;
         case 2048: launch_fused_t<FusedPlanPow2<2048>>(P, p); break;
-        default: launch_fused_t<FusedPlanPow2<4096>>(P, p); break;
+        default:
+            if (P->vpair) launch_fused_v(P, p); else launch_fused_t<FusedPlanPow2<4096>>(P, p);
+            break;
         }
         P->R_valid = false;
     } else if (which < 0 || which == 2 || which == 22) {   // 22: pre-sharpen tap requested for a fused plan
