@@ -12,6 +12,10 @@ PATCHES = {
     "nob": [("        lds_sync<true>();\n        const unsigned ard", "        const unsigned ard_unused"), ],
     "noc": [("    lane_transpose_hi3(v);\n    twiddle_powers", "    twiddle_powers")],
     "tk8": [],
+    # k_c2r_sharpen_g without the loads of the mirror partners (their values replaced by the thread's own elements)
+    "nomirror": [("kernels_pow2.hpp", """                in.a[m] = gload(ra, ko[m]); in.am[m] = gload(ra, kom[m]);
+                in.b[m] = gload(rb, ko[m]); in.bm[m] = gload(rb, kom[m]);""", """                in.a[m] = gload(ra, ko[m]); in.am[m] = in.a[m];
+                in.b[m] = gload(rb, ko[m]); in.bm[m] = in.b[m];""")],
     "nostore_unused": [("__builtin_nontemporal_store(lo, (f4t*)dst);", "if (p.uH < 0) __builtin_nontemporal_store(lo, (f4t*)dst);"),
                 ("__builtin_nontemporal_store(hi, (f4t*)(dst + 16));", "if (p.uH < 0) __builtin_nontemporal_store(hi, (f4t*)(dst + 16));")],
 }
@@ -21,12 +25,12 @@ def build(name):
     os.makedirs(tmp + "/vkresample_amd")
     shutil.copytree(ROOT + "/vkresample_amd/csrc", tmp + "/vkresample_amd/csrc")
     shutil.copytree(ROOT + "/include", tmp + "/include")
-    p = tmp + "/vkresample_amd/csrc/kernels_vpair.hpp"
-    s = open(p).read()
-    for a, b in PATCHES[name]:
+    for pt in PATCHES[name]:
+        f, a, b = pt if len(pt) == 3 else ("kernels_vpair.hpp",) + tuple(pt)
+        p = tmp + "/vkresample_amd/csrc/" + f
+        s = open(p).read()
         assert s.count(a) == 1, (name, a, s.count(a))
-        s = s.replace(a, b)
-    open(p, "w").write(s)
+        open(p, "w").write(s.replace(a, b))
     if name == "tk8":        # spectrum tiles of 8 columns instead of 4 (64-byte row pieces)
         q = tmp + "/vkresample_amd/csrc/fftup.hip"
         t = open(q).read()

@@ -358,7 +358,7 @@ __device__ __forceinline__ void reg_fft(float2 (&v)[E], float2* __restrict__ buf
 // between, so ONE barrier per exchange suffices (scatter, barrier, gather) -- and the last exchange always uses z, which
 // leaves c free for the caller's output while slower waves still gather.  Returns with v[i] = X[p + Tc*i].
 template <int N, int E, int DIR, int S = 0>
-__device__ __forceinline__ void reg_fft_pp(float2 (&v)[E], float2* __restrict__ c, float2* __restrict__ z, int p, const TwSet<N, E, 8>& tws)
+__device__ __forceinline__ void reg_fft_pp(float2 (&v)[E], float2* __restrict__ c, float2* __restrict__ z, int p, const TwSet<N, E, 8>& tws, int p0)
 {
     constexpr int Ns = stage_ns(N, S, 8);
     constexpr int R = stage_radix(N, Ns, 8);
@@ -367,10 +367,10 @@ __device__ __forceinline__ void reg_fft_pp(float2 (&v)[E], float2* __restrict__ 
     reg_butterflies<N, E, R, Ns, DIR>(v, tws.w[S > 0 ? S - 1 : 0]);
     if constexpr (Ns * R != N) {
         float2* __restrict__ b = ((NE - 1 - S) % 2 == 0) ? z : c;
-        reg_scatter<N, E, R, Ns, 1>(v, b, p, 0);
+        reg_scatter<N, E, R, Ns, 1>(v, b, S == 0 ? p0 : p, 0);         // (p0: the first stage's butterfly index, which need not be p)
         __syncthreads();
         reg_gather<N, E, 1>(v, b, p, 0);
-        reg_fft_pp<N, E, DIR, S + 1>(v, c, z, p, tws);
+        reg_fft_pp<N, E, DIR, S + 1>(v, c, z, p, tws, p0);
     }
 }
 
@@ -1008,11 +1008,24 @@ template <int UW_> struct FusedPlanPow2 {                   // radix-8 Stockham,
     static constexpr int WPE = T * 2 / 256 > 0 ? T * 2 / 256 : 1;      // two strips can share a compute unit
     static_assert((num_stages(UW, 8) - 1) % 2 == 1, "the first exchange must go through z");
     struct Tw { TwSet<UW, 8> t; };
-    static __device__ __forceinline__ int first_index(int lt) { return lt; }      // first-stage butterfly of thread lt
-    static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { w.t.load(tw, j); }
-    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w)
+    // MIRROR_SHARE: the first-stage butterfly jj of a thread needs Z[jj + NB0 m] and, for the conjugate half of the
+    // Hermitian spectrum, Z[KH - jj - NB0 m] -- which are the elements Z[jj' + NB0 (NI-1-m)] of butterfly jj' = NB0 - jj.
+    // So butterflies jj and NB0 - jj sit in lanes l and l ^ 32 of one wave (lanes 0-31: jj = 32 w + l, lanes 32-63:
+    // jj = NB0 - 32 w - (l - 32)), every thread loads its own elements only and takes the mirror ones from its partner
+    // through the LDS crossbar (ds_bpermute): half the prefetch requests.  (jj = 0 has no partner and jj = NB0/2 is its
+    // own: lanes 0 and 32 of wave 0, which load their mirror elements themselves.)
+    static constexpr bool MIRROR_SHARE = (T % 64 == 0);
+    static __device__ __forceinline__ int first_index(int lt)      // first-stage butterfly of thread lt
     {
-        reg_fft_pp<UW, 8, -1>(v, buf, zbuf, j, w.t);
+        if constexpr (!MIRROR_SHARE) return lt;
+        const int w = lt >> 6, l = lt & 63;
+        return l < 32 ? 32 * w + l : (lt == 32 ? NB0 / 2 : NB0 - 32 * w - (l - 32));
+    }
+    static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { w.t.load(tw, j); }
+    // jj = first_index(j): the butterfly of the first stage; from the first exchange on thread j owns X[j + T i]
+    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w, int jj)
+    {
+        reg_fft_pp<UW, 8, -1>(v, buf, zbuf, j, w.t, jj);
     }
 };
 
@@ -1248,9 +1261,10 @@ template <int UW_, int T_, int NBUF_, int WPE_, bool RR_, int... RS> struct Fuse
     static_assert(NBUF == 2 || (F::NST - 1) % 2 == 1, "three buffers: the first exchange must go through z");
     static_assert(XB % 128 == 0, "lds_put needs 128-byte aligned buffers");
     using Tw = typename F::Tw;
+    static constexpr bool MIRROR_SHARE = false;
     static __device__ __forceinline__ int first_index(int lt) { return lt < NB0 ? lt : NB0 - 1; }   // (threads beyond re-read)
     static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { F::load_tw(w, tw, j); }
-    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w)
+    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w, int = 0)
     {
         // The base twiddles are loop-invariant, so the compiler would hoist all power products of the twiddled stages
         // out of the strip loop and keep them (54 VGPRs for 8 * 8 * 4 * 15: spills).  Re-defining the bases here makes
@@ -1285,7 +1299,8 @@ template <int UW_, int R2_> struct FusedPlanMr16 {
     static constexpr int NBUF = FFTUP_3840X16_NBUF;
     static constexpr bool RING_REGS = FFTUP_3840X16_RR;
     static constexpr int WPE = 2;
-    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w)
+    static constexpr bool MIRROR_SHARE = false;
+    static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w, int = 0)
     {
         F::fft(v, buf, NBUF == 3 ? zbuf : buf, j, w);
     }
@@ -1422,22 +1437,34 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
         // inputs of the first-stage butterfly of thread lt for pair i: A (first row) and B (second row) at k = lt + NB0*m,
         // m < NI, and at the mirror partners KH - lt - NB0*m (vkFFT.h:2096-2106); thread 0 also needs Im of the DC column
         // of the two reference partners (leak).  Threads beyond the first stage (lt >= NB0) re-read valid elements.
+        // (MIRROR_SHARE plans: am, bm are loaded by the two lanes without a partner only, FusedPlanPow2)
+        constexpr bool MS = PL::MIRROR_SHARE;
         struct In { float2 a[NI], am[NI], b[NI], bm[NI]; float lka, lkb; };
         unsigned ko[NI], kom[NI];                   // column parts of the 2 * NI elements this thread prefetches per row
+        const int jj = PL::first_index(lt);
         {
-            const int jj = PL::first_index(lt);
 #pragma unroll
             for (int m = 0; m < NI; m++) { ko[m] = koff(jj + NB0 * m); kom[m] = koff(KH - jj - NB0 * m); }
         }
+        const bool ms_self = MS && lt < 64 && (lt & 31) == 0;        // butterflies 0 and NB0/2
         auto load_pair = [&](int i) -> In {
             In in;
             const int a = a0 + 2 * i;
             const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);       // rows past the plane: duplicate of the last row
             const gptr_t ra = rowbase(ya), rb = rowbase(yb);
+            if constexpr (MS) {
 #pragma unroll
-            for (int m = 0; m < NI; m++) {
-                in.a[m] = gload(ra, ko[m]); in.am[m] = gload(ra, kom[m]);
-                in.b[m] = gload(rb, ko[m]); in.bm[m] = gload(rb, kom[m]);
+                for (int m = 0; m < NI; m++) { in.a[m] = gload(ra, ko[m]); in.b[m] = gload(rb, ko[m]); in.am[m] = in.bm[m] = make_float2(0.f, 0.f); }
+                if (ms_self) {                      // (two lanes of wave 0; loads only inside the branch: nothing waits)
+#pragma unroll
+                    for (int m = 0; m < NI; m++) { in.am[m] = gload(ra, kom[m]); in.bm[m] = gload(rb, kom[m]); }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < NI; m++) {
+                    in.a[m] = gload(ra, ko[m]); in.am[m] = gload(ra, kom[m]);
+                    in.b[m] = gload(rb, ko[m]); in.bm[m] = gload(rb, kom[m]);
+                }
             }
             // (loaded by every lane, raw, so that no lane-dependent branch and no arithmetic -- hence no wait -- follows the loads)
             in.lka = dc_im(ya ^ 1);
@@ -1459,6 +1486,22 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
             asm volatile("" : "+v"(in.lka), "+v"(in.lkb));
         };
 
+        // MIRROR_SHARE: the mirror elements of butterfly jj are the own elements of butterfly NB0 - jj, in lane l ^ 32.  Fetched
+        // through the LDS crossbar right behind settle(), they arrive while the L rows are written and the rows sharpened.
+        auto share = [&](In& in) __attribute__((always_inline)) {
+            if constexpr (MS) {
+                const int pl = (((lt & 63) ^ 32) << 2);
+                auto part = [&](float2 z) -> float2 {
+                    return make_float2(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pl, __builtin_bit_cast(int, z.x))),
+                                       __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pl, __builtin_bit_cast(int, z.y))));
+                };
+#pragma unroll
+                for (int m = 0; m < NI; m++) {
+                    const float2 pa = part(in.a[NI - 1 - m]), pb = part(in.b[NI - 1 - m]);
+                    if (!ms_self) { in.am[m] = pa; in.bm[m] = pb; }
+                }
+            }
+        };
         if (need_corner) {
             float part = 0.f;
             for (int kk = lt + 1; kk <= KH; kk += T) part += S2at(kk, rs).x;
@@ -1472,6 +1515,7 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
         }
         In in = load_pair(0);
         settle(in);
+        share(in);
         __syncthreads();            // red[] published; the previous segment's last reads of X[] are over
         // the corner sample L(y1+1, 0) (SE tap of the strip's last pixel), kept in a register by every thread
         float corner = 0.f;
@@ -1513,8 +1557,9 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                 v[0] = make_float2(in.a[0].x + ((ya & 1) ? in.lka : -in.lka), in.b[0].x + ((yb & 1) ? in.lkb : -in.lkb));
             }
             in = load_pair(min(s + 1, npairs - 1));                                 // lands during this step (last step: a harmless re-read)
-            PL::fft(v, buf, (float2*)(smem + L::ZOFF), lt, tws);
+            PL::fft(v, buf, (float2*)(smem + L::ZOFF), lt, tws, jj);
             settle(in);
+            share(in);
             if constexpr (HALF) {
                 // C2R output stored as binary16 (vkFFT.h:7289-7290), then |u^2 g| clamped, each step rounded like the shader's
                 const h2v up2 = h2_splat(p.upsq), one2 = h2_splat(1.0f);
