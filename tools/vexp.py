@@ -3,6 +3,26 @@
 is not touched.   python tools/vexp.py name...   ->  tools/scratch/lib_<name>.so      (tools/gpu_ab.sh takes them as variants)"""
 import os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KO_FN = """template <int N, int E, int DIR, int TK, bool FINAL_TO_LDS, int S = 0, int RMAX = 8, bool WAVE = false>
+__device__ __forceinline__ void reg_fft_ko(float2 (&v)[E], float2* __restrict__ buf, int p, int col,
+                                        const TwSet<N, E, RMAX>& tws)
+{
+    constexpr int Ns = stage_ns(N, S, RMAX);
+    constexpr int R = stage_radix(N, Ns, RMAX);
+    reg_butterflies<N, E, R, Ns, DIR>(v, tws.w[S > 0 ? S - 1 : 0]);
+    constexpr bool last = (Ns * R == N);
+    if constexpr ((!last && S == 0) || (last && FINAL_TO_LDS)) {
+        reg_scatter<N, E, R, Ns, TK>(v, buf, p, col);
+        lds_sync<WAVE>();
+    }
+    if constexpr (!last) {
+        if constexpr (S == 0) { reg_gather<N, E, TK>(v, buf, p, col); lds_sync<WAVE>(); }
+        reg_fft_ko<N, E, DIR, TK, FINAL_TO_LDS, S + 1, RMAX, WAVE>(v, buf, p, col, tws);
+    }
+}
+
+// =================================================================================== row R2C
+struct RowR2CTParams {"""
 PATCHES = {
     "base": [],
     # both 16-byte stores of a row as if lane l owned quads l and 64 + l of its wave's 512 pixels (contiguous kilobytes per instruction)
@@ -12,6 +32,13 @@ PATCHES = {
     "nob": [("        lds_sync<true>();\n        const unsigned ard", "        const unsigned ard_unused"), ],
     "noc": [("    lane_transpose_hi3(v);\n    twiddle_powers", "    twiddle_powers")],
     "tk8": [],
+    # column kernel with ONE barrier-synchronised exchange per transform instead of three (results invalid): what a digit-swap column kernel could gain
+    "colnoex": [("kernels_pow2.hpp", """// =================================================================================== row R2C
+struct RowR2CTParams {""", KO_FN),
+                ("kernels_pow2.hpp", "    reg_fft<H, 8, +1, TK, true>(v, buf, pp, col, tws);            // F[k] natural order in LDS", "    reg_fft_ko<H, 8, +1, TK, true>(v, buf, pp, col, tws);"),
+                ("kernels_pow2.hpp", "    reg_fft<H, 8, -1, TK, false>(v, buf, pp, col, tws);\n    float2* dst = p.S2", "    reg_fft_ko<H, 8, -1, TK, false>(v, buf, pp, col, tws);\n    float2* dst = p.S2")],
+    "colwave": [("kernels_pow2.hpp", "    reg_fft<H, 8, +1, TK, true>(v, buf, pp, col, tws);            // F[k] natural order in LDS", "    reg_fft<H, 8, +1, TK, true, 0, 8, true>(v, buf, pp, col, tws);"),
+                ("kernels_pow2.hpp", "    reg_fft<H, 8, -1, TK, false>(v, buf, pp, col, tws);\n    float2* dst = p.S2", "    reg_fft<H, 8, -1, TK, false, 0, 8, true>(v, buf, pp, col, tws);\n    float2* dst = p.S2")],
     # k_c2r_sharpen_g without the loads of the mirror partners (their values replaced by the thread's own elements)
     "nomirror": [("kernels_pow2.hpp", """                in.a[m] = gload(ra, ko[m]); in.am[m] = gload(ra, kom[m]);
                 in.b[m] = gload(rb, ko[m]); in.bm[m] = gload(rb, kom[m]);""", """                in.a[m] = gload(ra, ko[m]); in.am[m] = in.a[m];

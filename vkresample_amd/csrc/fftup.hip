@@ -74,6 +74,7 @@ struct fftup_plan {
     float upsq = 0, coef = 0;
     bool tuned = false;
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
+    bool colv = true;                 // H = 1024: the column kernel is k_col_v (digit-swap exchanges, 3 barriers); FFTUP_COLV=0: k_col_t
     bool vpair = false;               // uW = 4096: the fused kernel is k_c2r_sharpen_v (kernels_vpair.hpp); FFTUP_VPAIR=0: k_c2r_sharpen_g
     bool u8out = false;               // FFTUP_FLAG_FUSE_U8_STORE in effect: the fused kernel stores 8-bit RGB, `out` slots hold [uH][uW][3] bytes
     int mixed = 0;                    // compile-time mixed-radix plans: 1 = 1920x1080 -> 3840x2160, 2 = 1280x720 -> 2560x1440,
@@ -581,7 +582,10 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             switch (H) {
             case 256: SET_LDS((k_col_t<256, TUNED_TK>), P->ldsCol); break;
             case 512: SET_LDS((k_col_t<512, TUNED_TK>), P->ldsCol); break;
-            default: SET_LDS((k_col_t<1024, TUNED_TK>), P->ldsCol); break;
+            default:
+                if (const char* e = getenv("FFTUP_COLV")) P->colv = atoi(e) != 0;
+                if (P->colv) SET_LDS((k_col_v<TUNED_TK>), 32768); else SET_LDS((k_col_t<1024, TUNED_TK>), P->ldsCol);
+                break;
             }
         }
 #undef SET_FUSED
@@ -816,7 +820,10 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
         switch (P->H) {
         case 256: launch_col_t<256>(P, p); break;
         case 512: launch_col_t<512>(P, p); break;
-        default: launch_col_t<1024>(P, p); break;
+        default:
+            if (P->colv) hipLaunchKernelGGL((k_col_v<TUNED_TK>), dim3(P->NT, 3), dim3(512), 32768, P->lanes[P->cur].stream, p);
+            else launch_col_t<1024>(P, p);
+            break;
         }
     }
     if ((which < 0 || which == 2) && P->fused) {
