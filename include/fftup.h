@@ -88,7 +88,10 @@ typedef struct fftup_config {
  *                            FFTUP_HIPRTC_LIB: the run-time compiler's shared object (default: libhiprtc.so of the ROCm install)
  *   FFTUP_AOT=0              experiments: sizes with ahead-of-time kernels go through the plan-time compiler as well
  *   FFTUP_3840_X16=0|1       1920x1080 -u 2: fused kernel on the 16*16*15 plan, 256 threads (1, default) or the
- *                            8*8*4*15 plan, 512 threads (0); same results up to fp32 rounding (tests) */
+ *                            8*8*4*15 plan, 512 threads (0); same results up to fp32 rounding (tests)
+ *   FFTUP_COLV=0|1           column length 1024: k_col_v, the column kernel with digit-swap exchanges (1, default) or k_col_t (0)
+ *   FFTUP_VPAIR=0|1          output rows of 4096 points: the fused kernel on vertical pairs, k_c2r_sharpen_v (1), or
+ *                            k_c2r_sharpen_g (0, default); same results up to fp32 / binary16 rounding (tests) */
 
 typedef struct fftup_plan fftup_plan;   /* opaque; replaces VkGPU + 2x VkFFTApplication +
                                            2x VkShiftApplication + the three device buffers      */

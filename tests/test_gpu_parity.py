@@ -791,3 +791,27 @@ def test_vpair_kernel_fused_u8_store(precision, flags, monkeypatch):
         up.execute(2)
         got = up.download_rgb8()
     assert np.array_equal(got, ref), (np.argwhere(got != ref)[:5], (got != ref).sum())
+
+
+@pytest.mark.parametrize("precision", [0, 2])
+def test_column_kernels_agree(precision):
+    """H = 1024: k_col_v (digit-swap exchanges: one through LDS per transform, the others by v_permlane swaps / DPP moves; the
+    default) and k_col_t (three LDS exchanges per transform, FFTUP_COLV=0) are the same transforms in another order of
+    operations: equal up to fp32 rounding -- and both within tolerance of the oracle (test_full_size_vs_oracle runs the
+    default, this test the other one)."""
+    a = _run_env({"FFTUP_COLV": "1"}, 2048, 1024, precision).astype(np.float64)
+    b = _run_env({"FFTUP_COLV": "0"}, 2048, 1024, precision).astype(np.float64)
+    d = np.abs(a - b)
+    if precision == 0:
+        assert d.max() <= 1e-5, d.max()
+    else:
+        assert d.max() <= 4e-3 and (d != 0).mean() <= 5e-4, (d.max(), (d != 0).mean())
+    old = os.environ.get("FFTUP_COLV")
+    os.environ["FFTUP_COLV"] = "0"
+    try:
+        _check_full_size(2048, 1024, precision, 2 if precision else 0, "N", " k_col_t")
+    finally:
+        if old is None:
+            os.environ.pop("FFTUP_COLV", None)
+        else:
+            os.environ["FFTUP_COLV"] = old

@@ -19,4 +19,5 @@ for SET in \
 done
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
 python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+rm -rf $OUT/pass[0-9]* $OUT/counters_list.txt      # (raw counter files: tens of MB; gpurun_out/ comes back only below 64 MiB)
 cat $OUT/summary.txt

@@ -21,7 +21,8 @@ for f in fp16_u8 1080p fp16_u8_u8store fp32_u8_u8store config5_1gpu fp32_streams
   python -c "import json,sys; d=json.load(open('$OUT/bench_$f.json')); print('%-24s %9.0f frames/s %.2f us/frame frac %.3f' % ('$f', d['value'], d['ms_per_frame']*1e3, d['frame_roofline_frac']), {k: round(v*1e3,1) for k,v in d['kernel_ms'].items()})"
 done
 prof() {  # tag, bench args
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_$1 -o bench -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-others ${@:2} > $R/$OUT/rocprof_$1.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$1 -o bench -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-others ${@:2} > $R/$OUT/rocprof_$1.log 2>&1)
+  mkdir -p $R/$OUT/prof_$1; cp $(find /tmp/prof_$1 -name "*kernel_stats.csv" | head -1) $R/$OUT/prof_$1/; rm -rf /tmp/prof_$1      # (the traces stay on the box)
 }
 prof fp32_s1 --streams 1
 prof fp32_s3

@@ -21,9 +21,9 @@ import sys
 src = sys.argv[1]            # gpurun_out/<tag>/summary.txt
 out = sys.argv[2]            # profiles/hbm_traffic.json (merged: one entry per configuration key)
 key = sys.argv[3]            # e.g. 2048x1024_p0_planar (bench.py: config_key)
-factor = {"k_row_r2c_t": 2.0, "k_row_r2c": 2.0, "k_col_t": 2.0, "k_row_r2c_m": 2.0, "k_col_m": 2.0, "k_row_r2c_n": 2.0, "k_col_n": 2.0}
-names = {"k_row_r2c_t": "row_r2c", "k_row_r2c": "row_r2c", "k_row_r2c_m": "row_r2c", "k_row_r2c_n": "row_r2c", "k_col_t": "col_fwd_pad_inv",
-         "k_col": "col_fwd_pad_inv", "k_col_m": "col_fwd_pad_inv", "k_col_n": "col_fwd_pad_inv", "k_c2r_sharpen_g": "row_c2r_sharpen",
+factor = {"k_row_r2c_t": 2.0, "k_row_r2c": 2.0, "k_col_t": 2.0, "k_col_v": 2.0, "k_row_r2c_m": 2.0, "k_col_m": 2.0, "k_row_r2c_n": 2.0, "k_col_n": 2.0}
+names = {"k_row_r2c_t": "row_r2c", "k_row_r2c": "row_r2c", "k_row_r2c_m": "row_r2c", "k_row_r2c_n": "row_r2c", "k_col_t": "col_fwd_pad_inv", "k_col_v": "col_fwd_pad_inv",
+         "k_col": "col_fwd_pad_inv", "k_col_m": "col_fwd_pad_inv", "k_col_n": "col_fwd_pad_inv", "k_c2r_sharpen_g": "row_c2r_sharpen", "k_c2r_sharpen_v": "row_c2r_sharpen",
          "k_row_c2r_t": "row_c2r", "k_row_c2r": "row_c2r", "k_sharpen_t": "sharpen", "k_sharpen": "sharpen"}
 cur, data = None, {}
 for line in open(src):

@@ -86,7 +86,6 @@ struct fftup_plan {
     bool inplaceF = false, inplaceI = false;   // ... whose forward / inverse rows are too long for two LDS buffers: fft_lds_inplace
     int ncols = 0;                    // spectrum columns kept: W/2 + 1, or W on the non-R2C path
     int pairs_per_strip = 6;
-    int phase_q = 0;                  // fused kernel: start offset between workgroup groups, in units of 512 cycles (fused_phase_delay)
     bool R_valid = false;             // pre-sharpen buffer holds the last frame (unfused path only)
 
     // device memory
@@ -233,7 +232,6 @@ static void set_strip_length(fftup_plan* P)
     const int total_pairs = 3 * (int)P->uH / 2, slots = std::max(1, P->prop.multiProcessorCount) * per_cu;
     P->pairs_per_strip = std::max(2, (total_pairs + slots - 1) / slots);
     if (const char* e = getenv("FFTUP_PAIRS_PER_STRIP")) P->pairs_per_strip = std::max(1, atoi(e));
-    if (const char* e = getenv("FFTUP_PHASE_Q")) P->phase_q = std::max(0, std::min(64, atoi(e)));
 }
 // what the tuner's findings are filed under: the device and whether consecutive frames overlap on several streams
 // (ring > 1: what fits beside a strip decides) or run one after the other (ring = 1: the kernel's own time decides)
@@ -793,7 +791,6 @@ static FusedParams fused_params(fftup_plan* P, uint32_t out_slot)
     p.out = P->out[out_slot]; p.tw = P->twUW; p.uH = (int)P->uH; p.NT = P->NT;
     p.pairs_per_strip = P->pairs_per_strip; p.upsq = P->upsq; p.coef = P->coef;
     p.u8_wrap = (P->cfg.flags & FFTUP_FLAG_U8_WRAP) ? 1 : 0;
-    p.phase_q = P->phase_q;
     return p;
 }
 

@@ -832,19 +832,7 @@ struct FusedParams {
     int pairs_per_strip;
     float upsq, coef;
     int u8_wrap;             // OUT_U8 kernels: `out` is the interleaved 8-bit RGB image [uH][uW][3]; FFTUP_FLAG_U8_WRAP
-    int phase_q;             // workgroup b starts (b & 3) * phase_q * 512 cycles late (fused_phase_delay)
 };
-// All strips of a launch start together and run steps of equal length, so every compute unit loads at the same moment and
-// every unit stores at the same moment: the output stores of a step (100 MB per frame in bursts that fill 40 % of the time)
-// then queue at the memory system, and the next step's prefetch queues behind them.  Starting the workgroups in four
-// groups a quarter of a step apart spreads the bursts.
-__device__ __forceinline__ void fused_phase_delay(const FusedParams& p)
-{
-    for (int i = (blockIdx.x & 3) * p.phase_q; i > 0; i--) __builtin_amdgcn_s_sleep(8);
-}
-
-__host__ __device__ constexpr size_t fused_buf_bytes(int uw) { return (sizeof(float2) * lswz_size(uw) + 15) & ~(size_t)15; }
-
 // min(|x|, 1) in one instruction.  (Written with fminf(fabsf(x), 1.0f) the compiler first canonicalises -- v_max x, x -- an
 // x that comes out of the inline-asm butterflies, since it cannot know that it is not a signalling NaN.)
 __device__ __forceinline__ float absmin1(float x)
@@ -1392,7 +1380,6 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
     const long plane = (long)UW * uH;
     typename PL::Tw tws;
     PL::load_tw(tws, p.tw, lt);                 // once: inside the loop a load would queue behind the output stores
-    fused_phase_delay(p);
 
     int f0 = blockIdx.x * p.pairs_per_strip;
     const int f1 = min(f0 + p.pairs_per_strip, 3 * pairs_per_plane);

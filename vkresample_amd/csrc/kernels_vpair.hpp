@@ -322,7 +322,6 @@ __global__ void __launch_bounds__(512, 4) k_c2r_sharpen_v(FusedParams p)
     const long plane = (long)UW * uH;
     VTwid tws;
     vfft_load_tw(tws, p.tw, lt);
-    fused_phase_delay(p);
 
     int f0 = blockIdx.x * p.pairs_per_strip;
     const int f1 = min(f0 + p.pairs_per_strip, 3 * pairs_per_plane);
