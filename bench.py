@@ -164,6 +164,53 @@ def other_configs(v, synth, dev, ring=8):
     return out
 
 
+class PowerSampler:
+    """Socket power and shader clock of one GPU sampled in a background thread while the timed regions run (sysfs hwmon files of
+    the amdgpu driver; best effort: every field is None where the files are missing).  The overlapped frame of this workload
+    runs INTO the board's power limit -- 1400 W, shader clock 2.05 instead of 2.4 GHz -- so the bench line says so itself."""
+
+    def __init__(self, index=0, period=0.1):
+        import glob
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        cards = [c for c in cards if any(os.path.exists(os.path.join(c, f)) for f in ("power1_average", "power1_input"))]
+        self.dir = cards[index] if index < len(cards) else None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            pw = self._read("power1_average")
+            if pw is None:
+                pw = self._read("power1_input")
+            self.samples.append((pw, self._read("freq1_input")))
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self.dir:
+            self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self.dir and self._thread.is_alive():
+            self._thread.join(timeout=2)
+        pw = [a * 1e-6 for a, _ in self.samples if a]
+        fr = [b * 1e-6 for _, b in self.samples if b]
+        cap = self._read("power1_cap") if self.dir else None
+        med = lambda x: sorted(x)[len(x) // 2] if x else None
+        return {"socket_power_w_median": med(pw), "socket_power_w_max": max(pw) if pw else None, "power_cap_w": cap * 1e-6 if cap else None,
+                "sclk_mhz_median": med(fr), "sclk_mhz_min": min(fr) if fr else None, "samples": len(self.samples),
+                "note": "sampled during the timed regions; at the cap the shader clock is throttled (DESIGN.md section 4)"}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -235,6 +282,7 @@ def main():
         slot = (slot + args.frames_per_step) % args.ring
 
     # ---- timed regions: EXACTLY --steps steps each, barrier + synchronize on both sides, MAX over ranks; median of --repeats
+    power = PowerSampler(dev).start() if rank == 0 else None
     region_s, region_dev_ms = [], []
     kms = [0.0] * len(up.kernel_names)
     for rep in range(max(1, args.repeats)):
@@ -263,6 +311,7 @@ def main():
             dt = float(t.item())
         region_s.append(dt)
         region_dev_ms.append(dev_ms)
+    power_stats = power.stop() if power is not None else None
     order = sorted(range(len(region_s)), key=lambda i: region_s[i])
     med = order[len(order) // 2]
     dt = region_s[med]
@@ -366,6 +415,7 @@ def main():
                          "frame_achieved": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 1e9,      # per GPU
                          "frame_frac": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 8e12},
         }
+        line["power"] = power_stats
         if args.host_streamed:
             pcie = 3.0 * (args.width * args.height + up.out_width * up.out_height)
             line["pcie_inclusive"] = True

@@ -37,6 +37,11 @@ def test_bench_single_rank_line():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["kernel_ms"]["-"] < 0.01                       # empty slot: event overhead is netted out (5 iterations: noisy)
     assert "built-in" in d["config"]["wisdom"]               # no tuner findings of earlier runs on this machine steer the run
+    # socket power and shader clock during the timed regions (best effort: None where the driver's hwmon files are missing)
+    pw = d["power"]
+    assert set(("socket_power_w_median", "power_cap_w", "sclk_mhz_median")) <= set(pw)
+    assert pw["socket_power_w_median"] is None or 100 < pw["socket_power_w_median"] < 2500
+    assert pw["sclk_mhz_median"] is None or 100 < pw["sclk_mhz_median"] < 3500
     # the other single-GPU BASELINE configurations and the reference's -n 1000 figure, in the same line
     o = d["others"]
     for k in ("config3", "config4"):

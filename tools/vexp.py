@@ -32,6 +32,11 @@ PATCHES = {
     "nob": [("        lds_sync<true>();\n        const unsigned ard", "        const unsigned ard_unused"), ],
     "noc": [("    lane_transpose_hi3(v);\n    twiddle_powers", "    twiddle_powers")],
     "tk8": [],
+    "colv_nomid": [("kernels_vpair.hpp", "    __syncthreads();                                         // everybody has read the forward exchange\n", "")],
+    "colv_nobar": [("kernels_vpair.hpp", "    __syncthreads();                                         // everybody has read the forward exchange\n", ""),
+                   ("kernels_vpair.hpp", "    for (int k = 0; k < 8; k++) { lds_f2raw r = {v[k].x, v[k].y}; *(lds_f2*)(size_t)(aw + 4096u * k) = r; }\n    __syncthreads();\n    const unsigned ar = zbase + 8u * (w * 512u + l);",
+                    "    for (int k = 0; k < 8; k++) { lds_f2raw r = {v[k].x, v[k].y}; *(lds_f2*)(size_t)(aw + 4096u * k) = r; }\n    lds_sync<true>();\n    const unsigned ar = zbase + 8u * (w * 512u + l);")],
+    "rowwave": [("kernels_pow2.hpp", "    reg_fft<W, E, +1, 1, true>(v, buf, tid, 0, tws);", "    reg_fft<W, E, +1, 1, true, 0, 8, true>(v, buf, tid, 0, tws);")],
     # column kernel with ONE barrier-synchronised exchange per transform instead of three (results invalid): what a digit-swap column kernel could gain
     "colnoex": [("kernels_pow2.hpp", """// =================================================================================== row R2C
 struct RowR2CTParams {""", KO_FN),
