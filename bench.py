@@ -169,13 +169,16 @@ class PowerSampler:
     the amdgpu driver; best effort: every field is None where the files are missing).  The overlapped frame of this workload
     runs INTO the board's power limit -- 1400 W, shader clock 2.05 instead of 2.4 GHz -- so the bench line says so itself."""
 
-    def __init__(self, index=0, period=0.1):
+    def __init__(self, pci_bus_id, period=0.1):
         import glob
         import threading
         self.period, self.samples, self._stop = period, [], threading.Event()
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
-        cards = [c for c in cards if any(os.path.exists(os.path.join(c, f)) for f in ("power1_average", "power1_input"))]
-        self.dir = cards[index] if index < len(cards) else None
+        self.dir = None
+        for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*")):
+            # the card whose PCI address is the HIP device's (several boards may be present, one visible)
+            addr = os.path.basename(os.path.realpath(os.path.join(c, "..", "..")))
+            if addr.lower() == (pci_bus_id or "").lower() and any(os.path.exists(os.path.join(c, f)) for f in ("power1_average", "power1_input")):
+                self.dir = c
         self._thread = threading.Thread(target=self._run, daemon=True)
 
     def _read(self, name):
@@ -282,7 +285,7 @@ def main():
         slot = (slot + args.frames_per_step) % args.ring
 
     # ---- timed regions: EXACTLY --steps steps each, barrier + synchronize on both sides, MAX over ranks; median of --repeats
-    power = PowerSampler(dev).start() if rank == 0 else None
+    power = PowerSampler(v.device_pci_bus_id(dev)).start() if rank == 0 else None
     region_s, region_dev_ms = [], []
     kms = [0.0] * len(up.kernel_names)
     for rep in range(max(1, args.repeats)):
