@@ -90,6 +90,9 @@ typedef struct fftup_config {
  *   FFTUP_3840_X16=0|1       1920x1080 -u 2: fused kernel on the 16*16*15 plan, 256 threads (1, default) or the
  *                            8*8*4*15 plan, 512 threads (0); same results up to fp32 rounding (tests)
  *   FFTUP_COLV=0|1           column length 1024: k_col_v, the column kernel with digit-swap exchanges (1, default) or k_col_t (0)
+ *   FFTUP_RGB8=0|1           -p 2 with FFTUP_FLAG_FUSE_U8_STORE, output rows of 4096 points: a strip owns its rows in all three colour planes and
+ *                            writes the 8-bit image once (1: k_c2r_sharpen_v_rgb8; WRITE_SIZE 25 instead of 77 MB, frame +2 %) or one
+ *                            plane per strip (0, default)
  *   FFTUP_VPAIR=0|1          output rows of 4096 points: the fused kernel on vertical pairs, k_c2r_sharpen_v (1), or
  *                            k_c2r_sharpen_g (0, default); same results up to fp32 / binary16 rounding (tests) */
 

@@ -815,3 +815,34 @@ def test_column_kernels_agree(precision):
             os.environ.pop("FFTUP_COLV", None)
         else:
             os.environ["FFTUP_COLV"] = old
+
+
+def test_rgb8_kernel_three_planes_per_strip(monkeypatch):
+    """FFTUP_RGB8=1: -p 2 + FFTUP_FLAG_FUSE_U8_STORE on k_c2r_sharpen_v_rgb8 -- a strip owns its row pairs in all three colour
+    planes and stores 24 interleaved bytes per thread and row (the 8-bit image is written once).  Against planes + conversion
+    launch of the default kernel: the same image up to the last binary16 digit of another transform order (<= 1 code, < 1e-4 of
+    the bytes); against the oracle: within two codes like every -p 2 path; for strips of 1, 2 and 17 pairs the same bytes."""
+    from vkresample_amd import FLAG_FUSE_U8_STORE, synth
+    rgb = synth.frame(31, 2048, 1024, "N")
+    with _up(2048, 1024, 2.0, 2, 0.2, 0, 2) as up:
+        up.upload_rgb8(rgb)
+        up.execute(1)
+        ref = up.download_rgb8()
+    monkeypatch.setenv("FFTUP_RGB8", "1")
+    outs = []
+    for pps in (None, "3", "6", "51"):
+        if pps:
+            monkeypatch.setenv("FFTUP_PAIRS_PER_STRIP", pps)
+        with _up(2048, 1024, 2.0, 2, 0.2, 0, 2 | FLAG_FUSE_U8_STORE) as up:
+            assert up.u8_store
+            up.upload_rgb8(rgb)
+            up.execute(2)
+            outs.append(up.download_rgb8())
+    got = outs[0]
+    d = np.abs(got.astype(int) - ref.astype(int))
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-4, (d.max(), (d != 0).mean())
+    _, _, ou8 = O.upscale_rgb8(rgb, 2.0, 2, 0.2)
+    assert np.abs(got[:-1].astype(int) - ou8[:-1].astype(int)).max() <= 2
+    for o in outs[1:]:
+        dd = np.abs(o.astype(int) - got.astype(int))
+        assert dd.max() <= 1 and (dd != 0).mean() <= 1e-4, (dd.max(), (dd != 0).mean())

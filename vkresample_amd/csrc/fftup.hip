@@ -74,6 +74,7 @@ struct fftup_plan {
     float upsq = 0, coef = 0;
     bool tuned = false;
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
+    bool rgb8 = false;                // FFTUP_RGB8=1: -p 2 + FFTUP_FLAG_FUSE_U8_STORE, rows of 4096: k_c2r_sharpen_v_rgb8 (three planes per strip, image written once)
     bool colv = true;                 // H = 1024: the column kernel is k_col_v (digit-swap exchanges, 3 barriers); FFTUP_COLV=0: k_col_t
     bool vpair = false;               // uW = 4096: the fused kernel is k_c2r_sharpen_v (kernels_vpair.hpp); FFTUP_VPAIR=0: k_c2r_sharpen_g
     bool u8out = false;               // FFTUP_FLAG_FUSE_U8_STORE in effect: the fused kernel stores 8-bit RGB, `out` slots hold [uH][uW][3] bytes
@@ -571,7 +572,10 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             case 2048: SET_FUSED(FusedPlanPow2<2048>, TUNED_TK); break;
             default:
                 if (const char* e = getenv("FFTUP_VPAIR")) P->vpair = atoi(e) != 0;     // (opt-in: same speed for -p 2, slower for -p 0)
-                if (!P->vpair) SET_FUSED(FusedPlanPow2<4096>, TUNED_TK);
+                if (const char* e = getenv("FFTUP_RGB8")) P->rgb8 = atoi(e) != 0;
+                P->rgb8 = P->rgb8 && P->u8out && P->half;
+                if (P->rgb8) SET_LDS((k_c2r_sharpen_v_rgb8<TUNED_TK>), VPlan4096::lds(true));
+                else if (!P->vpair) SET_FUSED(FusedPlanPow2<4096>, TUNED_TK);
                 else if (P->u8out) { if (P->half) SET_LDS((k_c2r_sharpen_v<true, TUNED_TK, true>), VPlan4096::lds(P->half)); else SET_LDS((k_c2r_sharpen_v<false, TUNED_TK, true>), VPlan4096::lds(P->half)); }
                 else if (P->half) SET_LDS((k_c2r_sharpen_v<true, TUNED_TK>), VPlan4096::lds(P->half));
                 else SET_LDS((k_c2r_sharpen_v<false, TUNED_TK>), VPlan4096::lds(P->half));
@@ -829,7 +833,15 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
         case 1024: launch_fused_t<FusedPlanPow2<1024>>(P, p); break;
         case 2048: launch_fused_t<FusedPlanPow2<2048>>(P, p); break;
         default:
-            if (P->vpair) launch_fused_v(P, p); else launch_fused_t<FusedPlanPow2<4096>>(P, p);
+            if (P->rgb8) {
+                // a strip = the same row pairs of all three planes (k_c2r_sharpen_v_rgb8): a third of the pairs per strip
+                FusedParams q = p;
+                const int ppl = (int)P->uH / 2;
+                q.pairs_per_strip = std::max(1, p.pairs_per_strip / 3);
+                hipLaunchKernelGGL((k_c2r_sharpen_v_rgb8<TUNED_TK>), dim3((ppl + q.pairs_per_strip - 1) / q.pairs_per_strip), dim3(VPlan4096::T),
+                                   VPlan4096::lds(true), P->lanes[P->cur].stream, q);
+            }
+            else if (P->vpair) launch_fused_v(P, p); else launch_fused_t<FusedPlanPow2<4096>>(P, p);
             break;
         }
         P->R_valid = false;

@@ -611,4 +611,265 @@ __global__ void __launch_bounds__(512, 4) k_c2r_sharpen_v(FusedParams p)
     }
 }
 
+// =================================================================================== -p 2, 8-bit RGB out: all three planes per strip
+// FFTUP_FLAG_FUSE_U8_STORE with k_c2r_sharpen_g / k_c2r_sharpen_v stores one colour plane per workgroup: byte stores at stride
+// 3, the three bytes of a pixel written by three workgroups at three times -- every 64-byte piece of the image is written
+// three times, partially (WRITE_SIZE 77 MB for a 25 MB image, profiles/r03_z_pmc_summary_fp16u8_u8store.txt), and the kernel
+// is slower than the one that writes 50 MB of binary16 planes.  Here a strip owns its row pairs in ALL THREE planes: per
+// step three transforms + three sharpen passes (the vertical-pair kernel needs ten saved registers per plane), the 8-bit
+// values of the three planes meet in registers, are interleaved with v_perm_b32 and leave as 24 contiguous bytes per thread
+// and row: the image is written once.  (Cost: a strip has four row pairs instead of twelve behind its one halo pair.)
+__device__ __forceinline__ constexpr unsigned rgb_sel_rg(int j)      // selector of perm(G, R): output dword j of 12 interleaved bytes
+{
+    unsigned s = 0;
+    for (int i = 0; i < 4; i++) {
+        const int pos = 4 * j + i, px = pos / 3, ch = pos % 3;
+        s |= (unsigned)(ch == 0 ? px : ch == 1 ? 4 + px : 0) << (8 * i);
+    }
+    return s;
+}
+__device__ __forceinline__ constexpr unsigned rgb_sel_b(int j)       // selector of perm(B, t): B bytes into their places, the rest passes
+{
+    unsigned s = 0;
+    for (int i = 0; i < 4; i++) {
+        const int pos = 4 * j + i, px = pos / 3, ch = pos % 3;
+        s |= (unsigned)(ch == 2 ? 4 + px : i) << (8 * i);
+    }
+    return s;
+}
+// four pixels: r, g, b = four bytes each (pixel k in byte k) -> 12 interleaved bytes
+__device__ __forceinline__ void rgb_interleave4(unsigned r, unsigned g, unsigned b, unsigned (&o)[3])
+{
+#pragma unroll
+    for (int j = 0; j < 3; j++) o[j] = __builtin_amdgcn_perm(b, __builtin_amdgcn_perm(g, r, rgb_sel_rg(j)), rgb_sel_b(j));
+}
+
+template <int TK>
+__global__ void __launch_bounds__(512, 3) k_c2r_sharpen_v_rgb8(FusedParams p)
+{
+    constexpr int UW = 4096, T = 512, NI = 2, KH = 1024, NB0 = 512, U = 2;
+    constexpr float inv = 0.5f / (float)UW;
+    constexpr unsigned ES = sizeof(h2v);
+    extern __shared__ __attribute__((aligned(128))) char smem[];
+    char* zb = smem + 4096 * ES;
+    float* red = (float*)zb;                     // [c][0..15] corner partial sums, [c][16] corner DC term (strip start only)
+    int lt = threadIdx.x;
+    const int uH = p.uH;
+    const int pairs_per_plane = uH / 2;
+    VTwid tws;
+    vfft_load_tw(tws, p.tw, lt);
+    // the strip: row pairs [j0, j1) of every plane
+    const int j0 = blockIdx.x * p.pairs_per_strip;
+    const int j1 = min(j0 + p.pairs_per_strip, pairs_per_plane);
+    if (j0 >= j1) return;
+    const int y0 = 2 * j0, y1 = 2 * j1;
+    const bool top = (y0 == 0);
+    const int a0 = top ? 0 : y0 - 1;
+    const int npairs = (j1 - j0) + 1;
+    const unsigned tile_stride32 = (unsigned)(uH / U) * TK;
+    auto koff = [&](int k) -> unsigned {
+        return (__umul24((unsigned)k / TK, tile_stride32) + ((unsigned)k % TK)) * (unsigned)sizeof(float2);
+    };
+    typedef const __attribute__((address_space(1))) char* gptr_t;
+    auto rowbase = [&](int c, int row) -> gptr_t {
+        const float2* base = p.S1 + (long)c * p.NT * (long)tile_stride32;
+        const unsigned off = (((unsigned)row / U) * TK + ((unsigned)row % U) * p.odd_delta) * (unsigned)sizeof(float2);
+        gptr_t r = (gptr_t)base + __builtin_amdgcn_readfirstlane(off);
+        asm("" : "+s"(r));
+        return r;
+    };
+    auto gload = [](gptr_t r, unsigned off) -> float2 {
+        asm("" : "+v"(off));
+        const lds_f2raw t = *(const __attribute__((address_space(1))) lds_f2raw*)(r + off);
+        return make_float2(t.x, t.y);
+    };
+    const bool need_corner = !top && (y1 + 1 < uH);
+    const int rs = y1 + 1;
+    struct In { float2 a[NI], am[NI], b[NI], bm[NI]; float lka, lkb; };
+    unsigned ko[NI], kom[NI];
+    {
+        const int jj = ((lt & 63) >> 3) + 8 * (lt & 7) + 64 * (lt >> 6);
+#pragma unroll
+        for (int m = 0; m < NI; m++) { ko[m] = koff(jj + NB0 * m); kom[m] = koff(KH - jj - NB0 * m); }
+    }
+    auto load_pair = [&](int i, int c) -> In {
+        In in;
+        const int a = a0 + 2 * i;
+        const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);
+        const gptr_t ra = rowbase(c, ya), rb = rowbase(c, yb);
+#pragma unroll
+        for (int m = 0; m < NI; m++) {
+            in.a[m] = gload(ra, ko[m]); in.am[m] = gload(ra, kom[m]);
+            in.b[m] = gload(rb, ko[m]); in.bm[m] = gload(rb, kom[m]);
+        }
+        in.lka = *(const __attribute__((address_space(1))) float*)(rowbase(c, ya ^ 1) + 4);
+        in.lkb = *(const __attribute__((address_space(1))) float*)(rowbase(c, yb ^ 1) + 4);
+        return in;
+    };
+    auto settle = [](In& in) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+        for (int m = 0; m < NI; m++)
+            asm volatile("" : "+v"(in.a[m].x), "+v"(in.a[m].y), "+v"(in.am[m].x), "+v"(in.am[m].y), "+v"(in.b[m].x), "+v"(in.b[m].y),
+                              "+v"(in.bm[m].x), "+v"(in.bm[m].y));
+        asm volatile("" : "+v"(in.lka), "+v"(in.lkb));
+    };
+    // corner samples L(y1 + 1, 0) of the three planes (SE tap of the strip's last pixel), as k_c2r_sharpen_g forms them
+    float corner[3] = {0.f, 0.f, 0.f};
+    if (need_corner) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float part = 0.f;
+            for (int kk = lt + 1; kk <= KH; kk += T) part += gload(rowbase(c, rs), koff(kk)).x;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+            if ((lt & 63) == 0) red[32 * c + (lt >> 6)] = part;
+            if (lt == T - 1) {
+                const float2 d = gload(rowbase(c, rs), koff(0)), dp = gload(rowbase(c, rs ^ 1), koff(0));
+                red[32 * c + 16] = (rs & 1) ? d.x + dp.y : d.x - dp.y;
+            }
+        }
+    }
+    In in = load_pair(0, 0);
+    settle(in);
+    __syncthreads();
+    if (need_corner) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float sum = 0.f;
+            for (int w2 = 0; w2 < T / 64; w2++) sum += red[32 * c + w2];
+            corner[c] = (red[32 * c + 16] + 2.0f * sum) * inv;
+        }
+    }
+    __syncthreads();            // red[] lives in the exchange buffer
+    float pn0[3] = {0.f, 0.f, 0.f}, pn1[3] = {0.f, 0.f, 0.f}, lprev0[3] = {0.f, 0.f, 0.f};      // thread T-1: taps of the deferred pixels
+    h2v P0[3][10];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int i = 0; i < 10; i++) P0[c][i] = h2v{};
+    auto nohook = [](int) {};
+
+    for (int s = 0; s < npairs; s++) {
+        const int a = a0 + 2 * s;
+        const bool out0 = (a - 1) >= y0 && (a - 1) < y1, out1 = a >= y0 && a < y1;
+        unsigned ob[3][2][2];                    // 8-bit values: [plane][row a-1 / a][pixels 0-3 / 4-7], pixel k in byte k
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            // ================= transform of pair s, plane c
+            asm volatile("" : "+v"(lt));
+            float2 v[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) v[m] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int m = 0; m < NI; m++) {
+                v[m] = cadd_i(in.a[m], in.b[m]);
+                v[8 - NI + m] = cadd_conj_i(in.am[m], in.bm[m]);
+            }
+            if (lt == 0) {
+                v[NI] = make_float2(in.am[0].x - in.bm[0].y, in.am[0].y + in.bm[0].x);
+                const int ya = min(a, uH - 1), yb = min(a + 1, uH - 1);
+                v[0] = make_float2(in.a[0].x + ((ya & 1) ? in.lka : -in.lka), in.b[0].x + ((yb & 1) ? in.lkb : -in.lkb));
+            }
+            in = (c < 2) ? load_pair(s, c + 1) : load_pair(min(s + 1, npairs - 1), 0);
+            vfft4096(v, zb, lt, tws, nohook);
+            settle(in);
+            {
+                const unsigned lw = lds_addr(smem) + ES * (512u * ((unsigned)lt >> 6) + ((unsigned)lt & 63u));
+                const h2v up2 = h2_splat(p.upsq), one2 = h2_splat(1.0f);
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const f2v sv = mk2(v[q].x, v[q].y) * mk2(inv, inv);
+                    const h2v g = {(_Float16)sv.x, (_Float16)sv.y};
+                    const h2v Lv = __builtin_elementwise_min(h2_bits(bits_h2(up2 * g) & 0x7fff7fffu), one2);
+                    *(__attribute__((address_space(3))) h2v*)(size_t)(lw + ES * 64u * q) = Lv;
+                }
+            }
+            __syncthreads();
+            // ================= sharpen rows a-1 and a of plane c
+            h2v P1[10];
+            {
+                const unsigned cb = lds_addr(smem) + ES * (unsigned)lt;
+                typedef __attribute__((address_space(3))) h2v lds_lp;
+#pragma unroll
+                for (int m = 0; m < 8; m++) P1[m + 1] = *(const lds_lp*)(size_t)(cb + ES * 512u * m);
+                P1[0] = *(const lds_lp*)(size_t)(cb + ES * (7u * 512u - 1u));
+                P1[9] = *(const lds_lp*)(size_t)(cb + ES);
+            }
+            const h2v la = *(const __attribute__((address_space(3))) h2v*)(size_t)lds_addr(smem);
+            const float la0 = (float)la.x, la1 = (float)la.y;
+            float lse = la1;
+            {
+                const int r2 = min(a + 2, uH - 1) - a;
+                if (r2 == 0) lse = la0;
+                else if (r2 > 1 && s == npairs - 1) lse = to_L<true>(corner[c], p.upsq);
+            }
+            if (lt == 0) P1[0] = P1[1];
+            if (lt == T - 1) {
+                P1[9].x = la.y;
+                P1[9].y = (_Float16)lse;
+                if (a != 0) P0[c][9].y = la.x;
+            }
+            if (a == 0) {
+                asm volatile("");
+#pragma unroll
+                for (int i = 0; i < 10; i++) { P0[c][i].x = 0; P0[c][i].y = P1[i].x; }
+            }
+            if (lt == T - 1) {
+                const float m0 = (float)P0[c][7].x, m1 = (float)P0[c][8].x, me = (float)P0[c][9].x;
+                const float s0 = (float)P0[c][7].y, s1 = (float)P0[c][8].y;
+                if (s > 0 && (a - 2) >= y0 && (a - 2) < y1 && a <= uH - 1)
+                    deferred_pixel<true, true>(p, ((long)(a - 2) * UW + (UW - 1)) * 3 + c, pn0[c], pn1[c], (a - 2 == 0) ? me : lprev0[c], m0, m1, me, s0, s1, la0);
+                if (a == 0) { pn0[c] = (float)P1[7].x; pn1[c] = (float)P1[8].x; }
+                else { pn0[c] = s0; pn1[c] = s1; }
+                lprev0[c] = la0;
+            }
+            ob[c][0][0] = ob[c][0][1] = ob[c][1][0] = ob[c][1][1] = 0u;
+            if (out0 || out1) {                  // (the halo step only fills the saved rows)
+#pragma clang fp contract(off)
+                const h2v ncoef = h2_splat(-p.coef);
+                h2v C[10], vmn[10], vmx[10];
+#pragma unroll
+                for (int i = 0; i < 10; i++) {
+                    C[i] = h2_bits(__builtin_amdgcn_alignbit(bits_h2(P1[i]), bits_h2(P0[c][i]), 16));
+                    vmn[i] = pk_min3(P0[c][i], C[i], P1[i]);
+                    vmx[i] = pk_max3(P0[c][i], C[i], P1[i]);
+                }
+                h2v o[8];
+#pragma unroll
+                for (int i = 1; i <= 8; i++) {
+                    const h2v mn1 = pk_min3(vmn[i - 1], vmn[i], vmn[i + 1]), mx1 = pk_max3(vmx[i - 1], vmx[i], vmx[i + 1]);
+                    const h2v mn0 = pk_min3(vmn[i], C[i - 1], C[i + 1]), mx0 = pk_max3(vmx[i], C[i - 1], C[i + 1]);
+                    o[i - 1] = sharpen_eval_pair_half(P0[c][i], P1[i], C[i - 1], C[i + 1], C[i], mn0, mn1, mx0, mx1, ncoef);
+                }
+#pragma unroll
+                for (int wr = 0; wr < 2; wr++) {
+                    uint8_t q0[4], q1[4];
+                    cvt4_f_u8((float)o[0][wr], (float)o[1][wr], (float)o[2][wr], (float)o[3][wr], p.u8_wrap, q0);
+                    cvt4_f_u8((float)o[4][wr], (float)o[5][wr], (float)o[6][wr], (float)o[7][wr], p.u8_wrap, q1);
+                    ob[c][wr][0] = q0[0] | (q0[1] << 8) | (q0[2] << 16) | ((unsigned)q0[3] << 24);
+                    ob[c][wr][1] = q1[0] | (q1[1] << 8) | (q1[2] << 16) | ((unsigned)q1[3] << 24);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 10; i++) P0[c][i] = P1[i];
+        }
+        // ================= the three planes meet: 24 interleaved bytes per thread and row
+#pragma unroll
+        for (int wr = 0; wr < 2; wr++) {
+            if (wr == 0 ? !out0 : !out1) continue;
+            unsigned lo[3], hi[3];
+            rgb_interleave4(ob[0][wr][0], ob[1][wr][0], ob[2][wr][0], lo);
+            rgb_interleave4(ob[0][wr][1], ob[1][wr][1], ob[2][wr][1], hi);
+            char* dst = (char*)p.out + (long)(a - 1 + wr) * UW * 3 + (unsigned)lt * 24u;
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            typedef unsigned u2v __attribute__((ext_vector_type(2)));
+            typedef u4v __attribute__((aligned(4))) u4v_u;
+            typedef u2v __attribute__((aligned(4))) u2v_u;
+            *(u4v_u*)dst = u4v{lo[0], lo[1], lo[2], hi[0]};
+            *(u2v_u*)(dst + 16) = u2v{hi[1], hi[2]};
+        }
+    }
+}
+
 }  // namespace fftup
