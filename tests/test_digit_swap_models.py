@@ -1,0 +1,152 @@
+"""CPU: the index algebra of the digit-swap transforms of csrc/kernels_vpair.hpp, replayed in numpy -- which element sits in
+which (wave, lane, register) after every exchange, and which twiddle it meets there.  These are the models the HIP kernels were
+written from (vfft4096: the fused kernel's 4096-point transform; k_col_v: forward decimation-in-time, phase, inverse
+decimation-in-frequency of the 1024-point column pass); the GPU parity tests check the kernels, these check the derivation."""
+import numpy as np
+
+W8 = {+1: np.exp(+2j * np.pi * np.outer(np.arange(8), np.arange(8)) / 8), -1: np.exp(-2j * np.pi * np.outer(np.arange(8), np.arange(8)) / 8)}
+
+
+def test_vfft4096_digit_swap_model():
+    N, DIR = 4096, -1
+    rng = np.random.default_rng(1)
+    Z = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    ref = np.fft.fft(Z)                                   # X[k] = sum x[n] exp(-2 pi i n k / N)
+    tw = np.conj(np.exp(2j * np.pi * np.arange(N) / N))   # twid<-1>(table)
+    v = np.zeros((8, 64, 8), complex)                     # [wave][lane][register]
+    for w in range(8):
+        for l in range(64):
+            a, b = l & 7, l >> 3
+            v[w, l, :] = Z[b + 8 * a + 64 * w + 512 * np.arange(8)]         # first-stage inputs of thread (w, l)
+    v = v @ W8[DIR].T
+    nv = np.zeros_like(v)                                 # exchange A: register <-> wave (LDS)
+    for w in range(8):
+        for k0 in range(8):
+            nv[k0, :, w] = v[w, :, k0]
+    v = nv
+    for w in range(8):
+        for m in range(8):
+            v[w, :, m] *= tw[(64 * m * w) % N]             # wave-uniform twiddles
+    v = v @ W8[DIR].T
+    nv = np.zeros_like(v)                                 # exchange B: register <-> lane bits 0-2, inside the wave's LDS block
+    for w in range(8):
+        blk = np.zeros(512, complex)
+        for l in range(64):
+            a, b = l & 7, l >> 3
+            for k1 in range(8):
+                blk[a * 64 + 8 * b + (a ^ k1)] = v[w, l, k1]
+        for l in range(64):
+            a, b = l & 7, l >> 3
+            for m in range(8):
+                nv[w, l, m] = blk[m * 64 + 8 * b + (m ^ a)]
+    v = nv
+    for w in range(8):
+        for l in range(64):
+            v[w, l, :] *= tw[(8 * np.arange(8) * (w + 8 * (l & 7))) % N]
+    v = v @ W8[DIR].T
+    nv = np.zeros_like(v)                                 # exchange C: register <-> lane bits 3-5 (permlane swaps, DPP)
+    for l in range(64):
+        a, b = l & 7, l >> 3
+        for k2 in range(8):
+            nv[:, a + 8 * k2, b] = v[:, l, k2]
+    v = nv
+    for w in range(8):
+        for l in range(64):
+            v[w, l, :] *= tw[(np.arange(8) * (w + 8 * l)) % N]
+    v = v @ W8[DIR].T
+    for w in range(8):
+        for l in range(64):
+            assert np.abs(v[w, l, :] - ref[w + 8 * l + 512 * np.arange(8)]).max() <= 1e-9      # X[w + 8 l + 512 q] in register q
+
+
+def test_k_col_v_digit_swap_model():
+    N = 1024
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    tw = lambda j, n=N: np.exp(2j * np.pi * j / n)
+    F = np.fft.ifft(x) * N                                # forward: exp(+2 pi i n k / N)
+    k = np.arange(N)
+    t = np.exp(-2j * np.pi * k / (2 * N)) * np.where(k < N // 2, 1, -1)
+    ref = np.fft.fft(F * t)                               # the odd rows of the zero-padded inverse (polyphase column pass)
+    v = np.zeros((8, 16, 8), complex)                     # [wave][h = lane >> 2][register]; pp = 16 w + h
+    for w in range(8):
+        for h in range(16):
+            v[w, h, :] = x[16 * w + h + 128 * np.arange(8)]
+    v = v @ W8[+1].T
+    nv = np.zeros_like(v)                                 # A: register <-> wave
+    for w in range(8):
+        for k0 in range(8):
+            nv[k0, :, w] = v[w, :, k0]
+    v = nv
+    for k0 in range(8):
+        for R in range(8):
+            v[k0, :, R] *= tw(16 * R * k0)
+    v = v @ W8[+1].T
+    nv = np.zeros_like(v)                                 # C: register <-> lane bits 5-3 (= h >> 1)
+    for h in range(16):
+        g, h0 = h >> 1, h & 1
+        for k1 in range(8):
+            nv[:, (k1 << 1) | h0, g] = v[:, h, k1]
+    v = nv
+    for w in range(8):
+        for h in range(16):
+            v[w, h, :] *= tw(2 * np.arange(8) * (w + 8 * (h >> 1)))
+    v = v @ W8[+1].T
+    nv = np.zeros_like(v)                                 # register bit 2 <-> lane bit 2 (= h & 1)
+    for h in range(16):
+        k1, h0 = h >> 1, h & 1
+        for k2 in range(8):
+            nv[:, (k1 << 1) | (k2 >> 2), (h0 << 2) | (k2 & 3)] = v[:, h, k2]
+    v = nv
+    for w in range(8):
+        for h in range(16):
+            k1, lb2 = h >> 1, h & 1
+            for r in range(4):
+                a, b = v[w, h, r], v[w, h, r + 4] * tw(w + 8 * k1 + 256 * lb2) * tw(64 * r)
+                v[w, h, r], v[w, h, r + 4] = a + b, a - b
+    for w in range(8):                                    # F[k] at k = w + 8 k1 + 256 lb2 + 64 r + 512 k3 in register r + 4 k3
+        for h in range(16):
+            for r in range(4):
+                for k3 in range(2):
+                    assert abs(v[w, h, r + 4 * k3] - F[w + 8 * (h >> 1) + 256 * (h & 1) + 64 * r + 512 * k3]) <= 1e-9
+    for w in range(8):                                    # the phase, where the elements are
+        for h in range(16):
+            base = np.conj(tw(w + 8 * (h >> 1) + 256 * (h & 1), 2 * N))
+            for r in range(4):
+                for k3 in range(2):
+                    v[w, h, r + 4 * k3] *= base * np.exp(-2j * np.pi * r / 32) * (1j if k3 else 1)
+    for w in range(8):                                    # inverse, decimation in frequency
+        for h in range(16):
+            for r in range(4):
+                a, b = v[w, h, r], v[w, h, r + 4]
+                v[w, h, r], v[w, h, r + 4] = a + b, a - b
+    nv = np.zeros_like(v)
+    for h in range(16):
+        k1, lb2 = h >> 1, h & 1
+        for R in range(8):
+            nv[:, (k1 << 1) | (R >> 2), (lb2 << 2) | (R & 3)] = v[:, h, R]
+    v = nv
+    for h in range(16):
+        v[:, h, :] *= np.exp(-2j * np.pi * np.arange(8) * (h & 1) / 16)
+    v = v @ W8[-1].T
+    nv = np.zeros_like(v)
+    for h in range(16):
+        k1, h0 = h >> 1, h & 1
+        for g in range(8):
+            nv[:, (g << 1) | h0, k1] = v[:, h, g]
+    v = nv
+    for h in range(16):
+        v[:, h, :] *= np.conj(tw(8 * h * np.arange(8)))
+    v = v @ W8[-1].T
+    nv = np.zeros_like(v)
+    for k0 in range(8):
+        for wp in range(8):
+            nv[wp, :, k0] = v[k0, :, wp]
+    v = nv
+    for w in range(8):
+        for h in range(16):
+            v[w, h, :] *= np.conj(tw((16 * w + h) * np.arange(8)))
+    v = v @ W8[-1].T
+    for w in range(8):
+        for h in range(16):
+            assert np.abs(v[w, h, :] - ref[16 * w + h + 128 * np.arange(8)]).max() <= 1e-8      # row pp + 128 i in register i: the load layout
