@@ -419,8 +419,8 @@ def main():
                          "frame_frac": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 8e12},
         }
         if power_stats and power_stats.get("socket_power_w_median"):
-            # at the power limit this is the number a kernel change has to move: joules per frame, whole job
-            power_stats["energy_mj_per_frame"] = power_stats["socket_power_w_median"] * wall_frame_ms * world
+            # at the power limit this is the number a kernel change has to move: joules per frame
+            power_stats["energy_mj_per_frame"] = power_stats["socket_power_w_median"] * wall_frame_ms       # (one GPU works on a frame)
         line["power"] = power_stats
         if args.host_streamed:
             pcie = 3.0 * (args.width * args.height + up.out_width * up.out_height)
