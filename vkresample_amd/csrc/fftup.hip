@@ -608,7 +608,8 @@ int fftup_plan_describe(const fftup_plan* P, char* buf, size_t buflen)
     if (!P || !buf || !buflen) return fail(FFTUP_E_INVALID_ARG, "null argument");
     std::string s;
     if (P->mixed == 3) s = "specialised at plan time: " + fftup_jit::describe(P->jit->choice);
-    else if (P->tuned) s = "ahead-of-time power-of-two kernels (radix 8, 8 points per thread; fused C2R+sharpen " + std::string(P->fused ? (P->vpair ? "on: k_c2r_sharpen_v" : "on") : "off") + ")";
+    else if (P->tuned) s = "ahead-of-time power-of-two kernels (radix 8, 8 points per thread; fused C2R+sharpen " + std::string(P->fused ? (P->rgb8 ? "on: k_c2r_sharpen_v_rgb8" : P->vpair ? "on: k_c2r_sharpen_v" : "on") : "off") + ")"
+                           + ((P->H == 1024 && P->colv) ? "; column kernel with digit-swap exchanges" : "");
     else if (P->mixed) s = std::string("ahead-of-time mixed-radix kernels: ") + (P->mixed == 1 ? "row 15*8*16, col 9*10*12, fused 16*16*15" : "row 5*16*16, col 9*8*10, fused 16*16*10");
     else if (P->cplx) s = "size-generic kernels, non-R2C path (full complex transforms)";
     else s = std::string("size-generic kernels (LDS ping-pong, run-time radix lists)") + (P->dbl ? ", double" : "");
