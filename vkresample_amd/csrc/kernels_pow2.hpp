@@ -1441,7 +1441,12 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
             const gptr_t ra = rowbase(ya), rb = rowbase(yb);
             if constexpr (MS) {
 #pragma unroll
-                for (int m = 0; m < NI; m++) { in.a[m] = gload(ra, ko[m]); in.b[m] = gload(rb, ko[m]); in.am[m] = in.bm[m] = make_float2(0.f, 0.f); }
+                for (int m = 0; m < NI; m++) {
+                    in.a[m] = gload(ra, ko[m]); in.b[m] = gload(rb, ko[m]);
+                    // (am, bm: whatever the registers hold -- the two lanes below load them, all others receive them in share();
+                    // an initialisation would be eight vector instructions per step for nothing)
+                    asm volatile("" : "=v"(in.am[m].x), "=v"(in.am[m].y), "=v"(in.bm[m].x), "=v"(in.bm[m].y));
+                }
                 if (ms_self) {                      // (two lanes of wave 0; loads only inside the branch: nothing waits)
 #pragma unroll
                     for (int m = 0; m < NI; m++) { in.am[m] = gload(ra, kom[m]); in.bm[m] = gload(rb, kom[m]); }
@@ -1482,10 +1487,9 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                     return make_float2(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pl, __builtin_bit_cast(int, z.x))),
                                        __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(pl, __builtin_bit_cast(int, z.y))));
                 };
+                if (!ms_self) {                      // (the permutes run under the execution mask: no selects)
 #pragma unroll
-                for (int m = 0; m < NI; m++) {
-                    const float2 pa = part(in.a[NI - 1 - m]), pb = part(in.b[NI - 1 - m]);
-                    if (!ms_self) { in.am[m] = pa; in.bm[m] = pb; }
+                    for (int m = 0; m < NI; m++) { in.am[m] = part(in.a[NI - 1 - m]); in.bm[m] = part(in.b[NI - 1 - m]); }
                 }
             }
         };
