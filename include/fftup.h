@@ -75,26 +75,14 @@ typedef struct fftup_config {
     uint32_t ring;            /* resident input/output frame slots (0 or 1 = one, like the reference; <= 64) */
 } fftup_config;
 
-/* Environment read once by fftup_plan_create (tuning and test knobs, not part of the reference's surface):
- *   FFTUP_STREAMS=n          HIP streams consecutive frames of fftup_execute_ring / fftup_submit_rgb8 alternate on
- *                            (default 3, 1..4); fftup_execute always uses one
- *   FFTUP_G_PER_CU=n         strips (workgroups) of the fused C2R+sharpen kernel per compute unit (default: 1 for plans with a
- *                            ring of slots, whose frames overlap on the streams; 2 for plans without one when the fused
- *                            kernel's workgroup has at most 256 threads)
- *   FFTUP_PAIRS_PER_STRIP=n  row pairs per workgroup of the fused C2R+sharpen kernel (default: pairs / compute units)
- *   FFTUP_JIT=0|1            run-time specialised plans (default 1); FFTUP_JIT_VERBOSE=1 prints why one fell back;
- *                            FFTUP_JIT_TUNE=1 = FFTUP_FLAG_TUNE_PLAN for every plan;
- *                            FFTUP_KERNEL_DIR / FFTUP_CACHE_DIR: kernel headers / code-object cache (jit.hpp);
- *                            FFTUP_HIPRTC_LIB: the run-time compiler's shared object (default: libhiprtc.so of the ROCm install)
- *   FFTUP_AOT=0              experiments: sizes with ahead-of-time kernels go through the plan-time compiler as well
- *   FFTUP_3840_X16=0|1       1920x1080 -u 2: fused kernel on the 16*16*15 plan, 256 threads (1, default) or the
- *                            8*8*4*15 plan, 512 threads (0); same results up to fp32 rounding (tests)
- *   FFTUP_COLV=0|1           column length 1024: k_col_v, the column kernel with digit-swap exchanges (1, default) or k_col_t (0)
- *   FFTUP_RGB8=0|1           -p 2 with FFTUP_FLAG_FUSE_U8_STORE, output rows of 4096 points: a strip owns its rows in all three colour planes and
- *                            writes the 8-bit image once (1: k_c2r_sharpen_v_rgb8; WRITE_SIZE 25 instead of 77 MB, frame +2 %) or one
- *                            plane per strip (0, default)
- *   FFTUP_VPAIR=0|1          output rows of 4096 points: the fused kernel on vertical pairs, k_c2r_sharpen_v (1), or
- *                            k_c2r_sharpen_g (0, default); same results up to fp32 / binary16 rounding (tests) */
+/* Environment read by fftup_plan_create (operational knobs, not part of the reference's surface):
+ *   FFTUP_STREAMS=n     HIP streams consecutive frames of fftup_execute_ring / fftup_submit_rgb8 alternate on (default 3, 1..4);
+ *                       fftup_execute always uses one
+ *   FFTUP_JIT=0|1       run-time specialised plans (default 1); FFTUP_JIT_VERBOSE=1 prints why one fell back;
+ *                       FFTUP_JIT_TUNE=1 = FFTUP_FLAG_TUNE_PLAN for every plan
+ *   FFTUP_CACHE_DIR     code-object cache and wisdom file of those plans (default ~/.cache/fftup);
+ *   FFTUP_KERNEL_DIR    kernel headers, when not the ones embedded in the library; FFTUP_HIPRTC_LIB: the run-time compiler's
+ *                       shared object (default: libhiprtc.so of the ROCm install) */
 
 typedef struct fftup_plan fftup_plan;   /* opaque; replaces VkGPU + 2x VkFFTApplication +
                                            2x VkShiftApplication + the three device buffers      */
@@ -162,7 +150,8 @@ FFTUP_API int fftup_upload_planar(fftup_plan* plan, uint32_t slot, const void* p
                                   size_t row_stride_elems, size_t plane_stride_elems);
 
 /* performVulkanUpscale (VR:1249-1279): enqueue n_iter full pipelines back to back on the plan's ONE
- * stream (the reference records them into one command buffer on one queue), one synchronisation.
+ * stream, one synchronisation.  Like the reference, which records them into one command buffer on one queue
+ * (VR:1250-1273), the frame's launches are recorded once (hipGraph) and replayed.
  * *ms_per_iter = device time from before the first to after the last launch, divided by n_iter -- the
  * reference's "Time: X ms" (VR:1270-1278): single-queue frame latency, no overlap between iterations.
  * Every iteration reads input slot 0 and writes output slot 0. */
@@ -190,9 +179,11 @@ FFTUP_API int fftup_download_planar(fftup_plan* plan, uint32_t slot, void* plane
  * part of the complex image -- and the converted input planes [3][H][W]. */
 FFTUP_API int fftup_download_presharpen(fftup_plan* plan, void* planes);
 FFTUP_API int fftup_download_input_planar(fftup_plan* plan, uint32_t slot, void* planes);
-/* job accounting (batched / multi-GPU runs): 64-bit wrapping sum of the 32-bit words of output slot `slot` (the dense
- * [3][uH][uW] planes), computed on the device -- a frame's fingerprint without moving the frame over PCIe.  Sums over
- * the frames of a job do not depend on which rank or thread processed which frame. */
+/* job accounting (batched / multi-GPU runs): 64-bit wrapping sum of the 32-bit words of WHATEVER output slot `slot` holds --
+ * the dense [3][uH][uW] float / half planes, or the interleaved 8-bit image [uH][uW][3] of a plan with
+ * fftup_info.u8_store == 1 -- computed on the device: a frame's fingerprint without moving the frame over PCIe.  Sums over
+ * the frames of a job do not depend on which rank or thread processed which frame; they are comparable only between plans
+ * of the same precision and the same u8_store. */
 FFTUP_API int fftup_output_checksum(fftup_plan* plan, uint32_t slot, uint64_t* sum);
 
 /* Host-streamed batches (replaces the blocking transferDataFromCPU / transferDataToCPU + the two CPU

@@ -1,6 +1,6 @@
-"""CPU: the index algebra of the digit-swap transforms of csrc/kernels_vpair.hpp, replayed in numpy -- which element sits in
+"""CPU: the index algebra of the digit-swap transforms of csrc/kernels_dswap.hpp, replayed in numpy -- which element sits in
 which (wave, lane, register) after every exchange, and which twiddle it meets there.  These are the models the HIP kernels were
-written from (vfft4096: the fused kernel's 4096-point transform; k_col_v: forward decimation-in-time, phase, inverse
+written from (a 4096-point transform with one LDS exchange; k_col_v: forward decimation-in-time, phase, inverse
 decimation-in-frequency of the 1024-point column pass); the GPU parity tests check the kernels, these check the derivation."""
 import numpy as np
 

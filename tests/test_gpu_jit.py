@@ -117,7 +117,7 @@ def test_specialisation_can_be_switched_off(monkeypatch):
 
 
 def test_pinned_factorizations(monkeypatch):
-    """FFTUP_JIT_ROW / _COL / _FUSED pin a factorization (experiments): other valid choices give the same pixels up to
+    """FFTUP_EXPERIMENT keys jit_row / jit_col / jit_fused pin a factorization: other valid choices give the same pixels up to
     fp32 rounding"""
     from vkresample_amd import synth
     rgb = synth.frame(9, 640, 480, "N")
@@ -129,9 +129,7 @@ def test_pinned_factorizations(monkeypatch):
             up.execute(1)
             return up.download_planar().astype(np.float64)
     ref = run()
-    monkeypatch.setenv("FFTUP_JIT_ROW", "5,8,16")
-    monkeypatch.setenv("FFTUP_JIT_COL", "15,4,8")
-    monkeypatch.setenv("FFTUP_JIT_FUSED", "192:8,10,16")
+    monkeypatch.setenv("FFTUP_EXPERIMENT", "jit_row=5,8,16;jit_col=15,4,8;jit_fused=192:8,10,16")
     got = run()
     assert np.percentile(np.abs(ref - got), 99.99) <= 1e-5 and np.abs(ref - got).max() <= 2e-4
 

@@ -322,7 +322,7 @@ def test_fused_sharpen_equals_unfused(precision, pps, monkeypatch):
     sample) against the two-launch path on the same frame, for strip lengths that do / do not divide the
     plane, cross plane boundaries, or swallow whole planes."""
     from vkresample_amd import FLAG_UNFUSED_SHARPEN
-    monkeypatch.setenv("FFTUP_PAIRS_PER_STRIP", str(pps))
+    monkeypatch.setenv("FFTUP_EXPERIMENT", "pairs_per_strip=%d" % pps)
     (pre, out, u8), _ = _run(512, 256, 2.0, precision, "U", seed=3)
     (pre2, out2, u82), _ = _run(512, 256, 2.0, precision, "U", flags=FLAG_UNFUSED_SHARPEN, seed=3)
     if precision == 0:
@@ -726,7 +726,7 @@ def test_fused_output_independent_of_strip_length(W, H, precision):
     <= 1.8e-6 (fp32), 61 pixels in 1.5 M one or two binary16 ulps apart (-p 2).  A wrong halo, tap or cut costs >= 1e-3."""
     ref = _run_env({}, W, H, precision).astype(np.float64)
     for pairs in ((1, 2, 3, 5, 7, 50) if W == 512 else (3, 5, 7, 50)):
-        got = _run_env({"FFTUP_PAIRS_PER_STRIP": str(pairs)}, W, H, precision).astype(np.float64)
+        got = _run_env({"FFTUP_EXPERIMENT": "pairs_per_strip=%d" % pairs}, W, H, precision).astype(np.float64)
         d = np.abs(ref - got)
         if precision == 0:
             assert d.max() <= 5e-6, "pairs_per_strip = %d: %g" % (pairs, d.max())
@@ -734,115 +734,24 @@ def test_fused_output_independent_of_strip_length(W, H, precision):
             assert d.max() <= 4e-3 and (d != 0).mean() <= 2e-4, "pairs_per_strip = %d: %g, %g" % (pairs, d.max(), (d != 0).mean())
 
 
-@pytest.mark.parametrize("precision", [0, 2])
-def test_1080p_fused_plans_agree(precision):
-    """1920x1080: the 16*16*15 plan on 256 threads (default) and the 8*8*4*15 plan on 512 threads (FFTUP_3840_X16=0) are
-    different factorizations of the same transform: equal up to fp32 rounding, and both within tolerance of the oracle
-    (test_full_size_vs_oracle runs the default)."""
-    a = _run_env({}, 1920, 1080, precision).astype(np.float64)
-    b = _run_env({"FFTUP_3840_X16": "0"}, 1920, 1080, precision).astype(np.float64)
-    d = np.abs(a[:, :, :-1] - b[:, :, :-1]) if a.ndim == 3 else np.abs(a - b)
-    tol = 2e-4 if precision == 0 else 4e-3
-    assert d.max() <= tol and (d > (1e-5 if precision == 0 else 1e-3)).mean() <= 1e-3
-
-
-# ---- k_c2r_sharpen_v (csrc/kernels_vpair.hpp): the opt-in fused kernel for output rows of 4096 points (FFTUP_VPAIR=1) --
-# digit-swap transform (one workgroup-wide exchange, one inside the wave's LDS block, one by v_permlane swaps), L rows as
-# vertical pairs, sharpen on vertical pairs.  Same bars as the default kernel.
-@pytest.mark.parametrize("precision,flags", [(0, 0), (0, 2), (2, 0), (2, 2)])
-@pytest.mark.parametrize("dist", ["N", "U"])
-def test_vpair_kernel_full_size_vs_oracle(precision, flags, dist, monkeypatch):
-    monkeypatch.setenv("FFTUP_VPAIR", "1")
-    _check_full_size(2048, 1024, precision, flags, dist, " vpair")
-
-
-@pytest.mark.parametrize("precision", [0, 2])
-def test_vpair_kernel_strips_and_default_kernel(precision):
-    """strips of 3, 5, 7, 50 pairs (the last one crossing plane boundaries) agree with one strip per compute unit, and the
-    kernel agrees with the default one (k_c2r_sharpen_g) to rounding: same butterflies, another order of operations"""
-    ref = _run_env({"FFTUP_VPAIR": "1"}, 2048, 1024, precision).astype(np.float64)
-    for pairs in (3, 5, 7, 50):
-        got = _run_env({"FFTUP_VPAIR": "1", "FFTUP_PAIRS_PER_STRIP": str(pairs)}, 2048, 1024, precision).astype(np.float64)
-        d = np.abs(ref - got)
-        if precision == 0:
-            assert d.max() <= 5e-6, "pairs_per_strip = %d: %g" % (pairs, d.max())
-        else:
-            assert d.max() <= 4e-3 and (d != 0).mean() <= 2e-4, "pairs_per_strip = %d: %g, %g" % (pairs, d.max(), (d != 0).mean())
-    dflt = _run_env({"FFTUP_VPAIR": "0"}, 2048, 1024, precision).astype(np.float64)
-    d = np.abs(ref - dflt)
-    if precision == 0:
-        assert d.max() <= 1e-5, d.max()
-    else:
-        assert d.max() <= 4e-3 and (d != 0).mean() <= 5e-4, (d.max(), (d != 0).mean())
-
-
-@pytest.mark.parametrize("precision,flags", [(0, 0), (2, 2)])
-def test_vpair_kernel_fused_u8_store(precision, flags, monkeypatch):
-    """its 8-bit RGB store against planes + conversion launch of the same kernel: the same bytes"""
-    from vkresample_amd import FLAG_FUSE_U8_STORE, synth
-    monkeypatch.setenv("FFTUP_VPAIR", "1")
-    rgb = synth.frame(31, 2048, 1024, "N")
-    with _up(2048, 1024, 2.0, precision, 0.2, 0, flags) as up:
-        up.upload_rgb8(rgb)
-        up.execute(1)
-        ref = up.download_rgb8()
-    with _up(2048, 1024, 2.0, precision, 0.2, 0, flags | FLAG_FUSE_U8_STORE) as up:
-        up.upload_rgb8(rgb)
-        up.execute(2)
-        got = up.download_rgb8()
-    assert np.array_equal(got, ref), (np.argwhere(got != ref)[:5], (got != ref).sum())
-
-
-@pytest.mark.parametrize("precision", [0, 2])
-def test_column_kernels_agree(precision):
-    """H = 1024: k_col_v (digit-swap exchanges: one through LDS per transform, the others by v_permlane swaps / DPP moves; the
-    default) and k_col_t (three LDS exchanges per transform, FFTUP_COLV=0) are the same transforms in another order of
-    operations: equal up to fp32 rounding -- and both within tolerance of the oracle (test_full_size_vs_oracle runs the
-    default, this test the other one)."""
-    a = _run_env({"FFTUP_COLV": "1"}, 2048, 1024, precision).astype(np.float64)
-    b = _run_env({"FFTUP_COLV": "0"}, 2048, 1024, precision).astype(np.float64)
-    d = np.abs(a - b)
-    if precision == 0:
-        assert d.max() <= 1e-5, d.max()
-    else:
-        assert d.max() <= 4e-3 and (d != 0).mean() <= 5e-4, (d.max(), (d != 0).mean())
-    old = os.environ.get("FFTUP_COLV")
-    os.environ["FFTUP_COLV"] = "0"
-    try:
-        _check_full_size(2048, 1024, precision, 2 if precision else 0, "N", " k_col_t")
-    finally:
-        if old is None:
-            os.environ.pop("FFTUP_COLV", None)
-        else:
-            os.environ["FFTUP_COLV"] = old
-
-
-def test_rgb8_kernel_three_planes_per_strip(monkeypatch):
-    """FFTUP_RGB8=1: -p 2 + FFTUP_FLAG_FUSE_U8_STORE on k_c2r_sharpen_v_rgb8 -- a strip owns its row pairs in all three colour
-    planes and stores 24 interleaved bytes per thread and row (the 8-bit image is written once).  Against planes + conversion
-    launch of the default kernel: the same image up to the last binary16 digit of another transform order (<= 1 code, < 1e-4 of
-    the bytes); against the oracle: within two codes like every -p 2 path; for strips of 1, 2 and 17 pairs the same bytes."""
-    from vkresample_amd import FLAG_FUSE_U8_STORE, synth
-    rgb = synth.frame(31, 2048, 1024, "N")
-    with _up(2048, 1024, 2.0, 2, 0.2, 0, 2) as up:
-        up.upload_rgb8(rgb)
-        up.execute(1)
-        ref = up.download_rgb8()
-    monkeypatch.setenv("FFTUP_RGB8", "1")
-    outs = []
-    for pps in (None, "3", "6", "51"):
-        if pps:
-            monkeypatch.setenv("FFTUP_PAIRS_PER_STRIP", pps)
-        with _up(2048, 1024, 2.0, 2, 0.2, 0, 2 | FLAG_FUSE_U8_STORE) as up:
-            assert up.u8_store
-            up.upload_rgb8(rgb)
-            up.execute(2)
-            outs.append(up.download_rgb8())
-    got = outs[0]
-    d = np.abs(got.astype(int) - ref.astype(int))
-    assert d.max() <= 1 and (d != 0).mean() <= 1e-4, (d.max(), (d != 0).mean())
-    _, _, ou8 = O.upscale_rgb8(rgb, 2.0, 2, 0.2)
-    assert np.abs(got[:-1].astype(int) - ou8[:-1].astype(int)).max() <= 2
-    for o in outs[1:]:
-        dd = np.abs(o.astype(int) - got.astype(int))
-        assert dd.max() <= 1 and (dd != 0).mean() <= 1e-4, (dd.max(), (dd != 0).mean())
+@pytest.mark.parametrize("W,H,precision,flags", [(256, 128, 0, 0), (640, 480, 0, 2), (2048, 1024, 2, 2), (1920, 1080, 0, 0), (16, 8, 1, 0)])
+def test_recorded_frames_equal_eager_launches(W, H, precision, flags, monkeypatch):
+    """fftup_execute / fftup_execute_ring replay frames recorded once into a hipGraph (the reference records its dispatches
+    into one command buffer, VR:1250-1273); FFTUP_EXPERIMENT graphs=0 issues every launch eagerly.  Same kernels, same
+    arguments: the same bits, for -n 1 (single-frame graph), -n 35 (two graphs of 16 frames + 3 single ones) and a ring."""
+    from vkresample_amd import synth
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FFTUP_EXPERIMENT", "graphs=" + mode)
+        with _up(W, H, 2.0, precision, 0.2, 0, flags, ring=3) as up:
+            for s in range(3):
+                up.upload_rgb8(synth.frame(70 + s, W, H), slot=s)
+            up.execute(1)
+            a = up.download_planar(0).copy()
+            up.execute(35)
+            b = up.download_planar(0).copy()
+            up.execute_ring(7, 1)
+            res[mode] = [a, b] + [up.download_planar(s).copy() for s in range(3)]
+    for x, y in zip(res["0"], res["1"]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(res["1"][0], res["1"][1]) and not np.array_equal(res["1"][2], res["1"][3])

@@ -177,9 +177,9 @@ def test_jit_check_compiles_without_a_device(tmp_path, monkeypatch):
     assert lib.fftup_jit_check(2450, 1080, 2, 0, None, buf, 256) == 2          # FFTUP_E_UNSUPPORTED_SIZE: the generic kernels run it
     assert lib.fftup_jit_check(640, 480, 2, 1, None, buf, 256) == 3            # FFTUP_E_UNSUPPORTED_PRECISION
     # a pinned factorization that does not multiply to the size is ignored; a valid one is used
-    monkeypatch.setenv("FFTUP_JIT_ROW", "5,8,16")
+    monkeypatch.setenv("FFTUP_EXPERIMENT", "jit_row=5,8,16")
     assert lib.fftup_jit_check(640, 480, 2, 0, None, buf, 256) == 0 and "row 5*8*16" in buf.value.decode()
-    monkeypatch.setenv("FFTUP_JIT_ROW", "5,8,8")
+    monkeypatch.setenv("FFTUP_EXPERIMENT", "jit_row=5,8,8")
     assert lib.fftup_jit_check(640, 480, 2, 0, None, buf, 256) == 0 and "row 10*8*8" in buf.value.decode()
 
 

@@ -3,6 +3,6 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-sweep}; mkdir -p $OUT
 for pps in 3 4 6 8 12; do
-  echo "== FFTUP_PAIRS_PER_STRIP=$pps"
-  FFTUP_PAIRS_PER_STRIP=$pps python bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_frame'], d['kernel_ms'])"
+  echo "== pairs_per_strip=$pps"
+  FFTUP_EXPERIMENT=pairs_per_strip=$pps python bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_frame'], d['kernel_ms'])"
 done | tee $OUT/sweep.txt

@@ -1,9 +1,9 @@
 #!/bin/bash
 # registers / scratch / LDS of the kernels of a run-time specialised plan, compiled offline:
-#   tools/jit_resources.sh <W> <H> [precision] [upscale]      (FFTUP_JIT_ROW / _COL / _FUSED pins are honoured)
+#   tools/jit_resources.sh <W> <H> [precision] [upscale]      (FFTUP_EXPERIMENT jit_row / jit_col / jit_fused pins are honoured)
 W=$1; H=$2; P=${3:-0}; U=${4:-2}
 cd "$(dirname "$0")/.."
-FFTUP_CACHE_DIR=/tmp/jit_res_cache FFTUP_JIT_DUMP=/tmp/jit_res_$$.hip python - <<PY
+FFTUP_CACHE_DIR=/tmp/jit_res_cache FFTUP_EXPERIMENT="${FFTUP_EXPERIMENT:+$FFTUP_EXPERIMENT;}jit_dump=/tmp/jit_res_$$.hip" python - <<PY
 import ctypes as C, sys
 sys.path.insert(0, ".")
 from vkresample_amd import _lib

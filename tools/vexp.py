@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timing-only variants of k_c2r_sharpen_v (results INVALID): source patches applied to a temporary copy of csrc/, the tree
+"""Timing-only variants of the shipping kernels (results INVALID): source patches applied to a temporary copy of csrc/, the tree
 is not touched.   python tools/vexp.py name...   ->  tools/scratch/lib_<name>.so      (tools/gpu_ab.sh takes them as variants)"""
 import os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,16 +25,9 @@ __device__ __forceinline__ void reg_fft_ko(float2 (&v)[E], float2* __restrict__ 
 struct RowR2CTParams {"""
 PATCHES = {
     "base": [],
-    # both 16-byte stores of a row as if lane l owned quads l and 64 + l of its wave's 512 pixels (contiguous kilobytes per instruction)
-    "contigstore": [("char* dst = (char*)((float*)p.out + row_of) + (unsigned)lt * 32u;",
-                     "char* dst = (char*)((float*)p.out + row_of) + ((unsigned)lt >> 6) * 2048u + ((unsigned)lt & 63u) * 16u;"),
-                    ("__builtin_nontemporal_store(hi, (f4t*)(dst + 16));", "__builtin_nontemporal_store(hi, (f4t*)(dst + 1024));")],
-    "nob": [("        lds_sync<true>();\n        const unsigned ard", "        const unsigned ard_unused"), ],
-    "noc": [("    lane_transpose_hi3(v);\n    twiddle_powers", "    twiddle_powers")],
-    "tk8": [],
-    "colv_nomid": [("kernels_vpair.hpp", "    __syncthreads();                                         // everybody has read the forward exchange\n", "")],
-    "colv_nobar": [("kernels_vpair.hpp", "    __syncthreads();                                         // everybody has read the forward exchange\n", ""),
-                   ("kernels_vpair.hpp", "    for (int k = 0; k < 8; k++) { lds_f2raw r = {v[k].x, v[k].y}; *(lds_f2*)(size_t)(aw + 4096u * k) = r; }\n    __syncthreads();\n    const unsigned ar = zbase + 8u * (w * 512u + l);",
+    "colv_nomid": [("kernels_dswap.hpp", "    __syncthreads();                                         // everybody has read the forward exchange\n", "")],
+    "colv_nobar": [("kernels_dswap.hpp", "    __syncthreads();                                         // everybody has read the forward exchange\n", ""),
+                   ("kernels_dswap.hpp", "    for (int k = 0; k < 8; k++) { lds_f2raw r = {v[k].x, v[k].y}; *(lds_f2*)(size_t)(aw + 4096u * k) = r; }\n    __syncthreads();\n    const unsigned ar = zbase + 8u * (w * 512u + l);",
                     "    for (int k = 0; k < 8; k++) { lds_f2raw r = {v[k].x, v[k].y}; *(lds_f2*)(size_t)(aw + 4096u * k) = r; }\n    lds_sync<true>();\n    const unsigned ar = zbase + 8u * (w * 512u + l);")],
     "rowwave": [("kernels_pow2.hpp", "    reg_fft<W, E, +1, 1, true>(v, buf, tid, 0, tws);", "    reg_fft<W, E, +1, 1, true, 0, 8, true>(v, buf, tid, 0, tws);")],
     # column kernel with ONE barrier-synchronised exchange per transform instead of three (results invalid): what a digit-swap column kernel could gain
@@ -48,8 +41,6 @@ struct RowR2CTParams {""", KO_FN),
     "nomirror": [("kernels_pow2.hpp", """                in.a[m] = gload(ra, ko[m]); in.am[m] = gload(ra, kom[m]);
                 in.b[m] = gload(rb, ko[m]); in.bm[m] = gload(rb, kom[m]);""", """                in.a[m] = gload(ra, ko[m]); in.am[m] = in.a[m];
                 in.b[m] = gload(rb, ko[m]); in.bm[m] = in.b[m];""")],
-    "nostore_unused": [("__builtin_nontemporal_store(lo, (f4t*)dst);", "if (p.uH < 0) __builtin_nontemporal_store(lo, (f4t*)dst);"),
-                ("__builtin_nontemporal_store(hi, (f4t*)(dst + 16));", "if (p.uH < 0) __builtin_nontemporal_store(hi, (f4t*)(dst + 16));")],
 }
 def build(name):
     tmp = "/tmp/vexp_" + name
@@ -58,7 +49,7 @@ def build(name):
     shutil.copytree(ROOT + "/vkresample_amd/csrc", tmp + "/vkresample_amd/csrc")
     shutil.copytree(ROOT + "/include", tmp + "/include")
     for pt in PATCHES[name]:
-        f, a, b = pt if len(pt) == 3 else ("kernels_vpair.hpp",) + tuple(pt)
+        f, a, b = pt if len(pt) == 3 else ("kernels_dswap.hpp",) + tuple(pt)
         p = tmp + "/vkresample_amd/csrc/" + f
         s = open(p).read()
         assert s.count(a) == 1, (name, a, s.count(a))

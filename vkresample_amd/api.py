@@ -53,6 +53,8 @@ class Upscaler:
         info = _lib.Info()
         _check(self._lib.fftup_plan_info(self._h, C.byref(info)), "fftup_plan_info")
         if info.abi_version != _lib.ABI_VERSION:
+            self._lib.fftup_plan_destroy(self._h)
+            self._h = None
             raise RuntimeError("libfftup.so speaks ABI version %d, this binding %d: rebuild (python -c 'import __graft_entry__ as g; g.build()')"
                                % (info.abi_version, _lib.ABI_VERSION))
         self.width, self.height = width, height

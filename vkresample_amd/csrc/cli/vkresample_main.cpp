@@ -87,15 +87,19 @@ static int launchResample(ResampleConfiguration config)                      // 
             else n = ((int)claimed.size() < numLocalFiles || claimed.empty()) ? (int)claimed.size() * config.numThreads + config.threadId + 1 : 0;
             claimed.push_back(n);
         }
+        // static stripe with more threads than files: the reference still loads file threadId + 1 for the plan's size but
+        // processes nothing (VR:1622-1629) -- the first claim names that file, the loops see none
+        if (!config.workQueue && config.fileUpload && f >= numLocalFiles) return 0;
         return claimed[(size_t)f];
     };
     char fileName[1024];
     if (config.fileUpload) {
-        if (fileAt(0) == 0) {                                                  // -workqueue with more threads than files
+        if (config.workQueue && fileAt(0) == 0) {                              // -workqueue with more threads than files
             printf("Thread %d finished. No files left in the queue\n", config.threadId);
             return FFTUP_OK;
         }
-        snprintf(fileName, sizeof fileName, "%s/%06d.png", config.ifolder_prefix, fileAt(0));   // VR:1357
+        // (static stripe: the size comes from file threadId + 1 even when the thread has no file to process, VR:1357, 1622-1629)
+        snprintf(fileName, sizeof fileName, "%s/%06d.png", config.ifolder_prefix, config.workQueue ? fileAt(0) : config.threadId + 1);   // VR:1357
     }
     else snprintf(fileName, sizeof fileName, "%s", config.png_input_name);
 

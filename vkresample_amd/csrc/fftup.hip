@@ -7,14 +7,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/fftup.h"
 #include "kernels_generic.hpp"
 #include "kernels_pow2.hpp"
 #include "kernels_mixed.hpp"
-#include "kernels_vpair.hpp"
+#include "kernels_dswap.hpp"
 #include "jit.hpp"
 
 using namespace fftup;
@@ -74,15 +76,11 @@ struct fftup_plan {
     float upsq = 0, coef = 0;
     bool tuned = false;
     bool fused = false;               // sharpen fused into the C2R kernel (tuned plans)
-    bool rgb8 = false;                // FFTUP_RGB8=1: -p 2 + FFTUP_FLAG_FUSE_U8_STORE, rows of 4096: k_c2r_sharpen_v_rgb8 (three planes per strip, image written once)
-    bool colv = true;                 // H = 1024: the column kernel is k_col_v (digit-swap exchanges, 3 barriers); FFTUP_COLV=0: k_col_t
-    bool vpair = false;               // uW = 4096: the fused kernel is k_c2r_sharpen_v (kernels_vpair.hpp); FFTUP_VPAIR=0: k_c2r_sharpen_g
     bool u8out = false;               // FFTUP_FLAG_FUSE_U8_STORE in effect: the fused kernel stores 8-bit RGB, `out` slots hold [uH][uW][3] bytes
     int mixed = 0;                    // compile-time mixed-radix plans: 1 = 1920x1080 -> 3840x2160, 2 = 1280x720 -> 2560x1440,
                                       // 3 = specialised at plan time for this size (jit.hpp), kernels in `jit`
     fftup_jit::Module* jit = nullptr;
     int U = 2;                        // integer upscale factor of a polyphase plan (tuned / mixed): S1 + U-1 residue buffers
-    bool plan3840_x16 = true;         // 1080p: fused kernel on the 16*16*15 plan (256 threads, 120 VGPRs); false: 8*8*4*15 on 512 threads
     bool cplx = false;                // non-R2C path (VR:1424 false): full complex transforms, uW beyond the R2C limit
     bool inplaceF = false, inplaceI = false;   // ... whose forward / inverse rows are too long for two LDS buffers: fft_lds_inplace
     int ncols = 0;                    // spectrum columns kept: W/2 + 1, or W on the non-R2C path
@@ -112,6 +110,11 @@ struct fftup_plan {
     uint64_t* d_sum = nullptr;        // fftup_output_checksum accumulator (created on first use)
     size_t in_plane_stride = 0;
     int executed = 0;
+
+    // One frame's launches recorded once per (lane, input slot, output slot, input kind, repetitions) and replayed with
+    // hipGraphLaunch: the HIP counterpart of the reference's pre-recorded command buffer (VkResample.cpp:1250-1273)
+    std::map<std::tuple<int, uint32_t, uint32_t, int, int>, hipGraphExec_t> graphs;
+    bool use_graphs = true;           // FFTUP_EXPERIMENT graphs=0: every launch issued eagerly (A/B, tests)
 
     std::vector<void*> allocs;
 };
@@ -222,17 +225,17 @@ static std::string wisdom_device_key(const fftup_plan* P);
 // Plans that run one frame after the other (ring = 1: the CLI's single-image mode, the reference's -n timing): nothing
 // runs beside a strip, and a workgroup of at most 256 threads (one wave per SIMD) cannot hide its own latencies: two
 // strips per unit (1080p 98 -> 90 us per frame, 1000x1000 76 -> 62; no gain at 512 threads and beyond).
-// FFTUP_G_PER_CU / FFTUP_PAIRS_PER_STRIP override; how many workgroups are resident is the hardware's business.
+// FFTUP_EXPERIMENT keys g_per_cu / pairs_per_strip override; how many workgroups are resident is the hardware's business.
 static void set_strip_length(fftup_plan* P)
 {
-    const int fused_threads = P->tuned ? (int)P->uW / 8 : P->mixed == 3 ? P->jit->choice.fused_t : P->mixed == 2 ? 256 : (P->plan3840_x16 ? 256 : 512);
+    const int fused_threads = P->tuned ? (int)P->uW / 8 : P->mixed == 3 ? P->jit->choice.fused_t : 256;
     const std::string mode = wisdom_device_key(P);
     const bool sequential = mode.size() >= 10 && mode.compare(mode.size() - 10, 10, "sequential") == 0;
     int per_cu = (sequential && fused_threads <= 256) ? 2 : 1;
-    if (const char* e = getenv("FFTUP_G_PER_CU")) per_cu = std::max(1, std::min(4, atoi(e)));
+    if (const char* e = fftup_jit::experiment("g_per_cu")) per_cu = std::max(1, std::min(4, atoi(e)));
     const int total_pairs = 3 * (int)P->uH / 2, slots = std::max(1, P->prop.multiProcessorCount) * per_cu;
     P->pairs_per_strip = std::max(2, (total_pairs + slots - 1) / slots);
-    if (const char* e = getenv("FFTUP_PAIRS_PER_STRIP")) P->pairs_per_strip = std::max(1, atoi(e));
+    if (const char* e = fftup_jit::experiment("pairs_per_strip")) P->pairs_per_strip = std::max(1, atoi(e));
 }
 // what the tuner's findings are filed under: the device and whether consecutive frames overlap on several streams
 // (ring > 1: what fits beside a strip decides) or run one after the other (ring = 1: the kernel's own time decides)
@@ -315,6 +318,7 @@ void fftup_plan_destroy(fftup_plan* P)
     }
     for (auto& qs : P->q)
         if (qs.done) (void)hipEventDestroy(qs.done);
+    for (auto& g : P->graphs) (void)hipGraphExecDestroy(g.second);
     for (void* p : P->allocs) (void)hipFree(p);
     delete P->jit;
     if (P->ev0) (void)hipEventDestroy(P->ev0);
@@ -410,8 +414,9 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
 
         const size_t lds_max = P->prop.sharedMemPerBlock ? P->prop.sharedMemPerBlock : 65536;
         // size-specialised kernels: u == 2 and power-of-two sizes with instantiated plans
-        // (FFTUP_AOT=0: experiments -- the sizes with ahead-of-time kernels go through the plan-time compiler as well)
-        const bool aot = !(getenv("FFTUP_AOT") && atoi(getenv("FFTUP_AOT")) == 0);
+        // (experiment aot=0: the sizes with ahead-of-time kernels go through the plan-time compiler as well)
+        const char* const aot_e = fftup_jit::experiment("aot");
+        const bool aot = !(aot_e && atoi(aot_e) == 0);
         P->tuned = aot && !P->dbl && !cplx && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && uW == 2 * W && uH == 2 * H &&
                    (W == 512 || W == 1024 || W == 2048) && (H == 256 || H == 512 || H == 1024);
         P->TK = 0;
@@ -448,8 +453,8 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         }
         P->fused = (P->tuned || P->mixed) && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
         P->u8out = P->fused && (cfg->flags & FFTUP_FLAG_FUSE_U8_STORE);
-        if (const char* e = getenv("FFTUP_3840_X16")) P->plan3840_x16 = atoi(e) != 0;
         set_strip_length(P);
+        if (const char* e = fftup_jit::experiment("graphs")) P->use_graphs = atoi(e) != 0;
         P->NT = (P->ncols + P->TK - 1) / P->TK;
         P->ldsRowF = 2 * P->csz * (size_t)lpad_size((int)W);
         P->ldsRowI = 2 * P->csz * (size_t)lpad_size((int)uW);
@@ -520,9 +525,14 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         // allow > 64 KB dynamic LDS -- for the kernels THIS plan launches, nothing else
 #define SET_LDS(kern, bytes) PLAN_TRY(hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
         const bool generic = !P->tuned && !P->mixed;
+        // (same predicate as launch_frame: a plan-time plan without a row factorization runs the size-generic row kernel)
+        const bool generic_rows = generic || (P->mixed == 3 && P->jit->choice.row_kind == 2);
+        if (generic_rows && !cplx && !P->dbl) {
+            if (P->half) { SET_LDS(k_row_r2c<IN_F16>, P->ldsRowF); SET_LDS(k_row_r2c<IN_U8_F16>, P->ldsRowF); }
+            else { SET_LDS(k_row_r2c<IN_F32>, P->ldsRowF); SET_LDS(k_row_r2c<IN_U8_F32>, P->ldsRowF); }
+        }
         if (generic && !cplx && !P->dbl) {
-            if (P->half) { SET_LDS(k_row_r2c<IN_F16>, P->ldsRowF); SET_LDS(k_row_r2c<IN_U8_F16>, P->ldsRowF); SET_LDS(k_row_c2r<true>, P->ldsRowI); }
-            else { SET_LDS(k_row_r2c<IN_F32>, P->ldsRowF); SET_LDS(k_row_r2c<IN_U8_F32>, P->ldsRowF); SET_LDS(k_row_c2r<false>, P->ldsRowI); }
+            if (P->half) SET_LDS(k_row_c2r<true>, P->ldsRowI); else SET_LDS(k_row_c2r<false>, P->ldsRowI);
         }
         if (generic && !P->dbl) {
             switch (P->TK) {
@@ -563,31 +573,19 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
 #define SET_MIXED(CFG) do { SET_LDS(k_col_m<CFG>, P->ldsCol); \
         if (P->half) SET_LDS((k_row_c2r_ct<CFG::CT, true>), P->ldsRowI); else SET_LDS((k_row_c2r_ct<CFG::CT, false>), P->ldsRowI); \
         SET_FUSED(CFG::FUSED, 4); } while (0)
-        if (P->mixed == 1) { SET_MIXED(MixedCfg1080); if (!P->plan3840_x16) SET_FUSED(FusedPlan3840, 4); }
+        if (P->mixed == 1) { SET_MIXED(MixedCfg1080); }
         if (P->mixed == 2) { SET_MIXED(MixedCfg720); }
 #undef SET_MIXED
         if (P->tuned) {
             switch (uW) {
             case 1024: SET_FUSED(FusedPlanPow2<1024>, TUNED_TK); break;
             case 2048: SET_FUSED(FusedPlanPow2<2048>, TUNED_TK); break;
-            default:
-                if (const char* e = getenv("FFTUP_VPAIR")) P->vpair = atoi(e) != 0;     // (opt-in: same speed for -p 2, slower for -p 0)
-                if (const char* e = getenv("FFTUP_RGB8")) P->rgb8 = atoi(e) != 0;
-                P->rgb8 = P->rgb8 && P->u8out && P->half;
-                if (P->rgb8) SET_LDS((k_c2r_sharpen_v_rgb8<TUNED_TK>), VPlan4096::lds(true));
-                else if (!P->vpair) SET_FUSED(FusedPlanPow2<4096>, TUNED_TK);
-                else if (P->u8out) { if (P->half) SET_LDS((k_c2r_sharpen_v<true, TUNED_TK, true>), VPlan4096::lds(P->half)); else SET_LDS((k_c2r_sharpen_v<false, TUNED_TK, true>), VPlan4096::lds(P->half)); }
-                else if (P->half) SET_LDS((k_c2r_sharpen_v<true, TUNED_TK>), VPlan4096::lds(P->half));
-                else SET_LDS((k_c2r_sharpen_v<false, TUNED_TK>), VPlan4096::lds(P->half));
-                break;
+            default: SET_FUSED(FusedPlanPow2<4096>, TUNED_TK); break;
             }
             switch (H) {
             case 256: SET_LDS((k_col_t<256, TUNED_TK>), P->ldsCol); break;
             case 512: SET_LDS((k_col_t<512, TUNED_TK>), P->ldsCol); break;
-            default:
-                if (const char* e = getenv("FFTUP_COLV")) P->colv = atoi(e) != 0;
-                if (P->colv) SET_LDS((k_col_v<TUNED_TK>), 32768); else SET_LDS((k_col_t<1024, TUNED_TK>), P->ldsCol);
-                break;
+            default: SET_LDS((k_col_v<TUNED_TK>), 32768); break;
             }
         }
 #undef SET_FUSED
@@ -608,8 +606,8 @@ int fftup_plan_describe(const fftup_plan* P, char* buf, size_t buflen)
     if (!P || !buf || !buflen) return fail(FFTUP_E_INVALID_ARG, "null argument");
     std::string s;
     if (P->mixed == 3) s = "specialised at plan time: " + fftup_jit::describe(P->jit->choice);
-    else if (P->tuned) s = "ahead-of-time power-of-two kernels (radix 8, 8 points per thread; fused C2R+sharpen " + std::string(P->fused ? (P->rgb8 ? "on: k_c2r_sharpen_v_rgb8" : P->vpair ? "on: k_c2r_sharpen_v" : "on") : "off") + ")"
-                           + ((P->H == 1024 && P->colv) ? "; column kernel with digit-swap exchanges" : "");
+    else if (P->tuned) s = "ahead-of-time power-of-two kernels (radix 8, 8 points per thread; fused C2R+sharpen " + std::string(P->fused ? "on" : "off") + ")"
+                           + (P->H == 1024 ? "; column kernel with digit-swap exchanges" : "");
     else if (P->mixed) s = std::string("ahead-of-time mixed-radix kernels: ") + (P->mixed == 1 ? "row 15*8*16, col 9*10*12, fused 16*16*15" : "row 5*16*16, col 9*8*10, fused 16*16*10");
     else if (P->cplx) s = "size-generic kernels, non-R2C path (full complex transforms)";
     else s = std::string("size-generic kernels (LDS ping-pong, run-time radix lists)") + (P->dbl ? ", double" : "");
@@ -776,18 +774,6 @@ template <class PL> static void launch_fused_t(fftup_plan* P, const FusedParams&
     else if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_g<PL, true, TUNED_TK>), grid, block, FusedGLds<PL>::TOTAL, st, p);
     else hipLaunchKernelGGL((k_c2r_sharpen_g<PL, false, TUNED_TK>), grid, block, FusedGLds<PL>::TOTAL, st, p);
 }
-static void launch_fused_v(fftup_plan* P, const FusedParams& p)
-{
-    const int total_pairs = 3 * (int)P->uH / 2;
-    dim3 grid((total_pairs + p.pairs_per_strip - 1) / p.pairs_per_strip), block(VPlan4096::T);
-    hipStream_t st = P->lanes[P->cur].stream;
-    if (P->u8out) {
-        if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_v<true, TUNED_TK, true>), grid, block, VPlan4096::lds(P->half), st, p);
-        else hipLaunchKernelGGL((k_c2r_sharpen_v<false, TUNED_TK, true>), grid, block, VPlan4096::lds(P->half), st, p);
-    }
-    else if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_v<true, TUNED_TK>), grid, block, VPlan4096::lds(P->half), st, p);
-    else hipLaunchKernelGGL((k_c2r_sharpen_v<false, TUNED_TK>), grid, block, VPlan4096::lds(P->half), st, p);
-}
 static FusedParams fused_params(fftup_plan* P, uint32_t out_slot)
 {
     FusedParams p{};
@@ -822,10 +808,7 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
         switch (P->H) {
         case 256: launch_col_t<256>(P, p); break;
         case 512: launch_col_t<512>(P, p); break;
-        default:
-            if (P->colv) hipLaunchKernelGGL((k_col_v<TUNED_TK>), dim3(P->NT, 3), dim3(512), 32768, P->lanes[P->cur].stream, p);
-            else launch_col_t<1024>(P, p);
-            break;
+        default: hipLaunchKernelGGL((k_col_v<TUNED_TK>), dim3(P->NT, 3), dim3(512), 32768, P->lanes[P->cur].stream, p); break;
         }
     }
     if ((which < 0 || which == 2) && P->fused) {
@@ -833,17 +816,7 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
         switch (P->uW) {
         case 1024: launch_fused_t<FusedPlanPow2<1024>>(P, p); break;
         case 2048: launch_fused_t<FusedPlanPow2<2048>>(P, p); break;
-        default:
-            if (P->rgb8) {
-                // a strip = the same row pairs of all three planes (k_c2r_sharpen_v_rgb8): a third of the pairs per strip
-                FusedParams q = p;
-                const int ppl = (int)P->uH / 2;
-                q.pairs_per_strip = std::max(1, p.pairs_per_strip / 3);
-                hipLaunchKernelGGL((k_c2r_sharpen_v_rgb8<TUNED_TK>), dim3((ppl + q.pairs_per_strip - 1) / q.pairs_per_strip), dim3(VPlan4096::T),
-                                   VPlan4096::lds(true), P->lanes[P->cur].stream, q);
-            }
-            else if (P->vpair) launch_fused_v(P, p); else launch_fused_t<FusedPlanPow2<4096>>(P, p);
-            break;
+        default: launch_fused_t<FusedPlanPow2<4096>>(P, p); break;
         }
         P->R_valid = false;
     } else if (which < 0 || which == 2 || which == 22) {   // 22: pre-sharpen tap requested for a fused plan
@@ -1018,7 +991,7 @@ static void keep_first(hipError_t& first, hipError_t e) { if (first == hipSucces
 static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
 {
     const int kind = P->in_kind[in_slot];
-    if (kind == 0) return fail(FFTUP_E_NO_INPUT, "no input uploaded for this slot");
+    if (kind == 0 && which != 22) return fail(FFTUP_E_NO_INPUT, "no input uploaded for this slot");     // (22, the pre-sharpen tap, reads spectra only)
     if (P->cplx) return P->dbl ? launch_frame_cplx<double2>(P, in_slot, out_slot, which) : launch_frame_cplx<float2>(P, in_slot, out_slot, which);
     if (P->dbl) return launch_frame_f64(P, in_slot, out_slot, which);
     if (P->tuned) {
@@ -1083,8 +1056,7 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
             keep_first(jerr, fftup_jit::launch(P->jit->fn[fftup_jit::K_FUSED], dim3((total_pairs + fp.pairs_per_strip - 1) / fp.pairs_per_strip),
                                      dim3(P->jit->choice.fused_t), P->jit->choice.fused_lds, P->lanes[P->cur].stream, fp));
         } else if (P->mixed == 2) launch_fused_t<MixedCfg720::FUSED>(P, fused_params(P, out_slot));
-        else if (P->plan3840_x16) launch_fused_t<MixedCfg1080::FUSED>(P, fused_params(P, out_slot));
-        else launch_fused_t<FusedPlan3840>(P, fused_params(P, out_slot));       // (only the mixed plans are fused on this path)
+        else launch_fused_t<MixedCfg1080::FUSED>(P, fused_params(P, out_slot));       // (only the mixed plans are fused on this path)
         P->R_valid = false;
     } else if (which < 0 || which == 2 || which == 22) {                 // 22: pre-sharpen tap requested for a fused plan
         RowC2RParams p{};
@@ -1120,6 +1092,53 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
     return FFTUP_OK;
 }
 
+// ---- recorded frames.  The reference records its dispatches into ONE command buffer and submits that (VR:1250-1273); here a
+// frame's launches on lane P->cur are captured into a hipGraph the first time that (lane, slots, input kind) combination
+// runs and replayed afterwards -- one hipGraphLaunch instead of three or four kernel launches (what small frames are bound
+// by: 256x128 took 18 us per iteration with kernels of 4 us).  `reps` consecutive frames in one graph for fftup_execute.
+static void graphs_clear(fftup_plan* P)
+{
+    for (auto& g : P->graphs) (void)hipGraphExecDestroy(g.second);
+    P->graphs.clear();
+}
+static int frame_graph(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int reps, hipGraphExec_t* ex)
+{
+    const auto key = std::make_tuple(P->cur, in_slot, out_slot, P->in_kind[in_slot], reps);
+    auto it = P->graphs.find(key);
+    if (it != P->graphs.end()) { *ex = it->second; return FFTUP_OK; }
+    if (P->in_kind[in_slot] == 0) return fail(FFTUP_E_NO_INPUT, "no input uploaded for this slot");
+    hipStream_t st = P->lanes[P->cur].stream;
+    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = FFTUP_OK;
+    for (int r = 0; r < reps && !rc; r++) rc = launch_frame(P, in_slot, out_slot, -1);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &g);
+    if (!rc && e != hipSuccess) rc = fail(FFTUP_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    if (!rc) {
+        const hipError_t ei = hipGraphInstantiate(ex, g, nullptr, nullptr, 0);
+        if (ei != hipSuccess) rc = fail(FFTUP_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+    }
+    if (g) (void)hipGraphDestroy(g);
+    if (!rc) P->graphs[key] = *ex;
+    return rc;
+}
+// `reps` frames (input slot -> output slot) on lane P->cur
+static int run_frames(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int reps)
+{
+    if (!P->use_graphs) {
+        int rc = FFTUP_OK;
+        for (int r = 0; r < reps && !rc; r++) rc = launch_frame(P, in_slot, out_slot, -1);
+        return rc;
+    }
+    hipGraphExec_t ex = nullptr;
+    const int rc = frame_graph(P, in_slot, out_slot, reps, &ex);
+    if (rc) return rc;
+    HIP_TRY(hipGraphLaunch(ex, P->lanes[P->cur].stream));
+    if (P->fused) P->R_valid = false;                       // (what launch_frame notes when it runs)
+    else if (!P->dbl) P->R_valid = true;
+    return FFTUP_OK;
+}
+
 extern "C" {
 
 // shared body of fftup_execute_ring / fftup_execute_ring_timed.  With kernel_ms != NULL a HIP event is recorded
@@ -1140,9 +1159,18 @@ static int execute_ring_impl(fftup_plan* P, uint32_t n_frames, uint32_t first_sl
         int erc = ev.create((size_t)n_timed * (nk + 1));
         if (erc) return erc;
     }
-    HIP_TRY(hipEventRecord(P->ev0, P->stream));
     // consecutive frames go to distinct lanes; they must then also write distinct output slots
     const int nl = std::max(1, std::min(P->nlanes, (int)P->ring));
+    if (P->use_graphs && !kernel_ms) {                       // record what is not recorded yet before the clock starts
+        for (uint32_t i = 0; i < n_frames && i < P->ring * (uint32_t)nl; i++) {
+            hipGraphExec_t ex;
+            P->cur = (int)(i % (uint32_t)nl);
+            const int grc = frame_graph(P, (first_slot + i) % P->ring, (first_slot + i) % P->ring, 1, &ex);
+            P->cur = 0;
+            if (grc) return grc;
+        }
+    }
+    HIP_TRY(hipEventRecord(P->ev0, P->stream));
     for (int l = 1; l < nl; l++) HIP_TRY(hipStreamWaitEvent(P->lanes[l].stream, P->ev0, 0));
     int rc = FFTUP_OK;
     for (uint32_t i = 0; i < n_frames && !rc; i++) {
@@ -1156,7 +1184,7 @@ static int execute_ring_impl(fftup_plan* P, uint32_t n_frames, uint32_t first_sl
                 (void)hipEventRecord(e[k + 1], P->lanes[P->cur].stream);
             }
         } else {
-            rc = launch_frame(P, s, s, -1);
+            rc = run_frames(P, s, s, 1);
         }
         P->last_lane = P->cur;
         P->cur = 0;
@@ -1214,7 +1242,7 @@ static void tune_fused(fftup_plan* P)
     const fftup_jit::Choice base = P->jit->choice;
     const std::string key = fftup_jit::fused_key(base, wisdom_device_key(P));
     std::string known;
-    if (getenv("FFTUP_JIT_FUSED") || fftup_jit::wisdom_lookup(key, known)) return;
+    if (fftup_jit::experiment("jit_fused") || fftup_jit::wisdom_lookup(key, known)) return;
     const std::vector<int> kinds = P->in_kind;
     const int executed = P->executed;
     for (auto& k : P->in_kind) if (!k) k = 1;                                  // (uninitialised planar input: fine for timing)
@@ -1260,9 +1288,11 @@ static void tune_fused(fftup_plan* P)
         if (!m) continue;
         P->jit = m;
         set_strip_length(P);
+        graphs_clear(P);                                                        // (recorded frames name the module's kernels)
         const double t = time_plan();
         P->jit = original;
         set_strip_length(P);
+        graphs_clear(P);
         if (getenv("FFTUP_JIT_VERBOSE"))
             fprintf(stderr, "fftup: tuning %s: %s %.1f us/frame (default %s %.1f)\n", key.c_str(), fftup_jit::fused_value(m->choice).c_str(), t * 1e3,
                     fftup_jit::fused_value(base).c_str(), t_base * 1e3);
@@ -1270,6 +1300,7 @@ static void tune_fused(fftup_plan* P)
         else delete m;
     }
     if (best) { delete original; P->jit = best; set_strip_length(P); }
+    graphs_clear(P);
     P->in_kind = kinds;
     P->executed = executed;
     fftup_jit::wisdom_store(key, fftup_jit::fused_value(P->jit->choice));
@@ -1286,12 +1317,22 @@ int fftup_execute(fftup_plan* P, uint32_t n_iter, double* ms_per_iter)
     // reports wall time / n_iter (VR:1270-1278): back-to-back frames on the plan's own stream, no overlap between
     // iterations, every iteration writes output slot 0.  (Overlapped throughput is what fftup_execute_ring and
     // fftup_submit_rgb8 are for.)
-    HIP_TRY(hipEventRecord(P->ev0, P->stream));
-    for (uint32_t i = 0; i < n_iter; i++) {
-        P->cur = 0;
-        int rc = launch_frame(P, 0, 0, -1);
-        P->last_lane = 0;
+    // Recorded once, replayed: graphs of 16 frames while that many are left, single frames for the rest.
+    constexpr uint32_t REPS = 16;
+    P->cur = 0;
+    P->last_lane = 0;
+    if (P->use_graphs) {                                     // (record before the clock starts, like the reference's command buffer)
+        hipGraphExec_t ex;
+        int rc = n_iter >= REPS ? frame_graph(P, 0, 0, (int)REPS, &ex) : FFTUP_OK;
+        if (!rc && n_iter % REPS) rc = frame_graph(P, 0, 0, 1, &ex);
         if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(P->ev0, P->stream));
+    for (uint32_t i = 0; i < n_iter;) {
+        const uint32_t reps = (n_iter - i >= REPS) ? REPS : 1;
+        int rc = run_frames(P, 0, 0, (int)reps);
+        if (rc) return rc;
+        i += reps;
     }
     HIP_TRY(hipEventRecord(P->ev1, P->stream));
     HIP_TRY(hipEventSynchronize(P->ev1));
@@ -1527,7 +1568,7 @@ int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, ui
         P->in_kind[s] = 1;
     }
     P->cur = lane;
-    rc = launch_frame(P, s, s, -1);
+    rc = run_frames(P, s, s, 1);
     P->last_lane = lane;
     P->cur = 0;
     if (rc) return rc;

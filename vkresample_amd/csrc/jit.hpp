@@ -24,10 +24,10 @@
 // in-memory headers; $FFTUP_KERNEL_DIR overrides it with a directory (development), and a library built without the
 // generated file reads csrc/ next to libfftup.so.
 //
-// Environment (experiments, tests): FFTUP_JIT=0 off; FFTUP_JIT_VERBOSE=1 says why a plan fell back and what the tuner
-// measured; FFTUP_JIT_ROW / _COL / _COLI / _FUSED ("r0,r1,.." resp. "threads:r0,r1,..") pin a factorization;
-// FFTUP_JIT_FUSED_OPT="waves,ring" pins the fused kernel's register bound and ring-row placement;
-// FFTUP_JIT_NO_BUILTIN_WISDOM=1; FFTUP_JIT_DUMP=<file> writes the translation unit; FFTUP_HIPRTC_LIB=<libhiprtc.so>.
+// Environment: FFTUP_JIT=0 off; FFTUP_JIT_VERBOSE=1 says why a plan fell back and what the tuner measured;
+// FFTUP_HIPRTC_LIB=<libhiprtc.so>.  Experiments and tests (FFTUP_EXPERIMENT="key=value;..", see experiment()): jit_row / jit_col /
+// jit_coli / jit_fused ("r0,r1,.." resp. "threads:r0,r1,..") pin a factorization; jit_fused_opt="waves,ring" pins the fused
+// kernel's register bound and ring-row placement; jit_no_builtin_wisdom; jit_dump=<file> writes the translation unit.
 #pragma once
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -92,10 +92,32 @@ struct Choice {
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 static bool is_radix(int r) { for (int s : kRadices) if (s == r) return true; return false; }
 
-// "r0,r1,..." (optionally "T:r0,r1,...") from an environment variable: experiments and tests pin a factorization
+// Experiment switches (timing variants, pinned factorizations of tests and tools): ONE environment variable,
+// FFTUP_EXPERIMENT="key=value;key=value", not part of the documented surface (include/fftup.h lists the operational knobs).
+// Keys: aot, graphs, g_per_cu, pairs_per_strip, jit_row, jit_col, jit_coli, jit_fused, jit_fused_opt, jit_row_nstage, jit_col_nstage,
+// jit_no_builtin_wisdom, jit_dump, jit_threads.  Returns the value ("" for a bare key) or nullptr.
+static const char* experiment(const char* key)
+{
+    const char* e = getenv("FFTUP_EXPERIMENT");
+    if (!e || !*e) return nullptr;
+    static thread_local std::string val;
+    const std::string s = e, k = key;
+    size_t pos = 0;
+    while (pos <= s.size()) {
+        size_t end = s.find(';', pos);
+        if (end == std::string::npos) end = s.size();
+        const std::string item = s.substr(pos, end - pos);
+        const size_t eq = item.find('=');
+        if (item.substr(0, eq) == k) { val = eq == std::string::npos ? "" : item.substr(eq + 1); return val.c_str(); }
+        pos = end + 1;
+    }
+    return nullptr;
+}
+
+// "r0,r1,..." (optionally "T:r0,r1,...") from an experiment key: experiments and tests pin a factorization
 static bool env_radices(const char* name, std::vector<int>& r, int* threads)
 {
-    const char* e = getenv(name);
+    const char* e = experiment(name);
     if (!e || !*e) return false;
     r.clear();
     std::string s = e;
@@ -156,7 +178,7 @@ static bool choose_fused_n(int n, int D, std::vector<int>& out, int* threads)
     {
         int T = 0;
         std::vector<int> pin;
-        if (env_radices("FFTUP_JIT_FUSED", pin, &T) && T >= 64 && T <= 1024 && T % 64 == 0) {
+        if (env_radices("jit_fused", pin, &T) && T >= 64 && T <= 1024 && T % 64 == 0) {
             long prod = 1;
             bool ok = pin.size() >= 2 && pin[0] % D == 0;
             for (int q : pin) { ok &= is_radix(q); prod *= q; }
@@ -436,8 +458,8 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
     if (c.UW % 4) return false;        // the sharpen works on quads of pixels (-u 5 with W = 2 * odd: the size-generic kernels)
     // ---- row R2C
     if (is_pow2(W) && W >= 256) { c.row_kind = 0; c.row_block = W / 8; }
-    else if (!getenv("FFTUP_JIT_ROW_NSTAGE") && choose3(W, 1, 1024, c.rr, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 1; c.row_t = (c.row_t + 63) / 64 * 64; c.row_block = c.row_t; }
-    else if (choose_n(W, 1024, 64, c.rn, &c.row_t, "FFTUP_JIT_ROW")) { c.row_kind = 3; c.row_block = c.row_t; }
+    else if (!experiment("jit_row_nstage") && choose3(W, 1, 1024, c.rr, &c.row_t, "jit_row")) { c.row_kind = 1; c.row_t = (c.row_t + 63) / 64 * 64; c.row_block = c.row_t; }
+    else if (choose_n(W, 1024, 64, c.rn, &c.row_t, "jit_row")) { c.row_kind = 3; c.row_block = c.row_t; }
     else c.row_kind = 2;               // no supported factorization: the size-generic row kernel (same S1 layout) stays
     // ---- column (four columns of a spectrum tile per workgroup; two when a stage of a long column needs more than 256 threads)
     auto col_n = [&](int len, std::vector<int>& r, int* tpc, const char* env) {
@@ -448,20 +470,20 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
     if (U == 1) {
         int ti = 0;
         if (c.UH > 8192) return false;
-        const int cf = col_n(H, c.cn, &c.col_tpc, "FFTUP_JIT_COL"), ci = col_n(c.UH, c.ci, &ti, "FFTUP_JIT_COLI");
+        const int cf = col_n(H, c.cn, &c.col_tpc, "jit_col"), ci = col_n(c.UH, c.ci, &ti, "jit_coli");
         if (!cf || !ci) return false;
         c.col_cols = std::min(cf, ci);
         c.col_tpc = std::max(c.col_tpc, ti);
         c.col_kind = 5; c.col_block = c.col_cols * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((c.UH * c.col_cols + 15) & ~15);
         if (c.col_block > 1024 || c.col_lds > 160 * 1024) return false;
     } else if (U > 2) {
-        if (!(c.col_cols = col_n(H, c.cn, &c.col_tpc, "FFTUP_JIT_COL"))) return false;
+        if (!(c.col_cols = col_n(H, c.cn, &c.col_tpc, "jit_col"))) return false;
         c.col_kind = 4; c.col_block = c.col_cols * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * c.col_cols + 15) & ~15);
     } else if (is_pow2(H) && H >= 128 && H <= 2048) {
         c.col_kind = 0; c.col_block = 4 * H / 8; c.col_lds = sizeof(float2) * (size_t)((H * 4 + 15) & ~15);      // lswz_size
-    } else if (!getenv("FFTUP_JIT_COL_NSTAGE") && choose3(H, 4, 256, c.cr, &c.col_tpc, "FFTUP_JIT_COL")) {
+    } else if (!experiment("jit_col_nstage") && choose3(H, 4, 256, c.cr, &c.col_tpc, "jit_col")) {
         c.col_kind = 1; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)H * 4;
-    } else if ((c.col_cols = col_n(H, c.cn, &c.col_tpc, "FFTUP_JIT_COL"))) {
+    } else if ((c.col_cols = col_n(H, c.cn, &c.col_tpc, "jit_col"))) {
         c.col_kind = 3; c.col_block = c.col_cols * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * c.col_cols + 15) & ~15);
     } else return false;
     // ---- fused C2R + sharpen
@@ -470,13 +492,13 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
     int nbuf = 2;
     if ((UW == 1024 || UW == 2048 || UW == 4096) && 8 % D == 0) { c.fused_kind = 0; c.fused_t = UW / 8; nbuf = 3; }
     else {
-        const bool mr16 = UW % 256 == 0 && is_radix(UW / 256) && 16 % D == 0 && !getenv("FFTUP_JIT_FUSED");
+        const bool mr16 = UW % 256 == 0 && is_radix(UW / 256) && 16 % D == 0 && !experiment("jit_fused");
         if (mr16) {
             c.fused_kind = 1; c.fused_t = 256;
             xb = (sizeof(float2) * (size_t)(UW + (UW >> 4) + 1) + 15) & ~(size_t)15;                               // lpad_size(UW)
         } else if (choose_fused_n(UW, D, c.fr, &c.fused_t)) {
             set_fused_n(c, c.fused_t, std::vector<int>(c.fr));
-            if (const char* e = getenv("FFTUP_JIT_FUSED_OPT")) { int w = 0, r = 1; if (sscanf(e, "%d,%d", &w, &r) == 2) { c.fused_wpe = std::max(1, w); c.fused_rr = r != 0; } }
+            if (const char* e = experiment("jit_fused_opt")) { int w = 0, r = 1; if (sscanf(e, "%d,%d", &w, &r) == 2) { c.fused_wpe = std::max(1, w); c.fused_rr = r != 0; } }
         } else return false;
     }
     {
@@ -486,10 +508,10 @@ static bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_ra
         if (c.fused_lds > 160 * 1024) return false;
     }
     // what the plan-time tuner found best on this device for rows of this length (wisdom.txt)
-    if (use_wisdom && !getenv("FFTUP_JIT_FUSED")) {
+    if (use_wisdom && !experiment("jit_fused")) {
         std::string w;
         bool have = !arch.empty() && wisdom_lookup(fused_key(c, arch), w);
-        if (!have && !getenv("FFTUP_JIT_NO_BUILTIN_WISDOM"))
+        if (!have && !experiment("jit_no_builtin_wisdom"))
             for (const auto& e : kBuiltinWisdom)
                 if (e.uw == UW && e.d == D) { w = e.plan; have = true; }
         if (have && w != fused_value(c) && w != "pow2" && w != "mr16") {
@@ -770,7 +792,7 @@ static bool compile(const Choice& c, const std::string& arch, int part, Binary& 
     for (const auto& h : hdr) hdr_text += h;
     std::string names[K_COUNT];
     const std::string src = make_source(c, names, part);
-    if (const char* dump = getenv("FFTUP_JIT_DUMP")) {       // the generated translation unit, for inspection (tools/jit_resources.sh)
+    if (const char* dump = experiment("jit_dump")) {       // the generated translation unit, for inspection (tools/jit_resources.sh)
         if (FILE* f = fopen((std::string(dump) + (part ? ".fused.hip" : ".rowcol.hip")).c_str(), "w")) {
             fputs(src.c_str(), f);
             for (int k = 0; k < K_COUNT; k++) if (!names[k].empty()) fprintf(f, "template __global__ decltype(%s) %s;\n", names[k].c_str(), names[k].c_str());
@@ -851,11 +873,11 @@ static bool compile(const Choice& c, const std::string& arch, int part, Binary& 
     return true;
 }
 
-// both parts of a plan.  (FFTUP_JIT_THREADS=1 compiles the second one on a thread of its own: measured, no gain --
+// both parts of a plan.  (experiment jit_threads=1 compiles the second one on a thread of its own: measured, no gain --
 // hipRTC serialises its compilations internally, 48 plans take 54 s either way -- so one after the other is the default.)
 static bool compile_both(const Choice& c, const std::string& arch, Binary b[2], std::string& err)
 {
-    const char* e = getenv("FFTUP_JIT_THREADS");
+    const char* e = experiment("jit_threads");
     if (!e || atoi(e) == 0) return compile(c, arch, 0, b[0], err) && compile(c, arch, 1, b[1], err);
     std::string err1;
     bool ok1 = false;
@@ -886,7 +908,7 @@ static Module* load(Choice c, const std::string& arch, std::string& err)
     // `choose` filled the geometry for c.fused_wpe / c.fused_rr as they are; the variants below only change those two
     for (;;) {
         Module* m = load_once(c, arch, err);
-        if (!m || c.fused_kind != 2 || getenv("FFTUP_JIT_FUSED_OPT") || fused_scratch(m) == 0) return m;
+        if (!m || c.fused_kind != 2 || experiment("jit_fused_opt") || fused_scratch(m) == 0) return m;
         const int one_strip = std::max(1, c.fused_t / 256);
         const int npass = (c.UW + 4 * c.fused_t - 1) / (4 * c.fused_t);
         if (c.fused_wpe > one_strip) c.fused_wpe = one_strip;

@@ -44,7 +44,6 @@ template <typename C> struct RowR2CParamsT {
     StagePlan plan;          // n = W
     int W, H;
     long in_row_stride, in_plane_stride;
-    int inplace;             // non-R2C rows too long for two LDS buffers: one buffer, fft_lds_inplace
     int TK, NT;              // tile width (complex), number of tiles = ceil((W/2+1)/TK)
 };
 using RowR2CParams = RowR2CParamsT<float2>;
@@ -155,7 +154,6 @@ template <typename C> struct RowC2RParamsT {
     int TK, NT;
     int zlx, zrx;            // column-index read guard [zlx,zrx) (VkResample.cpp:1492-1493)
     scalar_t<C> inv_norm;    // 1/uW
-    int inplace;             // non-R2C rows too long for two LDS buffers: one buffer, fft_lds_inplace
 };
 using RowC2RParams = RowC2RParamsT<float2>;
 

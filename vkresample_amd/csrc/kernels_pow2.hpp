@@ -1148,10 +1148,7 @@ template <int N, int DIR, int TK, int R0, int R1, int R2, bool FINAL_TO_LDS> str
 #define FFTUP_3840_PKTW 1
 #endif
 // ---- any number of stages, at most 8 points per butterfly except the last: T threads run ceil(NB/T) butterflies per
-// stage, index map lswz.  3840 = 8 * 8 * 4 * 15 on 512 threads (FFTUP_3840_X16=0).  Written when the 16 * 16 * 15 plan
-// still needed 226 VGPRs; since the butterflies run on register pairs that plan needs 120 and is the default again:
-// one 256-thread workgroup per compute unit (ONE wave per SIMD) runs a strip as fast as this plan's 512 threads do and
-// leaves more issue slots to the kernels beside it (frame 78 -> 75 us).
+// stage, index map lswz.  What the run-time specialised plans (jit.hpp) instantiate for lengths without a three-stage plan.
 template <int N, int DIR, int T, int TK, int... RS> struct MrFftNT {
     static constexpr int NST = sizeof...(RS);
     static constexpr int rs(int s) { constexpr int r[] = {RS...}; return r[s]; }
@@ -1228,12 +1225,8 @@ template <int N, int DIR, int T, int TK, int... RS> struct MrFftNT {
 };
 template <int N, int DIR, int T, int... RS> using MrFftN = MrFftNT<N, DIR, T, 1, RS...>;
 
-#ifndef FFTUP_3840_NBUF
-#define FFTUP_3840_NBUF 2
-#endif
 // Rows of any length UW = R0 * ... on T threads, any number of stages (MrFftN): what the run-time specialised plans
-// (jit.hpp) instantiate when no three-stage 16 * 16 * R2 plan exists, and the 8 * 8 * 4 * 15 plan of 1920x1080 on 512
-// threads (FFTUP_3840_X16=0).  R0 must be a multiple of 2U (U = upscale factor: the non-zero 1/2U of the spectrum fills
+// (jit.hpp) instantiate when no three-stage 16 * 16 * R2 plan exists.  R0 must be a multiple of 2U (U = upscale factor: the non-zero 1/2U of the spectrum fills
 // whole first-stage inputs), T >= UW/R0 and T >= UW/Rlast.
 template <int UW_, int T_, int NBUF_, int WPE_, bool RR_, int... RS> struct FusedPlanN {
     using F = MrFftN<UW_, -1, T_, RS...>;
@@ -1265,7 +1258,6 @@ template <int UW_, int T_, int NBUF_, int WPE_, bool RR_, int... RS> struct Fuse
         F::template run<NBUF == 2>(v, buf, zbuf, j, t);
     }
 };
-using FusedPlan3840 = FusedPlanN<3840, 512, FFTUP_3840_NBUF, 4, true, 8, 8, 4, 15>;     // 1920x1080 -> 3840x2160, rows of 3840 = 8 * 8 * 4 * 15
 #ifndef FFTUP_3840X16_NBUF
 #define FFTUP_3840X16_NBUF 2
 #endif
