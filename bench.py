@@ -65,6 +65,10 @@ def parse_args():
     ap.add_argument("--job", action="store_true",
                     help="job accounting: rank r processes frames shard.frames_for_rank(frames_per_step * world, world, r), all distinct "
                          "(needs --ring >= --frames-per-step), output checksums reduced over the ranks (implied by --preset config5)")
+    ap.add_argument("--queue", action="store_true",
+                    help="with --job: dynamic sharding -- ranks claim chunks of frames from one shared counter (shard.FrameQueue, "
+                         "torch.distributed's store) instead of the static stripe; every rank keeps all frames of a step resident")
+    ap.add_argument("--queue-chunk", type=int, default=8, help="frames per claim of --queue")
     ap.add_argument("--profile-iters", type=int, default=50)
     ap.add_argument("--event-stride", type=int, default=32, help="kernel-timing events on every n-th frame of the first timed region")
     ap.add_argument("--streams", type=int, default=3,
@@ -78,6 +82,10 @@ def parse_args():
     if a.preset:
         for k, v in PRESETS[a.preset].items():
             setattr(a, k, v)
+    if a.queue and not a.job:
+        ap.error("--queue is a mode of --job")
+    if a.queue:
+        a.ring = a.frames_per_step * int(os.environ.get("WORLD_SIZE", "1"))       # any rank may be handed any frame of the step
     if a.job and a.ring < a.frames_per_step:
         ap.error("--job needs --ring >= --frames-per-step (every frame of a step resident and distinct)")
     return a
@@ -245,7 +253,14 @@ def main():
     flags = (v.FLAG_FUSE_U8_LOAD if args.fuse_u8 else 0) | (v.FLAG_GENERIC_KERNELS if args.generic else 0) | (v.FLAG_TUNE_PLAN if args.tune else 0) | \
             (v.FLAG_FUSE_U8_STORE if args.fuse_u8_store else 0)
     up = v.Upscaler(args.width, args.height, args.upscale, args.precision, 0.2, dev, flags, args.ring)
-    if args.job:
+    queue_store = None
+    if args.queue:
+        # dynamic sharding: frame g of the step lives in slot g on EVERY rank; who processes it is decided by the shared counter
+        my_frames = list(range(args.frames_per_step * world))
+        for g in my_frames:
+            up.upload_rgb8(synth.frame(g, args.width, args.height, "U"), slot=g)
+        queue_store = shard.FrameQueue.default_store(dist) if dist is not None else None
+    elif args.job:
         # the reference's stripe (VR:1622-1629): thread/rank t of T takes files f*T + t; slot f holds this rank's f-th frame
         my_frames = shard.frames_for_rank(args.frames_per_step * world, world, rank)
         assert len(my_frames) == args.frames_per_step
@@ -276,8 +291,35 @@ def main():
             up.submit_rgb8(pins[0].array[k % args.ring], pins[1].array[k % args.ring])
         up.drain()
 
+    class LocalStore:                          # one process: the same counter without a server
+        def __init__(self):
+            self.d = {}
+
+        def add(self, k, n):
+            self.d[k] = self.d.get(k, 0) + n
+            return self.d[k]
+
+    if args.queue and queue_store is None:
+        queue_store = LocalStore()
+    claimed = []                               # --queue: the chunks this rank processed in the step that ran last
+    step_no = [0]
+
+    def queue_step():
+        """one step of the job through the shared counter: claim, run, claim ... until the step's frames are handed out"""
+        q = shard.FrameQueue(queue_store, args.frames_per_step * world, args.queue_chunk, key="step%d" % step_no[0])
+        step_no[0] += 1
+        del claimed[:]
+        ms = 0.0
+        for (a, b) in q:
+            ms += up.execute_ring(b - a, a)
+            claimed.append((a, b))
+        return ms
+
     slot = 0
     for _ in range(args.warmup):
+        if args.queue:
+            queue_step()
+            continue
         if args.host_streamed:
             streamed_step()
             continue
@@ -297,6 +339,9 @@ def main():
                 t1 = time.perf_counter()
                 streamed_step()
                 dev_ms += (time.perf_counter() - t1) * 1e3
+                continue
+            if args.queue:
+                dev_ms += queue_step()
                 continue
             if rep == 0:
                 # HIP events before/after every kernel launch of every --event-stride-th frame, on the stream that runs it
@@ -338,11 +383,13 @@ def main():
                "sharding": "rank r owns resident frames r*ring .. r*ring+ring-1; no data-path collective"}
     if args.job:
         # every output slot holds the result of one distinct frame of the job: fingerprint them on the device, reduce
-        sums = [up.output_checksum(s) for s in range(args.frames_per_step)]
+        # (--queue: the frames this rank was handed in the last step -- over the ranks, every frame of the step exactly once)
+        mine = [g for (a, b) in claimed for g in range(a, b)] if args.queue else list(range(args.frames_per_step))
+        sums = [up.output_checksum(s) for s in mine]
         checksum = sum(sums) % (1 << 52)
-        frames_done, total, tmax = shard.reduce_summary(dist, args.frames_per_step, checksum, dt)
+        frames_done, total, tmax = shard.reduce_summary(dist, len(mine), checksum, dt)
         me = {"rank": rank, "device": dev, "pci_bus_id": v.device_pci_bus_id(dev), "name": up.device_name,
-              "first_frames": my_frames[:3], "frames": len(my_frames)}
+              "first_frames": (mine if args.queue else my_frames)[:3], "frames": len(mine)}
         ranks, nranks = [me], 1
         if dist is not None:
             ranks = [None] * world
@@ -353,7 +400,8 @@ def main():
         job = {"frames_per_step_total": args.frames_per_step * world, "frames_done": frames_done, "checksum": total % (1 << 52),
                "elapsed_max_s": tmax, "collective_ranks": nranks, "backend": dist.get_backend() if dist is not None else None,
                "ranks": ranks, "distinct_devices": len({(r["pci_bus_id"]) for r in ranks}),
-               "stripe": "frame f*world + rank (VkResample.cpp:1622-1629)"}
+               "stripe": ("shared counter, chunks of %d frames (shard.FrameQueue)" % args.queue_chunk) if args.queue
+                         else "frame f*world + rank (VkResample.cpp:1622-1629)"}
     line = None
     if rank == 0:
         # kms: average kernel durations inside the first timed region (consecutive frames overlap on --streams lanes, so a
@@ -361,9 +409,11 @@ def main():
         # iso: the same kernels launched strictly one after the other right after the timed regions, HIP events on the
         # launching stream, net of the cost of an empty event pair (= what rocprofv3 --kernel-trace --stats reports)
         iso = up.profile_kernels(args.profile_iters)
+        if max(iso) <= 0:                      # kernels shorter than an event pair's own cost (tiny frames, few iterations)
+            iso = list(kms)
         dom = max(range(len(iso)), key=lambda i: iso[i])
-        achieved = up.kernel_alg_bytes[dom] / (iso[dom] * 1e-3) / 1e9
-        if args.host_streamed:
+        achieved = up.kernel_alg_bytes[dom] / (max(iso[dom], 1e-6) * 1e-3) / 1e9
+        if args.host_streamed or args.queue:
             kms = list(iso)                   # no per-kernel events in the streamed loop
         achieved_ovl = up.kernel_alg_bytes[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else None
         frame_ms = region_dev_ms[med] / (args.steps * args.frames_per_step)

@@ -72,7 +72,7 @@ typedef struct fftup_config {
     float    sharpen;         /* -s sharpening constant (VR:1616)                                    */
     int32_t  device;          /* -d HIP device ordinal                                               */
     uint32_t flags;           /* FFTUP_FLAG_*                                                        */
-    uint32_t ring;            /* resident input/output frame slots (0 or 1 = one, like the reference; <= 64) */
+    uint32_t ring;            /* resident input/output frame slots (0 or 1 = one, like the reference; <= 1024) */
 } fftup_config;
 
 /* Environment read by fftup_plan_create (operational knobs, not part of the reference's surface):

@@ -110,3 +110,25 @@ def test_job_checksum_is_independent_of_the_sharding():
     assert one["frames_done"] == two["frames_done"] == 16
     assert one["checksum"] == two["checksum"] and one["checksum"] > 0
     assert two["rccl_ranks"] == 2 and one["rccl_ranks"] == 1
+
+
+def test_job_through_the_shared_counter_has_the_stripes_checksum():
+    """--queue: the same 16-frame job with the ranks claiming chunks of 4 frames from one counter (shard.FrameQueue) -- whoever
+    processed which frame, every frame was processed exactly once: frames_done and the checksum of the outputs equal the
+    stripe's (and the single-process run's)."""
+    env = dict(os.environ, FFTUP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    base = ["--steps", "2", "--warmup", "1", "--repeats", "1", "--precision", "2", "--fuse-u8", "--job", "--profile-iters", "2",
+            "--no-cpu-baseline", "--no-others", "--width", "512", "--height", "256"]
+    one = _job(1, 16, 0)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29523", "bench.py", "--gpus", "2", "--frames-per-step", "8", "--queue", "--queue-chunk", "4"] + base,
+                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    two = _line(r.stdout)
+    assert two["frames_done"] == one["frames_done"] == 16 and two["checksum"] == one["checksum"] > 0
+    assert two["rccl_ranks"] == 2 and "shared counter" in two["job"]["stripe"]
+    assert sum(x["frames"] for x in two["job"]["ranks"]) == 16
+    q1 = subprocess.run([sys.executable, "bench.py", "--frames-per-step", "16", "--queue", "--queue-chunk", "4"] + base,
+                        cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert q1.returncode == 0, q1.stderr[-3000:]
+    assert _line(q1.stdout)["checksum"] == one["checksum"]

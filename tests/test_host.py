@@ -147,6 +147,53 @@ def test_two_rank_gloo_sharding(tmp_path):
     assert int(line[1]) == 11 and int(line[2]) == expect and float(line[3]) == 1.5
 
 
+QUEUE_WORKER = """
+import os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from vkresample_amd import synth
+from vkresample_amd.shard import FrameQueue, reduce_summary
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+store = FrameQueue.default_store(dist)
+got = []
+for step in range(2):                                   # two steps = two counters
+    mine = []
+    for (a, b) in FrameQueue(store, 37, chunk=5, key="step%d" % step):
+        mine += list(range(a, b))
+        time.sleep(0.002 * (1 + 3 * rank))              # rank 1 is four times slower: rank 0 must end up with more frames
+    got.append(mine)
+chk = sum(int(synth.frame(k, 32, 16).astype(np.int64).sum()) for k in got[1])
+n, total, tmax = reduce_summary(dist, len(got[1]), chk, 0.5 + rank)
+all_frames = [None] * world
+dist.all_gather_object(all_frames, got)
+if rank == 0:
+    print("RESULT", n, total, [len(g[1]) for g in all_frames], sorted(sum((g[0] for g in all_frames), [])) == list(range(37)),
+          sorted(sum((g[1] for g in all_frames), [])) == list(range(37)))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_frame_queue(tmp_path):
+    """world_size 2 on CPU (gloo): the shared counter (shard.FrameQueue, chunks of 5 of 37 frames) hands every frame out exactly
+    once per step, the faster rank gets more of them, and the end-of-run reduction gives the stripe's totals."""
+    import numpy as np
+    from vkresample_amd import synth
+    script = tmp_path / "qworker.py"
+    script.write_text(QUEUE_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29743")
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                                   "--master-addr", "127.0.0.1", "--master-port", "29743", str(script)],
+                                  env=env, stderr=subprocess.STDOUT, timeout=240).decode()
+    line = [l for l in out.splitlines() if l.startswith("RESULT")][0]
+    f = line.split(None, 3)
+    expect = sum(int(synth.frame(k, 32, 16).astype(np.int64).sum()) for k in range(37))
+    assert int(f[1]) == 37 and int(f[2]) == expect
+    counts = eval(f[3].split("]")[0] + "]")
+    assert sum(counts) == 37 and counts[0] > counts[1], counts
+    assert f[3].endswith("True True"), line
+
+
 def test_jit_check_compiles_without_a_device(tmp_path, monkeypatch):
     """csrc/jit.hpp: factorizations are picked and the translation unit is compiled by hipRTC for gfx950 with no GPU
     present; the second request is served from the on-disk cache; a size without a specialised factorization says so."""

@@ -337,7 +337,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
     // the float -> uint32 casts below are undefined for NaN / out-of-range products: bound the inputs first
     if (!(cfg->upscale >= 1.0f && cfg->upscale <= 64.0f)) return fail(FFTUP_E_INVALID_ARG, "upscale must be a finite number in [1, 64]");
     if (W > (1u << 16) || H > (1u << 16)) return fail(FFTUP_E_INVALID_ARG, "width/height above 65536");
-    if (cfg->ring > 64) return fail(FFTUP_E_INVALID_ARG, "ring must be <= 64");
+    if (cfg->ring > 1024) return fail(FFTUP_E_INVALID_ARG, "ring must be <= 1024");
     if (!(cfg->sharpen == cfg->sharpen)) return fail(FFTUP_E_INVALID_ARG, "sharpen is NaN");
     const uint32_t uW = (uint32_t)(cfg->upscale * (float)W);     // VkResample.cpp:1417-1418
     const uint32_t uH = (uint32_t)(cfg->upscale * (float)H);
@@ -746,8 +746,9 @@ template <int W> static void launch_r2c_t(fftup_plan* P, const RowR2CTParams& p,
     switch (mode) {
     case IN_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F32, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
     case IN_F16: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F16, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
-    case IN_U8_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_U8_F32, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
-    default: hipLaunchKernelGGL((k_row_r2c_t<W, IN_U8_F16, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
+    // (8-bit image: one workgroup per row pair transforms all three planes from one read of the bytes)
+    case IN_U8_F32: hipLaunchKernelGGL((k_row_r2c_u8<W, false, TUNED_TK>), dim3(P->H / 2), block, 0, P->lanes[P->cur].stream, p); break;
+    default: hipLaunchKernelGGL((k_row_r2c_u8<W, true, TUNED_TK>), dim3(P->H / 2), block, 0, P->lanes[P->cur].stream, p); break;
     }
 }
 template <int H> static void launch_col_t(fftup_plan* P, const ColTParams& p)
@@ -762,10 +763,17 @@ template <int UW> static void launch_c2r_t(fftup_plan* P, const RowC2RTParams& p
     else hipLaunchKernelGGL((k_row_c2r_t<UW, false, TUNED_TK, true>), grid, block, 0, P->lanes[P->cur].stream, p);
 }
 
+// workgroups of the fused C2R+sharpen kernel.  Planes: strips in linear order over the 3 uH/2 row pairs.  Fused 8-bit store:
+// strips per plane, the three planes' strips of the same rows 8 workgroups apart, rows of 8 strips (k_c2r_sharpen_g, OUT_U8)
+static unsigned fused_grid(const fftup_plan* P, int pairs_per_strip)
+{
+    const int ppp = (int)P->uH / 2;
+    if (P->u8out) return (unsigned)(((ppp + pairs_per_strip - 1) / pairs_per_strip + 7) / 8 * 24);
+    return (unsigned)((3 * ppp + pairs_per_strip - 1) / pairs_per_strip);
+}
 template <class PL> static void launch_fused_t(fftup_plan* P, const FusedParams& p)
 {
-    const int total_pairs = 3 * (int)P->uH / 2;
-    dim3 grid((total_pairs + p.pairs_per_strip - 1) / p.pairs_per_strip), block(PL::T);
+    dim3 grid(fused_grid(P, p.pairs_per_strip)), block(PL::T);
     hipStream_t st = P->lanes[P->cur].stream;
     if (P->u8out) {
         if (P->half) hipLaunchKernelGGL((k_c2r_sharpen_g<PL, true, TUNED_TK, 2, 4, true>), grid, block, FusedGLds<PL>::TOTAL, st, p);
@@ -1052,8 +1060,7 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
     if ((which < 0 || which == 2) && P->fused) {
         if (P->mixed == 3) {
             const FusedParams fp = fused_params(P, out_slot);
-            const int total_pairs = 3 * (int)P->uH / 2;
-            keep_first(jerr, fftup_jit::launch(P->jit->fn[fftup_jit::K_FUSED], dim3((total_pairs + fp.pairs_per_strip - 1) / fp.pairs_per_strip),
+            keep_first(jerr, fftup_jit::launch(P->jit->fn[fftup_jit::K_FUSED], dim3(fused_grid(P, fp.pairs_per_strip)),
                                      dim3(P->jit->choice.fused_t), P->jit->choice.fused_lds, P->lanes[P->cur].stream, fp));
         } else if (P->mixed == 2) launch_fused_t<MixedCfg720::FUSED>(P, fused_params(P, out_slot));
         else launch_fused_t<MixedCfg1080::FUSED>(P, fused_params(P, out_slot));       // (only the mixed plans are fused on this path)
@@ -1094,8 +1101,11 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
 
 // ---- recorded frames.  The reference records its dispatches into ONE command buffer and submits that (VR:1250-1273); here a
 // frame's launches on lane P->cur are captured into a hipGraph the first time that (lane, slots, input kind) combination
-// runs and replayed afterwards -- one hipGraphLaunch instead of three or four kernel launches (what small frames are bound
-// by: 256x128 took 18 us per iteration with kernels of 4 us).  `reps` consecutive frames in one graph for fftup_execute.
+// runs and replayed afterwards; `reps` consecutive frames in one graph.  Used by fftup_execute, the counterpart of
+// performVulkanUpscale.  Measured (profiles/r04_a_graphs.txt): the replay costs what the launches cost -- a 256x128 frame takes
+// 16.3 us either way with kernels of 2-4 us, because a stream's kernels are serialised by the queue's barrier packets
+// (~4 us from the end of one kernel to the start of the next), recorded or not -- and per-frame graphs replayed on the
+// three streams of the batched mode are 1-8 % SLOWER than the launches, so fftup_execute_ring / fftup_submit_rgb8 launch.
 static void graphs_clear(fftup_plan* P)
 {
     for (auto& g : P->graphs) (void)hipGraphExecDestroy(g.second);
@@ -1161,15 +1171,6 @@ static int execute_ring_impl(fftup_plan* P, uint32_t n_frames, uint32_t first_sl
     }
     // consecutive frames go to distinct lanes; they must then also write distinct output slots
     const int nl = std::max(1, std::min(P->nlanes, (int)P->ring));
-    if (P->use_graphs && !kernel_ms) {                       // record what is not recorded yet before the clock starts
-        for (uint32_t i = 0; i < n_frames && i < P->ring * (uint32_t)nl; i++) {
-            hipGraphExec_t ex;
-            P->cur = (int)(i % (uint32_t)nl);
-            const int grc = frame_graph(P, (first_slot + i) % P->ring, (first_slot + i) % P->ring, 1, &ex);
-            P->cur = 0;
-            if (grc) return grc;
-        }
-    }
     HIP_TRY(hipEventRecord(P->ev0, P->stream));
     for (int l = 1; l < nl; l++) HIP_TRY(hipStreamWaitEvent(P->lanes[l].stream, P->ev0, 0));
     int rc = FFTUP_OK;
@@ -1184,7 +1185,7 @@ static int execute_ring_impl(fftup_plan* P, uint32_t n_frames, uint32_t first_sl
                 (void)hipEventRecord(e[k + 1], P->lanes[P->cur].stream);
             }
         } else {
-            rc = run_frames(P, s, s, 1);
+            rc = launch_frame(P, s, s, -1);
         }
         P->last_lane = P->cur;
         P->cur = 0;
@@ -1568,7 +1569,7 @@ int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, ui
         P->in_kind[s] = 1;
     }
     P->cur = lane;
-    rc = run_frames(P, s, s, 1);
+    rc = launch_frame(P, s, s, -1);
     P->last_lane = lane;
     P->cur = 0;
     if (rc) return rc;

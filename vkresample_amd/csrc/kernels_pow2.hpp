@@ -391,23 +391,13 @@ template <int MODE> __device__ __forceinline__ float load_px_t(const RowR2CTPara
     else return cvt_u8_f16(((const uint8_t*)p.in)[y * p.in_row_stride + 3l * x + c]);
 }
 
-// grid (H/2, 3), block W/8.  LDS: lswz_size(W) float2.
-template <int W, int MODE, int TK>
-__global__ void __launch_bounds__(W / 8) k_row_r2c_t(RowR2CTParams p)
+// R2C unpack of a row pair transformed as ONE complex row (vkFFT.h:4292-4323): Z in natural order in `buf` -> rows 2j (A) and
+// 2j + 1 (B) of the blocked half spectrum.  8 consecutive lanes cover one tile segment [A(TK) | B(TK)] of 2*TK float2; each
+// lane stores 16 bytes (two complex values).
+template <int W, int TK>
+__device__ __forceinline__ void row_unpack_store(const float2* __restrict__ buf, const RowR2CTParams& p, int c, int j, int tid)
 {
-    constexpr int E = 8, T = W / E;
-    __shared__ __attribute__((aligned(128))) float2 buf[lswz_size(W)];      // (128: reg_scatter / reg_gather)
-    const int tid = threadIdx.x, c = blockIdx.y;
-    const int j = blockIdx.x;      // (an XCD-aware pair order -- pairs 2i, 2i+1 on one XCD -- measured no gain)
-    float2 v[E];
-    TwSet<W, E> tws;
-    tws.load(p.tw, tid);
-#pragma unroll
-    for (int i = 0; i < E; i++)
-        v[i] = make_float2(load_px_t<MODE>(p, c, 2 * j, tid + T * i), load_px_t<MODE>(p, c, 2 * j + 1, tid + T * i));
-    reg_fft<W, E, +1, 1, true>(v, buf, tid, 0, tws);
-    // unpack (vkFFT.h:4292-4323).  8 consecutive lanes cover one tile segment [A(TK)|B(TK)] of
-    // 2*TK float2; each lane stores 16 bytes (two complex values).
+    constexpr int T = W / 8;
     static_assert(TK == 4 || TK == 8, "tile width");
     constexpr int LPT = TK;                         // lanes per tile segment (2*TK complex / 2 per lane)
     const long tile_stride = (long)p.H * TK;
@@ -432,6 +422,64 @@ __global__ void __launch_bounds__(W / 8) k_row_r2c_t(RowR2CTParams p)
         }
         float4* dst = (float4*)(base + (long)tile * tile_stride + (isB ? TK : 0) + kk);
         *dst = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+    }
+}
+
+// grid (H/2, 3), block W/8.  LDS: lswz_size(W) float2.
+template <int W, int MODE, int TK>
+__global__ void __launch_bounds__(W / 8) k_row_r2c_t(RowR2CTParams p)
+{
+    constexpr int E = 8, T = W / E;
+    __shared__ __attribute__((aligned(128))) float2 buf[lswz_size(W)];      // (128: reg_scatter / reg_gather)
+    const int tid = threadIdx.x, c = blockIdx.y;
+    const int j = blockIdx.x;      // (an XCD-aware pair order -- pairs 2i, 2i+1 on one XCD -- measured no gain)
+    float2 v[E];
+    TwSet<W, E> tws;
+    tws.load(p.tw, tid);
+#pragma unroll
+    for (int i = 0; i < E; i++)
+        v[i] = make_float2(load_px_t<MODE>(p, c, 2 * j, tid + T * i), load_px_t<MODE>(p, c, 2 * j + 1, tid + T * i));
+    reg_fft<W, E, +1, 1, true>(v, buf, tid, 0, tws);
+    row_unpack_store<W, TK>(buf, p, c, j, tid);
+}
+
+// The same from the interleaved 8-bit image (FFTUP_FLAG_FUSE_U8_LOAD, the pack loop of VkResample.cpp:1636-1685 fused into
+// the load), all three colour planes of a row pair in ONE workgroup: grid (H/2), block W/8.  The pair's 2 x 3 W bytes are read
+// once, as 16-byte pieces (three per thread), and staged in LDS; every plane's thread then picks its sixteen bytes from there
+// (stride 3: 64 lanes read 48 consecutive dwords, no bank conflict).  One plane per workgroup with per-thread byte loads at
+// stride 3 -- k_row_r2c_t<W, IN_U8_*> -- asks the texture addresser for 16 byte-loads per thread, each wave instruction
+// touching three lines of which it uses a third, three times over for the three planes: 12.1 us for 31.5 MB (round 3).
+// Same conversion (cvt_u8_f32 / cvt_u8_f16), same transform, same unpack: bit for bit the planar kernel's spectrum.
+template <int W, bool HALF, int TK>
+__global__ void __launch_bounds__(W / 8) k_row_r2c_u8(RowR2CTParams p)
+{
+    constexpr int E = 8, T = W / E;
+    static_assert(W % 16 == 0, "rows of 3 W bytes in 16-byte pieces");
+    __shared__ __attribute__((aligned(128))) float2 buf[lswz_size(W)];
+    __shared__ __attribute__((aligned(16))) uint8_t raw[2 * 3 * W];
+    const int tid = threadIdx.x, j = blockIdx.x;
+    const uint8_t* src = (const uint8_t*)p.in + (long)(2 * j) * p.in_row_stride;
+    constexpr int CPR = 3 * W / 16;                 // 16-byte pieces per row = 3 T / 2
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int q = tid + T * k, r = q >= CPR ? 1 : 0, o = (q - r * CPR) * 16;
+        *(uint4*)(raw + r * 3 * W + o) = *(const uint4*)(src + r * p.in_row_stride + o);
+    }
+    TwSet<W, E> tws;
+    tws.load(p.tw, tid);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float2 v[E];
+        const uint8_t* px = raw + 3 * tid + c;
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            if constexpr (HALF) v[i] = make_float2(cvt_u8_f16(px[3 * T * i]), cvt_u8_f16(px[3 * W + 3 * T * i]));
+            else v[i] = make_float2(cvt_u8_f32(px[3 * T * i]), cvt_u8_f32(px[3 * W + 3 * T * i]));
+        }
+        if (c > 0) __syncthreads();                  // the previous plane's unpack has read buf
+        reg_fft<W, E, +1, 1, true>(v, buf, tid, 0, tws);
+        row_unpack_store<W, TK>(buf, p, c, j, tid);
     }
 }
 
@@ -1340,6 +1388,27 @@ __device__ __forceinline__ void deferred_pixel(const FusedParams& p, long of, fl
     }
 }
 
+// OUT_U8: a thread's four pixels of ONE colour channel go to bytes 3 x + c of the interleaved row.  Stored as they lie -- lane l
+// owning pixels 4 l .. 4 l + 3 -- one byte-store instruction of a wave touches 768 bytes (twelve 64-byte lines) to write 64.
+// The wave first transposes its 256 bytes through the LDS crossbar (ds_bpermute: no LDS memory) so that lane l holds pixels
+// l, 64 + l, 128 + l, 192 + l of the wave's run: a store instruction then covers 64 consecutive pixels = 192 bytes, three or
+// four lines.  `px` = the four bytes of pixels 4 l .. 4 l + 3 packed in a dword, `dst` = address of byte (first pixel of the
+// wave's run) * 3 + c of the output row (wave-uniform), `na` = active lanes (64 but in the last wave of a row whose length is
+// not a multiple of 256; lanes 0 .. na - 1): lane l stores pixels l, na + l, 2 na + l, 3 na + l of the run.
+__device__ __forceinline__ void store_u8_run(uint8_t* dst, unsigned px, int lane, int na)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int q = k * na + lane;                        // pixel of the run: byte q & 3 of lane q >> 2
+        const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute((q >> 2) << 2, (int)px);
+        dst[3 * q] = (uint8_t)__builtin_amdgcn_ubfe(w, (unsigned)(q & 3) * 8u, 8u);
+    }
+}
+__device__ __forceinline__ unsigned pack_u8x4(const uint8_t (&b)[4])
+{
+    return (unsigned)b[0] | ((unsigned)b[1] << 8) | ((unsigned)b[2] << 16) | ((unsigned)b[3] << 24);
+}
+
 // (second argument: waves per SIMD the register allocation must allow -- 4 for 512 threads = 128 VGPRs, so that two strips
 // can share a compute unit; tighter caps were tried: 80 VGPRs spill in fp32 and buy nothing in binary16)
 // U = the (integer) upscale factor: the spectrum rows hold kx = 0..UW/2U, output row y is row y/U of spectrum buffer y%U
@@ -1373,8 +1442,23 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
     typename PL::Tw tws;
     PL::load_tw(tws, p.tw, lt);                 // once: inside the loop a load would queue behind the output stores
 
-    int f0 = blockIdx.x * p.pairs_per_strip;
-    const int f1 = min(f0 + p.pairs_per_strip, 3 * pairs_per_plane);
+    int f0, f1;
+    if constexpr (OUT_U8) {
+        // A 64-byte line of the interleaved image takes bytes from all three planes' workgroups.  Workgroups go round-robin
+        // over the 8 XCDs, each with its own L2: here strips never cross planes and the three strips of the same rows are
+        // workgroups b, b + 8, b + 16 -- same XCD, dispatched together, in step -- so that their partial writes of a line meet
+        // in ONE L2 and the line goes to HBM once (one plane per strip in linear order: every line written three times,
+        // WRITE_SIZE 75.7 MB for the 25.2 MB image; fused_grid() on the host knows the same map).
+        const int b = blockIdx.x, r = b >> 3;
+        const int st = (r / 3) * 8 + (b & 7);
+        const int j0u = st * p.pairs_per_strip;
+        if (j0u >= pairs_per_plane) return;
+        f0 = (r % 3) * pairs_per_plane + j0u;
+        f1 = f0 + min(p.pairs_per_strip, pairs_per_plane - j0u);
+    } else {
+        f0 = blockIdx.x * p.pairs_per_strip;
+        f1 = min(f0 + p.pairs_per_strip, 3 * pairs_per_plane);
+    }
     while (f0 < f1) {
         const int c = f0 / pairs_per_plane;
         const int j0 = f0 - c * pairs_per_plane;
@@ -1663,10 +1747,11 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                             h2v o01, o23;
                             sharpen_quad_half(R[w], R[w + 1], R[w + 2], ncoef, o01, o23);
                             if constexpr (OUT_U8) {
-                                uint8_t* d8 = (uint8_t*)p.out + ((long)(a - 1 + w) * UW * 3 + c) + (unsigned)x0 * 3u;    // (uniform base + x0 * 3)
                                 uint8_t b8[4];
                                 cvt4_f_u8((float)o01.x, (float)o01.y, (float)o23.x, (float)o23.y, p.u8_wrap, b8);
-                                d8[0] = b8[0]; d8[3] = b8[1]; d8[6] = b8[2]; d8[9] = b8[3];
+                                const int xw = __builtin_amdgcn_readfirstlane(x0 - 4 * (lt & 63));        // first pixel of the wave's run
+                                const int na = (UW % 256 == 0) ? 64 : min(64, (UW - xw) / 4);
+                                store_u8_run((uint8_t*)p.out + ((long)(a - 1 + w) * UW + xw) * 3 + c, pack_u8x4(b8), lt & 63, na);
                                 continue;
                             }
                             const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
@@ -1741,10 +1826,11 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                         sharpen_vminmax(t, w, vmn, vmx);
                         const f4t o = sharpen_quad_packed(t, w, vmn, vmx, p.coef);
                         if constexpr (OUT_U8) {
-                            uint8_t* d8 = (uint8_t*)p.out + ((long)(a - 1 + w) * UW * 3 + c) + (unsigned)x0 * 3u;        // (uniform base + x0 * 3)
                             uint8_t b8[4];
                             cvt4_f_u8(o.x, o.y, o.z, o.w, p.u8_wrap, b8);
-                            d8[0] = b8[0]; d8[3] = b8[1]; d8[6] = b8[2]; d8[9] = b8[3];
+                            const int xw = __builtin_amdgcn_readfirstlane(x0 - 4 * (lt & 63));            // first pixel of the wave's run
+                            const int na = (UW % 256 == 0) ? 64 : min(64, (UW - xw) / 4);
+                            store_u8_run((uint8_t*)p.out + ((long)(a - 1 + w) * UW + xw) * 3 + c, pack_u8x4(b8), lt & 63, na);
                             continue;
                         }
                         const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
