@@ -136,9 +136,25 @@ def reference_vulkan_baseline(args):
         return {"available": True, "ms_per_frame": float(m.group(1)), "frames_per_s": 1e3 / float(m.group(1)), "command": "-u 2 -n 1000"}
 
 
-def other_configs(v, synth, dev, ring=8):
+def frame_traffic(traffic_json, key, kernel_names):
+    """measured HBM bytes per launch of a configuration's kernels (committed rocprofv3 --pmc run, profiles/hbm_traffic.json):
+    (per-kernel dict, frame total, source text) or (None, None, None)"""
+    try:
+        tj = json.load(open(traffic_json)).get(key)
+        if not tj:
+            return None, None, None
+        per = {n: tj.get(n, {}).get("hbm_bytes_per_launch") for n in kernel_names if n != "-"}
+        total = sum(per.values()) if all(x is not None for x in per.values()) else None
+        return per, total, "static %s [%s] (%s)" % (os.path.relpath(traffic_json, ROOT), key, tj.get("_source", "?"))
+    except Exception:
+        return None, None, None
+
+
+def other_configs(v, synth, dev, traffic_json, ring=8):
     """Short runs of the other single-GPU BASELINE configurations on the same GPU, same method as the headline (ring of
-    resident frames, three streams, HIP events per kernel), and the reference's -n 1000 figure on ring-less plans."""
+    resident frames, three streams, HIP events per kernel), and the reference's -n 1000 figure on ring-less plans.  Every entry
+    carries, beside the B_alg fractions, the numbers that can still move: the fraction by MEASURED HBM bytes
+    (`real_traffic_frac`), by the bytes that must move at all (`b_min_frac`: input + output), and the energy per frame."""
     out = {}
     for name in ("config3", "config4", "config3_u8_store"):
         c = PRESETS[name.replace("_u8_store", "")]
@@ -147,9 +163,15 @@ def other_configs(v, synth, dev, ring=8):
             for s in range(ring):
                 up.upload_rgb8(synth.frame(s, c["width"], c["height"], "U"), slot=s)
             up.execute_ring(256, 0)
-            t = sorted(up.execute_ring(1024, 0) / 1024 for _ in range(3))[1]          # device ms per frame, median of three
+            power = PowerSampler(v.device_pci_bus_id(dev), period=0.02).start()
+            t = sorted(up.execute_ring(1024, 0) / 1024 for _ in range(5))[2]          # device ms per frame, median of five
+            pw = power.stop()
             iso = up.profile_kernels(30)
             dom = max(range(len(iso)), key=lambda i: iso[i])
+            esz = {0: 4, 1: 8, 2: 2}[c["precision"]]
+            b_min = 3.0 * (c["width"] * c["height"] * (1 if c["fuse_u8"] else esz) + up.out_width * up.out_height * (1 if up.u8_store else esz))
+            key = "%dx%d_p%d_%s%s" % (c["width"], c["height"], c["precision"], "u8" if c["fuse_u8"] else "planar", "_u8out" if up.u8_store else "")
+            per, frame_hbm, tsrc = frame_traffic(traffic_json, key, up.kernel_names)
             out[name] = {"workload": "%dx%d -u 2 -p %d%s%s" % (c["width"], c["height"], c["precision"], ", fused uint8 load" if c["fuse_u8"] else "",
                                                                   ", fused 8-bit RGB store (8-bit in, 8-bit out)" if up.u8_store else ""),
                          "ms_per_frame": t, "frames_per_s": 1e3 / t,
@@ -157,6 +179,12 @@ def other_configs(v, synth, dev, ring=8):
                          "kernel_ms": dict(zip(up.kernel_names, iso)),
                          "kernel_frac": up.kernel_alg_bytes[dom] / (iso[dom] * 1e-3) / 8e12,
                          "kernel_frac_real_bytes": up.kernel_min_bytes[dom] / (iso[dom] * 1e-3) / 8e12,
+                         "B_min": b_min, "b_min_frac": b_min / (t * 1e-3) / 8e12,
+                         "frame_hbm_bytes_measured": frame_hbm, "traffic_source": tsrc,
+                         "real_traffic_frac": (frame_hbm / (t * 1e-3) / 8e12) if frame_hbm else None,
+                         "kernel_hbm_bytes_measured": per,
+                         "socket_power_w_median": pw.get("socket_power_w_median"), "sclk_mhz_median": pw.get("sclk_mhz_median"),
+                         "energy_mj_per_frame": pw["socket_power_w_median"] * t if pw.get("socket_power_w_median") else None,
                          "plan": up.description}
     n1000 = {}
     for name in ("config2", "config3", "config4"):
@@ -421,17 +449,8 @@ def main():
         # measured HBM bytes (rocprofv3 --pmc, corrected as profiles/hbm_traffic.json documents) -- static: taken from the
         # committed profile of THIS configuration, not re-measured by this run
         key = config_key(args) + ("_u8out" if up.u8_store else "")
-        traffic, frame_hbm, tsrc = None, None, None
-        if os.path.exists(args.traffic_json):
-            try:
-                tj = json.load(open(args.traffic_json)).get(key)
-                if tj:
-                    traffic = tj.get(up.kernel_names[dom], {}).get("hbm_bytes_per_launch")
-                    parts = [tj.get(n, {}).get("hbm_bytes_per_launch") for n in up.kernel_names if n != "-"]
-                    frame_hbm = sum(parts) if all(x is not None for x in parts) else None
-                    tsrc = "static %s [%s] (%s)" % (os.path.relpath(args.traffic_json, ROOT), key, tj.get("_source", "?"))
-            except Exception:
-                traffic = None
+        per, frame_hbm, tsrc = frame_traffic(args.traffic_json, key, up.kernel_names)
+        traffic = per.get(up.kernel_names[dom]) if per else None
         esz = {0: 4, 1: 8, 2: 2}[args.precision]
         b_in = 1 if (args.fuse_u8 and args.precision != 1) else esz
         b_min = 3.0 * (args.width * args.height * b_in + up.out_width * up.out_height * (1 if up.u8_store else esz))
@@ -453,7 +472,7 @@ def main():
                        "wisdom": wisdom},
             "repeats": len(region_s), "region_s": region_s, "timed_region_s_median": dt,
             "ms_per_frame": wall_frame_ms, "ms_per_frame_device_events": frame_ms,
-            "frame_alg_bytes": up.alg_bytes_per_frame, "B_min": b_min,
+            "frame_alg_bytes": up.alg_bytes_per_frame, "B_min": b_min, "b_min_frac": b_min / (wall_frame_ms * 1e-3) / 8e12,
             "frame_roofline_frac": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 8e12,
             "frame_hbm_bytes_measured": frame_hbm,
             "real_traffic_frac": (frame_hbm / (wall_frame_ms * 1e-3) / 8e12) if frame_hbm else None,
@@ -489,7 +508,7 @@ def main():
     up.close()
     if rank == 0 and world == 1 and not args.no_others and not args.host_streamed and (args.preset or "config2") == "config2" \
             and (args.width, args.height, args.precision) == (2048, 1024, 0):
-        line["others"] = other_configs(v, synth, dev)
+        line["others"] = other_configs(v, synth, dev, args.traffic_json)
     if pins:
         pins[0].close()
         pins[1].close()

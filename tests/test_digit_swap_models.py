@@ -150,3 +150,56 @@ def test_k_col_v_digit_swap_model():
     for w in range(8):
         for h in range(16):
             assert np.abs(v[w, h, :] - ref[16 * w + h + 128 * np.arange(8)]).max() <= 1e-8      # row pp + 128 i in register i: the load layout
+
+
+def test_row_r2c_v_digit_swap_model():
+    """k_row_r2c_v<2048>: forward transform of 2048 = 8 (registers) x 4 (waves) x 8 (lane bits 5-3) x 8 (lane bits 2-0) points on
+    256 threads, decimation in time.  Exchanges: registers <-> wave through LDS (8 register values against 4 waves: a thread
+    comes out with 4 values of the wave digit x 2 of the 8 first-stage outputs, two radix-4 butterflies), registers <-> lane
+    bits 5-3 by permlane swaps, registers <-> lane bits 2-0 inside the wave's own LDS block."""
+    N = 2048
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    tw = lambda j: np.exp(2j * np.pi * (j % N) / N)       # the table (sign +)
+    F = np.fft.ifft(x) * N                                # forward: exp(+2 pi i n k / N)
+    W4 = np.exp(2j * np.pi * np.outer(np.arange(4), np.arange(4)) / 4)
+    v = np.zeros((4, 64, 8), complex)                     # [wave][lane][register]
+    for w in range(4):
+        for l in range(64):
+            v[w, l, :] = x[64 * w + l + 256 * np.arange(8)]                  # the load layout of k_row_r2c_t: x[tid + 256 i]
+    v = v @ W8[+1].T                                      # registers: k0
+    nv = np.zeros_like(v)                                 # A: element (k0, n2 = wave) -> thread wave k0 >> 1, register 4 (k0 & 1) + n2
+    for n2 in range(4):
+        for k0 in range(8):
+            nv[k0 >> 1, :, 4 * (k0 & 1) + n2] = v[n2, :, k0]
+    v = nv
+    for wp in range(4):
+        for b in range(2):
+            for n2 in range(4):
+                v[wp, :, 4 * b + n2] *= tw(64 * n2 * (2 * wp + b))          # exp(2 pi i n2 k0 / 32): wave-uniform
+            v[wp, :, 4 * b:4 * b + 4] = v[wp, :, 4 * b:4 * b + 4] @ W4.T     # registers: 4 b + k1
+    nv = np.zeros_like(v)                                 # C: register <-> lane bits 5-3
+    for l in range(64):
+        lo, hi = l & 7, l >> 3
+        for m in range(8):
+            nv[:, lo + 8 * m, hi] = v[:, l, m]
+    v = nv
+    for wp in range(4):
+        for l in range(64):
+            m = l >> 3
+            kk = 2 * wp + (m >> 2) + 8 * (m & 3)         # k0 + 8 k1
+            v[wp, l, :] *= tw(8 * np.arange(8) * kk)      # exp(2 pi i n1 (k0 + 8 k1) / 256)
+    v = v @ W8[+1].T                                      # registers: k2
+    nv = np.zeros_like(v)                                 # B: register <-> lane bits 2-0
+    for l in range(64):
+        lo, hi = l & 7, l >> 3
+        for k2 in range(8):
+            nv[:, 8 * hi + k2, lo] = v[:, l, k2]
+    v = nv
+    for wp in range(4):
+        for l in range(64):
+            m, k2 = l >> 3, l & 7
+            kk = 2 * wp + (m >> 2) + 8 * (m & 3) + 32 * k2
+            v[wp, l, :] *= tw(np.arange(8) * kk)
+            v[wp, l, :] = W8[+1] @ v[wp, l, :]
+            assert np.abs(v[wp, l, :] - F[kk + 256 * np.arange(8)]).max() <= 1e-8          # X[k'' + 256 k3] in register k3

@@ -626,7 +626,16 @@ def test_fused_u8_store_equals_planes_plus_conversion(W, H, precision, flags):
         with pytest.raises(v.FftupError):
             up.download_planar()
         assert up.output_checksum(0) == int(np.frombuffer(got.tobytes(), dtype=np.uint32).astype(np.uint64).sum())
-    assert np.array_equal(got, ref), (np.argwhere(got != ref)[:5], (got != ref).sum())
+    # Same conversion of the same sharpened values -- but the store variant cuts the planes into strips of their own (one plane
+    # per strip, the three planes' strips of the same rows on one XCD), and where a cut falls decides which rows share a complex
+    # transform and its rounding (test_fused_output_independent_of_strip_length: <= 5e-6 / a binary16 ulp): a value that close to
+    # k/255 may land on the other side.  Measured: 2 bytes of 25 M (fp32), none where the strips coincide.
+    d = np.abs(got.astype(int) - ref.astype(int))
+    print("U8STORE %dx%d p%d flags %d: %d of %d bytes differ, max %d" % (W, H, precision, flags, int((d != 0).sum()), d.size, int(d.max())))
+    if flags & 1:       # (wrapping store: a value a rounding below 0 wraps to 255)
+        assert (d != 0).mean() <= (1e-6 if precision == 0 else 1e-4)
+    else:
+        assert d.max() <= 1 and (d != 0).mean() <= (1e-6 if precision == 0 else 1e-4), (np.argwhere(got != ref)[:5], (got != ref).sum())
     if W * H <= 2048 * 1024 and not (flags & 1):
         _, _, ou8 = O.upscale_rgb8(rgb, 2.0, precision, 0.2)
         d = np.abs(got[:-1].astype(int) - ou8[:-1].astype(int))
@@ -649,7 +658,8 @@ def test_fused_u8_store_host_streamed_and_unfused_fallback():
                 up.submit_rgb8(pi.array[k], po.array[k])
             up.drain()
             outs.append(po.array.copy())
-    assert np.array_equal(outs[0], outs[1])
+    d01 = np.abs(outs[0].astype(int) - outs[1].astype(int))     # (strips of its own: see test_fused_u8_store_equals_planes_plus_conversion)
+    assert d01.max() <= 1 and (d01 != 0).mean() <= 1e-6
     d = np.abs(outs[2][:, :-1].astype(int) - outs[0][:, :-1].astype(int))
     assert d.max() <= 1 and (d != 0).mean() <= 1e-3          # size-generic kernels: other fp32 roundings, same pixels
 

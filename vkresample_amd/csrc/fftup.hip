@@ -235,6 +235,12 @@ static void set_strip_length(fftup_plan* P)
     if (const char* e = fftup_jit::experiment("g_per_cu")) per_cu = std::max(1, std::min(4, atoi(e)));
     const int total_pairs = 3 * (int)P->uH / 2, slots = std::max(1, P->prop.multiProcessorCount) * per_cu;
     P->pairs_per_strip = std::max(2, (total_pairs + slots - 1) / slots);
+    if (P->u8out) {
+        // fused 8-bit store: strips per plane, the three planes' strips of the same rows on ONE of the 8 XCDs (fused_grid):
+        // whole triples per XCD, or one compute unit of an XCD gets two strips and the launch takes twice as long
+        const int per_xcd = std::max(3, slots / 8) / 3, ppp = (int)P->uH / 2;
+        P->pairs_per_strip = std::max(2, (ppp + 8 * per_xcd - 1) / (8 * per_xcd));
+    }
     if (const char* e = fftup_jit::experiment("pairs_per_strip")) P->pairs_per_strip = std::max(1, atoi(e));
 }
 // what the tuner's findings are filed under: the device and whether consecutive frames overlap on several streams
@@ -746,9 +752,8 @@ template <int W> static void launch_r2c_t(fftup_plan* P, const RowR2CTParams& p,
     switch (mode) {
     case IN_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F32, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
     case IN_F16: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F16, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
-    // (8-bit image: one workgroup per row pair transforms all three planes from one read of the bytes)
-    case IN_U8_F32: hipLaunchKernelGGL((k_row_r2c_u8<W, false, TUNED_TK>), dim3(P->H / 2), block, 0, P->lanes[P->cur].stream, p); break;
-    default: hipLaunchKernelGGL((k_row_r2c_u8<W, true, TUNED_TK>), dim3(P->H / 2), block, 0, P->lanes[P->cur].stream, p); break;
+    case IN_U8_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_U8_F32, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
+    default: hipLaunchKernelGGL((k_row_r2c_t<W, IN_U8_F16, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
     }
 }
 template <int H> static void launch_col_t(fftup_plan* P, const ColTParams& p)

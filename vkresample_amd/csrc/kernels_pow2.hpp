@@ -443,45 +443,10 @@ __global__ void __launch_bounds__(W / 8) k_row_r2c_t(RowR2CTParams p)
     row_unpack_store<W, TK>(buf, p, c, j, tid);
 }
 
-// The same from the interleaved 8-bit image (FFTUP_FLAG_FUSE_U8_LOAD, the pack loop of VkResample.cpp:1636-1685 fused into
-// the load), all three colour planes of a row pair in ONE workgroup: grid (H/2), block W/8.  The pair's 2 x 3 W bytes are read
-// once, as 16-byte pieces (three per thread), and staged in LDS; every plane's thread then picks its sixteen bytes from there
-// (stride 3: 64 lanes read 48 consecutive dwords, no bank conflict).  One plane per workgroup with per-thread byte loads at
-// stride 3 -- k_row_r2c_t<W, IN_U8_*> -- asks the texture addresser for 16 byte-loads per thread, each wave instruction
-// touching three lines of which it uses a third, three times over for the three planes: 12.1 us for 31.5 MB (round 3).
-// Same conversion (cvt_u8_f32 / cvt_u8_f16), same transform, same unpack: bit for bit the planar kernel's spectrum.
-template <int W, bool HALF, int TK>
-__global__ void __launch_bounds__(W / 8) k_row_r2c_u8(RowR2CTParams p)
-{
-    constexpr int E = 8, T = W / E;
-    static_assert(W % 16 == 0, "rows of 3 W bytes in 16-byte pieces");
-    __shared__ __attribute__((aligned(128))) float2 buf[lswz_size(W)];
-    __shared__ __attribute__((aligned(16))) uint8_t raw[2 * 3 * W];
-    const int tid = threadIdx.x, j = blockIdx.x;
-    const uint8_t* src = (const uint8_t*)p.in + (long)(2 * j) * p.in_row_stride;
-    constexpr int CPR = 3 * W / 16;                 // 16-byte pieces per row = 3 T / 2
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int q = tid + T * k, r = q >= CPR ? 1 : 0, o = (q - r * CPR) * 16;
-        *(uint4*)(raw + r * 3 * W + o) = *(const uint4*)(src + r * p.in_row_stride + o);
-    }
-    TwSet<W, E> tws;
-    tws.load(p.tw, tid);
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        float2 v[E];
-        const uint8_t* px = raw + 3 * tid + c;
-#pragma unroll
-        for (int i = 0; i < E; i++) {
-            if constexpr (HALF) v[i] = make_float2(cvt_u8_f16(px[3 * T * i]), cvt_u8_f16(px[3 * W + 3 * T * i]));
-            else v[i] = make_float2(cvt_u8_f32(px[3 * T * i]), cvt_u8_f32(px[3 * W + 3 * T * i]));
-        }
-        if (c > 0) __syncthreads();                  // the previous plane's unpack has read buf
-        reg_fft<W, E, +1, 1, true>(v, buf, tid, 0, tws);
-        row_unpack_store<W, TK>(buf, p, c, j, tid);
-    }
-}
+// (Round 4 measured "read the row pair's 2 x 3 W bytes once, 16 bytes per thread, stage them in LDS, transform the three planes
+// in one workgroup" against this kernel's sixteen byte loads per thread and plane: 14.9 us with the planes one after the other
+// in a 256-thread workgroup, 12.7 us side by side in 768 threads, 12.1 us as it is -- the input loads are not what the row
+// kernel waits for; profiles/r04_c_row_u8_variants.txt.)
 
 // =================================================================================== column
 struct ColTParams {
@@ -1388,27 +1353,6 @@ __device__ __forceinline__ void deferred_pixel(const FusedParams& p, long of, fl
     }
 }
 
-// OUT_U8: a thread's four pixels of ONE colour channel go to bytes 3 x + c of the interleaved row.  Stored as they lie -- lane l
-// owning pixels 4 l .. 4 l + 3 -- one byte-store instruction of a wave touches 768 bytes (twelve 64-byte lines) to write 64.
-// The wave first transposes its 256 bytes through the LDS crossbar (ds_bpermute: no LDS memory) so that lane l holds pixels
-// l, 64 + l, 128 + l, 192 + l of the wave's run: a store instruction then covers 64 consecutive pixels = 192 bytes, three or
-// four lines.  `px` = the four bytes of pixels 4 l .. 4 l + 3 packed in a dword, `dst` = address of byte (first pixel of the
-// wave's run) * 3 + c of the output row (wave-uniform), `na` = active lanes (64 but in the last wave of a row whose length is
-// not a multiple of 256; lanes 0 .. na - 1): lane l stores pixels l, na + l, 2 na + l, 3 na + l of the run.
-__device__ __forceinline__ void store_u8_run(uint8_t* dst, unsigned px, int lane, int na)
-{
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int q = k * na + lane;                        // pixel of the run: byte q & 3 of lane q >> 2
-        const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute((q >> 2) << 2, (int)px);
-        dst[3 * q] = (uint8_t)__builtin_amdgcn_ubfe(w, (unsigned)(q & 3) * 8u, 8u);
-    }
-}
-__device__ __forceinline__ unsigned pack_u8x4(const uint8_t (&b)[4])
-{
-    return (unsigned)b[0] | ((unsigned)b[1] << 8) | ((unsigned)b[2] << 16) | ((unsigned)b[3] << 24);
-}
-
 // (second argument: waves per SIMD the register allocation must allow -- 4 for 512 threads = 128 VGPRs, so that two strips
 // can share a compute unit; tighter caps were tried: 80 VGPRs spill in fp32 and buy nothing in binary16)
 // U = the (integer) upscale factor: the spectrum rows hold kx = 0..UW/2U, output row y is row y/U of spectrum buffer y%U
@@ -1419,7 +1363,12 @@ __device__ __forceinline__ unsigned pack_u8x4(const uint8_t (&b)[4])
 // OUT_U8 (FFTUP_FLAG_FUSE_U8_STORE): the kernel stores the interleaved 8-bit RGB image itself -- the conversion
 // of VkResample.cpp:1708-1748 on the sharpened values in registers, bit for bit what k_pack_u8 makes of the stored planes
 // (cvt_f_u8) -- four byte stores per quad, one base register + immediate offsets; the float / half planes are never
-// written (100 MB less HBM traffic per 4096x2048 frame than planes + k_pack_u8).
+// written (100 MB less HBM traffic per 4096x2048 frame than planes + k_pack_u8).  A workgroup still owns ONE plane (a strip
+// that owns its rows in all three has 4 instead of 12 pairs behind each halo pair: measured slower, round 3), so every
+// 64-byte line of the image takes bytes from three workgroups: the strip map below puts those three on one XCD.
+// What the variant costs against the planes (68 vs 56 us at 4096x2048 -p 2, profiles/r04_d_*): 14 instead of 13 steps per
+// strip, and four store instructions per thread and row instead of one -- lines touched per instruction do not matter
+// (a wave-transposed form with 3-4 instead of 12 lines per instruction, ds_bpermute, ran 1 % slower: removed).
 template <class PL, bool HALF, int TK, int U = 2, int D = 2 * U, bool OUT_U8 = false>
 __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
 {
@@ -1749,9 +1698,8 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                             if constexpr (OUT_U8) {
                                 uint8_t b8[4];
                                 cvt4_f_u8((float)o01.x, (float)o01.y, (float)o23.x, (float)o23.y, p.u8_wrap, b8);
-                                const int xw = __builtin_amdgcn_readfirstlane(x0 - 4 * (lt & 63));        // first pixel of the wave's run
-                                const int na = (UW % 256 == 0) ? 64 : min(64, (UW - xw) / 4);
-                                store_u8_run((uint8_t*)p.out + ((long)(a - 1 + w) * UW + xw) * 3 + c, pack_u8x4(b8), lt & 63, na);
+                                uint8_t* d8 = (uint8_t*)p.out + ((long)(a - 1 + w) * UW * 3 + c) + (unsigned)x0 * 3u;    // (uniform base + x0 * 3)
+                                d8[0] = b8[0]; d8[3] = b8[1]; d8[6] = b8[2]; d8[9] = b8[3];
                                 continue;
                             }
                             const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
@@ -1828,9 +1776,8 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                         if constexpr (OUT_U8) {
                             uint8_t b8[4];
                             cvt4_f_u8(o.x, o.y, o.z, o.w, p.u8_wrap, b8);
-                            const int xw = __builtin_amdgcn_readfirstlane(x0 - 4 * (lt & 63));            // first pixel of the wave's run
-                            const int na = (UW % 256 == 0) ? 64 : min(64, (UW - xw) / 4);
-                            store_u8_run((uint8_t*)p.out + ((long)(a - 1 + w) * UW + xw) * 3 + c, pack_u8x4(b8), lt & 63, na);
+                            uint8_t* d8 = (uint8_t*)p.out + ((long)(a - 1 + w) * UW * 3 + c) + (unsigned)x0 * 3u;        // (uniform base + x0 * 3)
+                            d8[0] = b8[0]; d8[3] = b8[1]; d8[6] = b8[2]; d8[9] = b8[3];
                             continue;
                         }
                         const long row_of = c * plane + (long)(a - 1 + w) * UW;      // wave-uniform
