@@ -30,6 +30,12 @@ def _rel_l2(a, b):
     return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
 
 
+def _m(tag, **vals):
+    """measured error figures of a comparison, printed (pytest -s -> profiles/*_parity_small.txt): the asserted bounds sit at
+    about ten times the largest figure any parametrisation printed"""
+    print("MEASURED %s: %s" % (tag, "  ".join("%s %.3g" % kv for kv in vals.items())))
+
+
 def _run(W, H, u, precision, dist, flags=0, sharpen=0.2, seed=0):
     from vkresample_amd import synth
     rgb = synth.frame(seed, W, H, dist)
@@ -55,6 +61,8 @@ SIZES_FP32 = [
 def test_fp32_parity_small(W, H, u, dist):
     (pre, out, u8), (opre, oout, ou8) = _run(W, H, u, 0, dist)
     usq = u * u
+    _m("fp32_small %dx%d u%g %s" % (W, H, u, dist), pre_l2=_rel_l2(pre, opre), pre_max=np.abs(pre - opre).max() * usq,
+       out_l2=_rel_l2(out[:, :-1], oout[:, :-1]), out_max=np.abs(out[:, :-1] - oout[:, :-1]).max())
     assert _rel_l2(pre, opre) <= 1e-5
     assert np.abs(pre - opre).max() * usq <= 1e-4
     assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-4
@@ -64,6 +72,7 @@ def test_fp32_parity_small(W, H, u, dist):
     from vkresample_amd import FLAG_UNFUSED_SHARPEN
     (pre_u, out_u, _), _ = _run(W, H, u, 0, dist, flags=FLAG_UNFUSED_SHARPEN)
     sh = O.sharpen(pre_u, u, 0, 0.2)
+    _m("fp32_small sharpen alone %dx%d u%g %s" % (W, H, u, dist), max=np.abs(out_u[:, :-1] - sh[:, :-1]).max())
     # 5e-5: n = 1 - mx cancels in fp32 for near-saturated neighbourhoods (as in the reference's fp32 shader)
     assert np.abs(out_u[:, :-1] - sh[:, :-1]).max() <= 5e-5
     # u8 = trunc(255*x): a float error can flip the truncation by one code; for u == 1 every exact
@@ -90,6 +99,8 @@ def test_fp16_parity_small(W, H, u, dist):
     ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
     # (+5e-7: below |g| ~ 2^-14 the fp16 grid (2^-24) is finer than the fp32 transform's own noise)
     assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
+    _m("fp16_small %dx%d u%g %s" % (W, H, u, dist), pre_diff_frac=(pre != opre).mean(), out_l2=_rel_l2(out[:, :-1], oout[:, :-1]),
+       out_max=np.abs(out[:, :-1] - oout[:, :-1]).max(), out_diff_frac=(out[:, :-1] != oout[:, :-1]).mean())
     assert (pre != opre).mean() <= 0.05      # ringing around zero: fp16 ulp shrinks with |g|, fp32 noise does not
     assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-3
     assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 8e-3
@@ -106,6 +117,7 @@ def test_tuned_equals_generic(precision):
     from vkresample_amd import FLAG_GENERIC_KERNELS
     (pre, out, u8), _ = _run(512, 256, 2.0, precision, "N")
     (pre2, out2, u82), _ = _run(512, 256, 2.0, precision, "N", flags=FLAG_GENERIC_KERNELS)
+    _m("tuned_vs_generic p%d" % precision, pre_max=np.abs(pre - pre2).max() * 4, out_max=np.abs(out - out2).max(), out_diff_frac=(out != out2).mean())
     assert np.abs(pre - pre2).max() * 4 <= (2e-6 if precision == 0 else 1e-3)
     assert np.abs(out - out2).max() <= (1e-4 if precision == 0 else 4e-3)
 
@@ -349,12 +361,15 @@ def test_golden_vectors_gpu(name):
         assert np.abs(pre - d["pre"]).max() <= 1e-12 and np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 1e-9
         assert np.abs(u8[:-1].astype(int) - d["u8"][:-1].astype(int)).max() <= 1
     elif precision == 0:
+        _m("golden " + name, pre_max=np.abs(pre - d["pre"]).max() * 4, pre_l2=_rel_l2(pre, d["pre"]),
+           out_max=np.abs(out[:, :-1] - d["out"][:, :-1]).max(), out_l2=_rel_l2(out[:, :-1], d["out"][:, :-1]))
         assert np.abs(pre - d["pre"]).max() * 4 <= 1e-4 and _rel_l2(pre, d["pre"]) <= 1e-5
         assert np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 1e-3 and _rel_l2(out[:, :-1], d["out"][:, :-1]) <= 1e-4
         assert np.abs(u8[:-1].astype(int) - d["u8"][:-1].astype(int)).max() <= 1
     else:
         ulp = np.maximum(np.abs(d["pre"]), 2.0 ** -14) * 2.0 ** -10
         assert (np.abs(pre - d["pre"]) <= ulp * 1.0001 + 5e-7).all()
+        _m("golden " + name, out_max=np.abs(out[:, :-1] - d["out"][:, :-1]).max(), out_diff_frac=(out[:, :-1] != d["out"][:, :-1]).mean())
         assert np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 8e-3
 
 
@@ -417,6 +432,8 @@ def test_u8_wrap_flag():
 def test_largest_r2c_size_vs_oracle():
     """uW = 8192 is the largest width the reference's R2C path accepts (VkResample.cpp:1424)."""
     (pre, out, u8), (opre, oout, ou8) = _run(4096, 64, 2.0, 0, "N", seed=9)
+    _m("largest_r2c", pre_l2=_rel_l2(pre, opre), pre_max=np.abs(pre - opre).max() * 4, out_l2=_rel_l2(out[:, :-1], oout[:, :-1]),
+       out_max=np.abs(out[:, :-1] - oout[:, :-1]).max())
     assert _rel_l2(pre, opre) <= 1e-5 and np.abs(pre - opre).max() * 4 <= 1e-4
     assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-4
 
@@ -435,6 +452,7 @@ def test_non_r2c_complex_path_vs_oracle(W, H, u, precision, flags):
     (pre, out, u8), (opre, oout, ou8) = _run(W, H, u, precision, "N", flags=flags, seed=21)
     usq = u * u
     if precision == 0:
+        _m("non_r2c %dx%d u%g" % (W, H, u), pre_l2=_rel_l2(pre, opre), pre_max=np.abs(pre - opre).max() * usq, out_l2=_rel_l2(out[:, :-1], oout[:, :-1]))
         assert _rel_l2(pre, opre) <= 1e-5 and np.abs(pre - opre).max() * usq <= 1e-4
         so = _report("non-R2C %dx%d u%g out" % (W, H, u), out[:, :-1] - oout[:, :-1], 1e-4)
         assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-4 and so["max"] <= 1e-3 and so["p99.99"] <= 1e-4

@@ -687,7 +687,7 @@ static void launch_unpack(fftup_plan* P, uint32_t slot, hipStream_t st)
 
 static void launch_pack(fftup_plan* P, uint32_t slot, uint8_t* dst, hipStream_t st)
 {
-    dim3 grid((P->uW + 255) / 256, P->uH);
+    dim3 grid(P->dbl ? (P->uW + 255) / 256 : (P->uW + 1023) / 1024, P->uH);      // (float / half: four pixels per thread)
     const int wrap = (P->cfg.flags & FFTUP_FLAG_U8_WRAP) ? 1 : 0;
     if (P->dbl) hipLaunchKernelGGL(k_pack_u8_f64, grid, dim3(256), 0, st, (const double*)P->out[slot], dst, (int)P->uW, (int)P->uH, wrap);
     else if (P->half) hipLaunchKernelGGL(k_pack_u8<true>, grid, dim3(256), 0, st, P->out[slot], dst, (int)P->uW, (int)P->uH, wrap);
@@ -749,6 +749,15 @@ int fftup_upload_planar(fftup_plan* P, uint32_t slot, const void* planes, size_t
 template <int W> static void launch_r2c_t(fftup_plan* P, const RowR2CTParams& p, int mode)
 {
     dim3 grid(P->H / 2, 3), block(W / 8);
+    switch (mode) {
+            case IN_F32: hipLaunchKernelGGL((k_row_r2c_v<IN_F32, TUNED_TK>), grid, block, 0, st, p); break;
+            case IN_F16: hipLaunchKernelGGL((k_row_r2c_v<IN_F16, TUNED_TK>), grid, block, 0, st, p); break;
+            case IN_U8_F32: hipLaunchKernelGGL((k_row_r2c_v<IN_U8_F32, TUNED_TK>), grid, block, 0, st, p); break;
+            default: hipLaunchKernelGGL((k_row_r2c_v<IN_U8_F16, TUNED_TK>), grid, block, 0, st, p); break;
+            }
+            return;
+        }
+    }
     switch (mode) {
     case IN_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F32, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
     case IN_F16: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F16, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;

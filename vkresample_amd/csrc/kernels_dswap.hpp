@@ -219,4 +219,8 @@ __global__ void __launch_bounds__(512, FFTUP_COL_WAVES) k_col_v(ColTParams p)
     }
 }
 
+// (A digit-swap row kernel -- 2048 = 8 (registers) x 4 (waves) x 8 x 8 (lane bits), 3 barriers instead of 7, parity-green --
+// was measured in round 4 and runs exactly as fast as k_row_r2c_t<2048>: that kernel sits at the memory system's rate for a
+// 10-us launch; profiles/r04_f_row_digit_swap.txt.  Its index algebra stays in tests/test_digit_swap_models.py.)
+
 }  // namespace fftup
