@@ -750,15 +750,6 @@ template <int W> static void launch_r2c_t(fftup_plan* P, const RowR2CTParams& p,
 {
     dim3 grid(P->H / 2, 3), block(W / 8);
     switch (mode) {
-            case IN_F32: hipLaunchKernelGGL((k_row_r2c_v<IN_F32, TUNED_TK>), grid, block, 0, st, p); break;
-            case IN_F16: hipLaunchKernelGGL((k_row_r2c_v<IN_F16, TUNED_TK>), grid, block, 0, st, p); break;
-            case IN_U8_F32: hipLaunchKernelGGL((k_row_r2c_v<IN_U8_F32, TUNED_TK>), grid, block, 0, st, p); break;
-            default: hipLaunchKernelGGL((k_row_r2c_v<IN_U8_F16, TUNED_TK>), grid, block, 0, st, p); break;
-            }
-            return;
-        }
-    }
-    switch (mode) {
     case IN_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F32, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
     case IN_F16: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F16, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
     case IN_U8_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_U8_F32, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
