@@ -131,6 +131,9 @@ __device__ __forceinline__ void wave_exchange(float2 (&v)[8], unsigned zbase, un
     for (int i = 0; i < 8; i += 2) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i + 1].x), "+v"(v[i + 1].y));
 }
 
+// grid (NT, 3), one column tile per workgroup: all 771 workgroups of a 2048x1024 frame are resident at once.  (Round 4 measured one
+// workgroup per tile column running the three planes' tiles one after the other, the next tile's loads issued before this tile's
+// transform: 19.9 instead of 14.6 us -- two waves per SIMD do not hide their own latencies; profiles/r04_g_column_pipelined.txt.)
 template <int TK>
 __global__ void __launch_bounds__(512, FFTUP_COL_WAVES) k_col_v(ColTParams p)
 {
