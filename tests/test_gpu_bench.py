@@ -59,7 +59,9 @@ def test_bench_single_rank_line():
         assert set(e["kernel_hbm_bytes_measured"]) == {"row_r2c", "col_fwd_pad_inv", "row_c2r_sharpen"}
         assert e["energy_mj_per_frame"] is None or 10 < e["energy_mj_per_frame"] < 500
     assert d["b_min_frac"] < d["real_traffic_frac"] < d["frame_roofline_frac"]
-    assert o["config3_u8_store"]["frame_hbm_bytes_measured"] < 1.5e8          # (the 8-bit image is written once: 25 MB, not 76)
+    # (the 8-bit image is written once: the fused kernel's launch moves 91 MB -- 25 MB of writes, the spectra, and the L2's
+    # reads of the lines it merges the three planes' bytes into -- not the 111 MB of round 3 with 76 MB of writes)
+    assert o["config3_u8_store"]["kernel_hbm_bytes_measured"]["row_c2r_sharpen"] < 1.0e8
     n = o["execute_n1000"]
     for k in ("config2", "config3", "config4"):
         assert 0.01 < n[k]["ms_per_iter"] < 1.0

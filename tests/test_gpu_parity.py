@@ -1,14 +1,19 @@
 """GPU parity: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
 
-Tolerances (north_star: "within 1e-4 rel-err"):
-  fp32 (-p 0): pre-sharpen image t = u^2*g: relative L2 error <= 1e-5 (typ. 3e-7), max |err| <= 1e-4 of
-      full scale.  Sharpened output: relative L2 <= 1e-4, max |err| <= 1e-3 -- the reference's filter
-      has scale = -s*sqrt(min(a,b)), whose slope is unbounded at 0, so an fp32 rounding error of 1e-7 in
-      a neighbourhood minimum that is exactly 0 in fp64 becomes ~1e-4 in the output (black/white
-      pixels of the uniform-random frames hit this).  The sharpen kernel itself is checked to 2e-6
-      against the oracle's sharpen applied to the *device's own* pre-sharpen planes.
-  fp16 (-p 2): the path stores fp16 (half ulp 2.4e-4 at 0.5), so: pre-sharpen within 1 half-ulp of the
-      oracle's own fp16 value, sharpened output max |err| <= 8e-3 (a one-ulp flip of an fp16 input moves the fp16-arithmetic filter by a few ulps), relative L2 <= 1e-3.
+Tolerances (north_star: "within 1e-4 rel-err"); every bound is about ten times the largest figure any parametrisation of the
+test measured (printed as MEASURED / PARITY lines under pytest -s: profiles/r04_h_parity_small.txt), so it is the error budget
+of THIS code and not of the task:
+  fp32 (-p 0): pre-sharpen image t = u^2*g: relative L2 error <= 2e-6 (measured <= 2.2e-7), max |err| <= 1e-5 of full scale
+      (<= 9.5e-7).  Sharpened output, natural-like frames: relative L2 <= 5e-6, max |err| <= 2e-5 (4.4e-7 / 1.7e-6).
+      Uniform-noise frames: max |err| <= 5e-4 (4.4e-5) -- the reference's filter has scale = -s*sqrt(min(a,b)), whose slope is
+      unbounded at 0, so an fp32 rounding error of 1e-7 in a neighbourhood minimum that is exactly 0 in fp64 becomes ~1e-4 in the
+      output (black / white pixels of the uniform-random frames hit this; with -u 1, where every pixel keeps its exact 0 or
+      1, 2.5e-4 measured, 2.5e-3 allowed).  The sharpen kernel itself is checked against the oracle's sharpen applied to the
+      *device's own* pre-sharpen planes: <= 3e-6 natural (2.8e-7), <= 1e-4 uniform (1.1e-5).
+  fp16 (-p 2): the path stores fp16 (half ulp 2.4e-4 at 0.5), so: pre-sharpen within 1 half-ulp of the oracle's own fp16 value
+      and different from it in <= 1 % of the pixels (0.1 %), sharpened output relative L2 <= 3.5e-4 (3.5e-5), different from the
+      oracle in <= 2 % of the pixels (0.18 %), max |err| <= 8e-3 = 16 ulps (6 measured: errors come in whole ulps, a one-ulp
+      flip of an fp16 input moves the fp16-arithmetic filter by a few).
 The last output row reads stale padding memory in the reference (quirk B5) and is excluded.
 """
 import os
@@ -63,18 +68,20 @@ def test_fp32_parity_small(W, H, u, dist):
     usq = u * u
     _m("fp32_small %dx%d u%g %s" % (W, H, u, dist), pre_l2=_rel_l2(pre, opre), pre_max=np.abs(pre - opre).max() * usq,
        out_l2=_rel_l2(out[:, :-1], oout[:, :-1]), out_max=np.abs(out[:, :-1] - oout[:, :-1]).max())
-    assert _rel_l2(pre, opre) <= 1e-5
-    assert np.abs(pre - opre).max() * usq <= 1e-4
-    assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-4
-    assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1e-3
+    assert _rel_l2(pre, opre) <= 2e-6
+    assert np.abs(pre - opre).max() * usq <= 1e-5
+    # (uniform noise: the filter's sqrt at exact zeros, see the module docstring; -u 1 keeps every exact 0 and 1)
+    l2_max, out_max = (5e-6, 2e-5) if dist == "N" else ((3e-4, 2.5e-3) if u == 1.0 else (5e-6, 5e-4))
+    assert _rel_l2(out[:, :-1], oout[:, :-1]) <= l2_max
+    assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= out_max
     # sharpen kernel in isolation: same (device) input on both sides (two-launch path, where the
     # pre-sharpen planes are exactly what the sharpen kernel read)
     from vkresample_amd import FLAG_UNFUSED_SHARPEN
     (pre_u, out_u, _), _ = _run(W, H, u, 0, dist, flags=FLAG_UNFUSED_SHARPEN)
     sh = O.sharpen(pre_u, u, 0, 0.2)
     _m("fp32_small sharpen alone %dx%d u%g %s" % (W, H, u, dist), max=np.abs(out_u[:, :-1] - sh[:, :-1]).max())
-    # 5e-5: n = 1 - mx cancels in fp32 for near-saturated neighbourhoods (as in the reference's fp32 shader)
-    assert np.abs(out_u[:, :-1] - sh[:, :-1]).max() <= 5e-5
+    # uniform noise: n = 1 - mx cancels in fp32 for near-saturated neighbourhoods (as in the reference's fp32 shader)
+    assert np.abs(out_u[:, :-1] - sh[:, :-1]).max() <= (3e-6 if dist == "N" else 1e-4)
     # u8 = trunc(255*x): a float error can flip the truncation by one code; for u == 1 every exact
     # output sits ON a code boundary (x = k/255), so only the magnitude is asserted there
     d = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
@@ -101,8 +108,8 @@ def test_fp16_parity_small(W, H, u, dist):
     assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
     _m("fp16_small %dx%d u%g %s" % (W, H, u, dist), pre_diff_frac=(pre != opre).mean(), out_l2=_rel_l2(out[:, :-1], oout[:, :-1]),
        out_max=np.abs(out[:, :-1] - oout[:, :-1]).max(), out_diff_frac=(out[:, :-1] != oout[:, :-1]).mean())
-    assert (pre != opre).mean() <= 0.05      # ringing around zero: fp16 ulp shrinks with |g|, fp32 noise does not
-    assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-3
+    assert (pre != opre).mean() <= 0.01      # ringing around zero: fp16 ulp shrinks with |g|, fp32 noise does not
+    assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 3.5e-4 and (out[:, :-1] != oout[:, :-1]).mean() <= 0.02
     assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 8e-3
     # the half-arithmetic sharpen is bit-exact given the same fp16 input (two-launch path)
     from vkresample_amd import FLAG_UNFUSED_SHARPEN
@@ -118,8 +125,9 @@ def test_tuned_equals_generic(precision):
     (pre, out, u8), _ = _run(512, 256, 2.0, precision, "N")
     (pre2, out2, u82), _ = _run(512, 256, 2.0, precision, "N", flags=FLAG_GENERIC_KERNELS)
     _m("tuned_vs_generic p%d" % precision, pre_max=np.abs(pre - pre2).max() * 4, out_max=np.abs(out - out2).max(), out_diff_frac=(out != out2).mean())
-    assert np.abs(pre - pre2).max() * 4 <= (2e-6 if precision == 0 else 1e-3)
-    assert np.abs(out - out2).max() <= (1e-4 if precision == 0 else 4e-3)
+    assert np.abs(pre - pre2).max() * 4 <= (4e-6 if precision == 0 else 1e-3)           # (measured 4.2e-7 / one binary16 ulp)
+    assert np.abs(out - out2).max() <= (2e-5 if precision == 0 else 4e-3)              # (1.6e-6 / 2.4e-3 = five ulps)
+    assert precision == 0 or (out != out2).mean() <= 2.5e-3                              # (2.2e-4)
 
 
 def test_u8_conversion_bit_exact():
@@ -363,14 +371,14 @@ def test_golden_vectors_gpu(name):
     elif precision == 0:
         _m("golden " + name, pre_max=np.abs(pre - d["pre"]).max() * 4, pre_l2=_rel_l2(pre, d["pre"]),
            out_max=np.abs(out[:, :-1] - d["out"][:, :-1]).max(), out_l2=_rel_l2(out[:, :-1], d["out"][:, :-1]))
-        assert np.abs(pre - d["pre"]).max() * 4 <= 1e-4 and _rel_l2(pre, d["pre"]) <= 1e-5
-        assert np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 1e-3 and _rel_l2(out[:, :-1], d["out"][:, :-1]) <= 1e-4
+        assert np.abs(pre - d["pre"]).max() * 4 <= 4e-6 and _rel_l2(pre, d["pre"]) <= 2e-6                     # (measured 3.9e-7, 1.6e-7)
+        assert np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 1e-5 and _rel_l2(out[:, :-1], d["out"][:, :-1]) <= 3e-6     # (7.9e-7, 3.0e-7)
         assert np.abs(u8[:-1].astype(int) - d["u8"][:-1].astype(int)).max() <= 1
     else:
         ulp = np.maximum(np.abs(d["pre"]), 2.0 ** -14) * 2.0 ** -10
         assert (np.abs(pre - d["pre"]) <= ulp * 1.0001 + 5e-7).all()
         _m("golden " + name, out_max=np.abs(out[:, :-1] - d["out"][:, :-1]).max(), out_diff_frac=(out[:, :-1] != d["out"][:, :-1]).mean())
-        assert np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 8e-3
+        assert np.abs(out[:, :-1] - d["out"][:, :-1]).max() <= 4e-3 and (out[:, :-1] != d["out"][:, :-1]).mean() <= 2e-3      # (7.3e-4, 1.7e-4)
 
 
 @pytest.mark.parametrize("W,H", [(1920, 1080), (1280, 720)])
@@ -434,8 +442,8 @@ def test_largest_r2c_size_vs_oracle():
     (pre, out, u8), (opre, oout, ou8) = _run(4096, 64, 2.0, 0, "N", seed=9)
     _m("largest_r2c", pre_l2=_rel_l2(pre, opre), pre_max=np.abs(pre - opre).max() * 4, out_l2=_rel_l2(out[:, :-1], oout[:, :-1]),
        out_max=np.abs(out[:, :-1] - oout[:, :-1]).max())
-    assert _rel_l2(pre, opre) <= 1e-5 and np.abs(pre - opre).max() * 4 <= 1e-4
-    assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-4
+    assert _rel_l2(pre, opre) <= 2e-6 and np.abs(pre - opre).max() * 4 <= 6e-6                  # (measured 1.6e-7, 5.4e-7)
+    assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 4e-6 and np.abs(out[:, :-1] - oout[:, :-1]).max() <= 2e-5     # (4.0e-7, 1.7e-6)
 
 
 @pytest.mark.parametrize("W,H,u,precision,flags", [(4608, 64, 2.0, 0, 0), (4608, 64, 2.0, 0, 2), (3072, 32, 3.0, 0, 0),
@@ -453,9 +461,9 @@ def test_non_r2c_complex_path_vs_oracle(W, H, u, precision, flags):
     usq = u * u
     if precision == 0:
         _m("non_r2c %dx%d u%g" % (W, H, u), pre_l2=_rel_l2(pre, opre), pre_max=np.abs(pre - opre).max() * usq, out_l2=_rel_l2(out[:, :-1], oout[:, :-1]))
-        assert _rel_l2(pre, opre) <= 1e-5 and np.abs(pre - opre).max() * usq <= 1e-4
+        assert _rel_l2(pre, opre) <= 2e-6 and np.abs(pre - opre).max() * usq <= 6e-6               # (measured <= 1.8e-7, 5.2e-7)
         so = _report("non-R2C %dx%d u%g out" % (W, H, u), out[:, :-1] - oout[:, :-1], 1e-4)
-        assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 1e-4 and so["max"] <= 1e-3 and so["p99.99"] <= 1e-4
+        assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 5e-6 and so["max"] <= 1.5e-5 and so["p99.99"] <= 1e-5     # (4.3e-7, 1.4e-6, 1.1e-6)
     elif precision == 2:
         # -p 2 beyond the R2C limit (VERDICT r2 missing 1): half input and half complex pre-sharpen image around fp32
         # transforms (VR:1420-1424, VF:7282-7292), the complex sharpen in binary16 arithmetic (VR:865-907 with f16vec2)
