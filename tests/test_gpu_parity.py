@@ -482,19 +482,51 @@ def test_non_r2c_complex_path_vs_oracle(W, H, u, precision, flags):
 
 def test_non_r2c_limits():
     import vkresample_amd as v
-    for W, u in ((9216, 2.0), (8064, 2.0)):          # 18432 points: beyond one LDS buffer; 16128 = 2^8 * 63: a radix-7 stage beyond 14336 points
-        with pytest.raises(v.FftupError) as e:
-            v.Upscaler(W, 16, u)
-        assert e.value.code == 2
-    with pytest.raises(v.FftupError) as e:           # -p 1: 16-byte elements, two buffers of 5120 complex do not fit, no one-buffer form
-        v.Upscaler(2560, 16, 2.0, 1)
-    assert e.value.code == 2
+    with pytest.raises(v.FftupError) as e:           # 2 * 32771 (a prime): not 2,3,5,7-smooth
+        v.Upscaler(32771 * 2, 16, 1.0)
+    assert e.value.code in (1, 2)
     with _up(5120, 16, 2.0) as up:                   # 10240-point rows: the one-buffer form
         assert up.kernel_names == ["row_c2c", "col_fwd_pad_inv", "row_c2c_inv", "sharpen"] and not up.tuned
     with _up(4608, 16, 2.0, 2) as up:                # -p 2 beyond the R2C limit
         assert up.kernel_names[0] == "row_c2c"
     with _up(4608, 16, 2.0) as up:
         assert up.kernel_names == ["row_c2c", "col_fwd_pad_inv", "row_c2c_inv", "sharpen"] and not up.tuned
+    for W, u, p in ((9216, 2.0, 0), (8064, 2.0, 0), (2560, 2.0, 1)):      # beyond one LDS buffer: four steps (refused until round 4)
+        with _up(W, 16, u, p) as up:
+            assert up.kernel_names[0] == "row_c2c" and not up.tuned
+
+
+FOUR_STEP = [(9216, 8, 2.0, 0, 0),       # inverse rows of 18432 = 128 * 144 points in four steps, forward rows (9216) in one launch
+             (9216, 8, 2.0, 0, 2), (9216, 8, 2.0, 2, 2),    # ... from the uint8 image; -p 2
+             (17280, 4, 1.0, 0, 0),      # -u 1: forward AND inverse rows of 17280 = 2^7 3^3 5 points in four steps
+             (8064, 8, 2.0, 0, 0),       # 16128 = 2^8 * 63: the one-buffer form has no radix-7 stage that long
+             (20000, 4, 1.5, 0, 0),      # 30000-point inverse rows, 20000-point forward rows
+             (2560, 8, 2.0, 1, 0),       # -p 1: two buffers of 5120 double2 do not fit
+             (8748, 4, 2.0, 0, 0)]       # 17496 = 2^3 3^7: 72 * 243, no factor pair with 4 | both: one sequence per workgroup
+
+
+@pytest.mark.parametrize("W,H,u,precision,flags", FOUR_STEP)
+def test_four_step_rows_vs_oracle(W, H, u, precision, flags):
+    """Non-R2C rows beyond one LDS buffer (16 384 points; ~4 800 for -p 1): the reference switches to multi-upload plans with a
+    transposition through a temporary buffer (VF:4773-4992, 2290-2388, 6562-6576); here k_row4_a / k_row4_b run the row as
+    N1 x N2 in two launches through HBM.  Same bars as the one-launch non-R2C rows."""
+    assert O.uses_complex_path(W, H, u, precision)
+    (pre, out, u8), (opre, oout, ou8) = _run(W, H, u, precision, "N", flags=flags, seed=23)
+    usq = u * u
+    if precision == 0:
+        _m("four_step %dx%d u%g" % (W, H, u), pre_l2=_rel_l2(pre, opre), pre_max=np.abs(pre - opre).max() * usq, out_l2=_rel_l2(out[:, :-1], oout[:, :-1]),
+           out_max=np.abs(out[:, :-1] - oout[:, :-1]).max())
+        assert _rel_l2(pre, opre) <= 2e-6 and np.abs(pre - opre).max() * usq <= 6e-6
+        assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 5e-6 and np.abs(out[:, :-1] - oout[:, :-1]).max() <= 2e-5      # (measured <= 1.9e-7, 4.8e-7; 4.3e-7, 1.4e-6)
+    elif precision == 2:
+        ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
+        assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
+        so = _report("four-step -p 2 %dx%d u%g out" % (W, H, u), out[:, :-1] - oout[:, :-1], 2.0 ** -10)
+        assert so["max"] <= 8e-3 and so["p99"] == 0 and so["p99.99"] <= 3e-3
+    else:
+        assert np.abs(pre - opre).max() <= 1e-12 and np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1e-9
+    d = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
+    assert d.max() <= (2 if precision == 2 else 1)
 
 
 def test_4k_to_8k_properties():

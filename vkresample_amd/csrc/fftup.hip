@@ -83,6 +83,9 @@ struct fftup_plan {
     int U = 2;                        // integer upscale factor of a polyphase plan (tuned / mixed): S1 + U-1 residue buffers
     bool cplx = false;                // non-R2C path (VR:1424 false): full complex transforms, uW beyond the R2C limit
     bool inplaceF = false, inplaceI = false;   // ... whose forward / inverse rows are too long for two LDS buffers: fft_lds_inplace
+    // ... and rows too long for ONE buffer: four steps through HBM (k_row4_a / k_row4_b), row length = n1 * n2
+    struct Four { bool on = false; int n1 = 0, n2 = 0, tk = 1; StagePlan p1{}, p2{}; float2 *tw1 = nullptr, *tw2 = nullptr; size_t ldsA = 0, ldsB = 0; int thrA = 64, thrB = 64; };
+    Four fourF, fourI;
     int ncols = 0;                    // spectrum columns kept: W/2 + 1, or W on the non-R2C path
     int pairs_per_strip = 6;
     bool R_valid = false;             // pre-sharpen buffer holds the last frame (unfused path only)
@@ -95,7 +98,8 @@ struct fftup_plan {
     void* R = nullptr;                // pre-sharpen, dense [3][uH][uW]
     // batched mode runs consecutive frames on `nlanes` streams (the reference's -numthreads does the same with
     // several queues on one device); every lane owns its scratch spectra.  Lane 0 = the members above.
-    struct Lane { hipStream_t stream = nullptr; float2 *S1 = nullptr, *S2 = nullptr; void* R = nullptr; hipEvent_t done = nullptr; };
+    struct Lane { hipStream_t stream = nullptr; float2 *S1 = nullptr, *S2 = nullptr; void* R = nullptr; hipEvent_t done = nullptr;
+                  void* T4 = nullptr; };             // T4: the four-step rows' transposition buffer
     std::vector<Lane> lanes;
     int nlanes = 1, cur = 0, last_lane = 0;
     std::vector<void*> out;           // per slot: dense [3][uH][uW]
@@ -126,6 +130,22 @@ static bool is_smooth(uint32_t n)
     for (uint32_t p : {2u, 3u, 5u, 7u})
         while (n % p == 0) n /= p;
     return n == 1;
+}
+
+// Four-step split of a row of n points that does not fit the LDS (k_row4_a / k_row4_b): n = n1 * n2, both transforms with
+// their two Stockham buffers of tk interleaved sequences in 160 KB, as square as possible, tk = 4 where both factors allow it
+static bool split_four(uint32_t n, size_t el, int* n1, int* n2, int* tk)
+{
+    long best = -1;
+    for (uint32_t d = 2; d * d <= n; d++) {
+        if (n % d) continue;
+        const uint32_t a = d, b = n / d;                     // a <= b
+        const int t = (a % 4 == 0 && b % 4 == 0) ? 4 : 1;
+        if (2 * el * (size_t)lpad_size((int)b * t) > (size_t)160 * 1024) continue;
+        const long score = (t == 4 ? 0 : (1l << 40)) + (long)(b - a);
+        if (best < 0 || score < best) { best = score; *n1 = (int)a; *n2 = (int)b; *tk = t; }
+    }
+    return best >= 0;
 }
 
 // radix sequence: as many 8s as possible, then 4/2, then 3,5,7 (VkFFTScheduler vkFFT.h:4707-5189
@@ -257,6 +277,42 @@ static bool jit_tune_enabled()
     const char* e = getenv("FFTUP_JIT_TUNE");
     return e && atoi(e) != 0;
 }
+// four-step rows (k_row4_a / k_row4_b): launch both passes; ATTR: only allow their dynamic LDS sizes (plan creation)
+template <typename C, int DIR, int MODE, bool HALF_OUT, int TKS, bool ATTR>
+static hipError_t four_passes(const fftup_plan::Four& f, const Row4Params<C>& q, int rows, hipStream_t st)
+{
+    if constexpr (ATTR) {
+        hipError_t e = hipFuncSetAttribute((const void*)(k_row4_a<DIR, TKS, MODE, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.ldsA);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute((const void*)(k_row4_b<DIR, TKS, HALF_OUT, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.ldsB);
+    } else {
+        hipLaunchKernelGGL((k_row4_a<DIR, TKS, MODE, C>), dim3(rows, f.n2 / TKS, 3), dim3(f.thrA), f.ldsA, st, q);
+        hipLaunchKernelGGL((k_row4_b<DIR, TKS, HALF_OUT, C>), dim3(rows, f.n1 / TKS, 3), dim3(f.thrB), f.ldsB, st, q);
+        return hipSuccess;
+    }
+}
+template <typename C, int DIR, int MODE, bool HALF_OUT, bool ATTR>
+static hipError_t four_run(const fftup_plan::Four& f, const Row4Params<C>& q, int rows, hipStream_t st)
+{
+    return f.tk == 4 ? four_passes<C, DIR, MODE, HALF_OUT, 4, ATTR>(f, q, rows, st) : four_passes<C, DIR, MODE, HALF_OUT, 1, ATTR>(f, q, rows, st);
+}
+// forward rows of a plan: input mode from the slot's kind and the precision; inverse rows: output type from the precision
+template <typename C, bool ATTR> static hipError_t four_forward(fftup_plan* P, const Row4Params<C>& q, int kind, hipStream_t st)
+{
+    if constexpr (sizeof(scalar_t<C>) == 8) return four_run<C, +1, IN_F64, false, ATTR>(P->fourF, q, (int)P->H, st);
+    else {
+        if (kind == 2) return P->half ? four_run<C, +1, IN_U8_F16, false, ATTR>(P->fourF, q, (int)P->H, st) : four_run<C, +1, IN_U8_F32, false, ATTR>(P->fourF, q, (int)P->H, st);
+        return P->half ? four_run<C, +1, IN_F16, false, ATTR>(P->fourF, q, (int)P->H, st) : four_run<C, +1, IN_F32, false, ATTR>(P->fourF, q, (int)P->H, st);
+    }
+}
+template <typename C, bool ATTR> static hipError_t four_inverse(fftup_plan* P, const Row4Params<C>& q, hipStream_t st)
+{
+    if constexpr (sizeof(scalar_t<C>) == 4) {
+        if (P->half) return four_run<C, -1, IN_F32, true, ATTR>(P->fourI, q, (int)P->uH, st);
+    }
+    return four_run<C, -1, IN_F32, false, ATTR>(P->fourI, q, (int)P->uH, st);
+}
+
 static std::vector<int> stage_radices(const StagePlan& p)
 {
     std::vector<int> r;
@@ -366,8 +422,13 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             if (!stage_fits_inplace((int)n, sp.radix[st], 1024, 16)) return 0;
         return 1;
     };
-    if (cplx && (!rows_fit(uW) || !rows_fit(W)))
-        return fail(FFTUP_E_UNSUPPORTED_SIZE, "row too long for the LDS: non-R2C rows go up to 16384 points (-p 0 / -p 2), ~4800 for -p 1");
+    // ... and rows beyond one buffer run in four steps through HBM (k_row4_a / k_row4_b), as the reference's multi-upload plans
+    {
+        int a, b, t;
+        const size_t el = cfg->precision == 1 ? 16 : 8;
+        if (cplx && ((!rows_fit(uW) && !split_four(uW, el, &a, &b, &t)) || (!rows_fit(W) && !split_four(W, el, &a, &b, &t))))
+            return fail(FFTUP_E_UNSUPPORTED_SIZE, "row too long: no four-step split of the row length fits the LDS");
+    }
 
     int ndev = fftup_device_count();
     if (ndev <= 0) return fail(FFTUP_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
@@ -468,6 +529,16 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             P->inplaceF = rows_fit(W) == 1; P->inplaceI = rows_fit(uW) == 1;
             if (P->inplaceF) P->ldsRowF /= 2;
             if (P->inplaceI) P->ldsRowI /= 2;
+            auto four = [&](fftup_plan::Four& f, uint32_t n) {           // ... or four steps through HBM
+                f.on = split_four(n, P->csz, &f.n1, &f.n2, &f.tk);
+                f.p1 = make_stage_plan((uint32_t)f.n1); f.p2 = make_stage_plan((uint32_t)f.n2);
+                f.ldsA = 2 * P->csz * (size_t)lpad_size(f.n1 * f.tk); f.ldsB = 2 * P->csz * (size_t)lpad_size(f.n2 * f.tk);
+                const int tmax = P->dbl ? GenericMaxThreads<double2>::value : GenericMaxThreads<float2>::value;
+                f.thrA = std::min(tmax, std::max(64, round_up(f.n1 * f.tk / 8, 64)));
+                f.thrB = std::min(tmax, std::max(64, round_up(f.n2 * f.tk / 8, 64)));
+            };
+            if (!rows_fit(W)) { four(P->fourF, W); P->ldsRowF = 0; }
+            if (!rows_fit(uW)) { four(P->fourI, uW); P->ldsRowI = 0; }
         }
         if (P->ldsRowI > lds_max) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled width too large for LDS"); goto bad; }
         {
@@ -484,6 +555,8 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         PLAN_RC(make_twiddles(P, &P->twH, H));
         PLAN_RC(make_twiddles(P, &P->twUW, uW));
         PLAN_RC(make_twiddles(P, &P->twUH, uH));
+        for (fftup_plan::Four* f : {&P->fourF, &P->fourI})
+            if (f->on) { PLAN_RC(make_twiddles(P, &f->tw1, (uint32_t)f->n1)); PLAN_RC(make_twiddles(P, &f->tw2, (uint32_t)f->n2)); }
 
         const size_t esz = P->esz;
         P->in_plane_stride = (size_t)(W + 2) * H;                    // VkResample.cpp:1644
@@ -520,11 +593,14 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             P->nlanes = std::max(1, std::min(nl, 4));
             P->lanes.resize(P->nlanes);
             P->lanes[0].stream = P->stream; P->lanes[0].S1 = P->S1; P->lanes[0].S2 = P->S2; P->lanes[0].R = P->R;
+            const size_t t4_bytes = P->csz * 3 * std::max(P->fourF.on ? (size_t)W * H : 0, P->fourI.on ? (size_t)uW * uH : 0);
+            if (t4_bytes) PLAN_RC(dev_alloc(P, &P->lanes[0].T4, t4_bytes));
             for (int l = 1; l < P->nlanes; l++) {
                 PLAN_TRY(hipStreamCreateWithFlags(&P->lanes[l].stream, hipStreamNonBlocking));
                 PLAN_TRY(hipEventCreateWithFlags(&P->lanes[l].done, hipEventDisableTiming));
                 PLAN_RC(alloc_spectra(&P->lanes[l].S1, &P->lanes[l].S2));
                 if (!P->fused) PLAN_RC(dev_alloc(P, &P->lanes[l].R, P->r_bytes));
+                if (t4_bytes) PLAN_RC(dev_alloc(P, &P->lanes[l].T4, t4_bytes));
             }
         }
 
@@ -550,17 +626,30 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         }
         if (cplx) {
             // (one instantiation per input type / output type / one-or-two-buffer form: only this plan's)
-            if (P->dbl) { SET_LDS((k_row_c2c_fwd<IN_F64, double2>), P->ldsRowF); SET_LDS((k_row_c2c_inv<double2>), P->ldsRowI); }
+            const bool f1 = !P->fourF.on, i1 = !P->fourI.on;         // rows in one launch (else: four steps, below)
+            if (P->dbl) { if (f1) SET_LDS((k_row_c2c_fwd<IN_F64, double2>), P->ldsRowF); if (i1) SET_LDS((k_row_c2c_inv<double2>), P->ldsRowI); }
             else if (P->half) {
-                if (P->inplaceF) { SET_LDS((k_row_c2c_fwd<IN_F16, float2, true>), P->ldsRowF); SET_LDS((k_row_c2c_fwd<IN_U8_F16, float2, true>), P->ldsRowF); }
+                if (!f1) {}
+                else if (P->inplaceF) { SET_LDS((k_row_c2c_fwd<IN_F16, float2, true>), P->ldsRowF); SET_LDS((k_row_c2c_fwd<IN_U8_F16, float2, true>), P->ldsRowF); }
                 else { SET_LDS((k_row_c2c_fwd<IN_F16, float2>), P->ldsRowF); SET_LDS((k_row_c2c_fwd<IN_U8_F16, float2>), P->ldsRowF); }
-                if (P->inplaceI) SET_LDS((k_row_c2c_inv<float2, true, true>), P->ldsRowI);
+                if (!i1) {}
+                else if (P->inplaceI) SET_LDS((k_row_c2c_inv<float2, true, true>), P->ldsRowI);
                 else SET_LDS((k_row_c2c_inv<float2, true, false>), P->ldsRowI);
             } else {
-                if (P->inplaceF) { SET_LDS((k_row_c2c_fwd<IN_F32, float2, true>), P->ldsRowF); SET_LDS((k_row_c2c_fwd<IN_U8_F32, float2, true>), P->ldsRowF); }
+                if (!f1) {}
+                else if (P->inplaceF) { SET_LDS((k_row_c2c_fwd<IN_F32, float2, true>), P->ldsRowF); SET_LDS((k_row_c2c_fwd<IN_U8_F32, float2, true>), P->ldsRowF); }
                 else { SET_LDS((k_row_c2c_fwd<IN_F32, float2>), P->ldsRowF); SET_LDS((k_row_c2c_fwd<IN_U8_F32, float2>), P->ldsRowF); }
-                if (P->inplaceI) SET_LDS((k_row_c2c_inv<float2, false, true>), P->ldsRowI);
+                if (!i1) {}
+                else if (P->inplaceI) SET_LDS((k_row_c2c_inv<float2, false, true>), P->ldsRowI);
                 else SET_LDS((k_row_c2c_inv<float2, false, false>), P->ldsRowI);
+            }
+            if (P->fourF.on) {
+                if (P->dbl) PLAN_TRY((four_forward<double2, true>(P, Row4Params<double2>{}, 1, nullptr)));
+                else { PLAN_TRY((four_forward<float2, true>(P, Row4Params<float2>{}, 1, nullptr))); PLAN_TRY((four_forward<float2, true>(P, Row4Params<float2>{}, 2, nullptr))); }
+            }
+            if (P->fourI.on) {
+                if (P->dbl) PLAN_TRY((four_inverse<double2, true>(P, Row4Params<double2>{}, nullptr)));
+                else PLAN_TRY((four_inverse<float2, true>(P, Row4Params<float2>{}, nullptr)));
             }
         }
         if (P->dbl) {
@@ -918,7 +1007,15 @@ template <typename C> static int launch_frame_cplx(fftup_plan* P, uint32_t in_sl
     hipStream_t st = P->lanes[P->cur].stream;
     const int kind = P->in_kind[in_slot];
     using S = scalar_t<C>;
-    if (which < 0 || which == 0) {
+    if ((which < 0 || which == 0) && P->fourF.on) {             // rows beyond one LDS buffer: four steps through HBM
+        Row4Params<C> q{};
+        const fftup_plan::Four& f = P->fourF;
+        q.T = (C*)P->lanes[P->cur].T4; q.S1 = (C*)P->lanes[P->cur].S1; q.tw1 = (const C*)f.tw1; q.tw2 = (const C*)f.tw2; q.twN = (const C*)P->twW;
+        q.plan1 = f.p1; q.plan2 = f.p2; q.N = (int)P->W; q.N1 = f.n1; q.N2 = f.n2; q.rows = (int)P->H; q.W = (int)P->W; q.TK = P->TK; q.NT = P->NT;
+        if (kind == 2) { q.in = P->in_u8[in_slot]; q.in_row_stride = 3l * P->W; q.in_plane_stride = 0; }
+        else { q.in = P->in_planar[in_slot]; q.in_row_stride = P->W; q.in_plane_stride = (long)P->in_plane_stride; }
+        (void)four_forward<C, false>(P, q, kind, st);
+    } else if (which < 0 || which == 0) {
         RowR2CParamsT<C> p{};
         p.S1 = (C*)P->lanes[P->cur].S1; p.tw = (const C*)P->twW; p.plan = P->planW; p.W = (int)P->W; p.H = (int)P->H;
         p.TK = P->TK; p.NT = P->NT;
@@ -949,7 +1046,16 @@ template <typename C> static int launch_frame_cplx(fftup_plan* P, uint32_t in_sl
         default: hipLaunchKernelGGL((k_col<1, C>), grid, block, P->ldsCol, st, p); break;
         }
     }
-    if (which < 0 || which == 2) {
+    if ((which < 0 || which == 2) && P->fourI.on) {
+        Row4Params<C> q{};
+        const fftup_plan::Four& f = P->fourI;
+        q.spec = (const C*)P->lanes[P->cur].S2; q.T = (C*)P->lanes[P->cur].T4; q.R = P->lanes[P->cur].R;
+        q.tw1 = (const C*)f.tw1; q.tw2 = (const C*)f.tw2; q.twN = (const C*)P->twUW; q.plan1 = f.p1; q.plan2 = f.p2;
+        q.N = (int)P->uW; q.N1 = f.n1; q.N2 = f.n2; q.rows = (int)P->uH; q.W = (int)P->W; q.TK = P->TK; q.NT = P->NT; q.zlx = P->zlx; q.zrx = P->zrx;
+        q.inv_norm = (S)(1.0 / (double)P->uW);
+        (void)four_inverse<C, false>(P, q, st);
+        P->R_valid = true;
+    } else if (which < 0 || which == 2) {
         RowC2RParamsT<C> p{};
         p.S2 = (const C*)P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = (const C*)P->twUW; p.plan = P->planUW;
         p.W = (int)P->W; p.uW = (int)P->uW; p.uH = (int)P->uH; p.TK = P->TK; p.NT = P->NT; p.zlx = P->zlx; p.zrx = P->zrx;
@@ -1613,7 +1719,7 @@ const char* fftup_strerror(int code)
     switch (code) {
     case FFTUP_OK: return "success";
     case FFTUP_E_INVALID_ARG: return "invalid argument";
-    case FFTUP_E_UNSUPPORTED_SIZE: return "unsupported size (not 2,3,5,7-smooth, or a row too long for the LDS)";
+    case FFTUP_E_UNSUPPORTED_SIZE: return "unsupported size (not 2,3,5,7-smooth, or a column too long for the LDS)";
     case FFTUP_E_UNSUPPORTED_PRECISION: return "unsupported precision";
     case FFTUP_E_NO_DEVICE: return "no usable HIP device";
     case FFTUP_E_HIP: return "HIP runtime error";

@@ -272,6 +272,101 @@ __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_c2c_inv(Row
     }
 }
 
+// ---------------------------------------------------------------- non-R2C rows longer than an LDS buffer: four steps through HBM
+// Beyond 16 384 points (about 4 800 for -p 1) a complex row does not fit the 160 KB of LDS even once; the reference
+// switches such axes to multi-upload plans -- several dispatches with a transposition through a temporary buffer and the
+// "four-step" twiddles between them (vkFFT.h:4773-4992, 2290-2388, 6562-6576).  Same decomposition here, in two launches per
+// direction: N = N1 * N2, input index i = N2 i1 + i2, output index o = o1 + N1 o2,
+//     X[o1 + N1 o2] = sum_{i2} w_N2^(i2 o2) * [ w_N^(i2 o1) * sum_{i1} x[N2 i1 + i2] w_N1^(i1 o1) ]          (w_n = exp(DIR 2 pi i / n))
+//   pass A (k_row4_a): for TK consecutive i2 of one row: load (pixels, or the spectrum row with the x half of the shift and
+//                      the read guard, as k_row_c2c_inv), transform over i1 (length N1), multiply by w_N^(i2 o1), write T[o1][i2];
+//   pass B (k_row4_b): for TK consecutive o1 of one row: read T[o1][.] (contiguous), transform over i2 (length N2), store
+//                      element o1 + N1 o2 (blocked spectrum, or the complex pre-sharpen image scaled by 1/uW).
+// T: one complex row matrix per image row, [3][rows][N] in HBM (the reference's temporary buffer of those plans).
+template <typename C> struct Row4Params {
+    const void* in;          // forward pass A: planar float/half/double or u8 RGB
+    const C* spec;           // inverse pass A: blocked spectrum S2 (uH rows)
+    C* T;                    // scratch [3][rows][N]
+    C* S1;                   // forward pass B: blocked spectrum (H rows)
+    void* R;                 // inverse pass B: complex pre-sharpen image [3][uH][uW] (binary16 pairs for -p 2)
+    const C *tw1, *tw2, *twN;   // N1-th, N2-th, N-th roots
+    StagePlan plan1, plan2;
+    int N, N1, N2, rows;
+    long in_row_stride, in_plane_stride;
+    int W, TK, NT;           // input width; spectrum tile width and count
+    int zlx, zrx;            // inverse: column read guard [zlx, zrx) (VkResample.cpp:1497-1498)
+    scalar_t<C> inv_norm;    // inverse: 1/uW
+};
+
+// grid (rows, N2 / TKS, 3); dynamic LDS = 2 * lpad_size(N1 * TKS) complex.  DIR = +1: MODE = input type; DIR = -1: MODE unused.
+template <int DIR, int TKS, int MODE, typename C = float2>
+__global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row4_a(Row4Params<C> p)
+{
+    using S = scalar_t<C>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    C* a = (C*)smem;
+    C* b = a + lpad_size(p.N1 * TKS);
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int i20 = blockIdx.y * TKS, y = blockIdx.x, c = blockIdx.z;
+    const int N = p.N, N1 = p.N1, N2 = p.N2;
+    const long tile_stride = (long)p.rows * p.TK;
+    for (int e = tid; e < N1 * TKS; e += T) {
+        const int i1 = e / TKS, col = e % TKS;
+        const int i = N2 * i1 + i20 + col;
+        C v = mk<C>(S(0), S(0));
+        if constexpr (DIR > 0) {
+            v.x = (S)load_px<MODE>(p, c, y, i);           // (imaginary input: defined as 0, see k_row_c2c_fwd)
+        } else {
+            if (!(i >= p.zlx && i < p.zrx)) {
+                int k = -1;                               // columns >= W/2 of the forward spectrum sit N - W further on
+                if (i >= N - p.W / 2) k = i - (N - p.W);
+                else if (i < p.W) k = i;
+                if (k >= 0) v = p.spec[(long)c * p.NT * tile_stride + (long)(k / p.TK) * tile_stride + (long)y * p.TK + (k % p.TK)];
+            }
+        }
+        a[lpad(e)] = v;
+    }
+    __syncthreads();
+    const C* Z = fft_lds<DIR, TKS>(a, b, p.plan1, p.tw1, tid, T);
+    C* dst = p.T + ((long)c * p.rows + y) * N;
+    for (int e = tid; e < N1 * TKS; e += T) {
+        const int o1 = e / TKS, col = e % TKS, i2 = i20 + col;
+        dst[(long)o1 * N2 + i2] = cmul(Z[lpad(e)], twid<DIR>(p.twN[o1 * i2]));      // o1 i2 < N1 N2 = N
+    }
+}
+
+// grid (rows, N1 / TKS, 3); dynamic LDS = 2 * lpad_size(N2 * TKS) complex.  DIR = -1: HALF_OUT = binary16 pairs (-p 2).
+template <int DIR, int TKS, bool HALF_OUT, typename C = float2>
+__global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row4_b(Row4Params<C> p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    C* a = (C*)smem;
+    C* b = a + lpad_size(p.N2 * TKS);
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int o10 = blockIdx.y * TKS, y = blockIdx.x, c = blockIdx.z;
+    const int N = p.N, N1 = p.N1, N2 = p.N2;
+    const C* src = p.T + ((long)c * p.rows + y) * N + (long)o10 * N2;
+    for (int e = tid; e < N2 * TKS; e += T) {
+        const int col = e / N2, i2 = e % N2;             // (consecutive threads read consecutive i2 of one o1)
+        a[lpad(i2 * TKS + col)] = src[(long)col * N2 + i2];
+    }
+    __syncthreads();
+    const C* Z = fft_lds<DIR, TKS>(a, b, p.plan2, p.tw2, tid, T);
+    const long tile_stride = (long)p.rows * p.TK;
+    for (int e = tid; e < N2 * TKS; e += T) {
+        const int o2 = e / TKS, col = e % TKS;
+        const int o = o10 + col + N1 * o2;
+        const C z = Z[lpad(e)];
+        if constexpr (DIR > 0) {
+            p.S1[(long)c * p.NT * tile_stride + (long)(o / p.TK) * tile_stride + (long)y * p.TK + (o % p.TK)] = z;
+        } else {
+            const C v = cscale(z, p.inv_norm);
+            if constexpr (HALF_OUT) ((__half2*)p.R)[((long)c * p.rows + y) * N + o] = __floats2half2_rn((float)v.x, (float)v.y);
+            else ((C*)p.R)[((long)c * p.rows + y) * N + o] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- sharpen (VkResample.cpp:819-925)
 struct SharpenParams {
     const void* R;           // dense [3][uH][uW]
