@@ -70,8 +70,10 @@ def test_error_paths_without_device():
     assert b"unsupported size" in lib.fftup_strerror(2)
     assert lib.fftup_version().startswith(b"fftup")
     for kwargs, code in ((dict(width=2 * 11 * 64, height=64), 2), (dict(width=63, height=64), 1),
-                         (dict(width=64, height=64, precision=3), 3), (dict(width=4096, height=64, precision=1), 2), (dict(width=64, height=64, upscale=0.5), 1),
-                         (dict(width=9216, height=64), 2), (dict(width=8064, height=64), 2)):          # 18432-point rows; 16128 = 2^8 * 63: radix 7 beyond 14336
+                         (dict(width=64, height=64, precision=3), 3), (dict(width=64, height=64, upscale=0.5), 1),
+                         # rows too long for the LDS are no errors any more (round 4: four steps through HBM) -- without a device
+                         # such plans get as far as every other valid one: FFTUP_E_NO_DEVICE
+                         (dict(width=4096, height=64, precision=1), 4), (dict(width=9216, height=64), 4), (dict(width=8064, height=64), 4)):
         with pytest.raises(v.FftupError) as e:
             v.Upscaler(**kwargs)
         assert e.value.code == code, kwargs
