@@ -529,6 +529,36 @@ def test_four_step_rows_vs_oracle(W, H, u, precision, flags):
     assert d.max() <= (2 if precision == 2 else 1)
 
 
+TALL = [(16, 4900, 2.0, 0, 0),          # uH = 9800: two Stockham buffers of one column do not fit 160 KB; 4900 = 70 * 70, 9800 = 70 * 140
+        (16, 4900, 2.0, 0, 2), (32, 4900, 2.0, 2, 2),
+        (20, 9800, 1.5, 0, 0),          # H itself beyond one column's LDS, uH = 14700 = 105 * 140, non-integer factor
+        (16, 2500, 2.0, 1, 0),          # -p 1: uH = 5000 in double2
+        (2100, 2500, 2.0, 1, 0)]        # ... on the non-R2C path (uW = 4200 > 4096 for -p 1)
+
+
+@pytest.mark.parametrize("W,H,u,precision,flags", TALL)
+def test_four_step_columns_vs_oracle(W, H, u, precision, flags):
+    """Columns longer than the LDS (uH beyond ~9 600, ~4 800 for -p 1; refused until round 4; the reference: multi-upload plans,
+    VF:4773-4992): the spectrum keeps tiles of ONE column and both column transforms run through k_row4_a / k_row4_b -- forward in
+    place, inverse with the y half of the shift and the read guard in the load.  Same bars as every other size-generic plan."""
+    (pre, out, u8), (opre, oout, ou8) = _run(W, H, u, precision, "N", flags=flags, seed=29)
+    usq = u * u
+    if precision == 0:
+        _m("tall %dx%d u%g" % (W, H, u), pre_l2=_rel_l2(pre, opre), pre_max=np.abs(pre - opre).max() * usq, out_l2=_rel_l2(out[:, :-1], oout[:, :-1]),
+           out_max=np.abs(out[:, :-1] - oout[:, :-1]).max())
+        assert _rel_l2(pre, opre) <= 2e-6 and np.abs(pre - opre).max() * usq <= 6e-6
+        assert _rel_l2(out[:, :-1], oout[:, :-1]) <= 5e-6 and np.abs(out[:, :-1] - oout[:, :-1]).max() <= 2e-5
+    elif precision == 2:
+        ulp = np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10
+        assert (np.abs(pre - opre) <= ulp * 1.0001 + 5e-7).all()
+        so = _report("tall -p 2 %dx%d u%g out" % (W, H, u), out[:, :-1] - oout[:, :-1], 2.0 ** -10)
+        assert so["max"] <= 8e-3 and so["p99"] == 0 and so["p99.99"] <= 3e-3
+    else:
+        assert np.abs(pre - opre).max() <= 1e-12 and np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1e-9
+    d = np.abs(u8[:-1].astype(int) - ou8[:-1].astype(int))
+    assert d.max() <= (2 if precision == 2 else 1)
+
+
 def test_4k_to_8k_properties():
     """4096x2048 -> 8192x4096 (size-generic kernels, 0.4 GB of output): DC preservation and determinism."""
     from vkresample_amd import synth
@@ -615,9 +645,8 @@ def test_fp64_planar_input_and_limits():
         pre, out = up.download_presharpen(), up.download_planar()
     opre, oout = O.upscale_planes(planes, 2.0, 1)[:2]
     assert np.abs(pre - opre).max() <= 1e-12 and np.abs(out[:, :-1] - oout[:, :-1]).max() <= 1e-9
-    with pytest.raises(v.FftupError) as e:            # complexSizeCalc = 16 halves the R2C limit (VR:1424)
-        v.Upscaler(4096, 64, 2.0, 1)
-    assert e.value.code == 2
+    with v.Upscaler(4096, 16, 2.0, 1) as up:           # complexSizeCalc = 16 halves the R2C limit (VR:1424): the non-R2C path, its
+        assert up.kernel_names[0] == "row_c2c"         # 8192-point double2 rows in four steps (refused until round 4)
     # double vs single on the same frame: they differ by fp32 rounding only
     (pre64, _, _), _ = _run(256, 128, 2.0, 1, "N", seed=3)
     (pre32, _, _), _ = _run(256, 128, 2.0, 0, "N", seed=3)

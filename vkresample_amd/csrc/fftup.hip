@@ -86,6 +86,7 @@ struct fftup_plan {
     // ... and rows too long for ONE buffer: four steps through HBM (k_row4_a / k_row4_b), row length = n1 * n2
     struct Four { bool on = false; int n1 = 0, n2 = 0, tk = 1; StagePlan p1{}, p2{}; float2 *tw1 = nullptr, *tw2 = nullptr; size_t ldsA = 0, ldsB = 0; int thrA = 64, thrB = 64; };
     Four fourF, fourI;
+    Four colF, colI;                  // columns longer than the LDS (TK = 1): the same two kernels on dense columns
     int ncols = 0;                    // spectrum columns kept: W/2 + 1, or W on the non-R2C path
     int pairs_per_strip = 6;
     bool R_valid = false;             // pre-sharpen buffer holds the last frame (unfused path only)
@@ -278,39 +279,54 @@ static bool jit_tune_enabled()
     return e && atoi(e) != 0;
 }
 // four-step rows (k_row4_a / k_row4_b): launch both passes; ATTR: only allow their dynamic LDS sizes (plan creation)
-template <typename C, int DIR, int MODE, bool HALF_OUT, int TKS, bool ATTR>
+template <typename C, int DIR, int MODE, int OUT, int TKS, bool ATTR>
 static hipError_t four_passes(const fftup_plan::Four& f, const Row4Params<C>& q, int rows, hipStream_t st)
 {
     if constexpr (ATTR) {
         hipError_t e = hipFuncSetAttribute((const void*)(k_row4_a<DIR, TKS, MODE, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.ldsA);
         if (e != hipSuccess) return e;
-        return hipFuncSetAttribute((const void*)(k_row4_b<DIR, TKS, HALF_OUT, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.ldsB);
+        return hipFuncSetAttribute((const void*)(k_row4_b<DIR, TKS, OUT, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.ldsB);
     } else {
         hipLaunchKernelGGL((k_row4_a<DIR, TKS, MODE, C>), dim3(rows, f.n2 / TKS, 3), dim3(f.thrA), f.ldsA, st, q);
-        hipLaunchKernelGGL((k_row4_b<DIR, TKS, HALF_OUT, C>), dim3(rows, f.n1 / TKS, 3), dim3(f.thrB), f.ldsB, st, q);
+        hipLaunchKernelGGL((k_row4_b<DIR, TKS, OUT, C>), dim3(rows, f.n1 / TKS, 3), dim3(f.thrB), f.ldsB, st, q);
         return hipSuccess;
     }
 }
-template <typename C, int DIR, int MODE, bool HALF_OUT, bool ATTR>
+template <typename C, int DIR, int MODE, int OUT, bool ATTR>
 static hipError_t four_run(const fftup_plan::Four& f, const Row4Params<C>& q, int rows, hipStream_t st)
 {
-    return f.tk == 4 ? four_passes<C, DIR, MODE, HALF_OUT, 4, ATTR>(f, q, rows, st) : four_passes<C, DIR, MODE, HALF_OUT, 1, ATTR>(f, q, rows, st);
+    return f.tk == 4 ? four_passes<C, DIR, MODE, OUT, 4, ATTR>(f, q, rows, st) : four_passes<C, DIR, MODE, OUT, 1, ATTR>(f, q, rows, st);
 }
 // forward rows of a plan: input mode from the slot's kind and the precision; inverse rows: output type from the precision
 template <typename C, bool ATTR> static hipError_t four_forward(fftup_plan* P, const Row4Params<C>& q, int kind, hipStream_t st)
 {
-    if constexpr (sizeof(scalar_t<C>) == 8) return four_run<C, +1, IN_F64, false, ATTR>(P->fourF, q, (int)P->H, st);
+    if constexpr (sizeof(scalar_t<C>) == 8) return four_run<C, +1, IN_F64, OUT4_TILES, ATTR>(P->fourF, q, (int)P->H, st);
     else {
-        if (kind == 2) return P->half ? four_run<C, +1, IN_U8_F16, false, ATTR>(P->fourF, q, (int)P->H, st) : four_run<C, +1, IN_U8_F32, false, ATTR>(P->fourF, q, (int)P->H, st);
-        return P->half ? four_run<C, +1, IN_F16, false, ATTR>(P->fourF, q, (int)P->H, st) : four_run<C, +1, IN_F32, false, ATTR>(P->fourF, q, (int)P->H, st);
+        if (kind == 2) return P->half ? four_run<C, +1, IN_U8_F16, OUT4_TILES, ATTR>(P->fourF, q, (int)P->H, st) : four_run<C, +1, IN_U8_F32, OUT4_TILES, ATTR>(P->fourF, q, (int)P->H, st);
+        return P->half ? four_run<C, +1, IN_F16, OUT4_TILES, ATTR>(P->fourF, q, (int)P->H, st) : four_run<C, +1, IN_F32, OUT4_TILES, ATTR>(P->fourF, q, (int)P->H, st);
     }
 }
 template <typename C, bool ATTR> static hipError_t four_inverse(fftup_plan* P, const Row4Params<C>& q, hipStream_t st)
 {
     if constexpr (sizeof(scalar_t<C>) == 4) {
-        if (P->half) return four_run<C, -1, IN_F32, true, ATTR>(P->fourI, q, (int)P->uH, st);
+        if (P->half) return four_run<C, -1, IN4_TILES, OUT4_HALF, ATTR>(P->fourI, q, (int)P->uH, st);
     }
-    return four_run<C, -1, IN_F32, false, ATTR>(P->fourI, q, (int)P->uH, st);
+    return four_run<C, -1, IN4_TILES, OUT4_DENSE, ATTR>(P->fourI, q, (int)P->uH, st);
+}
+// columns longer than the LDS: forward in place in S1 (tiles of one column = dense columns), inverse S1 -> S2 with shift and guard
+template <typename C, bool ATTR> static hipError_t four_columns(fftup_plan* P, hipStream_t st)
+{
+    using S = scalar_t<C>;
+    Row4Params<C> q{};
+    const fftup_plan::Four &f = P->colF, &g = P->colI;
+    q.spec = (const C*)P->lanes[P->cur].S1; q.T = (C*)P->lanes[P->cur].T4; q.R = P->lanes[P->cur].S1;
+    q.tw1 = (const C*)f.tw1; q.tw2 = (const C*)f.tw2; q.twN = (const C*)P->twH; q.plan1 = f.p1; q.plan2 = f.p2;
+    q.N = (int)P->H; q.N1 = f.n1; q.N2 = f.n2; q.rows = P->ncols; q.W = (int)P->H; q.TK = 1; q.NT = P->ncols; q.inv_norm = (S)1;
+    hipError_t e = four_run<C, +1, IN4_DENSE, OUT4_DENSE, ATTR>(f, q, P->ncols, st);
+    if (e != hipSuccess) return e;
+    q.R = P->lanes[P->cur].S2; q.tw1 = (const C*)g.tw1; q.tw2 = (const C*)g.tw2; q.twN = (const C*)P->twUH; q.plan1 = g.p1; q.plan2 = g.p2;
+    q.N = (int)P->uH; q.N1 = g.n1; q.N2 = g.n2; q.zlx = P->zly; q.zrx = P->zry; q.inv_norm = (S)(1.0 / (double)P->uH);
+    return four_run<C, -1, IN4_DENSE_SHIFT, OUT4_DENSE, ATTR>(g, q, P->ncols, st);
 }
 
 static std::vector<int> stage_radices(const StagePlan& p)
@@ -497,7 +513,20 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
                 if (need <= lds_max) { P->TK = tk; P->ldsCol = need; break; }
             }
         }
-        if (!P->TK) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "upscaled height too large for LDS"); goto bad; }
+        if (!P->TK) {
+            // not even one column fits: tiles of one column, both column transforms in four steps through HBM (k_row4_a / k_row4_b)
+            P->TK = 1; P->ldsCol = 0;
+            for (auto fh : {std::make_pair(&P->colF, H), std::make_pair(&P->colI, uH)}) {
+                fftup_plan::Four& f = *fh.first;
+                f.on = split_four(fh.second, P->csz, &f.n1, &f.n2, &f.tk);
+                if (!f.on) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "column too long: no four-step split of the height fits the LDS"); goto bad; }
+                f.p1 = make_stage_plan((uint32_t)f.n1); f.p2 = make_stage_plan((uint32_t)f.n2);
+                f.ldsA = 2 * P->csz * (size_t)lpad_size(f.n1 * f.tk); f.ldsB = 2 * P->csz * (size_t)lpad_size(f.n2 * f.tk);
+                const int tmax = P->dbl ? GenericMaxThreads<double2>::value : GenericMaxThreads<float2>::value;
+                f.thrA = std::min(tmax, std::max(64, round_up(f.n1 * f.tk / 8, 64)));
+                f.thrB = std::min(tmax, std::max(64, round_up(f.n2 * f.tk / 8, 64)));
+            }
+        }
         if (aot && !P->dbl && !cplx && !P->tuned && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && uW == 2 * W && uH == 2 * H && P->TK >= 4) {
             if (W == MixedCfg1080::W && H == MixedCfg1080::H) P->mixed = 1;
             if (W == MixedCfg720::W && H == MixedCfg720::H) P->mixed = 2;
@@ -555,7 +584,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         PLAN_RC(make_twiddles(P, &P->twH, H));
         PLAN_RC(make_twiddles(P, &P->twUW, uW));
         PLAN_RC(make_twiddles(P, &P->twUH, uH));
-        for (fftup_plan::Four* f : {&P->fourF, &P->fourI})
+        for (fftup_plan::Four* f : {&P->fourF, &P->fourI, &P->colF, &P->colI})
             if (f->on) { PLAN_RC(make_twiddles(P, &f->tw1, (uint32_t)f->n1)); PLAN_RC(make_twiddles(P, &f->tw2, (uint32_t)f->n2)); }
 
         const size_t esz = P->esz;
@@ -593,7 +622,8 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             P->nlanes = std::max(1, std::min(nl, 4));
             P->lanes.resize(P->nlanes);
             P->lanes[0].stream = P->stream; P->lanes[0].S1 = P->S1; P->lanes[0].S2 = P->S2; P->lanes[0].R = P->R;
-            const size_t t4_bytes = P->csz * 3 * std::max(P->fourF.on ? (size_t)W * H : 0, P->fourI.on ? (size_t)uW * uH : 0);
+            const size_t t4_bytes = P->csz * 3 * std::max(std::max(P->fourF.on ? (size_t)W * H : 0, P->fourI.on ? (size_t)uW * uH : 0),
+                                                          P->colI.on ? (size_t)P->ncols * uH : 0);
             if (t4_bytes) PLAN_RC(dev_alloc(P, &P->lanes[0].T4, t4_bytes));
             for (int l = 1; l < P->nlanes; l++) {
                 PLAN_TRY(hipStreamCreateWithFlags(&P->lanes[l].stream, hipStreamNonBlocking));
@@ -616,7 +646,10 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         if (generic && !cplx && !P->dbl) {
             if (P->half) SET_LDS(k_row_c2r<true>, P->ldsRowI); else SET_LDS(k_row_c2r<false>, P->ldsRowI);
         }
-        if (generic && !P->dbl) {
+        if (P->colF.on) {                                    // columns in four steps (k_row4_a / k_row4_b on dense columns)
+            if (P->dbl) PLAN_TRY((four_columns<double2, true>(P, nullptr))); else PLAN_TRY((four_columns<float2, true>(P, nullptr)));
+        }
+        if (generic && !P->dbl && !P->colF.on) {
             switch (P->TK) {
             case 8: SET_LDS(k_col<8>, P->ldsCol); break;
             case 4: SET_LDS(k_col<4>, P->ldsCol); break;
@@ -654,7 +687,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         }
         if (P->dbl) {
             if (!cplx) { SET_LDS((k_row_r2c<IN_F64, double2>), P->ldsRowF); SET_LDS((k_row_c2r<false, double2>), P->ldsRowI); }
-            switch (P->TK) {
+            if (!P->colF.on) switch (P->TK) {
             case 8: SET_LDS((k_col<8, double2>), P->ldsCol); break;
             case 4: SET_LDS((k_col<4, double2>), P->ldsCol); break;
             case 2: SET_LDS((k_col<2, double2>), P->ldsCol); break;
@@ -954,7 +987,8 @@ static int launch_frame_f64(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, 
         p.in = P->in_planar[in_slot]; p.in_row_stride = P->W; p.in_plane_stride = (long)P->in_plane_stride;
         hipLaunchKernelGGL((k_row_r2c<IN_F64, double2>), dim3(P->H / 2, 3), dim3(P->thrW), P->ldsRowF, st, p);
     }
-    if (which < 0 || which == 1) {
+    if ((which < 0 || which == 1) && P->colF.on) (void)four_columns<double2, false>(P, st);
+    else if (which < 0 || which == 1) {
         ColParamsT<double2> p{};
         p.S1 = (const double2*)P->lanes[P->cur].S1; p.S2 = (double2*)P->lanes[P->cur].S2;
         p.twH = (const double2*)P->twH; p.twUH = (const double2*)P->twUH; p.planH = P->planH; p.planUH = P->planUH;
@@ -1032,7 +1066,8 @@ template <typename C> static int launch_frame_cplx(fftup_plan* P, uint32_t in_sl
             else launch_c2c_fwd<C, IN_F32>(P, p, st);
         }
     }
-    if (which < 0 || which == 1) {
+    if ((which < 0 || which == 1) && P->colF.on) (void)four_columns<C, false>(P, st);
+    else if (which < 0 || which == 1) {
         ColParamsT<C> p{};
         p.S1 = (const C*)P->lanes[P->cur].S1; p.S2 = (C*)P->lanes[P->cur].S2; p.twH = (const C*)P->twH; p.twUH = (const C*)P->twUH;
         p.planH = P->planH; p.planUH = P->planUH;
@@ -1145,7 +1180,8 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
             else hipLaunchKernelGGL(k_row_r2c<IN_F32>, grid, block, P->ldsRowF, P->lanes[P->cur].stream, p);
         }
     }
-    if (which < 0 || which == 1) {
+    if ((which < 0 || which == 1) && P->colF.on) (void)four_columns<float2, false>(P, P->lanes[P->cur].stream);
+    else if (which < 0 || which == 1) {
         ColParams p{};
         p.S1 = P->lanes[P->cur].S1; p.S2 = P->lanes[P->cur].S2; p.twH = P->twH; p.twUH = P->twUH; p.planH = P->planH; p.planUH = P->planUH;
         p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.ncols = P->ncols; p.zly = P->zly; p.zry = P->zry;

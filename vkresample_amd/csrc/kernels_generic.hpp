@@ -283,22 +283,31 @@ __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_c2c_inv(Row
 //   pass B (k_row4_b): for TK consecutive o1 of one row: read T[o1][.] (contiguous), transform over i2 (length N2), store
 //                      element o1 + N1 o2 (blocked spectrum, or the complex pre-sharpen image scaled by 1/uW).
 // T: one complex row matrix per image row, [3][rows][N] in HBM (the reference's temporary buffer of those plans).
+// COLUMNS longer than the LDS (uH beyond ~9 600) run through the same two kernels: such plans keep the spectrum with tiles of ONE
+// column (TK = 1: a column is a dense sequence), forward in place (S1 -> T -> S1), inverse with the y half of the shift and the
+// read guard in pass A's load (S1 -> T -> S2, scaled by 1/uH) -- what k_col does in one launch.
 template <typename C> struct Row4Params {
-    const void* in;          // forward pass A: planar float/half/double or u8 RGB
-    const C* spec;           // inverse pass A: blocked spectrum S2 (uH rows)
+    const void* in;          // pass A, pixel modes: planar float/half/double or u8 RGB
+    const C* spec;           // pass A, IN4_TILES: blocked spectrum S2 (uH rows); IN4_DENSE / IN4_DENSE_SHIFT: dense [3][rows][W]
     C* T;                    // scratch [3][rows][N]
-    C* S1;                   // forward pass B: blocked spectrum (H rows)
-    void* R;                 // inverse pass B: complex pre-sharpen image [3][uH][uW] (binary16 pairs for -p 2)
+    C* S1;                   // pass B, OUT4_TILES: blocked spectrum (H rows)
+    void* R;                 // pass B, OUT4_DENSE / _HALF: dense [3][rows][N], scaled by inv_norm (binary16 pairs for _HALF)
     const C *tw1, *tw2, *twN;   // N1-th, N2-th, N-th roots
     StagePlan plan1, plan2;
-    int N, N1, N2, rows;
+    int N, N1, N2, rows;     // sequence length = N1 * N2; sequences per plane
     long in_row_stride, in_plane_stride;
-    int W, TK, NT;           // input width; spectrum tile width and count
-    int zlx, zrx;            // inverse: column read guard [zlx, zrx) (VkResample.cpp:1497-1498)
-    scalar_t<C> inv_norm;    // inverse: 1/uW
+    int W, TK, NT;           // length of the un-padded sequence (shift / guard); spectrum tile width and count
+    int zlx, zrx;            // read guard [zlx, zrx) (VkResample.cpp:1494-1498)
+    scalar_t<C> inv_norm;    // pass B scale
 };
+// what pass A loads (beyond the pixel modes of InMode) and what pass B stores
+enum { IN4_TILES = 8,        // inverse rows: spectrum row y from the blocked spectrum, x half of the shift + read guard (k_row_c2c_inv)
+       IN4_DENSE = 9,        // forward columns: sequence y of a dense [3][rows][N] array
+       IN4_DENSE_SHIFT = 10  // inverse columns: the same with the y half of the shift + read guard (k_col), source length W
+};
+enum { OUT4_TILES = 0, OUT4_DENSE = 1, OUT4_HALF = 2 };
 
-// grid (rows, N2 / TKS, 3); dynamic LDS = 2 * lpad_size(N1 * TKS) complex.  DIR = +1: MODE = input type; DIR = -1: MODE unused.
+// grid (rows, N2 / TKS, 3); dynamic LDS = 2 * lpad_size(N1 * TKS) complex
 template <int DIR, int TKS, int MODE, typename C = float2>
 __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row4_a(Row4Params<C> p)
 {
@@ -314,15 +323,20 @@ __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row4_a(Row4Para
         const int i1 = e / TKS, col = e % TKS;
         const int i = N2 * i1 + i20 + col;
         C v = mk<C>(S(0), S(0));
-        if constexpr (DIR > 0) {
-            v.x = (S)load_px<MODE>(p, c, y, i);           // (imaginary input: defined as 0, see k_row_c2c_fwd)
-        } else {
+        if constexpr (MODE == IN4_DENSE) {
+            v = p.spec[((long)c * p.rows + y) * N + i];
+        } else if constexpr (MODE == IN4_TILES || MODE == IN4_DENSE_SHIFT) {
             if (!(i >= p.zlx && i < p.zrx)) {
-                int k = -1;                               // columns >= W/2 of the forward spectrum sit N - W further on
+                int k = -1;                               // elements >= W/2 of the un-padded spectrum sit N - W further on
                 if (i >= N - p.W / 2) k = i - (N - p.W);
                 else if (i < p.W) k = i;
-                if (k >= 0) v = p.spec[(long)c * p.NT * tile_stride + (long)(k / p.TK) * tile_stride + (long)y * p.TK + (k % p.TK)];
+                if (k >= 0) {
+                    if constexpr (MODE == IN4_TILES) v = p.spec[(long)c * p.NT * tile_stride + (long)(k / p.TK) * tile_stride + (long)y * p.TK + (k % p.TK)];
+                    else v = p.spec[((long)c * p.rows + y) * p.W + k];
+                }
             }
+        } else {
+            v.x = (S)load_px<MODE>(p, c, y, i);           // (imaginary input: defined as 0, see k_row_c2c_fwd)
         }
         a[lpad(e)] = v;
     }
@@ -335,8 +349,8 @@ __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row4_a(Row4Para
     }
 }
 
-// grid (rows, N1 / TKS, 3); dynamic LDS = 2 * lpad_size(N2 * TKS) complex.  DIR = -1: HALF_OUT = binary16 pairs (-p 2).
-template <int DIR, int TKS, bool HALF_OUT, typename C = float2>
+// grid (rows, N1 / TKS, 3); dynamic LDS = 2 * lpad_size(N2 * TKS) complex
+template <int DIR, int TKS, int OUT, typename C = float2>
 __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row4_b(Row4Params<C> p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -357,11 +371,11 @@ __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row4_b(Row4Para
         const int o2 = e / TKS, col = e % TKS;
         const int o = o10 + col + N1 * o2;
         const C z = Z[lpad(e)];
-        if constexpr (DIR > 0) {
+        if constexpr (OUT == OUT4_TILES) {
             p.S1[(long)c * p.NT * tile_stride + (long)(o / p.TK) * tile_stride + (long)y * p.TK + (o % p.TK)] = z;
         } else {
             const C v = cscale(z, p.inv_norm);
-            if constexpr (HALF_OUT) ((__half2*)p.R)[((long)c * p.rows + y) * N + o] = __floats2half2_rn((float)v.x, (float)v.y);
+            if constexpr (OUT == OUT4_HALF) ((__half2*)p.R)[((long)c * p.rows + y) * N + o] = __floats2half2_rn((float)v.x, (float)v.y);
             else ((C*)p.R)[((long)c * p.rows + y) * N + o] = v;
         }
     }
