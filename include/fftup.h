@@ -32,7 +32,7 @@ enum {
     FFTUP_OK = 0,
     FFTUP_E_INVALID_ARG = 1,    /* null pointer, bad slot, odd size, channels != 3 (VR:1368)            */
     FFTUP_E_UNSUPPORTED_SIZE = 2, /* a dimension is not 2,3,5,7-smooth: VF:4719-4726
-                                     (VK_ERROR_FORMAT_NOT_SUPPORTED), or a column is too long for the LDS  */
+                                     (VK_ERROR_FORMAT_NOT_SUPPORTED)                                   */
     FFTUP_E_UNSUPPORTED_PRECISION = 3, /* -p must be 0, 1 or 2                                         */
     FFTUP_E_NO_DEVICE = 4,      /* no HIP device / bad device id (VR:1292-1296)                         */
     FFTUP_E_HIP = 5,            /* a HIP runtime call failed (message in fftup_last_error)              */

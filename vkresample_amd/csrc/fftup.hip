@@ -1755,7 +1755,7 @@ const char* fftup_strerror(int code)
     switch (code) {
     case FFTUP_OK: return "success";
     case FFTUP_E_INVALID_ARG: return "invalid argument";
-    case FFTUP_E_UNSUPPORTED_SIZE: return "unsupported size (not 2,3,5,7-smooth, or a column too long for the LDS)";
+    case FFTUP_E_UNSUPPORTED_SIZE: return "unsupported size (not 2,3,5,7-smooth)";
     case FFTUP_E_UNSUPPORTED_PRECISION: return "unsupported precision";
     case FFTUP_E_NO_DEVICE: return "no usable HIP device";
     case FFTUP_E_HIP: return "HIP runtime error";
