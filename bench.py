@@ -163,8 +163,10 @@ def other_configs(v, synth, dev, traffic_json, ring=8):
             for s in range(ring):
                 up.upload_rgb8(synth.frame(s, c["width"], c["height"], "U"), slot=s)
             up.execute_ring(256, 0)
+            # (~1.5 s of frames: the driver's power figure is a moving average; only the second half of the samples is used)
             power = PowerSampler(v.device_pci_bus_id(dev), period=0.02).start()
-            t = sorted(up.execute_ring(1024, 0) / 1024 for _ in range(5))[2]          # device ms per frame, median of five
+            t = sorted(up.execute_ring(2048, 0) / 2048 for _ in range(11))[5]         # device ms per frame, median of eleven
+            power.samples = power.samples[len(power.samples) // 2:] if len(power.samples) > 8 else power.samples
             pw = power.stop()
             iso = up.profile_kernels(30)
             dom = max(range(len(iso)), key=lambda i: iso[i])
