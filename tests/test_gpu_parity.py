@@ -448,7 +448,7 @@ def test_largest_r2c_size_vs_oracle():
 
 @pytest.mark.parametrize("W,H,u,precision,flags", [(4608, 64, 2.0, 0, 0), (4608, 64, 2.0, 0, 2), (3072, 32, 3.0, 0, 0),
                                                    (2304, 32, 2.0, 1, 0), (6144, 16, 1.5, 0, 0),
-                                                   (4608, 64, 2.0, 2, 0), (4608, 64, 2.0, 2, 2), (3072, 32, 3.0, 2, 2),
+                                                   (4608, 16, 2.0, 2, 0), (4608, 16, 2.0, 2, 2), (3072, 8, 3.0, 2, 2),      # (-p 2: the oracle's binary16 sharpen is slow)
                                                    # rows beyond ~9600 points: one LDS buffer, in place (VERDICT r2 missing 2)
                                                    (5120, 16, 2.0, 0, 0), (6144, 16, 2.0, 0, 2), (8192, 8, 2.0, 0, 0), (7168, 8, 2.0, 2, 2),
                                                    (7680, 8, 2.0, 0, 0), (10240, 8, 1.5, 0, 0)])
