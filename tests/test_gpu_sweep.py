@@ -81,6 +81,17 @@ def _sweep_case(W, H, u, p, flags, sharpen, seed, expect_specialised=False):
         up.execute(1)
         pre = up.download_presharpen().astype(np.float64)
         out = up.download_planar().astype(np.float64)
+        u8_planes = up.download_rgb8() if expect_specialised else None
+    if expect_specialised:
+        # the fused 8-bit store of the same plan (strips per plane, the three planes' strips of the same rows 8 workgroups apart:
+        # every size draws its own strip length, ragged last strips, row lengths that are no multiple of 256): the bytes of
+        # planes + conversion launch, up to the few values a differently cut strip rounds to the other side of k/255
+        with v.Upscaler(W, H, u, p, sharpen, 0, flags | v.FLAG_FUSE_U8_STORE) as up8:
+            if up8.u8_store:
+                up8.upload_rgb8(rgb)
+                up8.execute(1)
+                d8 = np.abs(up8.download_rgb8().astype(int) - u8_planes.astype(int))
+                assert d8.max() <= 1 and (d8 != 0).sum() <= max(3, (1e-5 if p == 0 else 1e-4) * d8.size), (int(d8.max()), int((d8 != 0).sum()), d8.size)
     opre, oout, _ = O.upscale_rgb8(rgb, u, p, sharpen)
     scale = 1.0 / (np.float32(u) * np.float32(u))                      # the pre-sharpen image is g / u^2
     if p == 1:
