@@ -491,20 +491,37 @@ __device__ __forceinline__ uint8_t cvt_f_u8(float v, int wrap)
 
 // The same for four pixels in registers (the fused kernel's 8-bit store): saturating form without double arithmetic.
 // trunc(255 x) of the EXACT product = trunc of the product rounded TOWARD ZERO (an integer n <= 255 x is representable, so the
-// rounded product cannot fall below it): four v_mul_f32 between two changes of the rounding mode -- one asm statement, the
-// compiler cannot move anything affected in between -- then v_cvt_u32_f32 (truncates; negative and NaN -> 0) and a minimum.
-// Bit for bit cvt_f_u8 (tests: the fused store against planes + k_pack_u8 on whole frames).
+// rounded product cannot fall below it); and v_cvt_pk_u8_f32 -- float to a saturated byte, negative and NaN -> 0 -- follows the
+// rounding mode of the MODE register (measured: tools/ub/cvt_pk_u8.hip -- to nearest even by default, truncating under
+// round-toward-zero).  So: four v_mul_f32 and four v_cvt_pk_u8_f32 between two changes of the rounding mode -- one asm statement,
+// the compiler cannot move anything affected in between.  Bit for bit cvt_f_u8 (tests: the fused store against planes +
+// k_pack_u8 on whole frames).
 __device__ __forceinline__ void cvt4_f_u8(float a, float b, float c, float d, int wrap, uint8_t (&o)[4])
 {
     if (wrap) { o[0] = cvt_f_u8(a, 1); o[1] = cvt_f_u8(b, 1); o[2] = cvt_f_u8(c, 1); o[3] = cvt_f_u8(d, 1); return; }      // (wave-uniform)
-    float ta, tb, tc, td;
+    unsigned ta, tb, tc, td;
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
                  "v_mul_f32 %0, 0x437f0000, %4\n\tv_mul_f32 %1, 0x437f0000, %5\n\tv_mul_f32 %2, 0x437f0000, %6\n\tv_mul_f32 %3, 0x437f0000, %7\n\t"
+                 "v_cvt_pk_u8_f32 %0, %0, 0, 0\n\tv_cvt_pk_u8_f32 %1, %1, 0, 0\n\tv_cvt_pk_u8_f32 %2, %2, 0, 0\n\tv_cvt_pk_u8_f32 %3, %3, 0, 0\n\t"
                  "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
                  : "=&v"(ta), "=&v"(tb), "=&v"(tc), "=&v"(td) : "v"(a), "v"(b), "v"(c), "v"(d));
-    // (the instruction, not a C++ cast: out-of-range float -> unsigned is undefined in the language, saturating in the hardware)
-    auto cvt = [](float t) { unsigned k; asm("v_cvt_u32_f32 %0, %1" : "=v"(k) : "v"(t)); return (uint8_t)min(k, 255u); };
-    o[0] = cvt(ta); o[1] = cvt(tb); o[2] = cvt(tc); o[3] = cvt(td);
+    o[0] = (uint8_t)ta; o[1] = (uint8_t)tb; o[2] = (uint8_t)tc; o[3] = (uint8_t)td;
+}
+// ... and from two binary16 pairs (-p 2): v_fma_mix_f32 converts the half and multiplies it in one instruction (255 x of a
+// binary16 x is exact in fp32), v_cvt_pk_u8_f32 truncates under round-toward-zero: 8 instead of 16 vector instructions.
+typedef _Float16 cvt_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cvt4_h_u8(cvt_h2 ab, cvt_h2 cd, int wrap, uint8_t (&o)[4])
+{
+    if (wrap) { o[0] = cvt_f_u8((float)ab.x, 1); o[1] = cvt_f_u8((float)ab.y, 1); o[2] = cvt_f_u8((float)cd.x, 1); o[3] = cvt_f_u8((float)cd.y, 1); return; }
+    unsigned ta, tb, tc, td;
+    const float k255 = 255.0f;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "v_fma_mix_f32 %0, %4, %6, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %4, %6, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                 "v_fma_mix_f32 %2, %5, %6, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %5, %6, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                 "v_cvt_pk_u8_f32 %0, %0, 0, 0\n\tv_cvt_pk_u8_f32 %1, %1, 0, 0\n\tv_cvt_pk_u8_f32 %2, %2, 0, 0\n\tv_cvt_pk_u8_f32 %3, %3, 0, 0\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(ta), "=&v"(tb), "=&v"(tc), "=&v"(td) : "v"(ab), "v"(cd), "s"(k255));
+    o[0] = (uint8_t)ta; o[1] = (uint8_t)tb; o[2] = (uint8_t)tc; o[3] = (uint8_t)td;
 }
 
 // VkResample.cpp:1708-1748: planar float/half -> u8 interleaved, u8 = (unsigned char)(255.0*x).  One thread = four consecutive
@@ -520,16 +537,15 @@ __global__ void __launch_bounds__(256) k_pack_u8(const void* planes, uint8_t* rg
     const long plane = (long)uW * uH, at = (long)y * uW + x;
     uint8_t* dst = rgb + at * 3;
     if (x + 4 <= uW && (uW & 3) == 0) {                     // whole, aligned quad (rows of a multiple of 4 pixels: every quad)
-        float v[3][4];
+        uint8_t b[3][4];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             if constexpr (HALF) {
                 const uint2 r = *(const uint2*)((const __half*)planes + c * plane + at);
-                const __half2 h0 = *(const __half2*)&r.x, h1 = *(const __half2*)&r.y;
-                v[c][0] = __low2float(h0); v[c][1] = __high2float(h0); v[c][2] = __low2float(h1); v[c][3] = __high2float(h1);
+                cvt4_h_u8(__builtin_bit_cast(cvt_h2, r.x), __builtin_bit_cast(cvt_h2, r.y), wrap, b[c]);
             } else {
                 const float4 r = *(const float4*)((const float*)planes + c * plane + at);
-                v[c][0] = r.x; v[c][1] = r.y; v[c][2] = r.z; v[c][3] = r.w;
+                cvt4_f_u8(r.x, r.y, r.z, r.w, wrap, b[c]);
             }
         }
         unsigned o[3] = {0u, 0u, 0u};
@@ -537,8 +553,8 @@ __global__ void __launch_bounds__(256) k_pack_u8(const void* planes, uint8_t* rg
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const int b = 3 * i + c;
-                o[b >> 2] |= (unsigned)cvt_f_u8(v[c][i], wrap) << (8 * (b & 3));
+                const int k = 3 * i + c;
+                o[k >> 2] |= (unsigned)b[c][i] << (8 * (k & 3));
             }
         unsigned* d = (unsigned*)dst;                       // (12 x: a multiple of 4 bytes into a 16-byte aligned image)
         d[0] = o[0]; d[1] = o[1]; d[2] = o[2];

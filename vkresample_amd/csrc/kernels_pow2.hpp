@@ -1697,7 +1697,7 @@ __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
                             sharpen_quad_half(R[w], R[w + 1], R[w + 2], ncoef, o01, o23);
                             if constexpr (OUT_U8) {
                                 uint8_t b8[4];
-                                cvt4_f_u8((float)o01.x, (float)o01.y, (float)o23.x, (float)o23.y, p.u8_wrap, b8);
+                                cvt4_h_u8(o01, o23, p.u8_wrap, b8);
                                 uint8_t* d8 = (uint8_t*)p.out + ((long)(a - 1 + w) * UW * 3 + c) + (unsigned)x0 * 3u;    // (uniform base + x0 * 3)
                                 d8[0] = b8[0]; d8[3] = b8[1]; d8[6] = b8[2]; d8[9] = b8[3];
                                 continue;
