@@ -949,11 +949,26 @@ __device__ __forceinline__ h2v pk_max3(h2v a, h2v b, h2v c)
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// v_rcp_f16 / v_sqrt_f16 of both halves of a register, the second one through SDWA straight into the upper half (left to the
+// compiler: two one-half results and a v_pack_b32_f16, 24 extra instructions per thread and row pair).  The s_nop: a transcendental
+// result needs a wait state before the next vector instruction reads it -- here the preserved lower half)
+__device__ __forceinline__ h2v pk_rcp_h(h2v b)
+{
+    h2v r;
+    asm("v_rcp_f16_e32 %0, %1\n\ts_nop 0\n\tv_rcp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "=&v"(r) : "v"(b));
+    return r;
+}
+__device__ __forceinline__ h2v pk_sqrt_h(h2v b)
+{
+    h2v r;
+    asm("v_sqrt_f16_e32 %0, %1\n\ts_nop 0\n\tv_sqrt_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "=&v"(r) : "v"(b));
+    return r;
+}
 // a / b in packed binary16: native reciprocal plus one residual step -- RN(a / b) but for rare ties
 __device__ __forceinline__ h2v pk_div(h2v a, h2v b)
 {
 #pragma clang fp contract(off)
-    const h2v rc = {(_Float16)__builtin_amdgcn_rcph(b.x), (_Float16)__builtin_amdgcn_rcph(b.y)};
+    const h2v rc = pk_rcp_h(b);
     const h2v q = a * rc;
     return __builtin_elementwise_fma(__builtin_elementwise_fma(-q, b, a), rc, q);
 }
@@ -966,7 +981,7 @@ __device__ __forceinline__ h2v sharpen_eval_pair_half(h2v N, h2v S, h2v Wv, h2v 
     const h2v n2 = __builtin_elementwise_min(smn, u);
     const h2v d2 = two - n2;                           // = max(2 - smn, smx) exactly (see sharpen_eval_pair); in [1, 2]
     const h2v q = pk_div(n2, d2);
-    const h2v r = {(_Float16)__builtin_amdgcn_sqrth(q.x), (_Float16)__builtin_amdgcn_sqrth(q.y)};
+    const h2v r = pk_sqrt_h(q);
     const h2v scale = ncoef * r;
     const h2v s4 = ((N + Wv) + E) + S;
     const h2v prod = scale * s4;
