@@ -1767,6 +1767,6 @@ const char* fftup_strerror(int code)
 }
 
 const char* fftup_last_error(void) { return g_last_error.c_str(); }
-const char* fftup_version(void) { return "fftup 0.3.0 (gfx950, ABI 2)"; }
+const char* fftup_version(void) { return "fftup 0.4.0 (gfx950, ABI 2)"; }
 
 }  // extern "C"
