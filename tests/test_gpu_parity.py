@@ -491,9 +491,13 @@ def test_non_r2c_limits():
         assert up.kernel_names[0] == "row_c2c"
     with _up(4608, 16, 2.0) as up:
         assert up.kernel_names == ["row_c2c", "col_fwd_pad_inv", "row_c2c_inv", "sharpen"] and not up.tuned
-    for W, u, p in ((9216, 2.0, 0), (8064, 2.0, 0), (2560, 2.0, 1)):      # beyond one LDS buffer: four steps (refused until round 4)
-        with _up(W, 16, u, p) as up:
-            assert up.kernel_names[0] == "row_c2c" and not up.tuned
+    for W, u, p, what in ((9216, 2.0, 0, "inverse rows in four steps 128*144"), (8064, 2.0, 0, "inverse rows in four steps 112*144"),
+                          (2560, 2.0, 1, "inverse rows in four steps 64*80"), (17280, 1.0, 0, "forward rows in four steps 120*144"),
+                          (8748, 2.0, 0, "inverse rows in four steps 108*162 (one sequence per workgroup)")):
+        with _up(W, 16, u, p) as up:               # beyond one LDS buffer: four steps (refused until round 4)
+            assert up.kernel_names[0] == "row_c2c" and not up.tuned and what in up.description, up.description
+    with _up(16, 4900, 2.0) as up:
+        assert "forward columns in four steps 70*70" in up.description and "inverse columns in four steps 98*100" in up.description, up.description
 
 
 FOUR_STEP = [(9216, 8, 2.0, 0, 0),       # inverse rows of 18432 = 128 * 144 points in four steps, forward rows (9216) in one launch
@@ -529,7 +533,7 @@ def test_four_step_rows_vs_oracle(W, H, u, precision, flags):
     assert d.max() <= (2 if precision == 2 else 1)
 
 
-TALL = [(16, 4900, 2.0, 0, 0),          # uH = 9800: two Stockham buffers of one column do not fit 160 KB; 4900 = 70 * 70, 9800 = 70 * 140
+TALL = [(16, 4900, 2.0, 0, 0),          # uH = 9800: two Stockham buffers of one column do not fit 160 KB; 4900 = 70 * 70, 9800 = 98 * 100
         (16, 4900, 2.0, 0, 2), (32, 4900, 2.0, 2, 2),
         (20, 9800, 1.5, 0, 0),          # H itself beyond one column's LDS, uH = 14700 = 105 * 140, non-integer factor
         (16, 2500, 2.0, 1, 0),          # -p 1: uH = 5000 in double2

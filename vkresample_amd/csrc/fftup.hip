@@ -739,6 +739,10 @@ int fftup_plan_describe(const fftup_plan* P, char* buf, size_t buflen)
     else if (P->mixed) s = std::string("ahead-of-time mixed-radix kernels: ") + (P->mixed == 1 ? "row 15*8*16, col 9*10*12, fused 16*16*15" : "row 5*16*16, col 9*8*10, fused 16*16*10");
     else if (P->cplx) s = "size-generic kernels, non-R2C path (full complex transforms)";
     else s = std::string("size-generic kernels (LDS ping-pong, run-time radix lists)") + (P->dbl ? ", double" : "");
+    auto four = [&](const char* what, const fftup_plan::Four& f) {
+        if (f.on) s += std::string("; ") + what + " in four steps " + std::to_string(f.n1) + "*" + std::to_string(f.n2) + (f.tk == 4 ? "" : " (one sequence per workgroup)");
+    };
+    four("forward rows", P->fourF); four("inverse rows", P->fourI); four("forward columns", P->colF); four("inverse columns", P->colI);
     if (P->u8out) s += "; fused 8-bit RGB store";
     snprintf(buf, buflen, "%s", s.c_str());
     return FFTUP_OK;
