@@ -20,15 +20,17 @@ python bench.py --host-streamed --fuse-u8 --fuse-u8-store --no-cpu-baseline --ri
 for f in fp16_u8 1080p fp16_u8_u8store fp32_u8_u8store config5_1gpu fp32_streams1 host_streamed_fp32 host_streamed_u8store; do
   python -c "import json,sys; d=json.load(open('$OUT/bench_$f.json')); print('%-24s %9.0f frames/s %.2f us/frame frac %.3f' % ('$f', d['value'], d['ms_per_frame']*1e3, d['frame_roofline_frac']), {k: round(v*1e3,1) for k,v in d['kernel_ms'].items()})"
 done
-prof() {  # tag, bench args
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$1 -o bench -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-others ${@:2} > $R/$OUT/rocprof_$1.log 2>&1)
+prof() {  # tag, clock_check.py args: rocprofv3 ON fftup_profile_kernels of the DEFAULT plan (ring of 8, three streams: one strip per compute unit), the
+          # very launches bench.py's roofline figure comes from (a --streams 1 plan cuts the frame into two strips per unit: another kernel time)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$1 -o bench -- python $R/tools/clock_check.py --mode profile --n 300 ${@:2} > $R/$OUT/rocprof_$1.log 2>&1)
   mkdir -p $R/$OUT/prof_$1; cp $(find /tmp/prof_$1 -name "*kernel_stats.csv" | head -1) $R/$OUT/prof_$1/; rm -rf /tmp/prof_$1      # (the traces stay on the box)
 }
-prof fp32_s1 --streams 1
-prof fp32_s3
-prof fp16_u8_s1 --preset config3 --streams 1
-prof 1080p_s1 --preset config4 --streams 1
-prof fp16_u8_u8store_s1 --preset config3 --fuse-u8-store --streams 1
+prof fp32_s1 --width 2048 --height 1024
+prof fp16_u8_s1 --width 2048 --height 1024 --precision 2 --flags 2
+prof 1080p_s1 --width 1920 --height 1080
+prof fp16_u8_u8store_s1 --width 2048 --height 1024 --precision 2 --flags 34
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s3 -o bench -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-others > $R/$OUT/rocprof_fp32_s3.log 2>&1)
+mkdir -p $R/$OUT/prof_fp32_s3; cp $(find /tmp/prof_s3 -name "*kernel_stats.csv" | head -1) $R/$OUT/prof_fp32_s3/; rm -rf /tmp/prof_s3
 head -5 $(find $OUT/prof_fp32_s1 -name "*kernel_stats.csv" | head -1)
 bash tools/gpu_pmc.sh $TAG/pmc_fp32 > /dev/null 2>&1
 bash tools/gpu_pmc.sh $TAG/pmc_fp16u8 --preset config3 > /dev/null 2>&1

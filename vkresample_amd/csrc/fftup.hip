@@ -244,15 +244,16 @@ static std::string wisdom_device_key(const fftup_plan* P);
 // Plans whose frames overlap on several streams (ring > 1): ONE strip per compute unit -- the rest of every unit is left
 // to the row and column kernels of the frames on the other streams, and the frame time is what counts.
 // Plans that run one frame after the other (ring = 1: the CLI's single-image mode, the reference's -n timing): nothing
-// runs beside a strip, and a workgroup of at most 256 threads (one wave per SIMD) cannot hide its own latencies: two
-// strips per unit (1080p 98 -> 90 us per frame, 1000x1000 76 -> 62; no gain at 512 threads and beyond).
+// runs beside a strip, and a workgroup of at most 512 threads (one or two waves per SIMD) does not hide its own latencies: two
+// strips per unit (1080p 100 -> 91 us per iteration, 1000x1000 75 -> 62, 2048x1024 77.2 -> 76.0, -p 2 82.7 -> 79.7; 768 and 1024
+// threads: 2-7 % slower with two; profiles/r04_s_strips_per_unit_sequential.txt).
 // FFTUP_EXPERIMENT keys g_per_cu / pairs_per_strip override; how many workgroups are resident is the hardware's business.
 static void set_strip_length(fftup_plan* P)
 {
     const int fused_threads = P->tuned ? (int)P->uW / 8 : P->mixed == 3 ? P->jit->choice.fused_t : 256;
     const std::string mode = wisdom_device_key(P);
     const bool sequential = mode.size() >= 10 && mode.compare(mode.size() - 10, 10, "sequential") == 0;
-    int per_cu = (sequential && fused_threads <= 256) ? 2 : 1;
+    int per_cu = (sequential && fused_threads <= 512) ? 2 : 1;
     if (const char* e = fftup_jit::experiment("g_per_cu")) per_cu = std::max(1, std::min(4, atoi(e)));
     const int total_pairs = 3 * (int)P->uH / 2, slots = std::max(1, P->prop.multiProcessorCount) * per_cu;
     P->pairs_per_strip = std::max(2, (total_pairs + slots - 1) / slots);
