@@ -150,7 +150,22 @@ def frame_traffic(traffic_json, key, kernel_names):
         return None, None, None
 
 
-def other_configs(v, synth, dev, traffic_json, ring=8):
+def valu_busy(traffic_json, key, kernel_names, ms_per_frame, sclk_mhz, n_cu):
+    """Share of the frame's vector-ALU issue slots in use: wave-level vector instructions of the frame's launches (SQ_INSTS_VALU of
+    the committed PMC run) x 4 cycles each, over 4 SIMDs per compute unit x shader clock x frame time.  With `real_traffic_frac`
+    it says what the frame is NOT bound by; the power figure says what it is.  None where a number is missing."""
+    try:
+        tj = json.load(open(traffic_json)).get(key) or {}
+        insts = [tj.get(n, {}).get("valu_insts_per_launch") for n in kernel_names if n != "-"]
+        if not insts or any(x is None for x in insts) or not sclk_mhz or not n_cu:
+            return None, None
+        total = float(sum(insts))
+        return total, total * 4.0 / (4.0 * n_cu * sclk_mhz * 1e6 * ms_per_frame * 1e-3)
+    except Exception:
+        return None, None
+
+
+def other_configs(v, synth, dev, traffic_json, n_cu, ring=8):
     """Short runs of the other single-GPU BASELINE configurations on the same GPU, same method as the headline (ring of
     resident frames, three streams, HIP events per kernel), and the reference's -n 1000 figure on ring-less plans.  Every entry
     carries, beside the B_alg fractions, the numbers that can still move: the fraction by MEASURED HBM bytes
@@ -185,6 +200,8 @@ def other_configs(v, synth, dev, traffic_json, ring=8):
                          "frame_hbm_bytes_measured": frame_hbm, "traffic_source": tsrc,
                          "real_traffic_frac": (frame_hbm / (t * 1e-3) / 8e12) if frame_hbm else None,
                          "kernel_hbm_bytes_measured": per,
+                         "frame_valu_insts": valu_busy(traffic_json, key, up.kernel_names, t, pw.get("sclk_mhz_median"), n_cu)[0],
+                         "valu_busy_frac": valu_busy(traffic_json, key, up.kernel_names, t, pw.get("sclk_mhz_median"), n_cu)[1],
                          "socket_power_w_median": pw.get("socket_power_w_median"), "sclk_mhz_median": pw.get("sclk_mhz_median"),
                          "energy_mj_per_frame": pw["socket_power_w_median"] * t if pw.get("socket_power_w_median") else None,
                          "plan": up.description}
@@ -280,6 +297,10 @@ def main():
     if v.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
     dev = local_rank % v.device_count()
+    try:
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count if torch.cuda.is_available() else None
+    except Exception:
+        n_cu = None
     flags = (v.FLAG_FUSE_U8_LOAD if args.fuse_u8 else 0) | (v.FLAG_GENERIC_KERNELS if args.generic else 0) | (v.FLAG_TUNE_PLAN if args.tune else 0) | \
             (v.FLAG_FUSE_U8_STORE if args.fuse_u8_store else 0)
     up = v.Upscaler(args.width, args.height, args.upscale, args.precision, 0.2, dev, flags, args.ring)
@@ -489,6 +510,8 @@ def main():
                          "frame_achieved": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 1e9,      # per GPU
                          "frame_frac": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 8e12},
         }
+        fvi, vbusy = valu_busy(args.traffic_json, key, up.kernel_names, wall_frame_ms, (power_stats or {}).get("sclk_mhz_median"), n_cu)
+        line["frame_valu_insts"], line["valu_busy_frac"] = fvi, vbusy
         if power_stats and power_stats.get("socket_power_w_median"):
             # at the power limit this is the number a kernel change has to move: joules per frame
             power_stats["energy_mj_per_frame"] = power_stats["socket_power_w_median"] * wall_frame_ms       # (one GPU works on a frame)
@@ -510,7 +533,7 @@ def main():
     up.close()
     if rank == 0 and world == 1 and not args.no_others and not args.host_streamed and (args.preset or "config2") == "config2" \
             and (args.width, args.height, args.precision) == (2048, 1024, 0):
-        line["others"] = other_configs(v, synth, dev, args.traffic_json)
+        line["others"] = other_configs(v, synth, dev, args.traffic_json, n_cu)
     if pins:
         pins[0].close()
         pins[1].close()

@@ -59,6 +59,10 @@ def test_bench_single_rank_line():
         assert set(e["kernel_hbm_bytes_measured"]) == {"row_r2c", "col_fwd_pad_inv", "row_c2r_sharpen"}
         assert e["energy_mj_per_frame"] is None or 10 < e["energy_mj_per_frame"] < 500
     assert d["b_min_frac"] < d["real_traffic_frac"] < d["frame_roofline_frac"]
+    # what the frame is NOT bound by: vector-ALU issue slots in use (committed SQ_INSTS_VALU x 4 cycles over SIMDs x clock x time)
+    assert 1.5e7 < d["frame_valu_insts"] < 3e7 and (d["valu_busy_frac"] is None or 0.3 < d["valu_busy_frac"] < 1.0)
+    for k in ("config3", "config4", "config3_u8_store"):
+        assert 1.5e7 < o[k]["frame_valu_insts"] < 3e7 and (o[k]["valu_busy_frac"] is None or 0.3 < o[k]["valu_busy_frac"] < 1.0)
     # (the 8-bit image is written once: the fused kernel's launch moves 91 MB -- 25 MB of writes, the spectra, and the L2's
     # reads of the lines it merges the three planes' bytes into -- not the 111 MB of round 3 with 76 MB of writes)
     assert o["config3_u8_store"]["kernel_hbm_bytes_measured"]["row_c2r_sharpen"] < 1.0e8

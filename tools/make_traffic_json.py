@@ -48,7 +48,9 @@ for k, c in data.items():
     rd = c["FETCH_SIZE"] * 1024 * f
     wr = c["WRITE_SIZE"] * 1024
     res[names[k]] = {"kernel": k, "fetch_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
-                     "fetch_correction": f, "l2_hit_rate": c.get("TCC_HIT_sum", 0) / max(1.0, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0))}
+                     "fetch_correction": f, "l2_hit_rate": c.get("TCC_HIT_sum", 0) / max(1.0, c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)),
+                     # wave-level instruction counts of one launch (SQ_INSTS_*): what the vector ALUs and the LDS have to issue
+                     "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "lds_insts_per_launch": c.get("SQ_INSTS_LDS")}
 allres[key] = res
 json.dump(allres, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if not k.startswith("_")}, indent=1))
