@@ -350,3 +350,34 @@ def test_oracle_reproduces_reference_output_whole_frame():
     _, _, u8 = O.upscale_rgb8(b["rgb"], 2.0, 0, 0.2)
     mean, p99, mx = M.compare(u8, b["fft"], 2 * b["yA"] + b["py"], 2 * b["xA"] + b["px"])
     assert mean <= 0.2 and p99 <= 1 and mx <= 2, (mean, p99, mx)
+
+
+@pytest.mark.parametrize("W,H", [(32, 16), (24, 20), (64, 12)])
+def test_x_split_identities_of_the_u2_inverse(W, H):
+    """The x direction of the u = 2 inverse in the folded form DESIGN.md section 4 prices ("Why the x direction is not split"; VERDICT r3
+    next 1 asked for the derivation before any kernel): of every output row, the even and the odd columns are two real transforms
+    of length W of the row's half spectrum Z[0..W/2] -- the odd ones behind the phase exp(2 pi i k / 2W), the Nyquist column (quirk
+    B1: kept at full weight on both sides) folded in as 2 Re Z[W/2] resp. -2 Im Z[W/2] -- and on the EVEN rows the even columns are the
+    input image itself plus (-1)^x alt_y / W (B1) plus one constant per row (the DC leak between the rows of a C2R pair, B2 + B3):
+    three complex transforms of length W per four output rows instead of two of length 2W.  Checked against the oracle's pre-sharpen
+    image (the reference's literal kernel sequence)."""
+    rng = np.random.default_rng(W * 1000 + H)
+    x = rng.random((3, H, W))
+    pre, _, _ = O.upscale_planes(x, 2.0, 1)                  # fp64 arithmetic: g, before the sharpen shader multiplies by u^2
+    uW = 2 * W
+    k = np.arange(W // 2 + 1)
+    for c in range(3):
+        for r in range(2 * H - 1):                           # (the last output row is excluded from parity everywhere: quirk B5)
+            Z = np.fft.rfft(pre[c, r])                       # the row's spectrum: kx = 0..uW/2, zero beyond W/2
+            assert np.abs(Z[W // 2 + 1:]).max() <= 1e-12
+            Xe = Z[:W // 2 + 1].copy()
+            Xe[W // 2] = 2 * Z[W // 2].real
+            Xo = Z[:W // 2 + 1] * np.exp(2j * np.pi * k / uW)
+            Xo[W // 2] = -2 * Z[W // 2].imag
+            assert np.abs(pre[c, r, 0::2] - 0.5 * np.fft.irfft(Xe, n=W)).max() <= 1e-13
+            assert np.abs(pre[c, r, 1::2] - 0.5 * np.fft.irfft(Xo, n=W)).max() <= 1e-13
+        alt = (x[c] * (-1.0) ** np.arange(W)).sum(axis=1)    # Re F[W/2] of every input row (its imaginary part is 0)
+        res = 4 * pre[c, 0:2 * H - 1:2, 0::2] - x[c, :H] - np.outer(alt[:H], (-1.0) ** np.arange(W)) / W
+        assert np.abs(res - res[:, :1]).max() <= 1e-12      # one constant per even row ...
+        s_nyq = (x[c] * ((-1.0) ** np.arange(H))[:, None]).sum()          # S[H/2, 0]
+        assert np.abs(np.abs(res[:, 0]) - abs(s_nyq) / (W * H)).max() <= 1e-12 and np.abs(res[0::2, 0] + res[1::2, 0]).max() <= 1e-12   # ... +- S[H/2,0] / WH, alternating
