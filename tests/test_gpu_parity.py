@@ -408,7 +408,8 @@ def test_timed_ring_and_profile_api():
         got = [up.download_planar(s) for s in range(2)]
         iso = up.profile_kernels(3)
         assert up.kernel_names[:3] == ["row_r2c", "col_fwd_pad_inv", "row_c2r_sharpen"]
-    assert ms > 0 and all(k > 0 for k in km[:3]) and all(k > 0 for k in iso[:3])
+    # (isolated durations are net of an empty event pair's own cost: a 4-us kernel of this small size may come out as 0)
+    assert ms > 0 and all(k > 0 for k in km[:3]) and all(k >= 0 for k in iso[:3])
     for a, b in zip(ref, got):
         assert np.array_equal(a, b)
 
