@@ -147,24 +147,36 @@ static void fft1d(const fft_plan* p, cpx* x, cpx* work, int sign)
         const uint32_t R = p->fac[s];
         const uint32_t nb = n / R;
         const uint32_t tstep = n / (Ns * R);
+        /* the R x R DFT matrix of this stage, exp(sign 2 pi i m q / R), taken from the table once per stage */
+        double mr[7][7], mi[7][7];
+        for (uint32_t q = 0; q < R; q++)
+            for (uint32_t m = 0; m < R; m++) {
+                const uint32_t ti = (uint32_t)(((uint64_t)m * q * nb) % n);
+                mr[q][m] = p->tw[ti].re;
+                mi[q][m] = sign * p->tw[ti].im;
+            }
         for (uint32_t j = 0; j < nb; j++) {
             const uint32_t k = j % Ns;
             cpx v[7];
-            for (uint32_t m = 0; m < R; m++) {
+            v[0] = in[j];                                   /* twiddle exp(0) = 1 */
+            for (uint32_t m = 1; m < R; m++) {
                 cpx a = in[j + m * nb];
-                uint32_t ti = (uint32_t)(((uint64_t)k * m * tstep) % n);
+                const uint32_t ti = k * m * tstep;           /* k < Ns, m < R: k m tstep < n */
                 double wr = p->tw[ti].re, wi = sign * p->tw[ti].im;
                 v[m].re = a.re * wr - a.im * wi;
                 v[m].im = a.re * wi + a.im * wr;
             }
             const uint32_t j0 = (j - k) * R + k;
+            if (R == 2) {                                    /* exp(i pi) = -1 exactly (the table's sin(pi) is 1.2e-16) */
+                out[j0].re = v[0].re + v[1].re;      out[j0].im = v[0].im + v[1].im;
+                out[j0 + Ns].re = v[0].re - v[1].re; out[j0 + Ns].im = v[0].im - v[1].im;
+                continue;
+            }
             for (uint32_t q = 0; q < R; q++) {
                 double sr = 0, si = 0;
                 for (uint32_t m = 0; m < R; m++) {
-                    uint32_t ti = (uint32_t)(((uint64_t)m * q * nb) % n);   /* exp(2 pi i m q / R) */
-                    double wr = p->tw[ti].re, wi = sign * p->tw[ti].im;
-                    sr += v[m].re * wr - v[m].im * wi;
-                    si += v[m].re * wi + v[m].im * wr;
+                    sr += v[m].re * mr[q][m] - v[m].im * mi[q][m];
+                    si += v[m].re * mi[q][m] + v[m].im * mr[q][m];
                 }
                 out[j0 + q * Ns].re = sr;
                 out[j0 + q * Ns].im = si;
