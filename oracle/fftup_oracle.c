@@ -328,7 +328,10 @@ static int upscale_planes_complex(const orc_config* c, const double* in_planes, 
     for (int ch = 0; ch < 3; ch++) {
         const double* x = in_planes + (uint64_t)ch * W * H;
         cpx* buf = (cpx*)malloc(sizeof(cpx) * plane);
-        for (uint64_t i = 0; i < plane; i++) { buf[i].re = NAN; buf[i].im = NAN; }
+        {
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < (int64_t)plane; i++) { buf[i].re = NAN; buf[i].im = NAN; }
+        }
         cpx* F = (cpx*)malloc(sizeof(cpx) * (uint64_t)W * H);          /* pristine forward spectrum */
 #pragma omp parallel
         {
@@ -451,7 +454,10 @@ ORC_API int orc_upscale_planes(const orc_config* c, const double* in_planes, dou
         const double* x = in_planes + (uint64_t)ch * W * H;
         /* "buffer": uH rows x HX columns; column kx.  NaN = never written. */
         cpx* buf = (cpx*)malloc(sizeof(cpx) * (uint64_t)uH * HX);
-        for (uint64_t i = 0; i < (uint64_t)uH * HX; i++) { buf[i].re = NAN; buf[i].im = NAN; }
+        {
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < (int64_t)((uint64_t)uH * HX); i++) { buf[i].re = NAN; buf[i].im = NAN; }
+        }
 
         /* F0: R2C rows, two real rows as one complex FFT (VF:1945-2058, 4274-4377) */
 #pragma omp parallel
@@ -593,15 +599,19 @@ ORC_API int orc_upscale_rgb8(const orc_config* c, const uint8_t* rgb, double* pr
     double lut[256];
     for (int v = 0; v < 256; v++) lut[v] = orc_load_u8(c->precision, (uint8_t)v);
     double* in = (double*)malloc(sizeof(double) * 3ull * W * H);
-    for (int ch = 0; ch < 3; ch++)
-        for (uint64_t i = 0; i < (uint64_t)W * H; i++) in[(uint64_t)ch * W * H + i] = lut[rgb[i * 3 + ch]];
+    for (int ch = 0; ch < 3; ch++) {
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)W * H; i++) in[(uint64_t)ch * W * H + i] = lut[rgb[i * 3 + ch]];
+    }
     double* o = out;
     if (!o && rgb_out) o = (double*)malloc(sizeof(double) * 3ull * uW * uH);
     rc = orc_upscale_planes(c, in, pre, o, NULL);
     if (!rc && rgb_out)
-        for (int ch = 0; ch < 3; ch++)
-            for (uint64_t i = 0; i < (uint64_t)uW * uH; i++)
+        for (int ch = 0; ch < 3; ch++) {
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < (int64_t)uW * uH; i++)
                 rgb_out[i * 3 + ch] = orc_store_u8(o[(uint64_t)ch * uW * uH + i], c->u8_wrap);
+        }
     if (o != out) free(o);
     free(in);
     return rc;
