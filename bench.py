@@ -60,7 +60,7 @@ def parse_args():
     ap.add_argument("--generic", action="store_true", help="size-generic kernels (FFTUP_FLAG_GENERIC_KERNELS): no tuned, no plan-time specialised plan")
     ap.add_argument("--tune", action="store_true", help="FFTUP_FLAG_TUNE_PLAN: plan-time tuner for sizes specialised at plan time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-baseline sample (~8 s on 128 threads)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the bounded CPU-baseline sample (~11 s on 128 threads)")
     ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other BASELINE configurations (`others`)")
     ap.add_argument("--job", action="store_true",
                     help="job accounting: rank r processes frames shard.frames_for_rank(frames_per_step * world, world, r), all distinct "
