@@ -58,7 +58,8 @@
 
 namespace fftup_jit {
 
-static const char* const kHeaderNames[] = {"fft_engine.hpp", "kernels_generic.hpp", "kernels_pow2.hpp", "kernels_mixed.hpp"};
+static const char* const kHeaderNames[] = {"fft_engine.hpp", "kernels_generic.hpp", "kernels_pow2.hpp", "kernels_mixed.hpp", "kernels_dswap.hpp"};
+static constexpr int kNumHeaders = (int)(sizeof kHeaderNames / sizeof kHeaderNames[0]);
 
 // radices the register engines have butterflies for (fft_engine.hpp bfly<R>, kernels_pow2.hpp twiddle_all<R>)
 static const int kRadices[] = {2, 3, 4, 5, 7, 8, 9, 10, 12, 15, 16};
@@ -560,7 +561,7 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT], int 
     std::string s;
     if (part == 0) {
         s += "// generated by fftup (jit.hpp): row and column kernels, " + W + "x" + H + " -> " + UW + "x" + std::to_string(c.UH) + (c.half ? ", binary16 storage\n" : ", fp32\n");
-        s += "#include \"kernels_mixed.hpp\"\nnamespace fftup {\n";
+        s += "#include \"kernels_mixed.hpp\"\n#include \"kernels_dswap.hpp\"\nnamespace fftup {\n";
         s += "struct JitCfg {\n    static constexpr int W = " + W + ", H = " + H + ";\n";
         if (c.row_kind == 1)
             s += "    static constexpr int RR0 = " + std::to_string(c.rr[0]) + ", RR1 = " + std::to_string(c.rr[1]) + ", RR2 = " + std::to_string(c.rr[2]) +
@@ -586,7 +587,8 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT], int 
             names[K_ROW_PLANAR] = k + "<fftup::JitCfg, " + fm + ">";
             names[K_ROW_U8] = k + "<fftup::JitCfg, " + um + ">";
         }
-        names[K_COL] = c.col_kind == 5 ? "fftup::k_col_pad<fftup::JitCfg>" : c.col_kind == 0 ? "fftup::k_col_t<" + H + ", 4>" : c.col_kind == 3 ? "fftup::k_col_n<fftup::JitCfg>" :
+        names[K_COL] = c.col_kind == 5 ? "fftup::k_col_pad<fftup::JitCfg>" : c.col_kind == 0 ? (c.H == 1024 ? std::string("fftup::k_col_v<4>") : "fftup::k_col_t<" + H + ", 4>") :      // (H = 1024: the digit-swap column kernel, kernels_dswap.hpp)
+                        c.col_kind == 3 ? "fftup::k_col_n<fftup::JitCfg>" :
                        c.col_kind == 4 ? "fftup::k_col_u<fftup::JitCfg, " + std::to_string(c.U) + ">" : "fftup::k_col_m<fftup::JitCfg>";
         return s;
     }
@@ -613,7 +615,7 @@ static std::string describe(const Choice& c)
     auto star = [](const std::vector<int>& v) { std::string t; for (size_t i = 0; i < v.size(); i++) t += (i ? "*" : "") + std::to_string(v[i]); return t; };
     s += c.row_kind == 2 ? "generic" : c.row_kind == 0 ? "pow2/8" : c.row_kind == 3 ? star(c.rn) : std::to_string(c.rr[0]) + "*" + std::to_string(c.rr[1]) + "*" + std::to_string(c.rr[2]);
     s += " x" + std::to_string(c.row_block) + ", col ";
-    s += c.col_kind == 0 ? "pow2/8" : c.col_kind == 5 ? star(c.cn) + " -> " + star(c.ci) : c.col_kind >= 3 ? star(c.cn) : std::to_string(c.cr[0]) + "*" + std::to_string(c.cr[1]) + "*" + std::to_string(c.cr[2]);
+    s += c.col_kind == 0 ? (c.H == 1024 ? "pow2/8 digit-swap" : "pow2/8") : c.col_kind == 5 ? star(c.cn) + " -> " + star(c.ci) : c.col_kind >= 3 ? star(c.cn) : std::to_string(c.cr[0]) + "*" + std::to_string(c.cr[1]) + "*" + std::to_string(c.cr[2]);
     s += " x" + std::to_string(c.col_block) + (c.col_kind >= 3 && c.col_cols == 2 ? " (2 columns)" : "") + ", fused ";
     if (c.fused_kind == 0) s += "pow2/8";
     else if (c.fused_kind == 1) s += "16*16*" + std::to_string(c.UW / 256);
@@ -773,17 +775,17 @@ static bool compile(const Choice& c, const std::string& arch, int part, Binary& 
     const Rtc& R = rtc();
     if (!R.ok) { err = "hipRTC (libhiprtc.so) not available"; return false; }
     // kernel headers: embedded text (default) or a directory
-    std::vector<std::string> hdr(4);
+    std::vector<std::string> hdr(kNumHeaders);
     std::string kdir;
     const bool from_dir = getenv("FFTUP_KERNEL_DIR") || !FFTUP_HAVE_EMBEDDED_SOURCES;
     if (from_dir) {
         kdir = kernel_dir();
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < kNumHeaders; i++)
             if (!read_file(kdir + "/" + kHeaderNames[i], hdr[i])) { err = "kernel header " + kdir + "/" + kHeaderNames[i] + " not found (set FFTUP_KERNEL_DIR)"; return false; }
     }
 #if FFTUP_HAVE_EMBEDDED_SOURCES
     else {
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < kNumHeaders; i++)
             for (const auto& e : fftup_kernel_sources)
                 if (!strcmp(e[0], kHeaderNames[i])) hdr[i] = e[1];
     }
@@ -840,9 +842,9 @@ static bool compile(const Choice& c, const std::string& arch, int part, Binary& 
     if (!cpath.empty() && load_cached(cpath, out)) { std::lock_guard<std::mutex> lock(mu); memo[key] = out; return true; }
 
     hiprtcProgram prog = nullptr;
-    const char* hdr_ptr[4] = {hdr[0].c_str(), hdr[1].c_str(), hdr[2].c_str(), hdr[3].c_str()};
-    const char* hdr_names[4] = {kHeaderNames[0], kHeaderNames[1], kHeaderNames[2], kHeaderNames[3]};
-    if (R.CreateProgram(&prog, src.c_str(), "fftup_jit.hip", 4, hdr_ptr, hdr_names) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return false; }
+    const char *hdr_ptr[kNumHeaders], *hdr_names[kNumHeaders];
+    for (int i = 0; i < kNumHeaders; i++) { hdr_ptr[i] = hdr[i].c_str(); hdr_names[i] = kHeaderNames[i]; }
+    if (R.CreateProgram(&prog, src.c_str(), "fftup_jit.hip", kNumHeaders, hdr_ptr, hdr_names) != HIPRTC_SUCCESS) { err = "hiprtcCreateProgram failed"; return false; }
     for (int k = 0; k < K_COUNT; k++) if (!names[k].empty()) R.AddNameExpression(prog, names[k].c_str());
     const hiprtcResult rc = R.CompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
     if (rc != HIPRTC_SUCCESS) {
