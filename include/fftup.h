@@ -77,8 +77,7 @@ typedef struct fftup_config {
 /* Environment read by fftup_plan_create (operational knobs, not part of the reference's surface):
  *   FFTUP_STREAMS=n     HIP streams consecutive frames of fftup_execute_ring / fftup_submit_rgb8 alternate on (default 3, 1..4);
  *                       fftup_execute always uses one
- *   FFTUP_JIT=0|1       run-time specialised plans (default 1); FFTUP_JIT_VERBOSE=1 prints why one fell back;
- *                       FFTUP_JIT_TUNE=1 = FFTUP_FLAG_TUNE_PLAN for every plan
+ *   FFTUP_JIT=0|1       run-time specialised plans (default 1); FFTUP_JIT_VERBOSE=1 prints why one fell back
  *   FFTUP_CACHE_DIR     code-object cache and wisdom file of those plans (default ~/.cache/fftup);
  *   FFTUP_KERNEL_DIR    kernel headers, when not the ones embedded in the library; FFTUP_HIPRTC_LIB: the run-time compiler's
  *                       shared object (default: libhiprtc.so of the ROCm install) */

@@ -276,7 +276,7 @@ static std::string wisdom_device_key(const fftup_plan* P)
 }
 static bool jit_tune_enabled()
 {
-    const char* e = getenv("FFTUP_JIT_TUNE");
+    const char* e = fftup_jit::experiment("jit_tune");
     return e && atoi(e) != 0;
 }
 // four-step rows (k_row4_a / k_row4_b): launch both passes; ATTR: only allow their dynamic LDS sizes (plan creation)
@@ -1382,7 +1382,7 @@ int fftup_execute_ring_timed(fftup_plan* P, uint32_t n_frames, uint32_t first_sl
 
 }  // extern "C"
 
-// Plan-time tuner (FFTUP_FLAG_TUNE_PLAN / FFTUP_JIT_TUNE=1) for a run-time specialised plan: the chooser's alternatives for
+// Plan-time tuner (FFTUP_FLAG_TUNE_PLAN / experiment jit_tune=1) for a run-time specialised plan: the chooser's alternatives for
 // the fused C2R+sharpen kernel -- the one that takes two thirds of a frame -- are compiled and the PLAN is timed with
 // each of them on this device, the way it will run (frames overlapping on the plan's streams when it has a ring of slots,
 // else one after the other: a kernel that is faster alone but fills the compute units' registers makes overlapping

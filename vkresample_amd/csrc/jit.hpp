@@ -95,7 +95,7 @@ static bool is_radix(int r) { for (int s : kRadices) if (s == r) return true; re
 
 // Experiment switches (timing variants, pinned factorizations of tests and tools): ONE environment variable,
 // FFTUP_EXPERIMENT="key=value;key=value", not part of the documented surface (include/fftup.h lists the operational knobs).
-// Keys: aot, graphs, g_per_cu, pairs_per_strip, jit_row, jit_col, jit_coli, jit_fused, jit_fused_opt, jit_row_nstage, jit_col_nstage,
+// Keys: aot, graphs, g_per_cu, pairs_per_strip, jit_tune, jit_row, jit_col, jit_coli, jit_fused, jit_fused_opt, jit_row_nstage, jit_col_nstage,
 // jit_no_builtin_wisdom, jit_dump, jit_threads.  Returns the value ("" for a bare key) or nullptr.
 static const char* experiment(const char* key)
 {
@@ -233,7 +233,7 @@ static bool choose_fused_n(int n, int D, std::vector<int>& out, int* threads)
 }
 
 // The chooser's alternatives for the fused kernel, for the plan-time tuner (fftup_plan_create with FFTUP_FLAG_TUNE_PLAN /
-// FFTUP_JIT_TUNE=1): the best factorization (by the ranking above, first radix aside) of every (first radix, number of
+// experiment jit_tune=1): the best factorization (by the ranking above, first radix aside) of every (first radix, number of
 // stages, thread count) class, at most `max` of them, the chooser's own pick first.
 struct FusedCand { int T; std::vector<int> r; };
 static std::string cache_dir();
