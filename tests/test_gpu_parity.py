@@ -858,3 +858,25 @@ def test_recorded_frames_equal_eager_launches(W, H, precision, flags, monkeypatc
     for x, y in zip(res["0"], res["1"]):
         assert np.array_equal(x, y)
     assert np.array_equal(res["1"][0], res["1"][1]) and not np.array_equal(res["1"][2], res["1"][3])
+
+
+def test_four_step_plans_in_a_ring():
+    """rows and columns in four steps with frames overlapping on the plan's streams: every lane has its own transposition
+    buffer -- three distinct frames through fftup_execute_ring equal the same frames one at a time"""
+    from vkresample_amd import synth
+    for (W, H) in ((9216, 8), (16, 4900)):
+        frames = [synth.frame(90 + k, W, H) for k in range(3)]
+        single = []
+        with _up(W, H, 2.0, 0) as up:
+            for f in frames:
+                up.upload_rgb8(f)
+                up.execute(1)
+                single.append(up.download_planar().copy())
+        with _up(W, H, 2.0, 0, ring=3) as up:
+            assert "four steps" in up.description
+            for s, f in enumerate(frames):
+                up.upload_rgb8(f, slot=s)
+            up.execute_ring(9, 0)
+            for s in range(3):
+                assert np.array_equal(up.download_planar(s), single[s])
+        assert not np.array_equal(single[0], single[1])
