@@ -116,7 +116,10 @@ FFTUP_API int fftup_device_name(int device, char* buf, size_t buflen);
 FFTUP_API int fftup_device_pci_bus_id(int device, char* buf, size_t buflen);
 
 /* initializeVulkanFFT x2 + createShiftApp + createSharpenApp + 3x allocateFFTBuffer
- * (VR:1437-1448, 1506-1509, 1562, 1617) */
+ * (VR:1437-1448, 1506-1509, 1562, 1617).  Every even 2,3,5,7-smooth width and height up to 65536 whose upscaled sizes are
+ * even and smooth is a valid plan, as in the reference: upscaled widths beyond 8192 (4096 for -p 1) take the reference's
+ * non-R2C path (VR:1424); rows and columns too long for the compute unit's local memory run as two-launch "four-step"
+ * transforms through device memory (the reference's multi-upload plans, VF:4773-4992).  fftup_plan_describe says which. */
 FFTUP_API int fftup_plan_create(fftup_plan** out, const fftup_config* cfg);
 /* deleteVulkanFFT x2, deleteShiftApp x2, buffer frees (VR:1759-1771) */
 FFTUP_API void fftup_plan_destroy(fftup_plan* plan);
