@@ -203,3 +203,103 @@ def test_row_r2c_v_digit_swap_model():
             v[wp, l, :] *= tw(np.arange(8) * kk)
             v[wp, l, :] = W8[+1] @ v[wp, l, :]
             assert np.abs(v[wp, l, :] - F[kk + 256 * np.arange(8)]).max() <= 1e-8          # X[k'' + 256 k3] in register k3
+
+
+import pytest
+
+
+@pytest.mark.parametrize("WV", [8, 4, 2])
+def test_k_col_v_general_wave_digit_model(WV):
+    """k_col_v for H = 128 * WV (1024, 512, 256): the wave digit has WV values against 8 registers, so the wave exchange hands
+    every thread WV values of the wave digit x Q = 8 / WV of the eight first-stage outputs and the second stage is Q butterflies of
+    radix WV; everything else as in the H = 1024 kernel.  Forward decimation in time, phase, inverse decimation in frequency."""
+    H, Q = 128 * WV, 8 // WV
+    rng = np.random.default_rng(10 + WV)
+    x = rng.standard_normal(H) + 1j * rng.standard_normal(H)
+    tw = lambda j, n=H: np.exp(2j * np.pi * j / n)
+    F = np.fft.ifft(x) * H
+    k = np.arange(H)
+    t = np.exp(-2j * np.pi * k / (2 * H)) * np.where(k < H // 2, 1, -1)
+    ref = np.fft.fft(F * t)
+    WR = {+1: np.exp(+2j * np.pi * np.outer(np.arange(WV), np.arange(WV)) / WV), -1: np.exp(-2j * np.pi * np.outer(np.arange(WV), np.arange(WV)) / WV)}
+    v = np.zeros((WV, 16, 8), complex)                    # [wave][h = lane >> 2][register]; pp = 16 w + h
+    for w in range(WV):
+        for h in range(16):
+            v[w, h, :] = x[16 * w + h + (H // 8) * np.arange(8)]
+    v = v @ W8[+1].T                                      # registers: k0
+    nv = np.zeros_like(v)                                 # A: element (k0, wave n_w) -> thread wave k0 // Q, register WV (k0 % Q) + n_w
+    for nw in range(WV):
+        for k0 in range(8):
+            nv[k0 // Q, :, WV * (k0 % Q) + nw] = v[nw, :, k0]
+    v = nv
+    for wp in range(WV):
+        for b in range(Q):
+            for nw in range(WV):
+                v[wp, :, WV * b + nw] *= tw(16 * nw * (Q * wp + b))           # exp(2 pi i n_w k0 / 8 WV): wave-uniform
+            v[wp, :, WV * b:WV * b + WV] = v[wp, :, WV * b:WV * b + WV] @ WR[+1].T      # registers: WV b + k1
+    kk = lambda wp, s: Q * wp + s // WV + 8 * (s % WV)   # k0 + 8 k1 of a thread whose lane bits 5-3 hold s = WV b + k1
+    nv = np.zeros_like(v)                                 # C: register <-> lane bits 5-3 (= h >> 1)
+    for h in range(16):
+        g, h0 = h >> 1, h & 1
+        for s in range(8):
+            nv[:, (s << 1) | h0, g] = v[:, h, s]
+    v = nv
+    for wp in range(WV):
+        for h in range(16):
+            v[wp, h, :] *= tw(2 * np.arange(8) * kk(wp, h >> 1))               # exp(2 pi i g (k0 + 8 k1) / 64 WV)
+    v = v @ W8[+1].T                                      # registers: k2
+    nv = np.zeros_like(v)                                 # register bit 2 <-> lane bit 2 (= h & 1)
+    for h in range(16):
+        s, h0 = h >> 1, h & 1
+        for k2 in range(8):
+            nv[:, (s << 1) | (k2 >> 2), (h0 << 2) | (k2 & 3)] = v[:, h, k2]
+    v = nv
+    kt = lambda wp, h: kk(wp, h >> 1) + 32 * WV * (h & 1)
+    for wp in range(WV):
+        for h in range(16):
+            for r in range(4):
+                a, b_ = v[wp, h, r], v[wp, h, r + 4] * tw(kt(wp, h)) * tw(8 * WV * r)
+                v[wp, h, r], v[wp, h, r + 4] = a + b_, a - b_
+            for r in range(4):
+                for k3 in range(2):
+                    assert abs(v[wp, h, r + 4 * k3] - F[kt(wp, h) + 8 * WV * r + 64 * WV * k3]) <= 1e-9
+            base = np.conj(tw(kt(wp, h), 2 * H))          # the phase, where the elements are
+            for r in range(4):
+                for k3 in range(2):
+                    v[wp, h, r + 4 * k3] *= base * np.exp(-2j * np.pi * r / 32) * (1j if k3 else 1)
+            for r in range(4):                            # inverse, decimation in frequency: radix 2 over k3
+                a, b_ = v[wp, h, r], v[wp, h, r + 4]
+                v[wp, h, r], v[wp, h, r + 4] = a + b_, a - b_
+    nv = np.zeros_like(v)                                 # bit-2 swap back: registers k2, lane bit 2 = h0
+    for h in range(16):
+        s, lb2 = h >> 1, h & 1
+        for R in range(8):
+            nv[:, (s << 1) | (R >> 2), (lb2 << 2) | (R & 3)] = v[:, h, R]
+    v = nv
+    for h in range(16):
+        v[:, h, :] *= np.exp(-2j * np.pi * np.arange(8) * (h & 1) / 16)
+    v = v @ W8[-1].T                                      # registers: g
+    nv = np.zeros_like(v)                                 # C back: lane bits 5-3 = g, registers s = WV b + k1
+    for h in range(16):
+        s, h0 = h >> 1, h & 1
+        for g in range(8):
+            nv[:, (g << 1) | h0, s] = v[:, h, g]
+    v = nv
+    for wp in range(WV):
+        for h in range(16):
+            for b in range(Q):
+                v[wp, h, WV * b:WV * b + WV] *= np.conj(tw(8 * h * np.arange(WV)))       # exp(-2 pi i k1 h / 16 WV)
+                v[wp, h, WV * b:WV * b + WV] = WR[-1] @ v[wp, h, WV * b:WV * b + WV]      # registers: WV b + n_w
+    nv = np.zeros_like(v)                                 # A back: thread wave n_w, register k0 = Q wp + b
+    for wp in range(WV):
+        for b in range(Q):
+            for nw in range(WV):
+                nv[nw, :, Q * wp + b] = v[wp, :, WV * b + nw]
+    v = nv
+    for w in range(WV):
+        for h in range(16):
+            v[w, h, :] *= np.conj(tw((16 * w + h) * np.arange(8)))               # exp(-2 pi i k0 pp / H)
+    v = v @ W8[-1].T
+    for w in range(WV):
+        for h in range(16):
+            assert np.abs(v[w, h, :] - ref[16 * w + h + (H // 8) * np.arange(8)]).max() <= 1e-8

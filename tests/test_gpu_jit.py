@@ -23,6 +23,8 @@ JIT_SIZES = [
     (1600, 900),    # 10*10*16 / 9*10*10 / 16*2*10*10: 5 butterflies of radix 2 per thread
     (896, 504),     # radix 7: 7*8*16 / 7*8*9 / 16*16*7
     (128, 64),      # smallest sizes that are specialised
+    (1200, 512),    # 512 rows: the digit-swap column kernel on four waves (k_col_v<4, 512>)
+    (960, 256),     # 256 rows: ... on two waves
     (2000, 1250),   # no three-stage factorization: N-stage row 8*5*5*10, column 5*5*5*10 on 1024 threads, fused 8*5*10*10
     (486, 294),     # 9*2*3*9 / 7*2*3*7 / 12*9*9
     (640, 3000),    # a column length whose first and last stage need 300 threads: two columns per workgroup (10*3*10*10)

@@ -711,10 +711,10 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             case 2048: SET_FUSED(FusedPlanPow2<2048>, TUNED_TK); break;
             default: SET_FUSED(FusedPlanPow2<4096>, TUNED_TK); break;
             }
-            switch (H) {
-            case 256: SET_LDS((k_col_t<256, TUNED_TK>), P->ldsCol); break;
-            case 512: SET_LDS((k_col_t<512, TUNED_TK>), P->ldsCol); break;
-            default: SET_LDS((k_col_v<TUNED_TK>), 32768); break;
+            switch (H) {                                      // (digit-swap column kernels: 4 KB of LDS per wave)
+            case 256: SET_LDS((k_col_v<TUNED_TK, 256>), 8192); break;
+            case 512: SET_LDS((k_col_v<TUNED_TK, 512>), 16384); break;
+            default: SET_LDS((k_col_v<TUNED_TK, 1024>), 32768); break;
             }
         }
 #undef SET_FUSED
@@ -736,7 +736,7 @@ int fftup_plan_describe(const fftup_plan* P, char* buf, size_t buflen)
     std::string s;
     if (P->mixed == 3) s = "specialised at plan time: " + fftup_jit::describe(P->jit->choice);
     else if (P->tuned) s = "ahead-of-time power-of-two kernels (radix 8, 8 points per thread; fused C2R+sharpen " + std::string(P->fused ? "on" : "off") + ")"
-                           + (P->H == 1024 ? "; column kernel with digit-swap exchanges" : "");
+                           + "; column kernel with digit-swap exchanges";
     else if (P->mixed) s = std::string("ahead-of-time mixed-radix kernels: ") + (P->mixed == 1 ? "row 15*8*16, col 9*10*12, fused 16*16*15" : "row 5*16*16, col 9*8*10, fused 16*16*10");
     else if (P->cplx) s = "size-generic kernels, non-R2C path (full complex transforms)";
     else s = std::string("size-generic kernels (LDS ping-pong, run-time radix lists)") + (P->dbl ? ", double" : "");
@@ -883,11 +883,6 @@ template <int W> static void launch_r2c_t(fftup_plan* P, const RowR2CTParams& p,
     default: hipLaunchKernelGGL((k_row_r2c_t<W, IN_U8_F16, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
     }
 }
-template <int H> static void launch_col_t(fftup_plan* P, const ColTParams& p)
-{
-    dim3 grid(P->NT, 3), block(TUNED_TK * H / 8);
-    hipLaunchKernelGGL((k_col_t<H, TUNED_TK>), grid, block, P->ldsCol, P->lanes[P->cur].stream, p);
-}
 template <int UW> static void launch_c2r_t(fftup_plan* P, const RowC2RTParams& p)
 {
     dim3 grid(P->uH / 2, 3), block(UW / 8);
@@ -946,9 +941,9 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
         ColTParams p{};
         p.S1 = P->lanes[P->cur].S1; p.S2 = P->lanes[P->cur].S2; p.twH = P->twH; p.twUH = P->twUH; p.W = (int)P->W; p.NT = P->NT;
         switch (P->H) {
-        case 256: launch_col_t<256>(P, p); break;
-        case 512: launch_col_t<512>(P, p); break;
-        default: hipLaunchKernelGGL((k_col_v<TUNED_TK>), dim3(P->NT, 3), dim3(512), 32768, P->lanes[P->cur].stream, p); break;
+        case 256: hipLaunchKernelGGL((k_col_v<TUNED_TK, 256>), dim3(P->NT, 3), dim3(128), 8192, P->lanes[P->cur].stream, p); break;
+        case 512: hipLaunchKernelGGL((k_col_v<TUNED_TK, 512>), dim3(P->NT, 3), dim3(256), 16384, P->lanes[P->cur].stream, p); break;
+        default: hipLaunchKernelGGL((k_col_v<TUNED_TK, 1024>), dim3(P->NT, 3), dim3(512), 32768, P->lanes[P->cur].stream, p); break;
         }
     }
     if ((which < 0 || which == 2) && P->fused) {

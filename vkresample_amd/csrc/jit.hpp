@@ -587,7 +587,7 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT], int 
             names[K_ROW_PLANAR] = k + "<fftup::JitCfg, " + fm + ">";
             names[K_ROW_U8] = k + "<fftup::JitCfg, " + um + ">";
         }
-        names[K_COL] = c.col_kind == 5 ? "fftup::k_col_pad<fftup::JitCfg>" : c.col_kind == 0 ? (c.H == 1024 ? std::string("fftup::k_col_v<4>") : "fftup::k_col_t<" + H + ", 4>") :      // (H = 1024: the digit-swap column kernel, kernels_dswap.hpp)
+        names[K_COL] = c.col_kind == 5 ? "fftup::k_col_pad<fftup::JitCfg>" : c.col_kind == 0 ? ((c.H == 1024 || c.H == 512 || c.H == 256) ? "fftup::k_col_v<4, " + H + ">" : "fftup::k_col_t<" + H + ", 4>") :      // (H = 256, 512, 1024: the digit-swap column kernel, kernels_dswap.hpp)
                         c.col_kind == 3 ? "fftup::k_col_n<fftup::JitCfg>" :
                        c.col_kind == 4 ? "fftup::k_col_u<fftup::JitCfg, " + std::to_string(c.U) + ">" : "fftup::k_col_m<fftup::JitCfg>";
         return s;
@@ -615,7 +615,7 @@ static std::string describe(const Choice& c)
     auto star = [](const std::vector<int>& v) { std::string t; for (size_t i = 0; i < v.size(); i++) t += (i ? "*" : "") + std::to_string(v[i]); return t; };
     s += c.row_kind == 2 ? "generic" : c.row_kind == 0 ? "pow2/8" : c.row_kind == 3 ? star(c.rn) : std::to_string(c.rr[0]) + "*" + std::to_string(c.rr[1]) + "*" + std::to_string(c.rr[2]);
     s += " x" + std::to_string(c.row_block) + ", col ";
-    s += c.col_kind == 0 ? (c.H == 1024 ? "pow2/8 digit-swap" : "pow2/8") : c.col_kind == 5 ? star(c.cn) + " -> " + star(c.ci) : c.col_kind >= 3 ? star(c.cn) : std::to_string(c.cr[0]) + "*" + std::to_string(c.cr[1]) + "*" + std::to_string(c.cr[2]);
+    s += c.col_kind == 0 ? ((c.H == 1024 || c.H == 512 || c.H == 256) ? "pow2/8 digit-swap" : "pow2/8") : c.col_kind == 5 ? star(c.cn) + " -> " + star(c.ci) : c.col_kind >= 3 ? star(c.cn) : std::to_string(c.cr[0]) + "*" + std::to_string(c.cr[1]) + "*" + std::to_string(c.cr[2]);
     s += " x" + std::to_string(c.col_block) + (c.col_kind >= 3 && c.col_cols == 2 ? " (2 columns)" : "") + ", fused ";
     if (c.fused_kind == 0) s += "pow2/8";
     else if (c.fused_kind == 1) s += "16*16*" + std::to_string(c.UW / 256);

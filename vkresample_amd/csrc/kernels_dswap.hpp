@@ -131,14 +131,56 @@ __device__ __forceinline__ void wave_exchange(float2 (&v)[8], unsigned zbase, un
     for (int i = 0; i < 8; i += 2) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i + 1].x), "+v"(v[i + 1].y));
 }
 
+// registers <-> wave for WV < 8 waves (H = 512, 256): the wave digit has WV values against 8 registers, so a thread comes out of
+// the exchange with the WV values of the wave digit x Q = 8 / WV of the eight first-stage outputs: element (k0, wave n_w, lane)
+// at (k0 * WV + n_w) * 64 + lane; thread of wave w' reads register m = WV b + n_w from (8 w' + m) * 64 + lane, i.e. k0 = Q w' + b.
+// FWD: registers k0 -> registers WV b + n_w; !FWD: the way back.  One barrier inside; the buffer must be free on entry.
+template <int WV, bool FWD>
+__device__ __forceinline__ void wave_exchange_q(float2 (&v)[8], unsigned zbase, unsigned w, unsigned l)
+{
+    const unsigned a_k0 = zbase + 8u * (w * 64u + l);         // + 512 WV k0: element (k0, wave w)
+    const unsigned a_m = zbase + 8u * (w * 512u + l);         // + 512 m:     register m of wave w
+#pragma unroll
+    for (int k = 0; k < 8; k++) { lds_f2raw r = {v[k].x, v[k].y}; *(lds_f2*)(size_t)((FWD ? a_k0 + 512u * WV * k : a_m + 512u * k)) = r; }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 8; m++) { const lds_f2raw r = *(const lds_f2*)(size_t)((FWD ? a_m + 512u * m : a_k0 + 512u * WV * m)); v[m] = make_float2(r.x, r.y); }
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i + 1].x), "+v"(v[i + 1].y));
+}
+// Q butterflies of radix WV on registers WV b .. WV b + WV - 1
+template <int WV, int DIR> __device__ __forceinline__ void bfly_groups(float2 (&v)[8])
+{
+    if constexpr (WV == 8) bfly8_pk<DIR>(v);
+    else if constexpr (WV == 4) {
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            pk2 a0 = {v[4 * b].x, v[4 * b].y}, a1 = {v[4 * b + 1].x, v[4 * b + 1].y}, a2 = {v[4 * b + 2].x, v[4 * b + 2].y}, a3 = {v[4 * b + 3].x, v[4 * b + 3].y};
+            bfly4_pk<DIR>(a0, a1, a2, a3);
+            v[4 * b] = make_float2(a0.x, a0.y); v[4 * b + 1] = make_float2(a1.x, a1.y);
+            v[4 * b + 2] = make_float2(a2.x, a2.y); v[4 * b + 3] = make_float2(a3.x, a3.y);
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const pk2 a = {v[2 * b].x, v[2 * b].y}, c = {v[2 * b + 1].x, v[2 * b + 1].y};
+            const pk2 s0 = pk_add(a, c), s1 = pk_sub(a, c);
+            v[2 * b] = make_float2(s0.x, s0.y); v[2 * b + 1] = make_float2(s1.x, s1.y);
+        }
+    }
+}
+
 // grid (NT, 3), one column tile per workgroup: all 771 workgroups of a 2048x1024 frame are resident at once.  (Round 4 measured one
 // workgroup per tile column running the three planes' tiles one after the other, the next tile's loads issued before this tile's
 // transform: 19.9 instead of 14.6 us -- two waves per SIMD do not hide their own latencies; profiles/r04_g_column_pipelined.txt.)
-template <int TK>
-__global__ void __launch_bounds__(512, FFTUP_COL_WAVES) k_col_v(ColTParams p)
+// H = 128 WV rows on 64 WV threads, WV = 8, 4, 2 waves (H = 1024, 512, 256): n = (H/8) r + 16 w + 2 g + h0 -- registers r, wave w, lane
+// bits 5-3 g, lane bit 2 h0 (lane bits 1-0: the tile's column) -- and k = k0 + 8 k1 + 8 WV k2 + 64 WV k3 (k1: WV values).
+template <int TK, int H = 1024>
+__global__ void __launch_bounds__(H / 2, FFTUP_COL_WAVES) k_col_v(ColTParams p)
 {
-    static_assert(TK == 4, "four columns of 128 threads: lane bits 0-1 = column, bits 2-5 and the wave = pp");
-    constexpr int H = 1024;
+    static_assert(TK == 4, "four columns of H/8 threads: lane bits 0-1 = column, bits 2-5 and the wave = pp");
+    static_assert(H == 1024 || H == 512 || H == 256, "8, 4 or 2 waves");
+    constexpr int WV = H / 128, Q = 8 / WV, T = 64 * WV;
     extern __shared__ __attribute__((aligned(128))) char smem[];
     const unsigned zbase = lds_addr(smem);
     const int tid = threadIdx.x;
@@ -148,27 +190,33 @@ __global__ void __launch_bounds__(512, FFTUP_COL_WAVES) k_col_v(ColTParams p)
     const bool valid = tile * TK + col <= p.W / 2;
     const float2* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
     const int wu = __builtin_amdgcn_readfirstlane((int)w);
-    const int k1 = (int)(l >> 3), lb2 = (int)((l >> 2) & 1u), hh = (int)(l >> 2);
-    const int kt = wu + 8 * k1 + 256 * lb2;                   // the thread's part of k after the forward transform
+    const int s1 = (int)(l >> 3), lb2 = (int)((l >> 2) & 1u), hh = (int)(l >> 2);
+    const int kk = Q * wu + s1 / WV + 8 * (s1 % WV);          // k0 + 8 k1 of the thread once lane bits 5-3 hold s = WV b + k1
+    const int kt = kk + 32 * WV * lb2;                        // the thread's part of k after the forward transform
     float2 v[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = valid ? src[tid + 512 * i] : make_float2(0.f, 0.f);      // row pp + 128 i
+    for (int i = 0; i < 8; i++) v[i] = valid ? src[tid + T * i] : make_float2(0.f, 0.f);        // row pp + (H/8) i
     // ---- forward, exp(+2 pi i n k / H), decimation in time
-    float2 ta[7];
+    float2 ta[Q][WV - 1];                                     // exp(2 pi i n_w k0 / 8 WV), k0 = Q wave + b: wave-uniform, scalar registers
 #pragma unroll
-    for (int m = 1; m < 8; m++) ta[m - 1] = p.twH[(16 * m * wu) & (H - 1)];                     // wave-uniform: scalar registers
-    const float2 tb = p.twH[2 * (wu + 8 * k1)], tc = p.twH[kt];
+    for (int b = 0; b < Q; b++)
+#pragma unroll
+        for (int m = 1; m < WV; m++) ta[b][m - 1] = p.twH[(16 * m * (Q * wu + b)) & (H - 1)];
+    const float2 tb = p.twH[2 * kk], tc = p.twH[kt];
     const float2 tph = twid<-1>(p.twUH[kt]);                                                   // exp(-2 pi i kt / 2H)
     bfly8_pk<+1>(v);
-    wave_exchange(v, zbase, w, l);
+    if constexpr (WV == 8) wave_exchange(v, zbase, w, l);
+    else wave_exchange_q<WV, true>(v, zbase, w, l);
 #pragma unroll
-    for (int m = 1; m < 8; m++) v[m] = cmul_tw_s(v[m], ta[m - 1]);
-    bfly8_pk<+1>(v);
+    for (int b = 0; b < Q; b++)
+#pragma unroll
+        for (int m = 1; m < WV; m++) v[WV * b + m] = cmul_tw_s(v[WV * b + m], ta[b][m - 1]);
+    bfly_groups<WV, +1>(v);
     lane_transpose_hi3(v);
     twiddle_powers<8>(v, tb);
     bfly8_pk<+1>(v);
     lane_swap_bit2(v);
-    {   // radix 2 over the bit that came out of the lane: twiddle exp(2 pi i (kt + 64 r) / H) on the upper element
+    {   // radix 2 over the bit that came out of the lane: twiddle exp(2 pi i (kt + 8 WV r) / H) on the upper element
         v[4] = cmul_tw(v[4], tc);
         v[5] = cmul_tw(v[5], cmul_tw(tc, rot16<1>()));
         v[6] = cmul_tw(v[6], cmul_tw(tc, rot16<2>()));
@@ -176,11 +224,11 @@ __global__ void __launch_bounds__(512, FFTUP_COL_WAVES) k_col_v(ColTParams p)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const pk2 a = {v[r].x, v[r].y}, b = {v[r + 4].x, v[r + 4].y};
-            const pk2 s0 = pk_add(a, b), s1 = pk_sub(a, b);
-            v[r] = make_float2(s0.x, s0.y); v[r + 4] = make_float2(s1.x, s1.y);
+            const pk2 s0 = pk_add(a, b), s1_ = pk_sub(a, b);
+            v[r] = make_float2(s0.x, s0.y); v[r + 4] = make_float2(s1_.x, s1_.y);
         }
     }
-    // ---- phase: register r + 4 k3 holds F[k], k = kt + 64 r + 512 k3;  t[k] = exp(-2 pi i k / 2H) * (k < H/2 ? 1 : -1),
+    // ---- phase: register r + 4 k3 holds F[k], k = kt + 8 WV r + 64 WV k3;  t[k] = exp(-2 pi i k / 2H) * (k < H/2 ? 1 : -1),
     // i.e. exp(-2 pi i kt / 2H) * exp(-2 pi i r / 32) * (k3 ? +i : 1)
     {
         const float2 t1 = cmul_tw(tph, twid<-1>(rot32<1>())), t2 = cmul_tw(tph, twid<-1>(rot32<2>())), t3 = cmul_tw(tph, twid<-1>(rot32<3>()));
@@ -197,8 +245,8 @@ __global__ void __launch_bounds__(512, FFTUP_COL_WAVES) k_col_v(ColTParams p)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const pk2 a = {v[r].x, v[r].y}, b = {v[r + 4].x, v[r + 4].y};
-        const pk2 s0 = pk_add(a, b), s1 = pk_sub(a, b);
-        v[r] = make_float2(s0.x, s0.y); v[r + 4] = make_float2(s1.x, s1.y);
+        const pk2 s0 = pk_add(a, b), s1_ = pk_sub(a, b);
+        v[r] = make_float2(s0.x, s0.y); v[r + 4] = make_float2(s1_.x, s1_.y);
     }
     lane_swap_bit2(v);                                       // lane bit 2 = h0 now, registers = k2
     {
@@ -207,18 +255,26 @@ __global__ void __launch_bounds__(512, FFTUP_COL_WAVES) k_col_v(ColTParams p)
         twiddle_powers<8>(v, base);
     }
     bfly8_pk<-1>(v);
-    lane_transpose_hi3(v);                                   // lane bits 5-3 = g, registers = k1
-    twiddle_powers<8>(v, twid<-1>(p.twH[8 * hh]));           // exp(-2 pi i k1 h / 128)
-    bfly8_pk<-1>(v);
+    lane_transpose_hi3(v);                                   // lane bits 5-3 = g, registers = WV b + k1
+    {
+        const float2 w1 = twid<-1>(p.twH[8 * hh]);           // exp(-2 pi i k1 h / 16 WV)
+        if constexpr (WV == 8) twiddle_powers<8>(v, w1);
+        else {
+#pragma unroll
+            for (int b = 0; b < Q; b++) twiddle_powers<WV>(&v[WV * b], w1);
+        }
+    }
+    bfly_groups<WV, -1>(v);                                  // registers = WV b + n_w
     __syncthreads();                                         // everybody has read the forward exchange
-    wave_exchange(v, zbase, w, l);                           // wave = 16s digit of pp, registers = k0
+    if constexpr (WV == 8) wave_exchange(v, zbase, w, l);    // wave = 16s digit of pp, registers = k0
+    else wave_exchange_q<WV, false>(v, zbase, w, l);
     twiddle_powers<8>(v, twid<-1>(p.twH[pp]));               // exp(-2 pi i k0 pp / H)
     bfly8_pk<-1>(v);
     float2* dst = p.S2 + ((long)c * p.NT + tile) * H * TK;
     constexpr float inv = 1.0f / (float)H;
     if (valid) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) dst[tid + 512 * i] = cscale(v[i], inv);
+        for (int i = 0; i < 8; i++) dst[tid + T * i] = cscale(v[i], inv);
     }
 }
 
