@@ -206,7 +206,8 @@ def test_jit_check_compiles_without_a_device(tmp_path, monkeypatch):
     lib = _lib.load()
     buf = C.create_string_buffer(256)
     cases = [(640, 480, 0, "fused 8*10*16"),          # (the built-in wisdom table's pick for rows of 1280; the chooser's is 16*16*5)
-             (896, 504, 0, "fused 16*16*7"), (1000, 1000, 2, "fused 8*5*5*10"), (1024, 768, 0, "row pow2/8")]
+             (896, 504, 0, "fused 16*16*7"), (1000, 1000, 2, "fused 8*5*5*10"), (1024, 768, 0, "row pow2/8"),
+             (1200, 512, 0, "col pow2/8 digit-swap x256")]     # (k_col_v<4, 512>: kernels_dswap.hpp, the fifth embedded header)
     for (W, H, p, expect) in cases:
         rc = lib.fftup_jit_check(W, H, 2, p, None, buf, 256)
         assert rc == 0, lib.fftup_last_error().decode()
