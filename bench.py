@@ -194,8 +194,8 @@ def other_configs(v, synth, dev, traffic_json, n_cu, ring=8):
                          "ms_per_frame": t, "frames_per_s": 1e3 / t,
                          "frame_frac": up.alg_bytes_per_frame / (t * 1e-3) / 8e12,
                          "kernel_ms": dict(zip(up.kernel_names, iso)),
-                         "kernel_frac": up.kernel_alg_bytes[dom] / (iso[dom] * 1e-3) / 8e12,
-                         "kernel_frac_real_bytes": up.kernel_min_bytes[dom] / (iso[dom] * 1e-3) / 8e12,
+                         "kernel_frac": up.kernel_alg_bytes[dom] / (max(iso[dom], 1e-6) * 1e-3) / 8e12,
+                         "kernel_frac_real_bytes": up.kernel_min_bytes[dom] / (max(iso[dom], 1e-6) * 1e-3) / 8e12,
                          "B_min": b_min, "b_min_frac": b_min / (t * 1e-3) / 8e12,
                          "frame_hbm_bytes_measured": frame_hbm, "traffic_source": tsrc,
                          "real_traffic_frac": (frame_hbm / (t * 1e-3) / 8e12) if frame_hbm else None,
@@ -504,8 +504,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": up.kernel_names[dom], "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": tsrc,
                          # the same kernel priced by the bytes it really has to move (a fused launch never writes R)
-                         "achieved_real_bytes": up.kernel_min_bytes[dom] / (iso[dom] * 1e-3) / 1e9,
-                         "frac_real_bytes": up.kernel_min_bytes[dom] / (iso[dom] * 1e-3) / 8e12,
+                         "achieved_real_bytes": up.kernel_min_bytes[dom] / (max(iso[dom], 1e-6) * 1e-3) / 1e9,
+                         "frac_real_bytes": up.kernel_min_bytes[dom] / (max(iso[dom], 1e-6) * 1e-3) / 8e12,
                          "achieved_overlapped": achieved_ovl,
                          "frame_achieved": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 1e9,      # per GPU
                          "frame_frac": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 8e12},
