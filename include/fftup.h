@@ -194,7 +194,11 @@ FFTUP_API int fftup_output_checksum(fftup_plan* plan, uint32_t slot, uint64_t* s
  * its neighbours (each frame runs start to end on one of the plan's streams, consecutive frames on different ones).  A submit that finds its ring slot
  * still busy first waits for that slot's frame.  fftup_wait(ticket) returns when rgb_out of that submission is
  * complete; fftup_drain waits for everything submitted.  For the copies to be asynchronous both host buffers
- * must be page-locked: allocate them with fftup_host_alloc (pageable memory works, the copies then block). */
+ * must be page-locked: allocate them with fftup_host_alloc (pageable memory works, the copies then block).
+ * Threads: fftup_submit_rgb8 / fftup_wait / fftup_drain of ONE plan may be called from several host threads at once (a
+ * pool of PNG decode/encode workers feeding one plan per GPU -- plan creation is serialised by the HIP runtime, ~20 ms per
+ * plan, so sixty-four plans of sixty-four threads cost seconds where one shared plan costs none); tickets are global to the plan.
+ * Every other entry point needs one thread per plan at a time, as in the reference (one application per host thread). */
 FFTUP_API void* fftup_host_alloc(size_t bytes);      /* NULL on failure (fftup_last_error) */
 FFTUP_API void fftup_host_free(void* ptr);
 FFTUP_API int fftup_submit_rgb8(fftup_plan* plan, const uint8_t* rgb_in, size_t in_stride_bytes, uint8_t* rgb_out,

@@ -86,6 +86,17 @@ def test_png_encode_roundtrip_through_stb_and_variants(tmp_path):
     back, ch = _stb_load(ref, str(out))
     assert ch == 3 and np.array_equal(back, img)
     assert np.array_equal(np.asarray(Image.open(out).convert("RGB")), img)
+    # a smooth image of several deflate blocks (the encoder's Huffman-only stream) and a flat one (its zlib path), read back by stb
+    yy, xx = np.mgrid[0:320, 0:480]
+    big = np.clip(np.stack([128 + 100 * np.sin(xx / 31.0 + yy / 77.0), 128 + 90 * np.cos(xx / 59.0), 30 + 0.4 * yy + 0.2 * xx], axis=2)
+                  + rng.normal(0, 2, (320, 480, 3)), 0, 255).astype(np.uint8)
+    flat = np.full((64, 96, 3), 17, np.uint8)
+    for name, im in (("big", big), ("flat", flat)):
+        im.tofile(tmp_path / (name + ".rgb"))
+        subprocess.check_call([tool, "enc", str(tmp_path / (name + ".rgb")), str(tmp_path / (name + ".png")), str(im.shape[1]), str(im.shape[0])])
+        back, ch = _stb_load(ref, str(tmp_path / (name + ".png")))
+        assert ch == 3 and np.array_equal(back, im), name
+        assert np.array_equal(np.asarray(Image.open(tmp_path / (name + ".png")).convert("RGB")), im), name
     # decoder: other colour types / bit depths / interlacing written by PIL, checked against stb
     base = Image.fromarray(img)
     variants = {"rgba.png": base.convert("RGBA"), "gray.png": base.convert("L"), "pal.png": base.convert("P"),

@@ -118,6 +118,33 @@ def test_cli_batched_work_queue(tmp_path, threads, extra):
         assert d.max() <= 1 and (d != 0).mean() <= 5e-3
 
 
+def test_cli_batched_threads_share_the_plan_of_their_size(tmp_path):
+    """Batched threads of one GPU share one plan per image size (the reference: one application per thread, sized by the
+    thread's first file): stripe of two threads over files of two sizes -- thread 0 gets the 128x64 files 1, 3, 5, 7, thread 1 the
+    64x32 files 2, 4, 6 -- and four threads over eight files of one size; every output against the oracle."""
+    from vkresample_amd import synth
+    for d in ("inp", "outp", "in8", "out8"):
+        os.makedirs(tmp_path / d)
+    frames = [synth.frame(80 + k, *((128, 64) if k % 2 == 0 else (64, 32)), "N") for k in range(7)]
+    for k, f in enumerate(frames):
+        _png_write(tmp_path / "inp" / ("%06d.png" % (k + 1)), f)
+    r = subprocess.run([CLI, "-ifolder", "inp", "-ofolder", "outp", "-numfiles", "7", "-numthreads", "2", "-u", "2", "-p", "0"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and r.stdout.count("finished.") == 2, r.stdout + r.stderr
+    same = [synth.frame(90 + k, 128, 64, "N") for k in range(8)]
+    for k, f in enumerate(same):
+        _png_write(tmp_path / "in8" / ("%06d.png" % (k + 1)), f)
+    r = subprocess.run([CLI, "-ifolder", "in8", "-ofolder", "out8", "-numfiles", "8", "-numthreads", "4", "-u", "2", "-p", "0"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and r.stdout.count("finished.") == 4, r.stdout + r.stderr
+    for folder, fr in (("outp", frames), ("out8", same)):
+        for k, f in enumerate(fr):
+            a = _png_read(tmp_path / folder / ("%06d.png" % (k + 1)))
+            _, _, ou8 = O.upscale_rgb8(f, 2.0, 0, 0.2)
+            d = np.abs(a[:-1].astype(int) - ou8[:-1].astype(int))
+            assert a.shape == ou8.shape and d.max() <= 1 and (d != 0).mean() <= 5e-3, (folder, k)
+
+
 def test_cli_batched_queue_one_thread_and_missing_file(tmp_path):
     """one thread, 7 files: the double-buffered queue (fftup_submit_rgb8) writes every frame; -n 3 takes the
     blocking path with identical files; a missing file ends the thread like the reference (VR:1631-1634)."""

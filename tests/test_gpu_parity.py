@@ -626,6 +626,57 @@ def test_host_streamed_queue_equals_blocking_calls(W, H, precision, flags, ring,
             pin_out.close()
 
 
+@pytest.mark.parametrize("W,H,precision,flags,ring", [(256, 128, 0, 0, 4), (512, 256, 2, 6, 16), (240, 126, 0, 0, 2)])
+def test_one_plan_fed_by_several_host_threads(W, H, precision, flags, ring):
+    """fftup_submit_rgb8 / fftup_wait of ONE plan from several host threads at once (the batched CLI: codec workers sharing the
+    GPU's plan): six threads, each double-buffered over its own page-locked buffers like the CLI's loop, 7 frames each -- every
+    frame comes back byte-identical to the blocking calls, tickets are issued exactly once."""
+    import threading
+    import vkresample_amd as v
+    from vkresample_amd import synth
+    T, per = 6, 7
+    frames = [synth.frame(300 + k, W, H, "N" if k % 3 else "U") for k in range(T * per)]
+    with _up(W, H, 2.0, precision, flags=flags, ring=ring) as up:
+        want = []
+        for f in frames:
+            up.upload_rgb8(f)
+            up.execute(1)
+            want.append(up.download_rgb8())
+        got = [None] * len(frames)
+        tickets = [[] for _ in range(T)]
+        errors = []
+
+        def worker(t):
+            try:
+                pin, pout = v.PinnedArray((2, H, W, 3)), v.PinnedArray((2, 2 * H, 2 * W, 3))
+                tk = [None, None]
+                mine = list(range(t, T * per, T))                  # the stripe f*T + t
+                for i, g in enumerate(mine):
+                    pin.array[i & 1] = frames[g]
+                    tk[i & 1] = up.submit_rgb8(pin.array[i & 1], pout.array[i & 1])
+                    tickets[t].append(tk[i & 1])
+                    if i > 0:
+                        up.wait(tk[(i - 1) & 1])
+                        got[mine[i - 1]] = pout.array[(i - 1) & 1].copy()
+                up.wait(tk[(len(mine) - 1) & 1])
+                got[mine[-1]] = pout.array[(len(mine) - 1) & 1].copy()
+                pin.close()
+                pout.close()
+            except Exception as e:                                 # noqa: BLE001 (reported by the main thread)
+                errors.append((t, repr(e)))
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errors, errors
+        assert sorted(sum(tickets, [])) == list(range(T * per))
+        for k in range(len(frames)):
+            assert np.array_equal(got[k], want[k]), k
+        up.drain()
+
+
 @pytest.mark.parametrize("W,H,u", [(16, 8, 2.0), (60, 42, 2.0), (24, 16, 3.0), (16, 8, 1.5), (256, 128, 2.0),
                                    (240, 270, 2.0), (1024, 512, 2.0), (2048, 64, 2.0)])
 @pytest.mark.parametrize("dist", ["U", "N"])

@@ -82,13 +82,31 @@ def test_png_roundtrip_under_asan_ubsan(png_driver, tmp_path):
     for name, (w, h) in {"a": (1, 1), "b": (2, 5), "c": (67, 33)}.items():
         Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(tmp_path / (name + ".png"))
     Image.fromarray(rng.integers(0, 256, (13, 17, 4), dtype=np.uint8)).save(tmp_path / "d.png")
-    files = [str(tmp_path / (n + ".png")) for n in "abcd"]
+    # the encoder's two paths: smooth content over several 256 KB blocks (Huffman-only deflate), flat content (zlib run lengths)
+    yy, xx = np.mgrid[0:300, 0:500]
+    smooth = np.stack([128 + 100 * np.sin(xx / 37.0 + yy / 91.0), 128 + 90 * np.cos(xx / 53.0), 40 + 0.3 * yy + 0.1 * xx], axis=2)
+    Image.fromarray(np.clip(smooth + rng.normal(0, 2, smooth.shape), 0, 255).astype(np.uint8)).save(tmp_path / "e.png")
+    flat = np.full((90, 120, 3), 200, np.uint8)
+    flat[20:40, 30:60] = (10, 250, 0)
+    Image.fromarray(flat).save(tmp_path / "f.png")
+    Image.fromarray((rng.integers(0, 2, (64, 80, 3)) * 255).astype(np.uint8)).save(tmp_path / "g.png")
+    files = [str(tmp_path / (n + ".png")) for n in "abcdefg"]
     r = subprocess.run([png_driver] + files, capture_output=True, text=True, env=ENV)
-    assert r.returncode == 0 and r.stdout.count(" ok") == 4, r.stdout + r.stderr[-3000:]
+    assert r.returncode == 0 and r.stdout.count(" ok") == 7, r.stdout + r.stderr[-3000:]
     for f in files:
         a = np.asarray(Image.open(f).convert("RGB"))
         b = np.asarray(Image.open(f + ".out.png"))
         assert np.array_equal(a, b)
+
+
+def test_png_encoder_huffman_deflate_under_asan_ubsan(tmp_path):
+    """The encoder's own deflate (Huffman-only dynamic blocks): code lengths complete and within 15 / 7 bits for Fibonacci
+    frequencies (trees deeper than the limit), single symbols and 3000 random sets; streams of flat, uniform, geometric and
+    Fibonacci-distributed bytes and of lengths around the 256 KB block size inflate (zlib) to the input."""
+    exe = str(tmp_path / "huffman_driver")
+    subprocess.check_call(["g++", "-std=c++17"] + SAN + [os.path.join(ROOT, "tests", "sanitize", "huffman_driver.cpp"), "-o", exe, "-lz"])
+    r = subprocess.run([exe], capture_output=True, text=True, env=ENV)
+    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout + r.stderr[-3000:]
 
 
 def test_oracle_under_asan_ubsan(tmp_path):

@@ -7,6 +7,7 @@ file I/O) is timed alone with one thread for scale.
 """
 import argparse
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -66,12 +67,18 @@ def main():
             cli_s = float(tot[0].split()[2]) if tot else float("nan")
             ok = "" if (r.returncode == 0 and n_out == files) else "  FAILED rc %d, %d outputs" % (r.returncode, n_out)
             say("%-44s %8.2f %8.2f %10.1f %12.1f%s" % (label, wall, cli_s, files / wall, wall / files * 1e3, ok))
+            st = [re.findall(r"([a-z+]+) (\d+)", l.split(":", 2)[2]) for l in r.stdout.splitlines() if l.startswith("Thread") and " files in " in l]
+            if st:                                       # -stagetimes: mean over the threads, ms per thread
+                keys = [k for k, _ in st[0]]
+                mean = {k: np.mean([float(dict(x)[k]) for x in st]) for k in keys}
+                nf = np.mean([float(l.split(":")[1].split()[0]) for l in r.stdout.splitlines() if l.startswith("Thread") and " files in " in l])
+                say("    per thread (mean of %d, %.1f files each), ms: " % (len(st), nf) + ", ".join("%s %.0f" % (k, mean[k]) for k in keys))
             return wall
 
         threads = [int(t) for t in a.threads.split(",")]
         run("warm-up (first plan of the process image)", ["-p", "0", "-workqueue"], 4, files=8)
         for T in threads:
-            run("-p 0 -numthreads %d -workqueue" % T, ["-p", "0", "-workqueue"], T)
+            run("-p 0 -numthreads %d -workqueue" % T, ["-p", "0", "-workqueue", "-stagetimes"], T)
         mid = threads[len(threads) // 2 + 1] if len(threads) > 2 else threads[-1]
         run("-p 0 -numthreads %d (the reference's stripe)" % mid, ["-p", "0"], mid)
         for T in (mid, threads[-1]):

@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 
@@ -20,28 +21,37 @@ int paeth(int a, int b, int c)
     return pb <= pc ? b : c;
 }
 
-// undo the per-row filters of one (sub)image; in: h rows of (1 + rowbytes); out: h rows of rowbytes
+// undo the per-row filters of one (sub)image; in: h rows of (1 + rowbytes); out: h rows of rowbytes.  One loop per row and
+// filter type (the first bpp bytes have no left neighbour).
 bool unfilter(const uint8_t* in, uint8_t* out, int h, size_t rowbytes, int bpp)
 {
+    const size_t bp = (size_t)bpp < rowbytes ? (size_t)bpp : rowbytes;
     for (int y = 0; y < h; y++) {
         const uint8_t ft = in[(size_t)y * (rowbytes + 1)];
         const uint8_t* src = in + (size_t)y * (rowbytes + 1) + 1;
         uint8_t* cur = out + (size_t)y * rowbytes;
         const uint8_t* up = y ? cur - rowbytes : nullptr;
-        for (size_t i = 0; i < rowbytes; i++) {
-            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0;
-            const int b = up ? up[i] : 0;
-            const int c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
-            int v = src[i];
-            switch (ft) {
-            case 0: break;
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) >> 1; break;
-            case 4: v += paeth(a, b, c); break;
-            default: return false;
-            }
-            cur[i] = (uint8_t)v;
+        switch (ft) {
+        case 0: memcpy(cur, src, rowbytes); break;
+        case 1:
+            for (size_t i = 0; i < bp; i++) cur[i] = src[i];
+            for (size_t i = bp; i < rowbytes; i++) cur[i] = (uint8_t)(src[i] + cur[i - bp]);
+            break;
+        case 2:
+            if (!up) memcpy(cur, src, rowbytes);
+            else for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(src[i] + up[i]);
+            break;
+        case 3:
+            for (size_t i = 0; i < bp; i++) cur[i] = (uint8_t)(src[i] + ((up ? up[i] : 0) >> 1));
+            if (up) for (size_t i = bp; i < rowbytes; i++) cur[i] = (uint8_t)(src[i] + ((cur[i - bp] + up[i]) >> 1));
+            else for (size_t i = bp; i < rowbytes; i++) cur[i] = (uint8_t)(src[i] + (cur[i - bp] >> 1));
+            break;
+        case 4:
+            for (size_t i = 0; i < bp; i++) cur[i] = (uint8_t)(src[i] + (up ? up[i] : 0));             // paeth(0, b, 0) = b
+            if (up) for (size_t i = bp; i < rowbytes; i++) cur[i] = (uint8_t)(src[i] + paeth(cur[i - bp], up[i], up[i - bp]));
+            else for (size_t i = bp; i < rowbytes; i++) cur[i] = (uint8_t)(src[i] + cur[i - bp]);         // paeth(a, 0, 0) = a
+            break;
+        default: return false;
         }
     }
     return true;
@@ -79,6 +89,16 @@ void emit_pixel(const Header& hd, const uint8_t* row, int x, const uint8_t* pal,
     }
 }
 
+// per-thread work buffers, kept between files: a batch thread en/decodes hundreds of equal-sized images, and fresh 25 MB
+// vectors per file mean an mmap, 6000 page faults and a munmap each -- with dozens of codec threads in one process those
+// serialise on the address-space lock (64 threads: 514 ms per encode instead of 185, profiles/r04_zl_cli_batch.txt)
+struct Scratch { std::vector<uint8_t> file, idat, raw, img, comp; };
+Scratch& scratch()
+{
+    static thread_local Scratch s;
+    return s;
+}
+
 }  // namespace
 
 bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& width, int& height, int& channels_in_file,
@@ -86,16 +106,24 @@ bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& width, i
 {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) { err = "cannot open " + path; return false; }
-    std::vector<uint8_t> file;
-    uint8_t tmp[65536];
-    size_t n;
-    while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) file.insert(file.end(), tmp, tmp + n);
+    std::vector<uint8_t>& file = scratch().file;
+    file.clear();
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long sz = ftell(f);
+        rewind(f);
+        if (sz > 0) {
+            try { file.resize((size_t)sz); } catch (const std::bad_alloc&) { fclose(f); err = "image too large"; return false; }
+            file.resize(fread(file.data(), 1, (size_t)sz, f));
+        }
+    }
     fclose(f);
     static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     if (file.size() < 8 || memcmp(file.data(), sig, 8)) { err = "not a PNG file"; return false; }
     Header hd{};
     bool have_hdr = false;
-    std::vector<uint8_t> idat, pal;
+    std::vector<uint8_t>& idat = scratch().idat;
+    std::vector<uint8_t> pal;
+    idat.clear();
     size_t pos = 8;
     while (pos + 12 <= file.size()) {
         const uint32_t len = be32(&file[pos]);
@@ -115,7 +143,9 @@ bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& width, i
             if (len == 0 || len % 3 != 0 || len > 768) { err = "bad PLTE"; return false; }
             pal.assign(d, d + len);
         }
-        else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), d, d + len);
+        else if (!memcmp(type, "IDAT", 4)) {
+            try { idat.insert(idat.end(), d, d + len); } catch (const std::bad_alloc&) { err = "image too large"; return false; }
+        }
         else if (!memcmp(type, "IEND", 4)) break;
         pos += 12 + (size_t)len;
     }
@@ -144,10 +174,10 @@ bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& width, i
         const int ph = hd.interlace ? (hd.h - ys[p] + dy[p] - 1) / dy[p] : hd.h;
         if (pw > 0 && ph > 0) raw_size += (size_t)ph * (rowbytes(pw) + 1);
     }
-    std::vector<uint8_t> raw;
+    std::vector<uint8_t>& raw = scratch().raw;
     try {
         raw.resize(raw_size);
-        rgb.assign((size_t)hd.w * hd.h * 3, 0);
+        rgb.resize((size_t)hd.w * hd.h * 3);
     } catch (const std::bad_alloc&) { err = "image too large"; return false; }
     uLongf dl = (uLongf)raw_size;
     int zr = uncompress(raw.data(), &dl, idat.data(), (uLong)idat.size());
@@ -155,14 +185,18 @@ bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& width, i
 
     width = hd.w; height = hd.h;
     channels_in_file = hd.ctype == 3 ? 3 : nch;
+    if (hd.ctype == 2 && hd.depth == 8 && !hd.interlace) {         // the common case: the unfiltered rows ARE the image
+        if (!unfilter(raw.data(), rgb.data(), hd.h, rowbytes(hd.w), bpp)) { err = "bad filter type"; return false; }
+        return true;
+    }
     size_t off = 0;
-    std::vector<uint8_t> img;
+    std::vector<uint8_t>& img = scratch().img;
     for (int p = 0; p < npass; p++) {
         const int pw = hd.interlace ? (hd.w - xs[p] + dx[p] - 1) / dx[p] : hd.w;
         const int ph = hd.interlace ? (hd.h - ys[p] + dy[p] - 1) / dy[p] : hd.h;
         if (pw <= 0 || ph <= 0) continue;
         const size_t rb = rowbytes(pw);
-        img.resize((size_t)ph * rb);
+        try { img.resize((size_t)ph * rb); } catch (const std::bad_alloc&) { err = "image too large"; return false; }
         if (!unfilter(raw.data() + off, img.data(), ph, rb, bpp)) { err = "bad filter type"; return false; }
         off += (size_t)ph * (rb + 1);
         for (int y = 0; y < ph; y++)
@@ -174,63 +208,281 @@ bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& width, i
     return true;
 }
 
+// ---- encoder ------------------------------------------------------------------------------------------------------
+// The CLI's batched mode is bound by this function (a 4096x2048 frame: 0.06 ms of kernels, 0.5 ms of PCIe, ~200 ms of PNG
+// encoding with zlib at its fastest setting), so the two stages are written for speed:
+//  * row filters: the five sums of |residual| (the selection heuristic stb_image_write uses too) in reductions the compiler
+//    vectorises (AVX2 clone chosen at load time), then only the winner is materialised;
+//  * deflate: filtered rows of an interpolated image are small residuals without repeats worth a match search -- zlib's
+//    Z_RLE and Z_HUFFMAN_ONLY strategies produce the same size -- so the stream is Huffman-only: per 256 KB block a byte
+//    histogram, length-limited canonical codes, and two symbols per 64-bit store.  3-6 x zlib's rate, same size within 1 %.
+namespace {
+
+#define PNGIO_SIMD __attribute__((target_clones("avx2", "default")))
+
+inline uint8_t mag8(uint8_t r) { const uint8_t n = (uint8_t)(0 - r); return r < n ? r : n; }      // |(int8_t) r|
+
+// PNG filter type with the smallest sum of |residual| for one row of 8-bit RGB (bpp 3); `up` may be NULL (first row)
+PNGIO_SIMD int choose_filter(const uint8_t* cur, const uint8_t* up, size_t rb)
+{
+    unsigned s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+    const size_t h = rb < 3 ? rb : 3;
+    for (size_t i = 0; i < h; i++) {                                                         // first pixel: a = c = 0
+        const uint8_t v = cur[i], b = up ? up[i] : 0;
+        s0 += mag8(v); s1 += mag8(v); s2 += mag8((uint8_t)(v - b)); s3 += mag8((uint8_t)(v - (b >> 1))); s4 += mag8((uint8_t)(v - b));
+    }
+    for (size_t i = 3; i < rb; i++) s0 += mag8(cur[i]);
+    for (size_t i = 3; i < rb; i++) s1 += mag8((uint8_t)(cur[i] - cur[i - 3]));
+    if (!up) {                                                                               // b = c = 0: Up = None, Paeth = Sub
+        for (size_t i = 3; i < rb; i++) s3 += mag8((uint8_t)(cur[i] - (cur[i - 3] >> 1)));
+        s2 = s0; s4 = s1;
+    } else {
+        for (size_t i = 3; i < rb; i++) s2 += mag8((uint8_t)(cur[i] - up[i]));
+        for (size_t i = 3; i < rb; i++) s3 += mag8((uint8_t)(cur[i] - (uint8_t)(((unsigned)cur[i - 3] + up[i]) >> 1)));
+        for (size_t i = 3; i < rb; i++) {
+            const int16_t a = cur[i - 3], b = up[i], c = up[i - 3];
+            const int16_t pa = (int16_t)(b > c ? b - c : c - b), pb = (int16_t)(a > c ? a - c : c - a);
+            const int16_t t = (int16_t)(a + b - 2 * c), pc = (int16_t)(t < 0 ? -t : t);
+            const uint8_t pr = (uint8_t)((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c));
+            s4 += mag8((uint8_t)(cur[i] - pr));
+        }
+    }
+    int best = 0;
+    unsigned bs = s0;
+    if (s1 < bs) { bs = s1; best = 1; }
+    if (s2 < bs) { bs = s2; best = 2; }
+    if (s3 < bs) { bs = s3; best = 3; }
+    if (s4 < bs) { bs = s4; best = 4; }
+    return best;
+}
+
+// residuals of one row under filter ft -> out[0 .. rb)
+PNGIO_SIMD void apply_filter(int ft, const uint8_t* cur, const uint8_t* up, size_t rb, uint8_t* out)
+{
+    const size_t h = rb < 3 ? rb : 3;
+    for (size_t i = 0; i < h; i++) {
+        const uint8_t v = cur[i], b = up ? up[i] : 0;
+        out[i] = ft == 0 || ft == 1 ? v : ft == 3 ? (uint8_t)(v - (b >> 1)) : (uint8_t)(v - b);
+    }
+    switch (ft) {
+    case 0: for (size_t i = 3; i < rb; i++) out[i] = cur[i]; break;
+    case 1: for (size_t i = 3; i < rb; i++) out[i] = (uint8_t)(cur[i] - cur[i - 3]); break;
+    case 2:
+        if (up) for (size_t i = 3; i < rb; i++) out[i] = (uint8_t)(cur[i] - up[i]);
+        else for (size_t i = 3; i < rb; i++) out[i] = cur[i];
+        break;
+    case 3:
+        if (up) for (size_t i = 3; i < rb; i++) out[i] = (uint8_t)(cur[i] - (uint8_t)(((unsigned)cur[i - 3] + up[i]) >> 1));
+        else for (size_t i = 3; i < rb; i++) out[i] = (uint8_t)(cur[i] - (cur[i - 3] >> 1));
+        break;
+    default:
+        if (!up) { for (size_t i = 3; i < rb; i++) out[i] = (uint8_t)(cur[i] - cur[i - 3]); break; }
+        for (size_t i = 3; i < rb; i++) {
+            const int16_t a = cur[i - 3], b = up[i], c = up[i - 3];
+            const int16_t pa = (int16_t)(b > c ? b - c : c - b), pb = (int16_t)(a > c ? a - c : c - a);
+            const int16_t t = (int16_t)(a + b - 2 * c), pc = (int16_t)(t < 0 ? -t : t);
+            const uint8_t pr = (uint8_t)((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c));
+            out[i] = (uint8_t)(cur[i] - pr);
+        }
+    }
+}
+
+// -- Huffman-only deflate (RFC 1951 dynamic blocks without length/distance symbols) --
+// Code lengths (<= maxbits) of an optimal prefix code for freq[0..n), 0 for unused symbols.  Two-queue Huffman construction
+// on the symbols sorted by frequency; the lengths beyond maxbits are folded back by the usual Kraft-sum repair (one code of
+// the longest length is removed, one shorter code made one bit longer, until the sum is exactly one).
+void huffman_lengths(const uint32_t* freq, int n, int maxbits, uint8_t* len)
+{
+    int order[288], used = 0;
+    for (int i = 0; i < n; i++) { len[i] = 0; if (freq[i]) order[used++] = i; }
+    if (used == 0) return;
+    if (used == 1) {                                   // a complete code needs two codes: one unused sibling
+        len[order[0]] = 1;
+        len[order[0] == 0 ? 1 : 0] = 1;
+        return;
+    }
+    for (int i = 1; i < used; i++) {                   // insertion sort by (frequency, symbol): n <= 288
+        const int v = order[i];
+        int j = i - 1;
+        while (j >= 0 && (freq[order[j]] > freq[v] || (freq[order[j]] == freq[v] && order[j] > v))) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = v;
+    }
+    uint64_t w[2 * 288];
+    int parent[2 * 288];
+    for (int i = 0; i < used; i++) w[i] = freq[order[i]];
+    int leaf = 0, inner = used, next = used;            // two queues: leaves [leaf, used), inner nodes [inner, next)
+    auto take = [&]() -> int {
+        if (leaf < used && (inner >= next || w[leaf] <= w[inner])) return leaf++;
+        return inner++;
+    };
+    while ((used - leaf) + (next - inner) > 1) {
+        const int a = take(), b = take();
+        w[next] = w[a] + w[b];
+        parent[a] = parent[b] = next;
+        next++;
+    }
+    const int root = next - 1;
+    int depth[2 * 288];
+    depth[root] = 0;
+    for (int i = root - 1; i >= 0; i--) depth[i] = depth[parent[i]] + 1;      // a parent is always created after its children
+    int count[64] = {0};
+    for (int i = 0; i < used; i++) count[depth[i] < 63 ? depth[i] : 63]++;
+    for (int l = maxbits + 1; l < 64; l++) { count[maxbits] += count[l]; count[l] = 0; }
+    uint64_t total = 0;
+    for (int l = 1; l <= maxbits; l++) total += (uint64_t)count[l] << (maxbits - l);
+    while (total > (1ull << maxbits)) {
+        count[maxbits]--;
+        for (int l = maxbits - 1; l > 0; l--)
+            if (count[l]) { count[l]--; count[l + 1] += 2; break; }
+        total--;
+    }
+    int k = 0;                                           // rarest symbols get the longest codes
+    for (int l = maxbits; l >= 1; l--)
+        for (int c = 0; c < count[l]; c++) len[order[k++]] = (uint8_t)l;
+}
+
+// canonical codes for the lengths, bit-reversed (deflate sends Huffman codes most significant bit first)
+void canonical_codes(const uint8_t* len, int n, int maxbits, uint16_t* code)
+{
+    int count[17] = {0}, next[17] = {0};
+    for (int i = 0; i < n; i++) count[len[i]]++;
+    count[0] = 0;
+    for (int l = 1, c = 0; l <= maxbits; l++) { c = (c + count[l - 1]) << 1; next[l] = c; }
+    for (int i = 0; i < n; i++) {
+        if (!len[i]) { code[i] = 0; continue; }
+        unsigned c = (unsigned)next[len[i]]++, r = 0;
+        for (int b = 0; b < len[i]; b++) { r = (r << 1) | (c & 1); c >>= 1; }
+        code[i] = (uint16_t)r;
+    }
+}
+
+struct BitWriter {                    // LSB-first bit stream; every put stores 8 bytes at the write position (little-endian host)
+    uint8_t* p;
+    uint64_t buf = 0;
+    unsigned cnt = 0;                 // < 8 between calls
+    inline void put(uint64_t bits, unsigned n)        // n <= 48
+    {
+        buf |= bits << cnt;
+        cnt += n;
+        memcpy(p, &buf, 8);
+        p += cnt >> 3;
+        buf >>= cnt & ~7u;
+        cnt &= 7;
+    }
+    void byte_align() { if (cnt) { *p++ = (uint8_t)buf; buf = 0; cnt = 0; } }
+};
+
+void huffman_block(BitWriter& bw, const uint8_t* src, size_t n, bool last)
+{
+    uint32_t f4[4][256];
+    memset(f4, 0, sizeof f4);
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) { f4[0][src[i]]++; f4[1][src[i + 1]]++; f4[2][src[i + 2]]++; f4[3][src[i + 3]]++; }
+    for (; i < n; i++) f4[0][src[i]]++;
+    uint32_t freq[257];
+    for (int s = 0; s < 256; s++) freq[s] = f4[0][s] + f4[1][s] + f4[2][s] + f4[3][s];
+    freq[256] = 1;                                       // end of block
+    uint8_t len[257];
+    uint16_t code[257];
+    huffman_lengths(freq, 257, 15, len);
+    canonical_codes(len, 257, 15, code);
+    // the code lengths are sent one by one (symbols 0..15 of the code-length alphabet, no repeat symbols: 259 lengths per
+    // 256 KB block), followed by two distance codes of one bit that are never used (a complete set, like zlib sends)
+    uint8_t seq[259];
+    memcpy(seq, len, 257);
+    seq[257] = seq[258] = 1;
+    uint32_t cfreq[19] = {0};
+    for (int k = 0; k < 259; k++) cfreq[seq[k]]++;
+    uint8_t clen[19];
+    uint16_t ccode[19];
+    huffman_lengths(cfreq, 19, 7, clen);
+    canonical_codes(clen, 19, 7, ccode);
+    static const int perm[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    int hclen = 19;
+    while (hclen > 4 && clen[perm[hclen - 1]] == 0) hclen--;
+    bw.put(last ? 1 : 0, 1);
+    bw.put(2, 2);                                        // dynamic Huffman codes
+    bw.put(257 - 257, 5);                                // HLIT: literals + end of block only
+    bw.put(2 - 1, 5);                                    // HDIST
+    bw.put((unsigned)hclen - 4, 4);
+    for (int k = 0; k < hclen; k++) bw.put(clen[perm[k]], 3);
+    for (int k = 0; k < 259; k++) bw.put(ccode[seq[k]], clen[seq[k]]);
+    uint32_t tab[256];                                   // code | length << 16
+    for (int s = 0; s < 256; s++) tab[s] = code[s] | ((uint32_t)len[s] << 16);
+    i = 0;
+    for (; i + 3 <= n; i += 3) {                         // three symbols (<= 45 bits) per store
+        const uint32_t a = tab[src[i]], b = tab[src[i + 1]], c = tab[src[i + 2]];
+        const unsigned la = a >> 16, lb = b >> 16, lc = c >> 16;
+        bw.put((uint64_t)(a & 0xffff) | ((uint64_t)(b & 0xffff) << la) | ((uint64_t)(c & 0xffff) << (la + lb)), la + lb + lc);
+    }
+    for (; i < n; i++) bw.put(tab[src[i]] & 0xffff, tab[src[i]] >> 16);
+    bw.put(code[256], len[256]);
+}
+
+// zlib stream (RFC 1950) of Huffman-only deflate blocks; returns the number of bytes written to out (capacity: bound below)
+size_t huffman_zlib_bound(size_t n) { return n + n / 8 + (n / (256 * 1024) + 2) * 512 + 64; }
+size_t huffman_zlib(const uint8_t* src, size_t n, uint8_t* out)
+{
+    BitWriter bw;
+    bw.p = out;
+    *bw.p++ = 0x78;                                      // deflate, 32 KB window
+    *bw.p++ = 0x01;                                      // fastest level, no dictionary, check bits
+    const size_t block = 256 * 1024;
+    size_t pos = 0;
+    do {
+        const size_t m = n - pos < block ? n - pos : block;
+        huffman_block(bw, src + pos, m, pos + m == n);
+        pos += m;
+    } while (pos < n);
+    bw.byte_align();
+    uLong ad = adler32(0L, Z_NULL, 0);
+    for (size_t o = 0; o < n; o += 1u << 30) ad = adler32(ad, src + o, (uInt)(n - o < (1u << 30) ? n - o : (1u << 30)));
+    put32(bw.p, (uint32_t)ad);
+    return (size_t)(bw.p + 4 - out);
+}
+
+}  // namespace
+
 bool write_rgb8(const std::string& path, const uint8_t* rgb, int width, int height, size_t row_stride, std::string& err)
 {
+    if (width <= 0 || height <= 0) { err = "bad image size"; return false; }
     const size_t rb = (size_t)width * 3;
-    std::vector<uint8_t> raw((size_t)height * (rb + 1));
-    // per row: the filter with the smallest sum of absolute values (the heuristic stb_image_write uses too).  One
-    // tight, branch-free loop per filter type (they vectorise) instead of a switch per byte.
-    std::vector<uint8_t> cand(5 * rb);
-    std::vector<uint8_t> zero(rb, 0);
+    std::vector<uint8_t>& raw = scratch().raw;
+    std::vector<uint8_t>& comp = scratch().comp;
+    try {
+        raw.resize((size_t)height * (rb + 1));
+        comp.resize(huffman_zlib_bound(raw.size()));
+    } catch (const std::bad_alloc&) { err = "image too large"; return false; }
     for (int y = 0; y < height; y++) {
         const uint8_t* cur = rgb + (size_t)y * row_stride;
-        const uint8_t* up = y ? rgb + (size_t)(y - 1) * row_stride : zero.data();
-        uint8_t* c0 = cand.data();
-        uint8_t* c1 = c0 + rb;
-        uint8_t* c2 = c1 + rb;
-        uint8_t* c3 = c2 + rb;
-        uint8_t* c4 = c3 + rb;
-        long sum[5] = {0, 0, 0, 0, 0};
-        auto mag = [](uint8_t v) -> int { return v < 128 ? v : 256 - v; };     // |(int8_t)v|
-        for (size_t i = 0; i < 3 && i < rb; i++) {                             // first pixel: a = c = 0
-            const int b = up[i], v = cur[i];
-            c0[i] = (uint8_t)v; c1[i] = (uint8_t)v; c2[i] = (uint8_t)(v - b); c3[i] = (uint8_t)(v - (b >> 1)); c4[i] = (uint8_t)(v - b);
-        }
-        for (size_t i = 3; i < rb; i++) c0[i] = cur[i];
-        for (size_t i = 3; i < rb; i++) c1[i] = (uint8_t)(cur[i] - cur[i - 3]);
-        for (size_t i = 3; i < rb; i++) c2[i] = (uint8_t)(cur[i] - up[i]);
-        for (size_t i = 3; i < rb; i++) c3[i] = (uint8_t)(cur[i] - ((cur[i - 3] + up[i]) >> 1));
-        for (size_t i = 3; i < rb; i++) {
-            const int a = cur[i - 3], bb = up[i], c = up[i - 3];
-            const int pa = abs(bb - c), pb = abs(a - c), pc = abs(a + bb - 2 * c);
-            const int pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c);
-            c4[i] = (uint8_t)(cur[i] - pr);
-        }
-        for (int ft = 0; ft < 5; ft++) {
-            const uint8_t* cc = c0 + (size_t)ft * rb;
-            long sacc = 0;
-            for (size_t i = 0; i < rb; i++) sacc += mag(cc[i]);
-            sum[ft] = sacc;
-        }
-        int best_ft = 0;
-        for (int ft = 1; ft < 5; ft++)
-            if (sum[ft] < sum[best_ft]) best_ft = ft;
+        const uint8_t* up = y ? cur - row_stride : nullptr;
         uint8_t* out = &raw[(size_t)y * (rb + 1)];
-        out[0] = (uint8_t)best_ft;
-        memcpy(out + 1, c0 + (size_t)best_ft * rb, rb);
+        const int ft = choose_filter(cur, up, rb);
+        out[0] = (uint8_t)ft;
+        apply_filter(ft, cur, up, rb, out + 1);
     }
-    // filtered image rows are small residuals: the run-length strategy compresses them as well as the default
-    // one at level 3 and in two thirds of the time (25 MB per 4096x2048 frame: the encoder is the CLI's bottleneck)
-    z_stream zs{};
-    if (deflateInit2(&zs, 1, Z_DEFLATED, 15, 9, Z_RLE) != Z_OK) { err = "zlib deflate failed"; return false; }
-    uLongf cl = deflateBound(&zs, (uLong)raw.size());
-    std::vector<uint8_t> comp(cl);
-    zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size();
-    zs.next_out = comp.data(); zs.avail_out = (uInt)cl;
-    const int zr = deflate(&zs, Z_FINISH);
-    cl = zs.total_out;
-    deflateEnd(&zs);
-    if (zr != Z_STREAM_END) { err = "zlib deflate failed"; return false; }
+    // flat content (drawings, borders: most residuals zero) is what a Huffman-only stream cannot shrink below one bit per
+    // byte; there zlib's run-length strategy is both small and fast.  Decided on a sample of the rows.
+    size_t zeros = 0, sampled = 0;
+    for (int y = 0; y < height; y += 8) {
+        const uint8_t* r = &raw[(size_t)y * (rb + 1) + 1];
+        for (size_t i = 0; i < rb; i++) zeros += r[i] == 0;
+        sampled += rb;
+    }
+    size_t cl;
+    if (zeros * 2 > sampled) {
+        uLongf bound = (uLongf)comp.size();
+        z_stream zs{};
+        if (deflateInit2(&zs, 1, Z_DEFLATED, 15, 9, Z_RLE) != Z_OK) { err = "zlib deflate failed"; return false; }
+        if (deflateBound(&zs, (uLong)raw.size()) > bound) { bound = deflateBound(&zs, (uLong)raw.size()); comp.resize(bound); }
+        zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size();
+        zs.next_out = comp.data(); zs.avail_out = (uInt)bound;
+        const int zr = deflate(&zs, Z_FINISH);
+        cl = zs.total_out;
+        deflateEnd(&zs);
+        if (zr != Z_STREAM_END) { err = "zlib deflate failed"; return false; }
+    } else cl = huffman_zlib(raw.data(), raw.size(), comp.data());
+    if (cl > 0xffffffffu - 16) { err = "image too large for one IDAT chunk"; return false; }
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { err = "cannot create " + path; return false; }
     static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
@@ -242,7 +494,7 @@ bool write_rgb8(const std::string& path, const uint8_t* rgb, int width, int heig
         fwrite(hdr, 1, 8, f);
         if (len) fwrite(d, 1, len, f);
         uLong crc = crc32(0L, (const Bytef*)type, 4);
-        if (len) crc = crc32(crc, d, len);
+        for (size_t o = 0; o < len; o += 1u << 30) crc = crc32(crc, d + o, (uInt)(len - o < (1u << 30) ? len - o : (1u << 30)));
         uint8_t c4[4];
         put32(c4, (uint32_t)crc);
         fwrite(c4, 1, 4, f);
@@ -254,9 +506,8 @@ bool write_rgb8(const std::string& path, const uint8_t* rgb, int width, int heig
     chunk("IDAT", comp.data(), (uint32_t)cl);
     chunk("IEND", nullptr, 0);
     const bool ok = !ferror(f);
-    fclose(f);
-    if (!ok) err = "write error";
-    return ok;
+    if (fclose(f) != 0 || !ok) { err = "write error"; return false; }
+    return true;
 }
 
 }  // namespace pngio

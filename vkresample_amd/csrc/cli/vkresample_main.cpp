@@ -20,8 +20,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "fftup.h"
@@ -44,6 +47,7 @@ struct ResampleConfiguration {           // VkResampleConfiguration, VR:45-59
     bool allDevices = false;
     uint32_t flags = 0;
     std::atomic<int>* workQueue = nullptr;   // -workqueue: next file number - 1, shared by all threads
+    bool stageTimes = false;                 // -stagetimes: per-thread host time by stage (batched mode)
 };
 
 static bool findFlag(char** start, char** end, const std::string& flag)      // VR:1782-1784: exact token match
@@ -69,9 +73,45 @@ static int devices_list()                                                     //
     return n > 0 ? 0 : FFTUP_E_NO_DEVICE;
 }
 
+// Batched mode: the host threads of one GPU share ONE plan.  The reference gives every thread its own application (VR:1959-1969)
+// because a Vulkan queue submission blocks its thread; here a thread's share of the GPU work is one asynchronous
+// fftup_submit_rgb8 per file (0.5 ms of device time against ~250 ms of PNG decode + encode), and plan creation is serialised
+// by the HIP runtime (~20 ms each, tools/plan_create_time.py): 64 plans for 64 threads cost 2.6 s of a 3.7 s job
+// (profiles/r04_zi_cli_batch.txt).  Plans are keyed by (device, width, height) -- threads whose first file has another size
+// get another plan, as in the reference -- and live until main() has joined the threads.
+static double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct SharedPlan { fftup_plan* plan = nullptr; fftup_info info{}; };
+static std::mutex g_plans_mu;
+static std::map<std::tuple<int, int, int>, SharedPlan> g_plans;
+static int shared_plan(const fftup_config& cfg, SharedPlan* out)
+{
+    std::lock_guard<std::mutex> lock(g_plans_mu);
+    SharedPlan& sp = g_plans[std::make_tuple((int)cfg.device, (int)cfg.width, (int)cfg.height)];
+    if (!sp.plan) {
+        const int res = fftup_plan_create(&sp.plan, &cfg);
+        if (res != FFTUP_OK) { sp.plan = nullptr; return res; }
+        fftup_plan_info(sp.plan, &sp.info);
+    }
+    *out = sp;
+    return FFTUP_OK;
+}
+static void shared_plans_destroy()
+{
+    std::lock_guard<std::mutex> lock(g_plans_mu);
+    for (auto& kv : g_plans)
+        if (kv.second.plan) { fftup_drain(kv.second.plan); fftup_plan_destroy(kv.second.plan); }
+    g_plans.clear();
+}
+
 static int launchResample(ResampleConfiguration config)                      // VR:1280-1780
 {
     if (config.threadId == 0) printf("VkResample - FFT based upscaling\n");
+    const double tStart = now_ms();
+    double tDecode = 0, tSubmit = 0, tWait = 0, tEncode = 0;   // -stagetimes
     // which file (1-based number) is this thread's f-th one, 0 = none left.  Static stripe of the reference: f*T + t + 1 for
     // f < numLocalFiles (VR:1622-1629); -workqueue: whatever the shared counter hands out next.
     int numLocalFiles = 1;
@@ -110,6 +150,7 @@ static int launchResample(ResampleConfiguration config)                      // 
         printf("Image not found\n");                                           // VR:1364-1367
         return FFTUP_E_INCOMPLETE;
     }
+    tDecode += now_ms() - tStart;
     int device = config.device_id;
     if (config.allDevices) {
         const int nd = fftup_device_count();
@@ -119,72 +160,93 @@ static int launchResample(ResampleConfiguration config)                      // 
     cfg.width = (uint32_t)width; cfg.height = (uint32_t)height; cfg.channels = 3;
     cfg.upscale = config.upscale; cfg.precision = config.precision; cfg.sharpen = config.sharpenConst;
     cfg.device = device; cfg.flags = config.flags; cfg.ring = config.fileUpload ? 2 : 1;
+    // the batched path below runs on the GPU's shared plan: one frame in flight per thread, sixteen slots at most
+    // (a slot is busy for ~0.5 ms per frame; a thread comes back after tens of ms of codec work)
+    const bool streamed = config.fileUpload && config.numIter == 1 && config.numFiles > 1;
+    int sharers = config.numThreads;
+    if (config.allDevices && fftup_device_count() > 0) sharers = (config.numThreads + fftup_device_count() - 1) / fftup_device_count();
+    if (streamed) cfg.ring = (uint32_t)std::min(16, std::max(2, sharers));
     fftup_plan* plan = nullptr;
-    int res = fftup_plan_create(&plan, &cfg);
+    fftup_info info{};
+    int res;
+    if (streamed) {
+        SharedPlan sp;
+        res = shared_plan(cfg, &sp);
+        plan = sp.plan; info = sp.info;
+    } else {
+        res = fftup_plan_create(&plan, &cfg);
+        if (res == FFTUP_OK) fftup_plan_info(plan, &info);
+    }
     if (res != FFTUP_OK) {
         printf("Plan creation failed: %s (%s)\n", fftup_strerror(res), fftup_last_error());
         return res;
     }
-    fftup_info info{};
-    fftup_plan_info(plan, &info);
-    if (config.threadId == 0)
-        printf("VRAM per thread: %d MB Total: %d MB\n", (int)(info.device_bytes / 1024 / 1024),
-               (int)(config.numThreads * (info.device_bytes / 1024 / 1024)));  // VR:1450
+    if (config.threadId == 0) {
+        const int mb = (int)(info.device_bytes / 1024 / 1024);                 // VR:1450 (a shared plan is counted once per GPU)
+        if (streamed) printf("VRAM per thread: %d MB Total: %d MB\n", mb / sharers, mb * ((config.numThreads + sharers - 1) / sharers));
+        else printf("VRAM per thread: %d MB Total: %d MB\n", mb, config.numThreads * mb);
+    }
     const uint32_t uW = info.out_width, uH = info.out_height;
-    std::vector<uint8_t> png_output((size_t)uW * uH * 3);
+    std::vector<uint8_t> png_output(streamed ? 0 : (size_t)uW * uH * 3);
 
-    const bool more = config.fileUpload && (config.workQueue ? config.numFiles > 1 : numLocalFiles > 1);
-    if (more && config.numIter == 1) {
-        // batched mode, double-buffered: frame f is on the device (fftup_submit_rgb8: H2D, kernels,
-        // D2H asynchronously from/to page-locked memory) while this thread encodes frame f-1 and decodes frame f+1
+    if (streamed) {
+        // batched mode: the frame travels through the GPU's shared plan as ONE asynchronous submission (H2D,
+        // kernels, D2H from/to this thread's page-locked buffers), ~1 ms between submit and wait; the thread's time is the
+        // PNG codec (tens of ms per file), so the overlap that matters is between the THREADS -- one frame and one pair of
+        // buffers per thread (a second pair would hide 1 ms per file and double the page-locking, which the driver serialises).
         const size_t inBytes = (size_t)width * height * 3, outBytes = (size_t)uW * uH * 3;
-        uint8_t* pin[2] = {(uint8_t*)fftup_host_alloc(inBytes), (uint8_t*)fftup_host_alloc(inBytes)};
-        uint8_t* pout[2] = {(uint8_t*)fftup_host_alloc(outBytes), (uint8_t*)fftup_host_alloc(outBytes)};
-        auto release = [&]() {
-            fftup_drain(plan);
-            for (int i = 0; i < 2; i++) { fftup_host_free(pin[i]); fftup_host_free(pout[i]); }
-            fftup_plan_destroy(plan);
-        };
-        if (!pin[0] || !pin[1] || !pout[0] || !pout[1]) {
+        uint8_t* pin = (uint8_t*)fftup_host_alloc(inBytes);
+        uint8_t* pout = (uint8_t*)fftup_host_alloc(outBytes);
+        auto release = [&]() { fftup_host_free(pin); fftup_host_free(pout); };     // (no frame of this thread is in flight here)
+        if (!pin || !pout) {
             printf("Upscale failed: %s (%s)\n", fftup_strerror(FFTUP_E_OUT_OF_MEMORY), fftup_last_error());
             release();
             return FFTUP_E_OUT_OF_MEMORY;
         }
-        auto fileIndex = [&](int f) { return fileAt(f); };
-        auto writeFrame = [&](int f, uint64_t ticket) -> int {
-            int r = fftup_wait(plan, ticket);
-            if (r != FFTUP_OK) { printf("Download failed: %s (%s)\n", fftup_strerror(r), fftup_last_error()); return r; }
-            char outName[1024];
-            snprintf(outName, sizeof outName, "%s/%06d.png", config.ofolder_prefix, fileIndex(f));
-            if (!pngio::write_rgb8(outName, pout[f & 1], (int)uW, (int)uH, (size_t)uW * 3, err))
-                printf("Could not write %s: %s\n", outName, err.c_str());
-            return FFTUP_OK;
-        };
-        uint64_t tickets[2] = {0, 0};
+        const double tSetup = now_ms() - tStart - tDecode;             // plan (shared: the first thread creates it) + page-locked buffers
         int f = 0;
         for (; fileAt(f) > 0; f++) {
+            double t0 = now_ms();
             if (f > 0) {
-                snprintf(fileName, sizeof fileName, "%s/%06d.png", config.ifolder_prefix, fileIndex(f));
+                snprintf(fileName, sizeof fileName, "%s/%06d.png", config.ifolder_prefix, fileAt(f));
                 int w2 = 0, h2 = 0;
                 if (!pngio::load_rgb8(fileName, png_input, w2, h2, channels, err) || w2 != width || h2 != height) {
-                    writeFrame(f - 1, tickets[(f - 1) & 1]);                   // the reference finished file f-1 before opening f
                     printf("Image not found\n");                               // VR:1631-1634
                     release();
                     return FFTUP_E_INCOMPLETE;
                 }
+                tDecode += now_ms() - t0;
+                t0 = now_ms();
             }
-            memcpy(pin[f & 1], png_input.data(), inBytes);          // frame f-2 (same buffers) was waited for below
-            res = fftup_submit_rgb8(plan, pin[f & 1], (size_t)width * 3, pout[f & 1], (size_t)uW * 3, &tickets[f & 1]);
+            memcpy(pin, png_input.data(), inBytes);
+            uint64_t ticket = 0;
+            res = fftup_submit_rgb8(plan, pin, (size_t)width * 3, pout, (size_t)uW * 3, &ticket);
             if (res != FFTUP_OK) {
                 printf("Upscale failed: %s (%s)\n", fftup_strerror(res), fftup_last_error());
                 release();
                 return res;
             }
-            if (f > 0 && (res = writeFrame(f - 1, tickets[(f - 1) & 1])) != FFTUP_OK) { release(); return res; }
+            double t1 = now_ms();
+            tSubmit += t1 - t0;
+            res = fftup_wait(plan, ticket);
+            t0 = now_ms();
+            tWait += t0 - t1;
+            if (res != FFTUP_OK) {
+                printf("Download failed: %s (%s)\n", fftup_strerror(res), fftup_last_error());
+                release();
+                return res;
+            }
+            char outName[1024];
+            snprintf(outName, sizeof outName, "%s/%06d.png", config.ofolder_prefix, fileAt(f));
+            if (!pngio::write_rgb8(outName, pout, (int)uW, (int)uH, (size_t)uW * 3, err))
+                printf("Could not write %s: %s\n", outName, err.c_str());
+            tEncode += now_ms() - t0;
         }
-        res = writeFrame(f - 1, tickets[(f - 1) & 1]);
+        const double tRel = now_ms();
         release();
-        if (res != FFTUP_OK) return res;
+        if (config.stageTimes)
+            printf("Thread %d: %d files in %.0f ms: setup %.0f, decode %.0f, copy+submit %.0f, wait %.0f, encode+write %.0f, release %.0f ms\n",
+                   config.threadId, f, now_ms() - tStart, tSetup, tDecode, tSubmit, tWait, tEncode, now_ms() - tRel);
         printf("Thread %d finished. Device name: %s API:HIP\n", config.threadId, info.device_name);   // VR:1773
         return FFTUP_OK;
     }
@@ -255,6 +317,7 @@ int main(int argc, char* argv[])
         printf("	-fuseu8out: the last kernel writes the 8-bit image directly (no float planes, no conversion pass)\n");
         printf("	-wrapu8: 8-bit store wraps like the original's C cast instead of saturating\n");
         printf("	-workqueue: batched mode: threads take the next unprocessed file from one shared counter instead of the fixed stripe\n");
+        printf("	-stagetimes: batched mode: every thread reports its host time by stage (decode, submit, wait, encode)\n");
         printf("	-tune: sizes whose kernels are specialised at plan time: measure the alternatives once, remember the fastest\n");
         return 0;
     }
@@ -292,6 +355,7 @@ int main(int argc, char* argv[])
     if (findFlag(B, E, "-fuseu8out")) config.flags |= FFTUP_FLAG_FUSE_U8_STORE;
     if (findFlag(B, E, "-wrapu8")) config.flags |= FFTUP_FLAG_U8_WRAP;
     if (findFlag(B, E, "-tune")) config.flags |= FFTUP_FLAG_TUNE_PLAN;
+    config.stageTimes = findFlag(B, E, "-stagetimes");
 
     if (!findFlag(B, E, "-ifolder")) {
         config.fileUpload = 0;
@@ -329,6 +393,7 @@ int main(int argc, char* argv[])
         threads.emplace_back([loc, i, &results]() { results[(size_t)i] = launchResample(loc); });
     }
     for (auto& t : threads) t.join();
+    shared_plans_destroy();
     auto timeEnd = std::chrono::system_clock::now();
     double totTime = std::chrono::duration_cast<std::chrono::microseconds>(timeEnd - timeSubmit).count() * 0.001;
     printf("Total time: %0.3f s\n", totTime / 1000);

@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -108,7 +110,8 @@ struct fftup_plan {
     // host-streamed queue (fftup_submit_rgb8): created on first use
     struct QSlot { uint8_t* out_u8 = nullptr; hipEvent_t done = nullptr; };
     std::vector<QSlot> q;
-    uint64_t q_next = 0;
+    std::atomic<uint64_t> q_next{0};   // next ticket; written under q_mu, read by fftup_wait without it
+    std::mutex q_mu;                   // fftup_submit_rgb8 may be called by several host threads (codec workers sharing a plan)
     float2 *twW = nullptr, *twH = nullptr, *twUW = nullptr, *twUH = nullptr;
     uint64_t device_bytes = 0;
     size_t r_bytes = 0;               // bytes of one pre-sharpen image
@@ -1694,9 +1697,12 @@ int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, ui
     if (!rgb_in || in_stride < (size_t)3 * P->W) return fail(FFTUP_E_INVALID_ARG, "bad input pointer/stride");
     if (!rgb_out || out_stride < (size_t)3 * P->uW) return fail(FFTUP_E_INVALID_ARG, "bad output pointer/stride");
     HIP_TRY(hipSetDevice(P->device));
+    // one submission at a time: slot choice, the lane's launches and the ticket are one critical section (a few tens of
+    // microseconds; the wait below is for the frame that used this slot `ring` submissions ago)
+    std::lock_guard<std::mutex> lock(P->q_mu);
     int rc = queue_init(P);
     if (rc) return rc;
-    const uint64_t t = P->q_next;
+    const uint64_t t = P->q_next.load(std::memory_order_relaxed);
     const uint32_t s = (uint32_t)(t % P->ring);
     fftup_plan::QSlot& Q = P->q[s];
     if (t >= P->ring) HIP_TRY(hipEventSynchronize(Q.done));          // the slot's previous frame has left the device
@@ -1725,7 +1731,7 @@ int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, ui
     if (out_stride == out_row) HIP_TRY(hipMemcpyAsync(rgb_out, Q.out_u8, out_row * P->uH, hipMemcpyDeviceToHost, cs));
     else HIP_TRY(hipMemcpy2DAsync(rgb_out, out_stride, Q.out_u8, out_row, out_row, P->uH, hipMemcpyDeviceToHost, cs));
     HIP_TRY(hipEventRecord(Q.done, cs));
-    P->q_next = t + 1;
+    P->q_next.store(t + 1, std::memory_order_release);
     P->executed = 1;
     if (ticket) *ticket = t;
     return FFTUP_OK;
@@ -1734,8 +1740,10 @@ int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, ui
 int fftup_wait(fftup_plan* P, uint64_t ticket)
 {
     if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
-    if (ticket >= P->q_next) return fail(FFTUP_E_INVALID_ARG, "ticket was never issued");
-    if (ticket + P->ring < P->q_next) return FFTUP_OK;        // its slot has been reused: submit already waited for it
+    const uint64_t next = P->q_next.load(std::memory_order_acquire);
+    if (ticket >= next) return fail(FFTUP_E_INVALID_ARG, "ticket was never issued");
+    if (ticket + P->ring < next) return FFTUP_OK;             // its slot has been reused: submit already waited for it
+    // (a submission of another thread may re-record this slot's event right now: the wait then covers the later frame too)
     HIP_TRY(hipSetDevice(P->device));
     HIP_TRY(hipEventSynchronize(P->q[ticket % P->ring].done));
     return FFTUP_OK;
@@ -1744,7 +1752,10 @@ int fftup_wait(fftup_plan* P, uint64_t ticket)
 int fftup_drain(fftup_plan* P)
 {
     if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
-    if (P->q.empty()) return FFTUP_OK;
+    {
+        std::lock_guard<std::mutex> lock(P->q_mu);
+        if (P->q.empty()) return FFTUP_OK;
+    }
     HIP_TRY(hipSetDevice(P->device));
     for (int l = 0; l < P->nlanes; l++) HIP_TRY(hipStreamSynchronize(P->lanes[l].stream));
     return FFTUP_OK;
