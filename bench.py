@@ -107,7 +107,7 @@ def cpu_baseline(args):
     for f in frames:
         O.upscale_rgb8(f, args.upscale, args.precision)
     dt = time.perf_counter() - t0
-    return {"value": len(frames) / dt, "unit": "frames/s", "cores": O.num_threads(), "kind": "port",
+    return {"value": len(frames) / dt, "unit": "frames/s", "cores": O.num_threads(), "cpu_quota": O.cpu_quota(), "kind": "port",
             "sample": "%d synthetic %dx%d frames through oracle/fftup_oracle.c (the fp64 restatement of the reference's algorithm, "
                       "naive mixed-radix FFTs, OpenMP over rows/columns/planes), %.1f s" % (len(frames), args.width, args.height, dt)}
 

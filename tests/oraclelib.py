@@ -1,5 +1,6 @@
 """ctypes binding of the CPU oracle (oracle/libfftup_oracle.so).  Test infrastructure only."""
 import ctypes as C
+import math
 import os
 import subprocess
 
@@ -131,12 +132,29 @@ def sharpen(R, upscale=2.0, precision=0, sharpen=0.2):
 _MAX_THREADS = None
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), None without a limit"""
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            return None if q == "max" else float(q) / float(p)
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def _fit_threads(pixels):
-    """a thread team sized to the image: one thread per ~64k output pixels, at most what the host offers"""
+    """a thread team sized to the image: one thread per ~64k output pixels, at most what the host offers -- the CPUs the
+    process may run on and the container's CPU quota (a team of 128 on a 16-CPU quota spends its time in throttled barriers)"""
     global _MAX_THREADS
     L = lib()
     if _MAX_THREADS is None:
-        _MAX_THREADS = L.orc_num_threads()
+        _MAX_THREADS = min(L.orc_num_threads(), len(os.sched_getaffinity(0)))
+        q = cpu_quota()
+        if q is not None:
+            _MAX_THREADS = max(1, min(_MAX_THREADS, int(math.ceil(q))))
     L.orc_set_num_threads(int(min(_MAX_THREADS, max(1, pixels // 65536))))
 
 

@@ -51,6 +51,12 @@ def main():
         in_mb = os.path.getsize(os.path.join(inp, "000001.png")) / 1e6
         say("# %d files of %dx%d (%d distinct, %.1f MB each as PNG), written in %.1f s; host: %d hardware threads"
             % (a.files, a.width, a.height, a.distinct, in_mb, time.perf_counter() - t0, os.cpu_count()))
+        quota = "none"
+        for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            if os.path.exists(p):
+                quota = open(p).read().strip() + " (" + p + ")"
+                break
+        say("# CPUs this process may run on: %d; cgroup CPU quota: %s" % (len(os.sched_getaffinity(0)), quota))
         say("# wall = clock around the process (plan creation, page-locked buffers, %d files); CLI = its own 'Total time' line" % a.files)
         say("%-44s %8s %8s %10s %12s" % ("vkresample -u 2 ... -numfiles %d" % a.files, "wall s", "CLI s", "files/s", "ms per file"))
 
