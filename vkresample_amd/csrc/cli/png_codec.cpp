@@ -222,24 +222,19 @@ namespace {
 
 inline uint8_t mag8(uint8_t r) { const uint8_t n = (uint8_t)(0 - r); return r < n ? r : n; }      // |(int8_t) r|
 
-// PNG filter type with the smallest sum of |residual| for one row of 8-bit RGB (bpp 3); `up` may be NULL (first row)
-PNGIO_SIMD int choose_filter(const uint8_t* cur, const uint8_t* up, size_t rb)
+// sums of |residual| of the five filter types over the bytes [lo, hi) of a row, lo >= 3; `up` may be NULL (first row)
+PNGIO_SIMD void filter_sums(const uint8_t* cur, const uint8_t* up, size_t lo, size_t hi, unsigned* s)
 {
     unsigned s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-    const size_t h = rb < 3 ? rb : 3;
-    for (size_t i = 0; i < h; i++) {                                                         // first pixel: a = c = 0
-        const uint8_t v = cur[i], b = up ? up[i] : 0;
-        s0 += mag8(v); s1 += mag8(v); s2 += mag8((uint8_t)(v - b)); s3 += mag8((uint8_t)(v - (b >> 1))); s4 += mag8((uint8_t)(v - b));
-    }
-    for (size_t i = 3; i < rb; i++) s0 += mag8(cur[i]);
-    for (size_t i = 3; i < rb; i++) s1 += mag8((uint8_t)(cur[i] - cur[i - 3]));
+    for (size_t i = lo; i < hi; i++) s0 += mag8(cur[i]);
+    for (size_t i = lo; i < hi; i++) s1 += mag8((uint8_t)(cur[i] - cur[i - 3]));
     if (!up) {                                                                               // b = c = 0: Up = None, Paeth = Sub
-        for (size_t i = 3; i < rb; i++) s3 += mag8((uint8_t)(cur[i] - (cur[i - 3] >> 1)));
+        for (size_t i = lo; i < hi; i++) s3 += mag8((uint8_t)(cur[i] - (cur[i - 3] >> 1)));
         s2 = s0; s4 = s1;
     } else {
-        for (size_t i = 3; i < rb; i++) s2 += mag8((uint8_t)(cur[i] - up[i]));
-        for (size_t i = 3; i < rb; i++) s3 += mag8((uint8_t)(cur[i] - (uint8_t)(((unsigned)cur[i - 3] + up[i]) >> 1)));
-        for (size_t i = 3; i < rb; i++) {
+        for (size_t i = lo; i < hi; i++) s2 += mag8((uint8_t)(cur[i] - up[i]));
+        for (size_t i = lo; i < hi; i++) s3 += mag8((uint8_t)(cur[i] - (uint8_t)(((unsigned)cur[i - 3] + up[i]) >> 1)));
+        for (size_t i = lo; i < hi; i++) {
             const int16_t a = cur[i - 3], b = up[i], c = up[i - 3];
             const int16_t pa = (int16_t)(b > c ? b - c : c - b), pb = (int16_t)(a > c ? a - c : c - a);
             const int16_t t = (int16_t)(a + b - 2 * c), pc = (int16_t)(t < 0 ? -t : t);
@@ -247,12 +242,27 @@ PNGIO_SIMD int choose_filter(const uint8_t* cur, const uint8_t* up, size_t rb)
             s4 += mag8((uint8_t)(cur[i] - pr));
         }
     }
+    s[0] += s0; s[1] += s1; s[2] += s2; s[3] += s3; s[4] += s4;
+}
+
+// PNG filter type with the smallest sum of |residual| for one row of 8-bit RGB (the heuristic of stb_image_write and libpng).
+// Rows of more than 3 KB are judged on a quarter of their bytes -- 192 of every 768, spread over the whole row: the heuristic
+// is a guess at the entropy anyway, and the five sums were a fifth of the encoder's time.
+int choose_filter(const uint8_t* cur, const uint8_t* up, size_t rb)
+{
+    unsigned s[5] = {0, 0, 0, 0, 0};
+    if (rb <= 3072) {
+        for (size_t i = 0; i < 3 && i < rb; i++) {                                           // first pixel: a = c = 0
+            const uint8_t v = cur[i], b = up ? up[i] : 0;
+            s[0] += mag8(v); s[1] += mag8(v); s[2] += mag8((uint8_t)(v - b)); s[3] += mag8((uint8_t)(v - (b >> 1))); s[4] += mag8((uint8_t)(v - b));
+        }
+        if (rb > 3) filter_sums(cur, up, 3, rb, s);
+    } else {
+        for (size_t lo = 3; lo < rb; lo += 768) filter_sums(cur, up, lo, lo + 192 < rb ? lo + 192 : rb, s);
+    }
     int best = 0;
-    unsigned bs = s0;
-    if (s1 < bs) { bs = s1; best = 1; }
-    if (s2 < bs) { bs = s2; best = 2; }
-    if (s3 < bs) { bs = s3; best = 3; }
-    if (s4 < bs) { bs = s4; best = 4; }
+    for (int ft = 1; ft < 5; ft++)
+        if (s[ft] < s[best]) best = ft;
     return best;
 }
 
@@ -419,6 +429,27 @@ void huffman_block(BitWriter& bw, const uint8_t* src, size_t n, bool last)
     bw.put(code[256], len[256]);
 }
 
+// Adler-32 (RFC 1950) in blocks of 256 bytes: a' = a + sum x_i, b' = b + 256 a + sum (256 - i) x_i -- two reductions the compiler
+// vectorises (zlib 1.2's byte-serial loop was a sixth of the encoder's time)
+PNGIO_SIMD uint32_t adler32_blocks(const uint8_t* p, size_t n)
+{
+    uint64_t a = 1, b = 0;
+    while (n >= 256) {
+        size_t blocks = n / 256 < 16 ? n / 256 : 16;                  // 4 KB between reductions modulo 65521
+        n -= blocks * 256;
+        for (; blocks; blocks--, p += 256) {
+            uint32_t s1 = 0, s2 = 0;
+            for (int i = 0; i < 256; i++) { s1 += p[i]; s2 += (uint32_t)(256 - i) * p[i]; }
+            b += 256 * a + s2;
+            a += s1;
+        }
+        a %= 65521;
+        b %= 65521;
+    }
+    for (size_t i = 0; i < n; i++) { a += p[i]; b += a; }
+    return (uint32_t)((b % 65521) << 16 | (a % 65521));
+}
+
 // zlib stream (RFC 1950) of Huffman-only deflate blocks; returns the number of bytes written to out (capacity: bound below)
 size_t huffman_zlib_bound(size_t n) { return n + n / 8 + (n / (256 * 1024) + 2) * 512 + 64; }
 size_t huffman_zlib(const uint8_t* src, size_t n, uint8_t* out)
@@ -435,9 +466,7 @@ size_t huffman_zlib(const uint8_t* src, size_t n, uint8_t* out)
         pos += m;
     } while (pos < n);
     bw.byte_align();
-    uLong ad = adler32(0L, Z_NULL, 0);
-    for (size_t o = 0; o < n; o += 1u << 30) ad = adler32(ad, src + o, (uInt)(n - o < (1u << 30) ? n - o : (1u << 30)));
-    put32(bw.p, (uint32_t)ad);
+    put32(bw.p, adler32_blocks(src, n));
     return (size_t)(bw.p + 4 - out);
 }
 
