@@ -147,7 +147,8 @@ class Upscaler:
     def submit_rgb8(self, rgb_in, rgb_out):
         """Enqueue one host frame end to end (H2D, convert, kernels, convert, D2H) and return its ticket; up to
         `ring` frames are in flight.  rgb_in [H][W][3] / rgb_out [uH][uW][3] uint8, C-contiguous, and they must
-        stay alive and untouched until wait(ticket) returns (pinned memory: PinnedArray)."""
+        stay alive and untouched until wait(ticket) returns (pinned memory: PinnedArray).  submit_rgb8 / wait / drain of
+        one Upscaler may be called from several threads at once (tickets are global to the plan)."""
         assert rgb_in.dtype == np.uint8 and rgb_in.shape == (self.height, self.width, 3) and rgb_in.flags.c_contiguous
         assert rgb_out.dtype == np.uint8 and rgb_out.shape == (self.out_height, self.out_width, 3) and rgb_out.flags.c_contiguous
         t = C.c_uint64()

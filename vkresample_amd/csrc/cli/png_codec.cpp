@@ -451,7 +451,9 @@ PNGIO_SIMD uint32_t adler32_blocks(const uint8_t* p, size_t n)
 }
 
 // zlib stream (RFC 1950) of Huffman-only deflate blocks; returns the number of bytes written to out (capacity: bound below)
-size_t huffman_zlib_bound(size_t n) { return n + n / 8 + (n / (256 * 1024) + 2) * 512 + 64; }
+// (a Huffman code for 257 symbols spends at most ~8.1 bits per symbol on average -- entropy <= 8.006 plus a redundancy below
+// p_max + 0.086 --; nine and an eighth are allowed for, plus 236 bytes of header per block)
+size_t huffman_zlib_bound(size_t n) { return n + n / 8 + n / 64 + (n / (256 * 1024) + 2) * 512 + 64; }
 size_t huffman_zlib(const uint8_t* src, size_t n, uint8_t* out)
 {
     BitWriter bw;
