@@ -13,7 +13,8 @@ static int check_lengths(const std::vector<uint32_t>& f, int maxbits, const char
 {
     const int n = (int)f.size();
     std::vector<uint8_t> len(n);
-    huffman_lengths(f.data(), n, maxbits, len.data());
+    fftup_huff::Work wk;
+    fftup_huff::huffman_lengths(f.data(), n, maxbits, len.data(), wk);
     int used = 0;
     unsigned long long kraft = 0;
     for (int i = 0; i < n; i++) {

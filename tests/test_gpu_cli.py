@@ -145,6 +145,24 @@ def test_cli_batched_threads_share_the_plan_of_their_size(tmp_path):
             assert a.shape == ou8.shape and d.max() <= 1 and (d != 0).mean() <= 5e-3, (folder, k)
 
 
+def test_cli_batched_png_from_the_device(tmp_path):
+    """-gpupng: the files the GPU encoded hold the pixels of the files the host encoded (three threads, one shared plan)"""
+    from vkresample_amd import synth
+    for d in ("inp", "og", "oh"):
+        os.makedirs(tmp_path / d)
+    frames = [synth.frame(70 + k, 256, 128, "N" if k % 2 else "U") for k in range(7)]
+    for k, f in enumerate(frames):
+        _png_write(tmp_path / "inp" / ("%06d.png" % (k + 1)), f)
+    base = [CLI, "-ifolder", "inp", "-numfiles", "7", "-numthreads", "3", "-u", "2", "-p", "0", "-workqueue"]
+    r = subprocess.run(base + ["-ofolder", "og", "-gpupng", "-stagetimes"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and r.stdout.count("finished.") == 3, r.stdout + r.stderr
+    r = subprocess.run(base + ["-ofolder", "oh"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for k in range(7):
+        a = _png_read(tmp_path / "og" / ("%06d.png" % (k + 1)))
+        assert np.array_equal(a, _png_read(tmp_path / "oh" / ("%06d.png" % (k + 1)))), k
+
+
 def test_cli_batched_queue_one_thread_and_missing_file(tmp_path):
     """one thread, 7 files: the double-buffered queue (fftup_submit_rgb8) writes every frame; -n 3 takes the
     blocking path with identical files; a missing file ends the thread like the reference (VR:1631-1634)."""

@@ -1,0 +1,126 @@
+"""GPU: the device-side PNG encoder (fftup_submit_png / fftup_wait_png, csrc/kernels_png.hpp).  A PNG stream has no reference
+bytes to be equal to; what must hold: the file is a valid PNG (PIL decodes it: chunk CRCs, zlib's Huffman-table and Adler-32
+checks) and its pixels are byte-identical to what fftup_submit_rgb8 returns for the same frame."""
+import io
+import struct
+import threading
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(W, H, n):
+    from vkresample_amd import synth
+    out = []
+    for k in range(n):
+        kind = k % 5
+        if kind == 0:
+            f = synth.frame(500 + k, W, H, "N")
+        elif kind == 1:
+            f = synth.frame(500 + k, W, H, "U")                       # noise: near-uniform residuals
+        elif kind == 2:
+            f = np.full((H, W, 3), (17, 200, 90), np.uint8)          # flat: one symbol carries everything (codes of 1 bit)
+        elif kind == 3:
+            yy, xx = np.mgrid[0:H, 0:W]
+            f = np.stack([xx * 255 // max(W - 1, 1), yy * 255 // max(H - 1, 1), (xx + yy) % 256], axis=2).astype(np.uint8)
+        else:
+            f = synth.frame(500 + k, W, H, "N")
+            f[H // 3: 2 * H // 3] = 0                                  # black band: blocks with very different statistics
+        out.append(np.ascontiguousarray(f))
+    return out
+
+
+def _decode(png_bytes):
+    from PIL import Image
+    Image.open(io.BytesIO(png_bytes)).verify()
+    return np.asarray(Image.open(io.BytesIO(png_bytes)).convert("RGB"))
+
+
+def _chunks(png):
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, out = 8, []
+    while pos < len(png):
+        n, = struct.unpack(">I", png[pos:pos + 4])
+        typ, data = png[pos + 4:pos + 8], png[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", png[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(typ + data) & 0xFFFFFFFF == crc, typ
+        out.append((typ, data))
+        pos += 12 + n
+    return out
+
+
+@pytest.mark.parametrize("W,H,u,precision,flags,ring", [(256, 128, 2.0, 0, 0, 3), (240, 126, 2.0, 0, 0, 2), (60, 36, 2.0, 0, 0, 1),
+                                                        (512, 256, 2.0, 2, 6, 4), (96, 64, 3.0, 0, 0, 2), (128, 64, 1.5, 0, 0, 2),
+                                                        (2048, 1024, 2.0, 0, 0, 2), (1920, 1080, 2.0, 2, 2, 2)])
+def test_png_from_the_device_decodes_to_the_frame(W, H, u, precision, flags, ring):
+    import vkresample_amd as v
+    n = 2 * ring + 1 if W < 1000 else 3
+    frames = _frames(W, H, max(n, 5))[:n] if W < 1000 else _frames(W, H, 5)[:3]
+    with v.Upscaler(W, H, u, precision, 0.2, 0, flags, ring) as up:
+        uW, uH = up.out_width, up.out_height
+        want = []
+        out = np.empty((uH, uW, 3), np.uint8)
+        for f in frames:
+            up.wait(up.submit_rgb8(f, out))
+            want.append(out.copy())
+        buf = v.PinnedArray((up.png_bound(),))
+        sizes = []
+        for k, f in enumerate(frames):
+            t = up.submit_png(f)
+            nbytes = up.wait_png(t, buf.array)
+            png = bytes(buf.array[:nbytes])
+            ch = _chunks(png)
+            assert [c[0] for c in ch] == [b"IHDR", b"IDAT", b"IEND"]
+            assert struct.unpack(">IIBBBBB", ch[0][1]) == (uW, uH, 8, 2, 0, 0, 0)
+            raw = zlib.decompress(ch[1][1])                            # Huffman tables, block structure, Adler-32
+            assert len(raw) == uH * (3 * uW + 1) and set(raw[::3 * uW + 1]) <= {0, 1, 2, 3, 4}
+            img = _decode(png)
+            assert img.shape == want[k].shape and np.array_equal(img, want[k]), k
+            sizes.append(nbytes)
+        print("MEASURED png %dx%d: %s bytes per frame, %d raw" % (uW, uH, sizes, uH * uW * 3))
+        assert sizes[2] < 0.2 * uH * uW * 3 if len(sizes) > 2 and W < 1000 else True      # the flat frame: one bit per byte + headers
+        # tickets of the two kinds share the queue; a buffer that is too small is an error, and the slot is free again afterwards
+        t = up.submit_png(frames[0])
+        with pytest.raises(v.FftupError):
+            up.wait_png(t, buf.array[:64])
+        t2 = up.submit_png(frames[1 % len(frames)])
+        nbytes = up.wait_png(t2, buf.array)
+        assert np.array_equal(_decode(bytes(buf.array[:nbytes])), want[1 % len(frames)])
+        with pytest.raises(v.FftupError):
+            up.wait_png(t2, buf.array)                                  # collected already
+        buf.close()
+
+
+def test_png_tickets_from_several_threads():
+    """four threads, one plan with two slots: every thread's PNGs decode to its frames (a slot with an uncollected stream makes
+    the next submission of that slot wait)"""
+    import vkresample_amd as v
+    W, H, T, per = 256, 128, 4, 5
+    frames = _frames(W, H, T * per)
+    with v.Upscaler(W, H, 2.0, 0, 0.2, 0, 0, 2) as up:
+        want, out = [], np.empty((2 * H, 2 * W, 3), np.uint8)
+        for f in frames:
+            up.wait(up.submit_rgb8(f, out))
+            want.append(out.copy())
+        errors = []
+
+        def worker(t):
+            try:
+                buf = v.PinnedArray((up.png_bound(),))
+                for g in range(t, T * per, T):
+                    n = up.wait_png(up.submit_png(frames[g]), buf.array)
+                    if not np.array_equal(_decode(bytes(buf.array[:n])), want[g]):
+                        errors.append((t, g, "pixels differ"))
+                buf.close()
+            except Exception as e:                                     # noqa: BLE001
+                errors.append((t, repr(e)))
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errors, errors

@@ -89,6 +89,8 @@ def main():
         run("-p 0 -numthreads %d (the reference's stripe)" % mid, ["-p", "0"], mid)
         for T in (mid, threads[-1]):
             run("-p 2 -fuseu8 -fuseu8out -numthreads %d -workqueue" % T, ["-p", "2", "-fuseu8", "-fuseu8out", "-workqueue"], T)
+        for T in threads:
+            run("-p 0 -gpupng -numthreads %d -workqueue" % T, ["-p", "0", "-gpupng", "-workqueue", "-stagetimes"], T)
         out_mb = os.path.getsize(os.path.join(outp, "000001.png")) / 1e6
         say("# output PNG: %.1f MB per %dx%d file" % (out_mb, 2 * a.width, 2 * a.height))
 

@@ -22,7 +22,7 @@ EXPORTS = [
     "fftup_profile_kernels", "fftup_download_rgb8", "fftup_download_planar", "fftup_download_presharpen",
     "fftup_download_input_planar", "fftup_host_alloc", "fftup_host_free", "fftup_submit_rgb8", "fftup_wait",
     "fftup_drain", "fftup_strerror", "fftup_last_error", "fftup_version", "fftup_jit_check", "fftup_plan_describe",
-    "fftup_device_pci_bus_id", "fftup_output_checksum",
+    "fftup_device_pci_bus_id", "fftup_output_checksum", "fftup_png_bound", "fftup_submit_png", "fftup_wait_png",
 ]
 ABI_VERSION = 2
 
@@ -79,6 +79,10 @@ def load():
     lib.fftup_submit_rgb8.argtypes = [vp, vp, sz, vp, sz, C.POINTER(C.c_uint64)]
     lib.fftup_wait.argtypes = [vp, C.c_uint64]
     lib.fftup_drain.argtypes = [vp]
+    lib.fftup_png_bound.argtypes = [vp]
+    lib.fftup_png_bound.restype = sz
+    lib.fftup_submit_png.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64)]
+    lib.fftup_wait_png.argtypes = [vp, C.c_uint64, vp, sz, C.POINTER(sz)]
     lib.fftup_strerror.argtypes = [C.c_int]
     lib.fftup_strerror.restype = C.c_char_p
     lib.fftup_last_error.restype = C.c_char_p

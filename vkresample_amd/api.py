@@ -156,6 +156,24 @@ class Upscaler:
                                            3 * self.out_width, C.byref(t)), "fftup_submit_rgb8")
         return t.value
 
+    def png_bound(self):
+        """bytes a PNG buffer of wait_png needs"""
+        return int(self._lib.fftup_png_bound(self._h))
+
+    def submit_png(self, rgb_in):
+        """Like submit_rgb8, but the frame is PNG-encoded on the device; collect it with wait_png(ticket, buffer)."""
+        assert rgb_in.dtype == np.uint8 and rgb_in.shape == (self.height, self.width, 3) and rgb_in.flags.c_contiguous
+        t = C.c_uint64()
+        _check(self._lib.fftup_submit_png(self._h, rgb_in.ctypes.data, 3 * self.width, C.byref(t)), "fftup_submit_png")
+        return t.value
+
+    def wait_png(self, ticket, buf):
+        """buf: uint8 array of at least png_bound() bytes (PinnedArray for a fast copy); returns the PNG file's bytes in it"""
+        assert buf.dtype == np.uint8 and buf.flags.c_contiguous
+        n = C.c_size_t()
+        _check(self._lib.fftup_wait_png(self._h, ticket, buf.ctypes.data, buf.size, C.byref(n)), "fftup_wait_png")
+        return int(n.value)
+
     def wait(self, ticket):
         _check(self._lib.fftup_wait(self._h, ticket), "fftup_wait")
 

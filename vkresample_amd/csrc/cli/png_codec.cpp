@@ -1,5 +1,7 @@
 #include "png_codec.hpp"
 
+#include "../huffman.hpp"
+
 #include <zlib.h>
 
 #include <cstdio>
@@ -297,74 +299,7 @@ PNGIO_SIMD void apply_filter(int ft, const uint8_t* cur, const uint8_t* up, size
     }
 }
 
-// -- Huffman-only deflate (RFC 1951 dynamic blocks without length/distance symbols) --
-// Code lengths (<= maxbits) of an optimal prefix code for freq[0..n), 0 for unused symbols.  Two-queue Huffman construction
-// on the symbols sorted by frequency; the lengths beyond maxbits are folded back by the usual Kraft-sum repair (one code of
-// the longest length is removed, one shorter code made one bit longer, until the sum is exactly one).
-void huffman_lengths(const uint32_t* freq, int n, int maxbits, uint8_t* len)
-{
-    int order[288], used = 0;
-    for (int i = 0; i < n; i++) { len[i] = 0; if (freq[i]) order[used++] = i; }
-    if (used == 0) return;
-    if (used == 1) {                                   // a complete code needs two codes: one unused sibling
-        len[order[0]] = 1;
-        len[order[0] == 0 ? 1 : 0] = 1;
-        return;
-    }
-    for (int i = 1; i < used; i++) {                   // insertion sort by (frequency, symbol): n <= 288
-        const int v = order[i];
-        int j = i - 1;
-        while (j >= 0 && (freq[order[j]] > freq[v] || (freq[order[j]] == freq[v] && order[j] > v))) { order[j + 1] = order[j]; j--; }
-        order[j + 1] = v;
-    }
-    uint64_t w[2 * 288];
-    int parent[2 * 288];
-    for (int i = 0; i < used; i++) w[i] = freq[order[i]];
-    int leaf = 0, inner = used, next = used;            // two queues: leaves [leaf, used), inner nodes [inner, next)
-    auto take = [&]() -> int {
-        if (leaf < used && (inner >= next || w[leaf] <= w[inner])) return leaf++;
-        return inner++;
-    };
-    while ((used - leaf) + (next - inner) > 1) {
-        const int a = take(), b = take();
-        w[next] = w[a] + w[b];
-        parent[a] = parent[b] = next;
-        next++;
-    }
-    const int root = next - 1;
-    int depth[2 * 288];
-    depth[root] = 0;
-    for (int i = root - 1; i >= 0; i--) depth[i] = depth[parent[i]] + 1;      // a parent is always created after its children
-    int count[64] = {0};
-    for (int i = 0; i < used; i++) count[depth[i] < 63 ? depth[i] : 63]++;
-    for (int l = maxbits + 1; l < 64; l++) { count[maxbits] += count[l]; count[l] = 0; }
-    uint64_t total = 0;
-    for (int l = 1; l <= maxbits; l++) total += (uint64_t)count[l] << (maxbits - l);
-    while (total > (1ull << maxbits)) {
-        count[maxbits]--;
-        for (int l = maxbits - 1; l > 0; l--)
-            if (count[l]) { count[l]--; count[l + 1] += 2; break; }
-        total--;
-    }
-    int k = 0;                                           // rarest symbols get the longest codes
-    for (int l = maxbits; l >= 1; l--)
-        for (int c = 0; c < count[l]; c++) len[order[k++]] = (uint8_t)l;
-}
-
-// canonical codes for the lengths, bit-reversed (deflate sends Huffman codes most significant bit first)
-void canonical_codes(const uint8_t* len, int n, int maxbits, uint16_t* code)
-{
-    int count[17] = {0}, next[17] = {0};
-    for (int i = 0; i < n; i++) count[len[i]]++;
-    count[0] = 0;
-    for (int l = 1, c = 0; l <= maxbits; l++) { c = (c + count[l - 1]) << 1; next[l] = c; }
-    for (int i = 0; i < n; i++) {
-        if (!len[i]) { code[i] = 0; continue; }
-        unsigned c = (unsigned)next[len[i]]++, r = 0;
-        for (int b = 0; b < len[i]; b++) { r = (r << 1) | (c & 1); c >>= 1; }
-        code[i] = (uint16_t)r;
-    }
-}
+// -- Huffman-only deflate: code construction and the block header are shared with the device-side encoder (../huffman.hpp) --
 
 struct BitWriter {                    // LSB-first bit stream; every put stores 8 bytes at the write position (little-endian host)
     uint8_t* p;
@@ -394,29 +329,12 @@ void huffman_block(BitWriter& bw, const uint8_t* src, size_t n, bool last)
     freq[256] = 1;                                       // end of block
     uint8_t len[257];
     uint16_t code[257];
-    huffman_lengths(freq, 257, 15, len);
-    canonical_codes(len, 257, 15, code);
-    // the code lengths are sent one by one (symbols 0..15 of the code-length alphabet, no repeat symbols: 259 lengths per
-    // 256 KB block), followed by two distance codes of one bit that are never used (a complete set, like zlib sends)
-    uint8_t seq[259];
-    memcpy(seq, len, 257);
-    seq[257] = seq[258] = 1;
-    uint32_t cfreq[19] = {0};
-    for (int k = 0; k < 259; k++) cfreq[seq[k]]++;
-    uint8_t clen[19];
-    uint16_t ccode[19];
-    huffman_lengths(cfreq, 19, 7, clen);
-    canonical_codes(clen, 19, 7, ccode);
-    static const int perm[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    int hclen = 19;
-    while (hclen > 4 && clen[perm[hclen - 1]] == 0) hclen--;
-    bw.put(last ? 1 : 0, 1);
-    bw.put(2, 2);                                        // dynamic Huffman codes
-    bw.put(257 - 257, 5);                                // HLIT: literals + end of block only
-    bw.put(2 - 1, 5);                                    // HDIST
-    bw.put((unsigned)hclen - 4, 4);
-    for (int k = 0; k < hclen; k++) bw.put(clen[perm[k]], 3);
-    for (int k = 0; k < 259; k++) bw.put(ccode[seq[k]], clen[seq[k]]);
+    fftup_huff::Work wk;
+    fftup_huff::huffman_lengths(freq, 257, 15, len, wk);
+    fftup_huff::canonical_codes(len, 257, 15, code, wk);
+    uint32_t hdr[64];
+    const int hbits = fftup_huff::dynamic_header(len, last, hdr, wk);
+    for (int k = 0; k < hbits; k += 32) bw.put(hdr[k >> 5], hbits - k < 32 ? (unsigned)(hbits - k) : 32u);
     uint32_t tab[256];                                   // code | length << 16
     for (int s = 0; s < 256; s++) tab[s] = code[s] | ((uint32_t)len[s] << 16);
     i = 0;

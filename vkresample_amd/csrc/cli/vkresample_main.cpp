@@ -48,6 +48,7 @@ struct ResampleConfiguration {           // VkResampleConfiguration, VR:45-59
     uint32_t flags = 0;
     std::atomic<int>* workQueue = nullptr;   // -workqueue: next file number - 1, shared by all threads
     bool stageTimes = false;                 // -stagetimes: per-thread host time by stage (batched mode)
+    bool gpuPng = false;                     // -gpupng: batched mode: the GPU delivers the finished PNG (fftup_submit_png)
 };
 
 static bool findFlag(char** start, char** end, const std::string& flag)      // VR:1782-1784: exact token match
@@ -195,8 +196,10 @@ static int launchResample(ResampleConfiguration config)                      // 
         // PNG codec (tens of ms per file), so the overlap that matters is between the THREADS -- one frame and one pair of
         // buffers per thread (a second pair would hide 1 ms per file and double the page-locking, which the driver serialises).
         const size_t inBytes = (size_t)width * height * 3, outBytes = (size_t)uW * uH * 3;
+        const bool gpuPng = config.gpuPng && config.precision != 1;    // (-p 1: the host encodes)
+        const size_t pngCap = gpuPng ? fftup_png_bound(plan) : 0;
         uint8_t* pin = (uint8_t*)fftup_host_alloc(inBytes);
-        uint8_t* pout = (uint8_t*)fftup_host_alloc(outBytes);
+        uint8_t* pout = (uint8_t*)fftup_host_alloc(gpuPng ? pngCap : outBytes);
         auto release = [&]() { fftup_host_free(pin); fftup_host_free(pout); };     // (no frame of this thread is in flight here)
         if (!pin || !pout) {
             printf("Upscale failed: %s (%s)\n", fftup_strerror(FFTUP_E_OUT_OF_MEMORY), fftup_last_error());
@@ -220,7 +223,8 @@ static int launchResample(ResampleConfiguration config)                      // 
             }
             memcpy(pin, png_input.data(), inBytes);
             uint64_t ticket = 0;
-            res = fftup_submit_rgb8(plan, pin, (size_t)width * 3, pout, (size_t)uW * 3, &ticket);
+            res = gpuPng ? fftup_submit_png(plan, pin, (size_t)width * 3, &ticket)
+                         : fftup_submit_rgb8(plan, pin, (size_t)width * 3, pout, (size_t)uW * 3, &ticket);
             if (res != FFTUP_OK) {
                 printf("Upscale failed: %s (%s)\n", fftup_strerror(res), fftup_last_error());
                 release();
@@ -228,7 +232,8 @@ static int launchResample(ResampleConfiguration config)                      // 
             }
             double t1 = now_ms();
             tSubmit += t1 - t0;
-            res = fftup_wait(plan, ticket);
+            size_t pngBytes = 0;
+            res = gpuPng ? fftup_wait_png(plan, ticket, pout, pngCap, &pngBytes) : fftup_wait(plan, ticket);
             t0 = now_ms();
             tWait += t0 - t1;
             if (res != FFTUP_OK) {
@@ -238,7 +243,11 @@ static int launchResample(ResampleConfiguration config)                      // 
             }
             char outName[1024];
             snprintf(outName, sizeof outName, "%s/%06d.png", config.ofolder_prefix, fileAt(f));
-            if (!pngio::write_rgb8(outName, pout, (int)uW, (int)uH, (size_t)uW * 3, err))
+            if (gpuPng) {                                           // the file arrived finished: filters, deflate, checksums
+                FILE* fo = fopen(outName, "wb");
+                const bool ok = fo && fwrite(pout, 1, pngBytes, fo) == pngBytes;
+                if ((fo && fclose(fo) != 0) || !ok) printf("Could not write %s: write error\n", outName);
+            } else if (!pngio::write_rgb8(outName, pout, (int)uW, (int)uH, (size_t)uW * 3, err))
                 printf("Could not write %s: %s\n", outName, err.c_str());
             tEncode += now_ms() - t0;
         }
@@ -317,6 +326,7 @@ int main(int argc, char* argv[])
         printf("	-fuseu8out: the last kernel writes the 8-bit image directly (no float planes, no conversion pass)\n");
         printf("	-wrapu8: 8-bit store wraps like the original's C cast instead of saturating\n");
         printf("	-workqueue: batched mode: threads take the next unprocessed file from one shared counter instead of the fixed stripe\n");
+        printf("	-gpupng: batched mode: the GPU also encodes the PNG (row filters, Huffman-only deflate, Adler-32); the host writes the file\n");
         printf("	-stagetimes: batched mode: every thread reports its host time by stage (decode, submit, wait, encode)\n");
         printf("	-tune: sizes whose kernels are specialised at plan time: measure the alternatives once, remember the fastest\n");
         return 0;
@@ -356,6 +366,7 @@ int main(int argc, char* argv[])
     if (findFlag(B, E, "-wrapu8")) config.flags |= FFTUP_FLAG_U8_WRAP;
     if (findFlag(B, E, "-tune")) config.flags |= FFTUP_FLAG_TUNE_PLAN;
     config.stageTimes = findFlag(B, E, "-stagetimes");
+    config.gpuPng = findFlag(B, E, "-gpupng");
 
     if (!findFlag(B, E, "-ifolder")) {
         config.fileUpload = 0;

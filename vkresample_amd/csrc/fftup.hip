@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
@@ -19,6 +20,7 @@
 #include "kernels_pow2.hpp"
 #include "kernels_mixed.hpp"
 #include "kernels_dswap.hpp"
+#include "kernels_png.hpp"
 #include "jit.hpp"
 
 using namespace fftup;
@@ -108,10 +110,17 @@ struct fftup_plan {
     std::vector<void*> out;           // per slot: dense [3][uH][uW]
     uint8_t* out_u8 = nullptr;        // staging for download_rgb8
     // host-streamed queue (fftup_submit_rgb8): created on first use
-    struct QSlot { uint8_t* out_u8 = nullptr; hipEvent_t done = nullptr; };
+    // (png: the device-side PNG encoder's buffers of the slot, created on the first fftup_submit_png; state 1 = a stream waits for
+    // its fftup_wait_png -- a later submission of the slot waits for that on q_cv)
+    struct PngSlot { PngParams p{}; unsigned long long* meta_host = nullptr; uint32_t* parts_host = nullptr; hipEvent_t copied = nullptr; int state = 0; };
+    struct QSlot { uint8_t* out_u8 = nullptr; hipEvent_t done = nullptr; PngSlot png; };
     std::vector<QSlot> q;
     std::atomic<uint64_t> q_next{0};   // next ticket; written under q_mu, read by fftup_wait without it
     std::mutex q_mu;                   // fftup_submit_rgb8 may be called by several host threads (codec workers sharing a plan)
+    std::condition_variable q_cv;
+    hipStream_t png_copy = nullptr;    // the sized D2H copies of fftup_wait_png
+    int png_rpb = 0, png_nblocks = 0;  // rows per deflate block, blocks per frame
+    size_t png_stream_bytes = 0;       // capacity of a slot's stream buffer
     float2 *twW = nullptr, *twH = nullptr, *twUW = nullptr, *twUH = nullptr;
     uint64_t device_bytes = 0;
     size_t r_bytes = 0;               // bytes of one pre-sharpen image
@@ -398,8 +407,13 @@ void fftup_plan_destroy(fftup_plan* P)
         if (P->lanes[l].stream) { (void)hipStreamSynchronize(P->lanes[l].stream); (void)hipStreamDestroy(P->lanes[l].stream); }
         if (P->lanes[l].done) (void)hipEventDestroy(P->lanes[l].done);
     }
-    for (auto& qs : P->q)
+    for (auto& qs : P->q) {
         if (qs.done) (void)hipEventDestroy(qs.done);
+        if (qs.png.copied) (void)hipEventDestroy(qs.png.copied);
+        if (qs.png.meta_host) (void)hipHostFree(qs.png.meta_host);
+        if (qs.png.parts_host) (void)hipHostFree(qs.png.parts_host);
+    }
+    if (P->png_copy) (void)hipStreamDestroy(P->png_copy);
     for (auto& g : P->graphs) (void)hipGraphExecDestroy(g.second);
     for (void* p : P->allocs) (void)hipFree(p);
     delete P->jit;
@@ -1690,22 +1704,74 @@ static int queue_init(fftup_plan* P)
     return FFTUP_OK;
 }
 
-int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, uint8_t* rgb_out, size_t out_stride,
-                      uint64_t* ticket)
+// ---- device-side PNG encoding (csrc/kernels_png.hpp) ----
+static size_t png_stream_bound(size_t raw_bytes, int nblocks)
+{
+    // a Huffman code for 257 symbols spends at most ~8.1 bits per symbol on average; nine and an eighth are allowed for, 236
+    // bytes of header per block, and the words the last atomicOr may touch
+    return (raw_bytes + raw_bytes / 8 + raw_bytes / 64 + ((size_t)nblocks + 2) * 512 + 64 + 15) / 16 * 16;
+}
+static void png_geometry(fftup_plan* P)
+{
+    if (P->png_rpb) return;
+    const size_t L = (size_t)3 * P->uW + 1;
+    P->png_rpb = (int)std::max<size_t>(1, (192 * 1024) / L);           // ~192 KB of residuals per deflate block, whole rows
+    P->png_nblocks = (int)((P->uH + (uint32_t)P->png_rpb - 1) / (uint32_t)P->png_rpb);
+    P->png_stream_bytes = png_stream_bound(L * P->uH, P->png_nblocks);
+}
+static int png_slot_init(fftup_plan* P, fftup_plan::QSlot& Q)
+{
+    fftup_plan::PngSlot& G = Q.png;
+    if (G.p.stream) return FFTUP_OK;
+    png_geometry(P);
+    const size_t L = (size_t)3 * P->uW + 1, nb = (size_t)P->png_nblocks, uH = P->uH;
+    PngParams p{};
+    int rc = dev_alloc(P, (void**)&p.raw, L * uH);
+    if (!rc) rc = dev_alloc(P, (void**)&p.rowhist, uH * 257 * sizeof(uint32_t));
+    if (!rc) rc = dev_alloc(P, (void**)&p.rowsum, uH * 2 * sizeof(unsigned long long));
+    if (!rc) rc = dev_alloc(P, (void**)&p.tab, nb * 257 * sizeof(uint32_t));
+    if (!rc) rc = dev_alloc(P, (void**)&p.hdr, nb * 64 * sizeof(uint32_t));
+    if (!rc) rc = dev_alloc(P, (void**)&p.hdr_bits, nb * sizeof(uint32_t));
+    if (!rc) rc = dev_alloc(P, (void**)&p.block_bits, nb * sizeof(unsigned long long));
+    if (!rc) rc = dev_alloc(P, (void**)&p.block_start, nb * sizeof(unsigned long long));
+    if (!rc) rc = dev_alloc(P, (void**)&p.row_off, uH * sizeof(unsigned long long));
+    if (!rc) rc = dev_alloc(P, (void**)&p.meta, 2 * sizeof(unsigned long long));
+    if (!rc) rc = dev_alloc(P, (void**)&p.crc_parts, (P->png_stream_bytes / 4096 + 1) * sizeof(uint32_t));
+    if (!rc) rc = dev_alloc(P, (void**)&p.stream, P->png_stream_bytes);
+    if (rc) return rc;                                            // (what was allocated stays owned by the plan)
+    p.uW = (int)P->uW; p.uH = (int)P->uH; p.rows_per_block = P->png_rpb; p.nblocks = P->png_nblocks;
+    if (!G.meta_host) HIP_TRY(hipHostMalloc((void**)&G.meta_host, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!G.parts_host) HIP_TRY(hipHostMalloc((void**)&G.parts_host, (P->png_stream_bytes / 4096 + 1) * sizeof(uint32_t), hipHostMallocDefault));
+    if (!G.copied) HIP_TRY(hipEventCreateWithFlags(&G.copied, hipEventDisableTiming));
+    if (!P->png_copy) HIP_TRY(hipStreamCreateWithFlags(&P->png_copy, hipStreamNonBlocking));
+    G.p = p;
+    return FFTUP_OK;
+}
+
+// shared body of fftup_submit_rgb8 / fftup_submit_png: one whole frame on one of the plan's streams
+static int submit_frame(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, uint8_t* rgb_out, size_t out_stride, bool png,
+                        uint64_t* ticket)
 {
     if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
     if (!rgb_in || in_stride < (size_t)3 * P->W) return fail(FFTUP_E_INVALID_ARG, "bad input pointer/stride");
-    if (!rgb_out || out_stride < (size_t)3 * P->uW) return fail(FFTUP_E_INVALID_ARG, "bad output pointer/stride");
+    if (!png && (!rgb_out || out_stride < (size_t)3 * P->uW)) return fail(FFTUP_E_INVALID_ARG, "bad output pointer/stride");
+    if (png && P->dbl) return fail(FFTUP_E_UNSUPPORTED_PRECISION, "device-side PNG encoding: -p 0 and -p 2 plans");
     HIP_TRY(hipSetDevice(P->device));
     // one submission at a time: slot choice, the lane's launches and the ticket are one critical section (a few tens of
     // microseconds; the wait below is for the frame that used this slot `ring` submissions ago)
-    std::lock_guard<std::mutex> lock(P->q_mu);
+    std::unique_lock<std::mutex> lock(P->q_mu);
     int rc = queue_init(P);
     if (rc) return rc;
-    const uint64_t t = P->q_next.load(std::memory_order_relaxed);
+    uint64_t t;
+    for (;;) {                                                        // (the lock is released while waiting: the ticket is re-read)
+        t = P->q_next.load(std::memory_order_relaxed);
+        if (P->q[t % P->ring].png.state == 0) break;
+        P->q_cv.wait(lock);                                           // a PNG stream of this slot is still to be collected
+    }
     const uint32_t s = (uint32_t)(t % P->ring);
     fftup_plan::QSlot& Q = P->q[s];
     if (t >= P->ring) HIP_TRY(hipEventSynchronize(Q.done));          // the slot's previous frame has left the device
+    if (png && (rc = png_slot_init(P, Q)) != FFTUP_OK) return rc;
     // The whole frame -- H2D, conversion, kernels, conversion, D2H -- goes to ONE stream (lane t % nlanes), so no
     // cross-stream dependency exists and nothing can stall behind a neighbour's wait when streams share a hardware
     // queue; the copies of one lane overlap the kernels and the opposite-direction copies of the other lanes.
@@ -1728,12 +1794,143 @@ int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, ui
     if (rc) return rc;
     if (!P->u8out) launch_pack(P, s, Q.out_u8, cs);
     HIP_TRY(hipGetLastError());
-    if (out_stride == out_row) HIP_TRY(hipMemcpyAsync(rgb_out, Q.out_u8, out_row * P->uH, hipMemcpyDeviceToHost, cs));
+    if (png) {
+        // the 8-bit image stays on the device: filter rows, code them, pack the bits; only the stream's size comes back now,
+        // the stream itself when fftup_wait_png knows how many bytes to ask for
+        PngParams pp = Q.png.p;
+        pp.rgb = Q.out_u8;
+        HIP_TRY(hipMemsetAsync(pp.stream, 0, P->png_stream_bytes, cs));
+        hipLaunchKernelGGL(k_png_filter, dim3(P->uH), dim3(256), 0, cs, pp);
+        hipLaunchKernelGGL(k_png_codes, dim3(P->png_nblocks), dim3(256), 0, cs, pp);
+        hipLaunchKernelGGL(k_png_layout, dim3(1), dim3(256), 0, cs, pp);
+        hipLaunchKernelGGL(k_png_pack, dim3(P->uH), dim3(256), 0, cs, pp);
+        const size_t max_pieces = P->png_stream_bytes / 4096;
+        hipLaunchKernelGGL(k_png_crc, dim3((unsigned)((max_pieces + 255) / 256)), dim3(256), 0, cs, pp);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(Q.png.meta_host, pp.meta, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipMemcpyAsync(Q.png.parts_host, pp.crc_parts, max_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+        Q.png.state = 1;
+    } else if (out_stride == out_row) HIP_TRY(hipMemcpyAsync(rgb_out, Q.out_u8, out_row * P->uH, hipMemcpyDeviceToHost, cs));
     else HIP_TRY(hipMemcpy2DAsync(rgb_out, out_stride, Q.out_u8, out_row, out_row, P->uH, hipMemcpyDeviceToHost, cs));
     HIP_TRY(hipEventRecord(Q.done, cs));
     P->q_next.store(t + 1, std::memory_order_release);
     P->executed = 1;
     if (ticket) *ticket = t;
+    return FFTUP_OK;
+}
+
+int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, uint8_t* rgb_out, size_t out_stride,
+                      uint64_t* ticket)
+{
+    return submit_frame(P, rgb_in, in_stride, rgb_out, out_stride, false, ticket);
+}
+
+int fftup_submit_png(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, uint64_t* ticket)
+{
+    return submit_frame(P, rgb_in, in_stride, nullptr, 0, true, ticket);
+}
+
+size_t fftup_png_bound(fftup_plan* P)
+{
+    if (!P) return 0;
+    png_geometry(P);
+    return P->png_stream_bytes + 57;                      // signature 8, IHDR 25, IDAT framing 12, IEND 12
+}
+
+// CRC-32 of the PNG chunks (ISO 3309, the zlib polynomial), eight bytes per step
+static uint32_t crc32_png(uint32_t crc, const uint8_t* p, size_t n)
+{
+    static uint32_t T[8][256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; i++)
+            for (int k = 1; k < 8; k++) T[k][i] = (T[k - 1][i] >> 8) ^ T[0][T[k - 1][i] & 255];
+    });
+    crc = ~crc;
+    while (n >= 8) {
+        uint32_t a, b;
+        memcpy(&a, p, 4);
+        memcpy(&b, p + 4, 4);
+        a ^= crc;
+        crc = T[7][a & 255] ^ T[6][(a >> 8) & 255] ^ T[5][(a >> 16) & 255] ^ T[4][a >> 24] ^
+              T[3][b & 255] ^ T[2][(b >> 8) & 255] ^ T[1][(b >> 16) & 255] ^ T[0][b >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) crc = T[0][(crc ^ *p++) & 255] ^ (crc >> 8);
+    return ~crc;
+}
+// crc(A || B) from crc(A) and crc(B) for |B| = 4096: the operator "append 4096 zero bytes" is linear over GF(2) -- the matrix of
+// one zero bit (the polynomial and a shift), squared fifteen times
+static uint32_t crc32_shift_4096(uint32_t crc)
+{
+    static uint32_t M[32];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        uint32_t a[32], b[32];
+        a[0] = 0xEDB88320u;
+        for (int n = 1; n < 32; n++) a[n] = 1u << (n - 1);
+        auto times = [](const uint32_t* m, uint32_t v) { uint32_t s = 0; for (int i = 0; v; v >>= 1, i++) if (v & 1) s ^= m[i]; return s; };
+        for (int k = 0; k < 15; k++) {                          // 2^15 bits = 4096 bytes
+            for (int n = 0; n < 32; n++) b[n] = times(a, a[n]);
+            memcpy(a, b, sizeof a);
+        }
+        memcpy(M, a, sizeof M);
+    });
+    uint32_t s = 0;
+    for (int i = 0; crc; crc >>= 1, i++)
+        if (crc & 1) s ^= M[i];
+    return s;
+}
+static void be32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; }
+
+int fftup_wait_png(fftup_plan* P, uint64_t ticket, uint8_t* png_out, size_t capacity, size_t* png_bytes)
+{
+    if (!P || !png_out || !png_bytes) return fail(FFTUP_E_INVALID_ARG, "null argument");
+    const uint64_t next = P->q_next.load(std::memory_order_acquire);
+    if (ticket >= next) return fail(FFTUP_E_INVALID_ARG, "ticket was never issued");
+    fftup_plan::QSlot& Q = P->q[ticket % P->ring];
+    if (ticket + P->ring < next || Q.png.state != 1) return fail(FFTUP_E_INVALID_ARG, "no PNG stream is waiting under this ticket");
+    HIP_TRY(hipSetDevice(P->device));
+    auto release = [&] {
+        { std::lock_guard<std::mutex> lock(P->q_mu); Q.png.state = 0; }
+        P->q_cv.notify_all();
+    };
+    hipError_t e = hipEventSynchronize(Q.done);
+    const size_t zbytes = e == hipSuccess ? (size_t)Q.png.meta_host[0] : 0;
+    if (e == hipSuccess && (zbytes < 6 || zbytes > P->png_stream_bytes || zbytes + 57 > capacity)) {
+        release();
+        return fail(FFTUP_E_INVALID_ARG, "PNG buffer too small: " + std::to_string(zbytes + 57) + " bytes needed (fftup_png_bound)");
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(png_out + 41, Q.png.p.stream, zbytes, hipMemcpyDeviceToHost, P->png_copy);
+    if (e == hipSuccess) e = hipEventRecord(Q.png.copied, P->png_copy);
+    if (e == hipSuccess) e = hipEventSynchronize(Q.png.copied);
+    uint32_t crc = 0;
+    if (e == hipSuccess) {                                 // "IDAT", then the stream: whole 4 KB pieces from the device, the tail here
+        crc = crc32_png(0, (const uint8_t*)"IDAT", 4);
+        const size_t pieces = zbytes / 4096;
+        for (size_t k = 0; k < pieces; k++) crc = crc32_shift_4096(crc) ^ Q.png.parts_host[k];
+        crc = crc32_png(crc, png_out + 41 + pieces * 4096, zbytes - pieces * 4096);
+    }
+    release();                                             // (the slot's host mailboxes are not read below)
+    if (e != hipSuccess) return fail(FFTUP_E_HIP, std::string("fftup_wait_png: ") + hipGetErrorString(e));
+    static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    memcpy(png_out, sig, 8);
+    uint8_t* q = png_out + 8;                              // IHDR: 8-bit RGB, no interlace
+    be32(q, 13); memcpy(q + 4, "IHDR", 4); be32(q + 8, P->uW); be32(q + 12, P->uH);
+    q[16] = 8; q[17] = 2; q[18] = 0; q[19] = 0; q[20] = 0;
+    be32(q + 21, crc32_png(0, q + 4, 17));
+    q = png_out + 33;
+    be32(q, (uint32_t)zbytes); memcpy(q + 4, "IDAT", 4);
+    be32(png_out + 41 + zbytes, crc);
+    q = png_out + 41 + zbytes + 4;
+    be32(q, 0); memcpy(q + 4, "IEND", 4); be32(q + 8, crc32_png(0, q + 4, 4));
+    *png_bytes = zbytes + 57;
     return FFTUP_OK;
 }
 
