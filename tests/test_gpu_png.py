@@ -91,6 +91,15 @@ def test_png_from_the_device_decodes_to_the_frame(W, H, u, precision, flags, rin
         assert np.array_equal(_decode(bytes(buf.array[:nbytes])), want[1 % len(frames)])
         with pytest.raises(v.FftupError):
             up.wait_png(t2, buf.array)                                  # collected already
+        t3 = up.submit_png(frames[0])
+        with pytest.raises(v.FftupError):
+            up.wait(t3)                                                 # the pixel path's wait does not collect a PNG
+        assert np.array_equal(_decode(bytes(buf.array[:up.wait_png(t3, buf.array)])), want[0])
+        t4 = up.submit_rgb8(frames[0], out)
+        with pytest.raises(v.FftupError):
+            up.wait_png(t4, buf.array)                                  # ... and the other way round
+        up.wait(t4)
+        assert np.array_equal(out, want[0])
         buf.close()
 
 

@@ -112,7 +112,7 @@ struct fftup_plan {
     // host-streamed queue (fftup_submit_rgb8): created on first use
     // (png: the device-side PNG encoder's buffers of the slot, created on the first fftup_submit_png; state 1 = a stream waits for
     // its fftup_wait_png -- a later submission of the slot waits for that on q_cv)
-    struct PngSlot { PngParams p{}; unsigned long long* meta_host = nullptr; uint32_t* parts_host = nullptr; hipEvent_t copied = nullptr; int state = 0; };
+    struct PngSlot { PngParams p{}; unsigned long long* meta_host = nullptr; uint32_t* parts_host = nullptr; hipEvent_t copied = nullptr; int state = 0; uint64_t ticket = 0; };
     struct QSlot { uint8_t* out_u8 = nullptr; hipEvent_t done = nullptr; PngSlot png; };
     std::vector<QSlot> q;
     std::atomic<uint64_t> q_next{0};   // next ticket; written under q_mu, read by fftup_wait without it
@@ -1810,6 +1810,7 @@ static int submit_frame(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, 
         HIP_TRY(hipMemcpyAsync(Q.png.meta_host, pp.meta, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
         HIP_TRY(hipMemcpyAsync(Q.png.parts_host, pp.crc_parts, max_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
         Q.png.state = 1;
+        Q.png.ticket = t;
     } else if (out_stride == out_row) HIP_TRY(hipMemcpyAsync(rgb_out, Q.out_u8, out_row * P->uH, hipMemcpyDeviceToHost, cs));
     else HIP_TRY(hipMemcpy2DAsync(rgb_out, out_stride, Q.out_u8, out_row, out_row, P->uH, hipMemcpyDeviceToHost, cs));
     HIP_TRY(hipEventRecord(Q.done, cs));
@@ -1895,7 +1896,8 @@ int fftup_wait_png(fftup_plan* P, uint64_t ticket, uint8_t* png_out, size_t capa
     const uint64_t next = P->q_next.load(std::memory_order_acquire);
     if (ticket >= next) return fail(FFTUP_E_INVALID_ARG, "ticket was never issued");
     fftup_plan::QSlot& Q = P->q[ticket % P->ring];
-    if (ticket + P->ring < next || Q.png.state != 1) return fail(FFTUP_E_INVALID_ARG, "no PNG stream is waiting under this ticket");
+    if (ticket + P->ring < next || Q.png.state != 1 || Q.png.ticket != ticket)
+        return fail(FFTUP_E_INVALID_ARG, "no PNG stream is waiting under this ticket");
     HIP_TRY(hipSetDevice(P->device));
     auto release = [&] {
         { std::lock_guard<std::mutex> lock(P->q_mu); Q.png.state = 0; }
@@ -1940,6 +1942,10 @@ int fftup_wait(fftup_plan* P, uint64_t ticket)
     const uint64_t next = P->q_next.load(std::memory_order_acquire);
     if (ticket >= next) return fail(FFTUP_E_INVALID_ARG, "ticket was never issued");
     if (ticket + P->ring < next) return FFTUP_OK;             // its slot has been reused: submit already waited for it
+    {
+        const fftup_plan::QSlot& Q = P->q[ticket % P->ring];
+        if (Q.png.state == 1 && Q.png.ticket == ticket) return fail(FFTUP_E_INVALID_ARG, "a ticket of fftup_submit_png is collected by fftup_wait_png");
+    }
     // (a submission of another thread may re-record this slot's event right now: the wait then covers the later frame too)
     HIP_TRY(hipSetDevice(P->device));
     HIP_TRY(hipEventSynchronize(P->q[ticket % P->ring].done));
