@@ -103,6 +103,26 @@ def test_png_from_the_device_decodes_to_the_frame(W, H, u, precision, flags, rin
         buf.close()
 
 
+def test_png_over_many_sizes():
+    """row lengths and heights of every residue (rows of 49 .. 24 001 bytes, one to dozens of deflate blocks, threads with and
+    without symbols, a last block of one row): one natural and one flat frame per size"""
+    import vkresample_amd as v
+    from vkresample_amd import synth
+    sizes = [(16, 8, 2.0), (18, 10, 3.0), (36, 16, 2.5), (50, 18, 2.0), (98, 54, 2.0), (128, 100, 1.5), (250, 250, 2.0), (486, 98, 2.0),
+             (1000, 490, 2.0), (2000, 36, 4.0), (80, 1250, 2.0), (4000, 16, 2.0), (162, 162, 3.0), (100, 8, 1.0)]
+    for (W, H, u) in sizes:
+        with v.Upscaler(W, H, u, 0, 0.2, 0, 0, 2) as up:
+            uW, uH = up.out_width, up.out_height
+            buf = np.empty(up.png_bound(), np.uint8)
+            out = np.empty((uH, uW, 3), np.uint8)
+            for f in (synth.frame(900 + W + H, W, H, "N"), np.full((H, W, 3), 131, np.uint8)):
+                up.wait(up.submit_rgb8(f, out))
+                n = up.wait_png(up.submit_png(f), buf)
+                png = bytes(buf[:n])
+                _chunks(png)
+                assert np.array_equal(_decode(png), out), (W, H, u)
+
+
 def test_png_tickets_from_several_threads():
     """four threads, one plan with two slots: every thread's PNGs decode to its frames (a slot with an uncollected stream makes
     the next submission of that slot wait)"""

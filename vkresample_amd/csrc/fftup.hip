@@ -1805,10 +1805,10 @@ static int submit_frame(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, 
         hipLaunchKernelGGL(k_png_layout, dim3(1), dim3(256), 0, cs, pp);
         hipLaunchKernelGGL(k_png_pack, dim3(P->uH), dim3(256), 0, cs, pp);
         const size_t max_pieces = P->png_stream_bytes / 4096;
-        hipLaunchKernelGGL(k_png_crc, dim3((unsigned)((max_pieces + 255) / 256)), dim3(256), 0, cs, pp);
+        if (max_pieces) hipLaunchKernelGGL(k_png_crc, dim3((unsigned)((max_pieces + 255) / 256)), dim3(256), 0, cs, pp);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(Q.png.meta_host, pp.meta, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
-        HIP_TRY(hipMemcpyAsync(Q.png.parts_host, pp.crc_parts, max_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+        if (max_pieces) HIP_TRY(hipMemcpyAsync(Q.png.parts_host, pp.crc_parts, max_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
         Q.png.state = 1;
         Q.png.ticket = t;
     } else if (out_stride == out_row) HIP_TRY(hipMemcpyAsync(rgb_out, Q.out_u8, out_row * P->uH, hipMemcpyDeviceToHost, cs));
