@@ -109,7 +109,8 @@ def test_png_over_many_sizes():
     import vkresample_amd as v
     from vkresample_amd import synth
     sizes = [(16, 8, 2.0), (18, 10, 3.0), (36, 16, 2.5), (50, 18, 2.0), (98, 54, 2.0), (128, 100, 1.5), (250, 250, 2.0), (486, 98, 2.0),
-             (1000, 490, 2.0), (2000, 36, 4.0), (80, 1250, 2.0), (4000, 16, 2.0), (162, 162, 3.0), (100, 8, 1.0)]
+             (1000, 490, 2.0), (2000, 36, 4.0), (80, 1250, 2.0), (4000, 16, 2.0), (162, 162, 3.0), (100, 8, 1.0),
+             (4608, 16, 2.0)]                                   # 9216-pixel rows: the non-R2C path's image
     for (W, H, u) in sizes:
         with v.Upscaler(W, H, u, 0, 0.2, 0, 0, 2) as up:
             uW, uH = up.out_width, up.out_height
@@ -121,6 +122,15 @@ def test_png_over_many_sizes():
                 png = bytes(buf[:n])
                 _chunks(png)
                 assert np.array_equal(_decode(png), out), (W, H, u)
+
+
+def test_png_is_refused_for_double_precision_plans():
+    import vkresample_amd as v
+    from vkresample_amd import synth
+    with v.Upscaler(64, 32, 2.0, 1, 0.2, 0, 0, 1) as up:
+        with pytest.raises(v.FftupError) as e:
+            up.submit_png(synth.frame(1, 64, 32, "N"))
+        assert e.value.code == 3                                    # FFTUP_E_UNSUPPORTED_PRECISION: the CLI encodes -p 1 frames on the host
 
 
 def test_png_tickets_from_several_threads():
