@@ -250,6 +250,14 @@ bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& width, i
         try { img.resize((size_t)ph * rb); } catch (const std::bad_alloc&) { err = "image too large"; return false; }
         if (!unfilter(raw.data() + off, img.data(), ph, rb, bpp)) { err = "bad filter type"; return false; }
         off += (size_t)ph * (rb + 1);
+        if (!hd.interlace && hd.depth == 8 && (hd.ctype == 6 || hd.ctype == 0 || hd.ctype == 4)) {     // RGBA / grey / grey + alpha, 8 bits: tight loops
+            const uint8_t* sp = img.data();
+            uint8_t* dp = rgb.data();
+            const size_t npx = (size_t)pw * ph;
+            if (hd.ctype == 6) for (size_t i = 0; i < npx; i++) { dp[3 * i] = sp[4 * i]; dp[3 * i + 1] = sp[4 * i + 1]; dp[3 * i + 2] = sp[4 * i + 2]; }
+            else { const int st = hd.ctype == 0 ? 1 : 2; for (size_t i = 0; i < npx; i++) dp[3 * i] = dp[3 * i + 1] = dp[3 * i + 2] = sp[st * i]; }
+            continue;
+        }
         for (int y = 0; y < ph; y++)
             for (int x = 0; x < pw; x++) {
                 const int X = hd.interlace ? xs[p] + x * dx[p] : x, Y = hd.interlace ? ys[p] + y * dy[p] : y;
