@@ -56,6 +56,28 @@ inline void unfilter_paeth_sse2(const uint8_t* src, uint8_t* cur, const uint8_t*
         c = b;
     }
 }
+// Sub and Average rows the same way: the left neighbour stays in a register instead of going through a store and a load per byte;
+// bytes wrap by themselves, floor((a + b) / 2) = (a & b) + ((a ^ b) >> 1).  `up` NULL: Sub.
+inline void unfilter_sub_avg_sse2(const uint8_t* src, uint8_t* cur, const uint8_t* up, size_t npix, int bpp)
+{
+    __m128i a = _mm_setzero_si128();
+    const __m128i m7f = _mm_set1_epi8(0x7f);
+    for (size_t k = 0; k < npix; k++, src += bpp, cur += bpp) {
+        int32_t wx, wb = 0;
+        memcpy(&wx, src, 4);
+        __m128i pred = a;
+        if (up) {
+            memcpy(&wb, up, 4);
+            up += bpp;
+            const __m128i b = _mm_cvtsi32_si128(wb);
+            pred = _mm_add_epi8(_mm_and_si128(a, b), _mm_and_si128(_mm_srli_epi16(_mm_xor_si128(a, b), 1), m7f));
+        }
+        a = _mm_add_epi8(_mm_cvtsi32_si128(wx), pred);
+        const int32_t out = _mm_cvtsi128_si32(a);
+        memcpy(cur, &out, 4);
+        if (bpp == 3) a = _mm_and_si128(a, _mm_cvtsi32_si128(0x00ffffff));      // (the fourth byte belongs to the next pixel)
+    }
+}
 #endif
 
 // undo the per-row filters of one (sub)image; in: h rows of (1 + rowbytes); out: h rows of rowbytes.  One loop per row and
@@ -70,19 +92,35 @@ bool unfilter(const uint8_t* in, uint8_t* out, int h, size_t rowbytes, int bpp)
         const uint8_t* up = y ? cur - rowbytes : nullptr;
         switch (ft) {
         case 0: memcpy(cur, src, rowbytes); break;
-        case 1:
-            for (size_t i = 0; i < bp; i++) cur[i] = src[i];
-            for (size_t i = bp; i < rowbytes; i++) cur[i] = (uint8_t)(src[i] + cur[i - bp]);
+        case 1: {
+            size_t i = 0;
+#if defined(__SSE2__)
+            if ((bpp == 3 || bpp == 4) && rowbytes >= (size_t)3 * bpp) {          // pixels 0 .. n-2; the last one below
+                unfilter_sub_avg_sse2(src, cur, nullptr, rowbytes / bpp - 1, bpp);
+                i = (rowbytes / bpp - 1) * bpp;
+            }
+#endif
+            for (; i < bp; i++) cur[i] = src[i];
+            for (; i < rowbytes; i++) cur[i] = (uint8_t)(src[i] + cur[i - bp]);
             break;
+        }
         case 2:
             if (!up) memcpy(cur, src, rowbytes);
             else for (size_t i = 0; i < rowbytes; i++) cur[i] = (uint8_t)(src[i] + up[i]);
             break;
-        case 3:
-            for (size_t i = 0; i < bp; i++) cur[i] = (uint8_t)(src[i] + ((up ? up[i] : 0) >> 1));
-            if (up) for (size_t i = bp; i < rowbytes; i++) cur[i] = (uint8_t)(src[i] + ((cur[i - bp] + up[i]) >> 1));
-            else for (size_t i = bp; i < rowbytes; i++) cur[i] = (uint8_t)(src[i] + (cur[i - bp] >> 1));
+        case 3: {
+            size_t i = 0;
+#if defined(__SSE2__)
+            if (up && (bpp == 3 || bpp == 4) && rowbytes >= (size_t)3 * bpp) {    // (pixel 0: a = 0 gives b >> 1, as the loop below)
+                unfilter_sub_avg_sse2(src, cur, up, rowbytes / bpp - 1, bpp);
+                i = (rowbytes / bpp - 1) * bpp;
+            }
+#endif
+            for (; i < bp; i++) cur[i] = (uint8_t)(src[i] + ((up ? up[i] : 0) >> 1));
+            if (up) for (; i < rowbytes; i++) cur[i] = (uint8_t)(src[i] + ((cur[i - bp] + up[i]) >> 1));
+            else for (; i < rowbytes; i++) cur[i] = (uint8_t)(src[i] + (cur[i - bp] >> 1));
             break;
+        }
         case 4:
             for (size_t i = 0; i < bp; i++) cur[i] = (uint8_t)(src[i] + (up ? up[i] : 0));             // paeth(0, b, 0) = b
             if (up) {
