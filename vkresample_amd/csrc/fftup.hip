@@ -614,7 +614,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         for (uint32_t s = 0; s < P->ring; s++) {
             PLAN_RC(dev_alloc(P, &P->in_planar[s], 3 * P->in_plane_stride * esz));
             PLAN_RC(dev_alloc(P, (void**)&P->in_u8[s], (size_t)3 * W * H));
-            PLAN_RC(dev_alloc(P, &P->out[s], (size_t)3 * uW * uH * (P->u8out ? 1 : esz)));
+            PLAN_RC(dev_alloc(P, &P->out[s], (size_t)3 * uW * uH * (P->u8out ? 1 : esz) + 8));          // (+ 8: readers of whole words)
         }
         // tuned plans (k_col_t): S2 holds the odd rows only and sits right behind S1 in ONE allocation (the fused
         // kernel addresses both with 32-bit offsets from one base)
@@ -633,7 +633,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         // only needs one for the fftup_download_presharpen tap, which allocates it on first use (ensure_R)
         P->r_bytes = (size_t)3 * uW * uH * (cplx ? (P->half ? 4 : P->csz) : esz);  // non-R2C path: complex pre-sharpen image (binary16 pairs for -p 2)
         if (!P->fused) PLAN_RC(dev_alloc(P, &P->R, P->r_bytes));
-        if (!P->u8out) PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH));       // staging of the conversion launch
+        if (!P->u8out) PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH + 8));   // staging of the conversion launch (+ 8: k_png_filter reads whole words)
         {
             int nl = 3;
             if (const char* e = getenv("FFTUP_STREAMS")) nl = atoi(e);
@@ -1689,7 +1689,7 @@ static int queue_init(fftup_plan* P)
     for (uint32_t s = 0; s < P->ring && !rc; s++) {
         if (P->u8out) q[s].out_u8 = (uint8_t*)P->out[s];                            // the output slot holds the bytes
         else if (s == 0) q[s].out_u8 = P->out_u8;
-        else rc = dev_alloc(P, (void**)&q[s].out_u8, (size_t)3 * P->uW * P->uH);     // owned by P->allocs either way
+        else rc = dev_alloc(P, (void**)&q[s].out_u8, (size_t)3 * P->uW * P->uH + 8); // owned by P->allocs either way
         if (!rc) {
             hipError_t e = hipEventCreateWithFlags(&q[s].done, hipEventDisableTiming);
             if (e != hipSuccess) { q[s].done = nullptr; rc = fail(FFTUP_E_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e)); }
@@ -1726,7 +1726,7 @@ static int png_slot_init(fftup_plan* P, fftup_plan::QSlot& Q)
     png_geometry(P);
     const size_t L = (size_t)3 * P->uW + 1, nb = (size_t)P->png_nblocks, uH = P->uH;
     PngParams p{};
-    int rc = dev_alloc(P, (void**)&p.raw, L * uH);
+    int rc = dev_alloc(P, (void**)&p.raw, L * uH + 8);            // (+ 8: k_png_pack reads whole words)
     if (!rc) rc = dev_alloc(P, (void**)&p.rowhist, uH * 257 * sizeof(uint32_t));
     if (!rc) rc = dev_alloc(P, (void**)&p.rowsum, uH * 2 * sizeof(unsigned long long));
     if (!rc) rc = dev_alloc(P, (void**)&p.tab, nb * 257 * sizeof(uint32_t));
@@ -1800,10 +1800,13 @@ static int submit_frame(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, 
         PngParams pp = Q.png.p;
         pp.rgb = Q.out_u8;
         HIP_TRY(hipMemsetAsync(pp.stream, 0, P->png_stream_bytes, cs));
+        const size_t rb = (size_t)3 * P->uW;
+        pp.row_in_lds = rb <= 48 * 1024 ? 1 : 0;                   // one row of residuals in LDS
+        const size_t lds_pack = pp.row_in_lds ? (rb + 12) / 4 * 4 : 0;
         hipLaunchKernelGGL(k_png_filter, dim3(P->uH), dim3(256), 0, cs, pp);
         hipLaunchKernelGGL(k_png_codes, dim3(P->png_nblocks), dim3(256), 0, cs, pp);
         hipLaunchKernelGGL(k_png_layout, dim3(1), dim3(256), 0, cs, pp);
-        hipLaunchKernelGGL(k_png_pack, dim3(P->uH), dim3(256), 0, cs, pp);
+        hipLaunchKernelGGL(k_png_pack, dim3(P->uH), dim3(256), lds_pack, cs, pp);
         const size_t max_pieces = P->png_stream_bytes / 4096;
         if (max_pieces) hipLaunchKernelGGL(k_png_crc, dim3((unsigned)((max_pieces + 255) / 256)), dim3(256), 0, cs, pp);
         HIP_TRY(hipGetLastError());

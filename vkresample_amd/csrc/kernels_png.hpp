@@ -37,6 +37,7 @@ struct PngParams {
     unsigned long long* meta;    // [0] bytes of the stream (with header and trailer), [1] Adler-32
     uint32_t* crc_parts;         // CRC-32 of every whole 4 KB piece of the stream (k_png_crc)
     int uW, uH, rows_per_block, nblocks;
+    int row_in_lds;              // k_png_pack was given LDS for a whole row
 };
 
 __device__ __forceinline__ unsigned png_mag8(unsigned r) { r &= 255u; return r < 256u - r ? r : 256u - r; }
@@ -244,7 +245,18 @@ __global__ __launch_bounds__(256) void k_png_pack(PngParams p)
     tab[t] = p.tab[(size_t)blk * 257 + t];
     if (t == 0) tab[256] = p.tab[(size_t)blk * 257 + 256];
     __syncthreads();
+    // the row goes through LDS: whole words, coalesced, instead of every thread walking its own 1/256 of the row in global memory
+    // (rows too long for the launch's LDS are read in place)
+    extern __shared__ uint32_t rowbuf[];
     const uint8_t* src = p.raw + (size_t)y * L;
+    if (p.row_in_lds) {
+        const size_t addr = (size_t)src;
+        const unsigned off = (unsigned)(addr & 3), nw = (off + L + 3) / 4;
+        const uint32_t* w = (const uint32_t*)(addr - off);             // (raw has eight bytes of slack behind the last row)
+        for (unsigned k = t; k < nw; k += 256) rowbuf[k] = w[k];
+        __syncthreads();
+        src = (const uint8_t*)rowbuf + off;
+    }
     const unsigned chunk = (L + 255) / 256, lo = min(L, t * chunk), hi = min(L, lo + chunk);
     unsigned long long bits = 0;
     for (unsigned i = lo; i < hi; i++) bits += tab[src[i]] >> 16;
