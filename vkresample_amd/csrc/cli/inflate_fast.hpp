@@ -240,8 +240,7 @@ inline bool zlib_decode(const uint8_t* in, size_t n, uint8_t* out, size_t out_le
             if (e.op == OP_END) { take(e.bits); break; }
             if ((e.op & 15) != OP_BASE) return false;
             take(e.bits);
-            const unsigned length = e.val + take(e.op >> 4);   // <= 15 + 5 bits used so far
-            refill();
+            const unsigned length = e.val + take(e.op >> 4);   // <= 15 + 5 of the >= 56 bits used so far: the distance's <= 15 + 13 are there
             Entry d = T.dist[buf & 255];
             if (d.op == OP_LINK) d = T.dist[d.val + ((buf >> 8) & ((1u << d.bits) - 1))];
             if ((d.op & 15) != OP_BASE) return false;
