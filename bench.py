@@ -76,6 +76,9 @@ def parse_args():
     ap.add_argument("--host-streamed", action="store_true",
                     help="NOT the headline: frames start and end in pinned host memory (fftup_submit_rgb8 queue, "
                          "uint8 RGB over PCIe both ways); the line is marked pcie_inclusive")
+    ap.add_argument("--png", action="store_true",
+                    help="with --host-streamed: the frames come back as finished PNG files encoded on the device (fftup_submit_png: "
+                         "row filters, Huffman-only deflate, checksums), the GPU writes each stream into the pinned buffer itself")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"),
                     help="per-launch HBM bytes of the kernels from committed rocprofv3 --pmc runs, keyed by configuration")
     a = ap.parse_args()
@@ -331,13 +334,26 @@ def main():
             torch.cuda.synchronize()
 
     pins = None
+    png_bytes = [0, 0]                         # --png: bytes and files of the step that ran last
     if args.host_streamed:
-        pins = (v.PinnedArray((args.ring, args.height, args.width, 3)),
-                v.PinnedArray((args.ring, up.out_height, up.out_width, 3)))
+        out_shape = (args.ring, (up.png_bound() + 63) // 64 * 64) if args.png else (args.ring, up.out_height, up.out_width, 3)
+        pins = (v.PinnedArray((args.ring, args.height, args.width, 3)), v.PinnedArray(out_shape))
         for s in range(args.ring):
-            pins[0].array[s] = synth.frame(rank * args.ring + s, args.width, args.height, "U")
+            # (--png: frames with structure -- uniform noise does not compress, and what PNG carries is images)
+            pins[0].array[s] = synth.frame(rank * args.ring + s, args.width, args.height, "N" if args.png else "U")
 
     def streamed_step():
+        if args.png:                           # a ticket is collected before its ring slot comes round again
+            tickets, nb = [None] * args.ring, 0
+            for k in range(args.frames_per_step + args.ring):
+                s = k % args.ring
+                if tickets[s] is not None:
+                    nb += up.wait_png(tickets[s], pins[1].array[s])
+                    tickets[s] = None
+                if k < args.frames_per_step:
+                    tickets[s] = up.submit_png(pins[0].array[s], pins[1].array[s])
+            png_bytes[0], png_bytes[1] = nb, args.frames_per_step
+            return
         for k in range(args.frames_per_step):
             up.submit_rgb8(pins[0].array[k % args.ring], pins[1].array[k % args.ring])
         up.drain()
@@ -518,8 +534,12 @@ def main():
         line["power"] = power_stats
         if args.host_streamed:
             pcie = 3.0 * (args.width * args.height + up.out_width * up.out_height)
+            if args.png:
+                pcie = 3.0 * args.width * args.height + png_bytes[0] / max(png_bytes[1], 1)
+                line["png_bytes_per_frame"] = png_bytes[0] / max(png_bytes[1], 1)
             line["pcie_inclusive"] = True
-            line["config"]["workload"] += ", HOST-STREAMED: uint8 RGB frames from/to pinned host memory"
+            line["config"]["workload"] += ", HOST-STREAMED: uint8 RGB frames from pinned host memory, " + \
+                ("finished PNG files (encoded on the device) back" if args.png else "uint8 RGB frames back")
             line["pcie_bytes_per_frame"] = pcie
             line["pcie_GBps"] = pcie / (wall_frame_ms * 1e-3) / 1e9
         if job is not None:

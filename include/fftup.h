@@ -210,11 +210,15 @@ FFTUP_API int fftup_drain(fftup_plan* plan);
  * fftup_submit_rgb8, but the 8-bit image stays on the device, where the PNG row filters (the reference writer's minimum-sum
  * heuristic), a Huffman-only deflate stream and its Adler-32 are computed (csrc/kernels_png.hpp); fftup_wait_png copies the
  * stream -- 14 MB instead of 25 MB of pixels for a 4096x2048 frame -- into png_out, frames it (signature, IHDR, IDAT, IEND,
- * CRCs) and returns the file's size.  png_out needs fftup_png_bound(plan) bytes (page-locked for a fast copy).  A ticket of
+ * CRCs) and returns the file's size.  png_out needs fftup_png_bound(plan) bytes (page-locked for a fast copy).  With png_out
+ * named at submission already (a 16-byte aligned buffer of fftup_host_alloc; NULL: not yet) the GPU writes the stream into it
+ * itself, sized by the count it knows, and fftup_wait_png(.., the same buffer, ..) only waits, adds the framing and the CRC --
+ * no size round trip through the host: several frames of one thread stream back to back.  A ticket of
  * fftup_submit_png must be collected by fftup_wait_png (a later submission of its ring slot waits for that); -p 0 and -p 2
  * plans; thread-safe like fftup_submit_rgb8 / fftup_wait. */
 FFTUP_API size_t fftup_png_bound(fftup_plan* plan);
-FFTUP_API int fftup_submit_png(fftup_plan* plan, const uint8_t* rgb_in, size_t in_stride_bytes, uint64_t* ticket);
+FFTUP_API int fftup_submit_png(fftup_plan* plan, const uint8_t* rgb_in, size_t in_stride_bytes, uint8_t* png_out, size_t capacity,
+                               uint64_t* ticket);
 FFTUP_API int fftup_wait_png(fftup_plan* plan, uint64_t ticket, uint8_t* png_out, size_t capacity, size_t* png_bytes);
 
 FFTUP_API const char* fftup_strerror(int code);

@@ -73,6 +73,24 @@ def test_bench_single_rank_line():
     assert n["config2"]["ms_per_iter"] >= 0.9 * d["ms_per_frame"] and n["config4"]["ms_per_iter"] >= 0.9 * o["config4"]["ms_per_frame"]
 
 
+@pytest.mark.parametrize("png", [False, True])
+def test_bench_host_streamed_lines(png):
+    """--host-streamed (PCIe-inclusive, never the headline): pixels back, or -- --png -- finished PNG files encoded on the device;
+    the line says which, and how many bytes crossed the link per frame"""
+    r = subprocess.run([sys.executable, "bench.py", "--host-streamed", "--steps", "2", "--warmup", "1", "--repeats", "1", "--frames-per-step", "16",
+                        "--ring", "4", "--width", "512", "--height", "256", "--no-cpu-baseline"] + (["--png"] if png else []),
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["pcie_inclusive"] is True and d["value"] > 100 and "HOST-STREAMED" in d["config"]["workload"]
+    pixels = 3.0 * (512 * 256 + 1024 * 512)
+    if png:
+        assert "PNG" in d["config"]["workload"] and 0.2 * 3 * 1024 * 512 < d["png_bytes_per_frame"] < 3 * 1024 * 512
+        assert abs(d["pcie_bytes_per_frame"] - (3 * 512 * 256 + d["png_bytes_per_frame"])) < 1
+    else:
+        assert d["pcie_bytes_per_frame"] == pixels and "png_bytes_per_frame" not in d
+
+
 def test_bench_two_ranks_config5_over_gloo():
     env = dict(os.environ, FFTUP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

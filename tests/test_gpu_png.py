@@ -69,7 +69,7 @@ def test_png_from_the_device_decodes_to_the_frame(W, H, u, precision, flags, rin
         buf = v.PinnedArray((up.png_bound(),))
         sizes = []
         for k, f in enumerate(frames):
-            t = up.submit_png(f)
+            t = up.submit_png(f, buf.array if k % 2 else None)          # odd frames: the GPU delivers the stream into the buffer itself
             nbytes = up.wait_png(t, buf.array)
             png = bytes(buf.array[:nbytes])
             ch = _chunks(png)
@@ -91,6 +91,13 @@ def test_png_from_the_device_decodes_to_the_frame(W, H, u, precision, flags, rin
         assert np.array_equal(_decode(bytes(buf.array[:nbytes])), want[1 % len(frames)])
         with pytest.raises(v.FftupError):
             up.wait_png(t2, buf.array)                                  # collected already
+        with pytest.raises(v.FftupError):
+            up.submit_png(frames[0], np.empty(up.png_bound(), np.uint8))   # a destination the GPU cannot write to (not page-locked)
+        other = v.PinnedArray((up.png_bound(),))
+        t5 = up.submit_png(frames[0], buf.array)
+        with pytest.raises(v.FftupError):
+            up.wait_png(t5, other.array)                                # the file is in the buffer named at submission (slot freed)
+        other.close()
         t3 = up.submit_png(frames[0])
         with pytest.raises(v.FftupError):
             up.wait(t3)                                                 # the pixel path's wait does not collect a PNG
@@ -150,7 +157,7 @@ def test_png_tickets_from_several_threads():
             try:
                 buf = v.PinnedArray((up.png_bound(),))
                 for g in range(t, T * per, T):
-                    n = up.wait_png(up.submit_png(frames[g]), buf.array)
+                    n = up.wait_png(up.submit_png(frames[g], buf.array if g % 3 else None), buf.array)
                     if not np.array_equal(_decode(bytes(buf.array[:n])), want[g]):
                         errors.append((t, g, "pixels differ"))
                 buf.close()

@@ -88,7 +88,7 @@ def test_error_paths_without_device():
     assert lib.fftup_execute(None, 1, None) == 1
     assert lib.fftup_submit_rgb8(None, None, 0, None, 0, None) == 1
     assert lib.fftup_wait(None, 0) == 1 and lib.fftup_drain(None) == 1
-    assert lib.fftup_submit_png(None, None, 0, None) == 1 and lib.fftup_wait_png(None, 0, None, 0, None) == 1 and lib.fftup_png_bound(None) == 0
+    assert lib.fftup_submit_png(None, None, 0, None, 0, None) == 1 and lib.fftup_wait_png(None, 0, None, 0, None) == 1 and lib.fftup_png_bound(None) == 0
     lib.fftup_host_free(None)                                      # no-op
     lib.fftup_plan_destroy(None)                                   # no-op
 

@@ -29,11 +29,11 @@ def main():
             for k in range(depth):
                 pin.array[k] = synth.frame(k, W, H, "N")
             pout = v.PinnedArray((depth, up.out_height, up.out_width, 3))
-            ppng = v.PinnedArray((depth, up.png_bound()))
+            ppng = v.PinnedArray((depth, (up.png_bound() + 63) // 64 * 64))      # (rows 16-byte aligned: the GPU writes into them)
             res = {}
             for mode in ("rgb8", "png"):
                 def submit(k):
-                    return up.submit_png(pin.array[k % depth]) if mode == "png" else up.submit_rgb8(pin.array[k % depth], pout.array[k % depth])
+                    return up.submit_png(pin.array[k % depth], ppng.array[k % depth]) if mode == "png" else up.submit_rgb8(pin.array[k % depth], pout.array[k % depth])
 
                 def wait(t, k):
                     return up.wait_png(t, ppng.array[k % depth]) if mode == "png" else (up.wait(t) or up.out_height * up.out_width * 3)

@@ -81,7 +81,7 @@ def load():
     lib.fftup_drain.argtypes = [vp]
     lib.fftup_png_bound.argtypes = [vp]
     lib.fftup_png_bound.restype = sz
-    lib.fftup_submit_png.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64)]
+    lib.fftup_submit_png.argtypes = [vp, vp, sz, vp, sz, C.POINTER(C.c_uint64)]
     lib.fftup_wait_png.argtypes = [vp, C.c_uint64, vp, sz, C.POINTER(sz)]
     lib.fftup_strerror.argtypes = [C.c_int]
     lib.fftup_strerror.restype = C.c_char_p

@@ -160,11 +160,14 @@ class Upscaler:
         """bytes a PNG buffer of wait_png needs"""
         return int(self._lib.fftup_png_bound(self._h))
 
-    def submit_png(self, rgb_in):
-        """Like submit_rgb8, but the frame is PNG-encoded on the device; collect it with wait_png(ticket, buffer)."""
+    def submit_png(self, rgb_in, png_out=None):
+        """Like submit_rgb8, but the frame is PNG-encoded on the device; collect it with wait_png(ticket, buffer).  With png_out
+        (a PinnedArray's uint8 array of png_bound() bytes) the GPU writes the file's stream into it itself; pass the same array to
+        wait_png."""
         assert rgb_in.dtype == np.uint8 and rgb_in.shape == (self.height, self.width, 3) and rgb_in.flags.c_contiguous
         t = C.c_uint64()
-        _check(self._lib.fftup_submit_png(self._h, rgb_in.ctypes.data, 3 * self.width, C.byref(t)), "fftup_submit_png")
+        dst, cap = (png_out.ctypes.data, png_out.size) if png_out is not None else (None, 0)
+        _check(self._lib.fftup_submit_png(self._h, rgb_in.ctypes.data, 3 * self.width, dst, cap, C.byref(t)), "fftup_submit_png")
         return t.value
 
     def wait_png(self, ticket, buf):

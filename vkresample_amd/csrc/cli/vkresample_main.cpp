@@ -223,7 +223,7 @@ static int launchResample(ResampleConfiguration config)                      // 
             }
             memcpy(pin, png_input.data(), inBytes);
             uint64_t ticket = 0;
-            res = gpuPng ? fftup_submit_png(plan, pin, (size_t)width * 3, &ticket)
+            res = gpuPng ? fftup_submit_png(plan, pin, (size_t)width * 3, pout, pngCap, &ticket)
                          : fftup_submit_rgb8(plan, pin, (size_t)width * 3, pout, (size_t)uW * 3, &ticket);
             if (res != FFTUP_OK) {
                 printf("Upscale failed: %s (%s)\n", fftup_strerror(res), fftup_last_error());

@@ -112,7 +112,7 @@ struct fftup_plan {
     // host-streamed queue (fftup_submit_rgb8): created on first use
     // (png: the device-side PNG encoder's buffers of the slot, created on the first fftup_submit_png; state 1 = a stream waits for
     // its fftup_wait_png -- a later submission of the slot waits for that on q_cv)
-    struct PngSlot { PngParams p{}; unsigned long long* meta_host = nullptr; uint32_t* parts_host = nullptr; hipEvent_t copied = nullptr; int state = 0; uint64_t ticket = 0; };
+    struct PngSlot { PngParams p{}; unsigned long long* meta_host = nullptr; uint32_t* parts_host = nullptr; hipEvent_t copied = nullptr; int state = 0; uint64_t ticket = 0; uint8_t* dest = nullptr; size_t dest_cap = 0; };
     struct QSlot { uint8_t* out_u8 = nullptr; hipEvent_t done = nullptr; PngSlot png; };
     std::vector<QSlot> q;
     std::atomic<uint64_t> q_next{0};   // next ticket; written under q_mu, read by fftup_wait without it
@@ -1752,10 +1752,22 @@ static int png_slot_init(fftup_plan* P, fftup_plan::QSlot& Q)
 static int submit_frame(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, uint8_t* rgb_out, size_t out_stride, bool png,
                         uint64_t* ticket)
 {
+    // (png: rgb_out / out_stride are the optional destination of the finished file and its capacity)
+    uint8_t* png_dest = png ? rgb_out : nullptr;
+    const size_t png_cap = png ? out_stride : 0;
     if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
     if (!rgb_in || in_stride < (size_t)3 * P->W) return fail(FFTUP_E_INVALID_ARG, "bad input pointer/stride");
     if (!png && (!rgb_out || out_stride < (size_t)3 * P->uW)) return fail(FFTUP_E_INVALID_ARG, "bad output pointer/stride");
     if (png && P->dbl) return fail(FFTUP_E_UNSUPPORTED_PRECISION, "device-side PNG encoding: -p 0 and -p 2 plans");
+    if (png_dest) {
+        png_geometry(P);
+        hipPointerAttribute_t at{};
+        if (((uintptr_t)png_dest & 15) || png_cap < P->png_stream_bytes + 57 || hipPointerGetAttributes(&at, png_dest) != hipSuccess ||
+            at.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            return fail(FFTUP_E_INVALID_ARG, "png_out of fftup_submit_png: fftup_png_bound() bytes from fftup_host_alloc (the GPU writes into it)");
+        }
+    }
     HIP_TRY(hipSetDevice(P->device));
     // one submission at a time: slot choice, the lane's launches and the ticket are one critical section (a few tens of
     // microseconds; the wait below is for the frame that used this slot `ring` submissions ago)
@@ -1776,7 +1788,8 @@ static int submit_frame(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, 
     // cross-stream dependency exists and nothing can stall behind a neighbour's wait when streams share a hardware
     // queue; the copies of one lane overlap the kernels and the opposite-direction copies of the other lanes.
     // (two lanes: with the copies in the streams a third one only adds contention, 0.56-0.75 ms/frame instead of 0.51)
-    const int lane = (int)(t % (uint64_t)std::min(P->nlanes, 2));
+    // (a PNG frame's chain is long -- nine more launches, most of them a handful of workgroups: all lanes take turns)
+    const int lane = (int)(t % (uint64_t)(png ? P->nlanes : std::min(P->nlanes, 2)));
     hipStream_t cs = P->lanes[lane].stream;
     const size_t in_row = (size_t)3 * P->W, out_row = (size_t)3 * P->uW;
     if (in_stride == in_row) HIP_TRY(hipMemcpyAsync(P->in_u8[s], rgb_in, in_row * P->H, hipMemcpyHostToDevice, cs));
@@ -1812,8 +1825,16 @@ static int submit_frame(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, 
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(Q.png.meta_host, pp.meta, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
         if (max_pieces) HIP_TRY(hipMemcpyAsync(Q.png.parts_host, pp.crc_parts, max_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+        if (png_dest) {                                            // the device knows the size: it delivers the stream itself
+            void* dev_view = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&dev_view, png_dest, 0));
+            hipLaunchKernelGGL(k_png_deliver, dim3(512), dim3(256), 0, cs, pp, (uint32_t*)dev_view);
+            HIP_TRY(hipGetLastError());
+        }
         Q.png.state = 1;
         Q.png.ticket = t;
+        Q.png.dest = png_dest;
+        Q.png.dest_cap = png_cap;
     } else if (out_stride == out_row) HIP_TRY(hipMemcpyAsync(rgb_out, Q.out_u8, out_row * P->uH, hipMemcpyDeviceToHost, cs));
     else HIP_TRY(hipMemcpy2DAsync(rgb_out, out_stride, Q.out_u8, out_row, out_row, P->uH, hipMemcpyDeviceToHost, cs));
     HIP_TRY(hipEventRecord(Q.done, cs));
@@ -1829,9 +1850,9 @@ int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, ui
     return submit_frame(P, rgb_in, in_stride, rgb_out, out_stride, false, ticket);
 }
 
-int fftup_submit_png(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, uint64_t* ticket)
+int fftup_submit_png(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, uint8_t* png_out, size_t capacity, uint64_t* ticket)
 {
-    return submit_frame(P, rgb_in, in_stride, nullptr, 0, true, ticket);
+    return submit_frame(P, rgb_in, in_stride, png_out, png_out ? capacity : 0, true, ticket);
 }
 
 size_t fftup_png_bound(fftup_plan* P)
@@ -1912,9 +1933,12 @@ int fftup_wait_png(fftup_plan* P, uint64_t ticket, uint8_t* png_out, size_t capa
         release();
         return fail(FFTUP_E_INVALID_ARG, "PNG buffer too small: " + std::to_string(zbytes + 57) + " bytes needed (fftup_png_bound)");
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(png_out + 41, Q.png.p.stream, zbytes, hipMemcpyDeviceToHost, P->png_copy);
-    if (e == hipSuccess) e = hipEventRecord(Q.png.copied, P->png_copy);
-    if (e == hipSuccess) e = hipEventSynchronize(Q.png.copied);
+    if (e == hipSuccess && Q.png.dest != png_out) {        // (delivered by the device already when the buffer was named at submission)
+        if (Q.png.dest) { release(); return fail(FFTUP_E_INVALID_ARG, "fftup_wait_png: the buffer named by fftup_submit_png holds this file"); }
+        e = hipMemcpyAsync(png_out + 41, Q.png.p.stream, zbytes, hipMemcpyDeviceToHost, P->png_copy);
+        if (e == hipSuccess) e = hipEventRecord(Q.png.copied, P->png_copy);
+        if (e == hipSuccess) e = hipEventSynchronize(Q.png.copied);
+    }
     uint32_t crc = 0;
     if (e == hipSuccess) {                                 // "IDAT", then the stream: whole 4 KB pieces from the device, the tail here
         crc = crc32_png(0, (const uint8_t*)"IDAT", 4);

@@ -338,4 +338,26 @@ __global__ __launch_bounds__(256) void k_png_crc(PngParams p)
     p.crc_parts[i] = ~crc;
 }
 
+// The stream goes to the caller's page-locked buffer by the GPU's own stores (the buffer is mapped into the device's address space),
+// sized by the byte count the device already knows -- no host round trip between "size known" and "copy issued".  The file's
+// stream starts at byte 41 of the buffer (signature, IHDR, IDAT framing): every aligned output word is the top byte of one stream
+// word and the low three of the next.  Word 10 (bytes 40-43) is written with a zero byte 40, which the host fills in afterwards.
+__global__ __launch_bounds__(256) void k_png_deliver(PngParams p, uint32_t* dst /* the buffer, 16-byte aligned */)
+{
+    const unsigned long long n = p.meta[0];                              // stream bytes
+    const unsigned long long words = (41 + n + 3) / 4;                   // buffer words that hold stream bytes: 10 .. words - 1
+    const unsigned long long groups = (words + 3) / 4;
+    for (unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (unsigned long long)gridDim.x * 256) {
+        if (g < 2) continue;                                             // words 0 .. 7: header bytes only (host)
+        uint32_t o[4];
+        for (int k = 0; k < 4; k++) {
+            const long long m = (long long)(4 * g + k);                  // o[k] = stream bytes 4m - 41 .. 4m - 38
+            const uint32_t lo = m >= 11 ? p.stream[m - 11] : 0u, hi = m >= 10 ? p.stream[m - 10] : 0u;
+            o[k] = (lo >> 24) | (hi << 8);
+        }
+        if (g == 2) { dst[10] = o[2]; dst[11] = o[3]; }                  // (words 8, 9: header)
+        else *(uint4*)(dst + 4 * g) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 }  // namespace fftup
