@@ -180,6 +180,8 @@ static StagePlan make_stage_plan(uint32_t n)
     return p;
 }
 
+static void png_geometry(fftup_plan* P);
+
 static int dev_alloc(fftup_plan* P, void** ptr, size_t bytes)
 {
     hipError_t e = hipMalloc(ptr, bytes);
@@ -738,6 +740,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
 #undef SET_LDS
         if (P->mixed == 3 && ((cfg->flags & FFTUP_FLAG_TUNE_PLAN) || jit_tune_enabled())) tune_fused(P);
     }
+    png_geometry(P);                       // (fixed per plan: fftup_png_bound may be asked by several threads at once)
     *out = P;
     return FFTUP_OK;
 bad:
