@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--generic", action="store_true", help="size-generic kernels (FFTUP_FLAG_GENERIC_KERNELS): no tuned, no plan-time specialised plan")
     ap.add_argument("--tune", action="store_true", help="FFTUP_FLAG_TUNE_PLAN: plan-time tuner for sizes specialised at plan time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rccl-check", action="store_true", help="skip the one-rank RCCL bring-up of N = 1 lines (`rccl_selfcheck`)")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the bounded CPU-baseline sample (~11 s on 128 threads)")
     ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other BASELINE configurations (`others`)")
     ap.add_argument("--job", action="store_true",
@@ -272,18 +273,84 @@ class PowerSampler:
                 "note": "sampled during the timed regions; at the cap the shader clock is throttled (DESIGN.md section 4)"}
 
 
+def launch_command(n, argv, port):
+    """the driver's own launch line for N ranks on one node (one process per GPU, rendezvous on 127.0.0.1)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside a torch.distributed.run environment: start the N ranks here -- the counterpart of the
+    reference fanning its threads out inside the process (VkResample.cpp:1959-1969).  Rank 0's JSON line passes through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    return subprocess.call(launch_command(n, argv, port), env=env)
+
+
+RCCL_SELFCHECK = r"""
+import json, socket, sys, time
+t0 = time.perf_counter()
+import torch, torch.distributed as dist
+from datetime import timedelta
+with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+torch.cuda.set_device(int(sys.argv[1]))
+dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, timeout=timedelta(seconds=60))
+x = torch.arange(8, dtype=torch.float64, device="cuda")
+dist.all_reduce(x)
+dist.barrier()
+torch.cuda.synchronize()
+ok = bool((x.cpu() == torch.arange(8, dtype=torch.float64)).all())
+ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+dist.destroy_process_group()
+print("RCCL " + json.dumps({"ok": ok, "backend": "nccl (RCCL)", "version": ver, "ranks": 1, "device": torch.cuda.get_device_name(),
+                            "seconds": time.perf_counter() - t0}))
+"""
+
+
+def rccl_selfcheck(dev):
+    """N = 1 only: bring RCCL up as a one-rank communicator on this GPU and push one all-reduce through it -- the library the
+    N > 1 runs depend on is loaded and initialised in every single-GPU line, not first on the day an 8-GPU node shows up.
+    In a process of its own with a time limit: a communicator that does not come up must not take the bench line with it."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", RCCL_SELFCHECK, str(dev)], capture_output=True, text=True, timeout=180)
+        for l in r.stdout.splitlines():
+            if l.startswith("RCCL "):
+                return json.loads(l[5:])
+        return {"ok": False, "error": "exit code %d: %s" % (r.returncode, r.stderr[-400:])}
+    except Exception as e:                                   # reported, never hidden: tests/test_gpu_bench.py asserts ok
+        return {"ok": False, "error": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # a line that says n_gpus = WORLD_SIZE while the caller asked for --gpus N would be a wrong scaling point: refuse
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or run `python bench.py --gpus %d`, "
+                         "which starts its ranks itself)\n" % (args.gpus, world, args.gpus, args.gpus))
+        sys.exit(2)
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL (backend "nccl") over xGMI; FFTUP_BENCH_BACKEND=gloo lets two ranks share one GPU in a dry run
+        # RCCL (backend "nccl") over xGMI; FFTUP_BENCH_BACKEND=gloo lets several ranks share one GPU in a dry run
         backend = os.environ.get("FFTUP_BENCH_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl" and torch.cuda.device_count() < world:
+            sys.stderr.write("bench.py: %d ranks but %d visible GPU(s): one rank per GPU over RCCL (FFTUP_BENCH_BACKEND=gloo is the "
+                             "dry run in which ranks share a device)\n" % (world, torch.cuda.device_count()))
+            sys.exit(2)
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -550,6 +617,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args)
             line["reference_vulkan_baseline"] = reference_vulkan_baseline(args)
+        if world == 1 and not args.no_rccl_check and torch.cuda.is_available():
+            line["rccl_selfcheck"] = rccl_selfcheck(dev)
     up.close()
     if rank == 0 and world == 1 and not args.no_others and not args.host_streamed and (args.preset or "config2") == "config2" \
             and (args.width, args.height, args.precision) == (2048, 1024, 0):

@@ -168,3 +168,69 @@ def test_job_through_the_shared_counter_has_the_stripes_checksum():
                         cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert q1.returncode == 0, q1.stderr[-3000:]
     assert _line(q1.stdout)["checksum"] == one["checksum"]
+
+
+# ---- N ranks started the way a user (or the driver) starts them --------------------------------------------
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it starts the two ranks itself (the reference fans its
+    threads out inside the process, VkResample.cpp:1959-1969): the line says n_gpus = 2 and the collective had two ranks.
+    (gloo dry run: the two ranks share this box's one GPU)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FFTUP_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--repeats", "1", "--frames-per-step", "32",
+                        "--profile-iters", "2"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["frames_done"] == 64 and d["job"]["backend"] == "gloo"
+    assert abs(d["value"] - 2 * 32 / d["timed_region_s_median"]) < 1e-6 * d["value"]
+
+
+def test_bench_refuses_rccl_ranks_without_a_gpu_each():
+    """without the dry-run override the ranks talk RCCL, one per GPU: two ranks on a one-GPU box is an error, not a line"""
+    import vkresample_amd as v
+    if v.device_count() >= 2:
+        pytest.skip("needs a box with one GPU")
+    env = {k: v_ for k, v_ in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FFTUP_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--repeats", "1", "--frames-per-step", "8"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "visible GPU" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_rccl_comes_up_on_this_gpu():
+    """RCCL (torch.distributed backend "nccl") initialises on the MI355X as a one-rank communicator and reduces: what every
+    N = 1 bench line carries as `rccl_selfcheck`"""
+    sys.path.insert(0, ROOT)
+    import bench
+    chk = bench.rccl_selfcheck(0)
+    print("RCCL selfcheck:", chk)
+    assert chk["ok"] is True and chk["ranks"] == 1 and chk["version"], chk
+
+
+def _config5(nproc, port, extra, frames_per_step=64):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(FFTUP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    args = ["bench.py", "--gpus", str(nproc), "--steps", "1", "--warmup", "1", "--repeats", "1", "--precision", "2", "--fuse-u8", "--job",
+            "--frames-per-step", str(frames_per_step), "--ring", str(frames_per_step), "--profile-iters", "2", "--no-cpu-baseline",
+            "--no-others", "--no-rccl-check"] + extra
+    r = subprocess.run([sys.executable] + args, cwd=ROOT, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return _line(r.stdout)
+
+
+def test_eight_rank_dry_run_of_config5():
+    """BASELINE config 5 -- 512 synthetic 2048x1024 frames, -u 2 -p 2, over 8 ranks -- as a dry run on this box's one GPU (gloo):
+    the 8-rank stripe (frame f*8 + r on rank r, 64 resident frames per rank) processes each of the 512 frames once and ends with
+    the checksum ONE rank gets for the same 512 frames; so does the shared counter (--queue) on a job of 128 frames."""
+    one = _config5(1, 0, [], frames_per_step=512)
+    assert one["frames_done"] == 512 and one["rccl_ranks"] == 1 and one["checksum"] > 0
+    eight = _config5(8, 0, ["--preset", "config5"])
+    assert eight["n_gpus"] == 8 and eight["rccl_ranks"] == 8 and eight["job"]["collective_ranks"] == 8
+    assert eight["frames_done"] == 512 and eight["job"]["frames_per_step_total"] == 512 and eight["checksum"] == one["checksum"]
+    assert [x["rank"] for x in eight["job"]["ranks"]] == list(range(8))
+    assert [x["first_frames"] for x in eight["job"]["ranks"]] == [[r, r + 8, r + 16] for r in range(8)]
+    assert abs(eight["value"] - 8 * 64 / eight["timed_region_s_median"]) < 1e-6 * eight["value"]
+    # the shared counter over 8 ranks (every rank keeps the step's 128 frames resident)
+    q1 = _config5(1, 0, [], frames_per_step=128)
+    q8 = _config5(8, 0, ["--queue", "--queue-chunk", "4"], frames_per_step=16)
+    assert q8["rccl_ranks"] == 8 and q8["frames_done"] == q1["frames_done"] == 128 and q8["checksum"] == q1["checksum"]
+    assert sum(x["frames"] for x in q8["job"]["ranks"]) == 128 and "shared counter" in q8["job"]["stripe"]
