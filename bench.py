@@ -140,6 +140,32 @@ def reference_vulkan_baseline(args):
         return {"available": True, "ms_per_frame": float(m.group(1)), "frames_per_s": 1e3 / float(m.group(1)), "command": "-u 2 -n 1000"}
 
 
+FRAME_KERNEL_SOURCES = ("fft_engine.hpp", "kernels_dswap.hpp", "kernels_generic.hpp", "kernels_mixed.hpp", "kernels_pow2.hpp")
+
+
+def kernel_sources_sha256():
+    """fingerprint of the sources of the frame's kernels (the headers the library embeds for its plan-time compiler, __graft_entry__.
+    KERNEL_HEADERS): committed counter / trace summaries carry the one they were measured on, so that a line can say whether its
+    static figures belong to the kernels that just ran"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in FRAME_KERNEL_SOURCES:
+        h.update(f.encode() + b"\0" + open(os.path.join(ROOT, "vkresample_amd", "csrc", f), "rb").read() + b"\0")
+    return h.hexdigest()
+
+
+def rocprof_kernel_us(key, short_name):
+    """average duration (us) of a kernel from the committed `rocprofv3 --kernel-trace --stats` summary of this configuration
+    (profiles/kernel_stats_index.json, written by tools/index_kernel_stats.py): (us, file, measured on these very kernel sources?)"""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "kernel_stats_index.json"))).get(key)
+        if not e or short_name not in e["kernels_avg_ns"]:
+            return None, None, None
+        return e["kernels_avg_ns"][short_name] * 1e-3, e["file"], e.get("kernel_sources_sha256") == kernel_sources_sha256()
+    except Exception:
+        return None, None, None
+
+
 def frame_traffic(traffic_json, key, kernel_names):
     """measured HBM bytes per launch of a configuration's kernels (committed rocprofv3 --pmc run, profiles/hbm_traffic.json):
     (per-kernel dict, frame total, source text) or (None, None, None)"""
@@ -149,9 +175,18 @@ def frame_traffic(traffic_json, key, kernel_names):
             return None, None, None
         per = {n: tj.get(n, {}).get("hbm_bytes_per_launch") for n in kernel_names if n != "-"}
         total = sum(per.values()) if all(x is not None for x in per.values()) else None
-        return per, total, "static %s [%s] (%s)" % (os.path.relpath(traffic_json, ROOT), key, tj.get("_source", "?"))
+        fresh = tj.get("_kernel_sources_sha256") == kernel_sources_sha256()
+        return per, total, "static %s [%s] (%s)%s" % (os.path.relpath(traffic_json, ROOT), key, tj.get("_source", "?"),
+                                                       "" if fresh else " STALE: measured on other kernel sources")
     except Exception:
         return None, None, None
+
+
+def traffic_is_current(traffic_json, key):
+    try:
+        return json.load(open(traffic_json))[key].get("_kernel_sources_sha256") == kernel_sources_sha256()
+    except Exception:
+        return None
 
 
 def valu_busy(traffic_json, key, kernel_names, ms_per_frame, sclk_mhz, n_cu):
@@ -209,17 +244,25 @@ def other_configs(v, synth, dev, traffic_json, n_cu, ring=8):
                          "socket_power_w_median": pw.get("socket_power_w_median"), "sclk_mhz_median": pw.get("sclk_mhz_median"),
                          "energy_mj_per_frame": pw["socket_power_w_median"] * t if pw.get("socket_power_w_median") else None,
                          "plan": up.description}
+    # the reference's own figure, performVulkanUpscale(.., 1000) (VkResample.cpp:1260-1278), on the CLI's single-image plan (no
+    # ring): the 1000 identical iterations alternate on the plan's streams (default), or stay on one queue (`sequential_*`:
+    # FFTUP_FLAG_SEQUENTIAL_EXECUTE, single-frame latency)
     n1000 = {}
     for name in ("config2", "config3", "config4"):
         c = PRESETS[name]
         flags = v.FLAG_FUSE_U8_LOAD if c["fuse_u8"] else 0
-        with v.Upscaler(c["width"], c["height"], 2.0, c["precision"], 0.2, dev, flags, 1) as up:      # no ring: the CLI's single-image plan
-            up.upload_rgb8(synth.frame(0, c["width"], c["height"], "U"))
-            up.execute(100)
-            ms = sorted(up.execute(1000) for _ in range(3))[1]
-            n1000[name] = {"ms_per_iter": ms, "frame_frac": up.alg_bytes_per_frame / (ms * 1e-3) / 8e12}
+        e = {}
+        for mode, fl in (("", 0), ("sequential_", v.FLAG_SEQUENTIAL_EXECUTE)):
+            with v.Upscaler(c["width"], c["height"], 2.0, c["precision"], 0.2, dev, flags | fl, 1) as up:
+                up.upload_rgb8(synth.frame(0, c["width"], c["height"], "U"))
+                up.execute(100)
+                ms = sorted(up.execute(1000) for _ in range(3))[1]
+                e[mode + "ms_per_iter"] = ms
+                e[mode + "frame_frac"] = up.alg_bytes_per_frame / (ms * 1e-3) / 8e12
+        n1000[name] = e
     out["execute_n1000"] = dict(n1000, note="fftup_execute(plan, 1000) on a plan without a ring = performVulkanUpscale(.., 1000), "
-                                            "VkResample.cpp:1260-1278: one stream, nothing overlaps; the CLI prints this as Time:")
+                                            "VkResample.cpp:1260-1278; the CLI prints ms_per_iter as Time: (-n 1000); sequential_* = one "
+                                            "queue, nothing overlaps (FFTUP_FLAG_SEQUENTIAL_EXECUTE)")
     return out
 
 
@@ -591,8 +634,15 @@ def main():
                          "frac_real_bytes": up.kernel_min_bytes[dom] / (max(iso[dom], 1e-6) * 1e-3) / 8e12,
                          "achieved_overlapped": achieved_ovl,
                          "frame_achieved": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 1e9,      # per GPU
-                         "frame_frac": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 8e12},
+                         "frame_frac": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 8e12,
+                         # do the static figures (traffic, vector instructions) belong to the kernel sources that just ran?
+                         "traffic_kernel_sources_current": traffic_is_current(args.traffic_json, key)},
         }
+        # the same fraction from the committed rocprofv3 --kernel-trace --stats summary of this configuration, when there is one
+        rp_us, rp_file, rp_fresh = rocprof_kernel_us(key, up.kernel_names[dom])
+        if rp_us:
+            line["roofline"].update({"rocprof_avg_us": rp_us, "frac_rocprof": up.kernel_alg_bytes[dom] / (rp_us * 1e-6) / 8e12,
+                                     "rocprof_source": rp_file, "rocprof_kernel_sources_current": rp_fresh})
         fvi, vbusy = valu_busy(args.traffic_json, key, up.kernel_names, wall_frame_ms, (power_stats or {}).get("sclk_mhz_median"), n_cu)
         line["frame_valu_insts"], line["valu_busy_frac"] = fvi, vbusy
         if power_stats and power_stats.get("socket_power_w_median"):
@@ -622,7 +672,13 @@ def main():
     up.close()
     if rank == 0 and world == 1 and not args.no_others and not args.host_streamed and (args.preset or "config2") == "config2" \
             and (args.width, args.height, args.precision) == (2048, 1024, 0):
-        line["others"] = other_configs(v, synth, dev, args.traffic_json, n_cu)
+        line["others"] = o = other_configs(v, synth, dev, args.traffic_json, n_cu)
+        # the figures a reader of the one line needs without opening `others`: the reference's -n 1000 number per configuration
+        # and the frame fractions of configs 3 and 4
+        line["execute_n1000"] = {k: {m: e[m] for m in ("ms_per_iter", "frame_frac", "sequential_ms_per_iter", "sequential_frame_frac")}
+                                 for k, e in o["execute_n1000"].items() if isinstance(e, dict)}
+        line["config3_frame_frac"], line["config3_ms_per_frame"] = o["config3"]["frame_frac"], o["config3"]["ms_per_frame"]
+        line["config4_frame_frac"], line["config4_ms_per_frame"] = o["config4"]["frame_frac"], o["config4"]["ms_per_frame"]
     if pins:
         pins[0].close()
         pins[1].close()

@@ -59,6 +59,9 @@ enum {
                                         conversion launch, fftup_download_planar fails with FFTUP_E_INVALID_ARG.  Plans without a
                                         fused kernel (size-generic, -p 1, non-R2C, FFTUP_FLAG_UNFUSED_SHARPEN) ignore the flag:
                                         fftup_info.u8_store says which it is                                               */
+    , FFTUP_FLAG_SEQUENTIAL_EXECUTE = 64u /* fftup_execute keeps every iteration on the plan's ONE stream (the strict single-queue
+                                        form of performVulkanUpscale); default: the identical iterations of an n_iter > 1 call
+                                        alternate on the plan's streams, same bits, overlapped                              */
 };
 
 /* Replaces VkResampleConfiguration (VR:45-59) + the part of VkFFTConfiguration (VF:22-94) that
@@ -75,8 +78,8 @@ typedef struct fftup_config {
 } fftup_config;
 
 /* Environment read by fftup_plan_create (operational knobs, not part of the reference's surface):
- *   FFTUP_STREAMS=n     HIP streams consecutive frames of fftup_execute_ring / fftup_submit_rgb8 alternate on (default 3, 1..4);
- *                       fftup_execute always uses one
+ *   FFTUP_STREAMS=n     HIP streams consecutive frames of fftup_execute_ring / fftup_submit_rgb8 and the iterations of
+ *                       fftup_execute (n_iter > 1) alternate on (default 3, 1..4)
  *   FFTUP_JIT=0|1       run-time specialised plans (default 1); FFTUP_JIT_VERBOSE=1 prints why one fell back
  *   FFTUP_CACHE_DIR     code-object cache and wisdom file of those plans (default ~/.cache/fftup);
  *   FFTUP_KERNEL_DIR    kernel headers, when not the ones embedded in the library; FFTUP_HIPRTC_LIB: the run-time compiler's
@@ -150,12 +153,14 @@ FFTUP_API int fftup_upload_rgb8_slot(fftup_plan* plan, uint32_t slot, const uint
 FFTUP_API int fftup_upload_planar(fftup_plan* plan, uint32_t slot, const void* planes,
                                   size_t row_stride_elems, size_t plane_stride_elems);
 
-/* performVulkanUpscale (VR:1249-1279): enqueue n_iter full pipelines back to back on the plan's ONE
- * stream, one synchronisation.  Like the reference, which records them into one command buffer on one queue
- * (VR:1250-1273), the frame's launches are recorded once (hipGraph) and replayed.
+/* performVulkanUpscale (VR:1249-1279): enqueue n_iter full pipelines, one synchronisation.
  * *ms_per_iter = device time from before the first to after the last launch, divided by n_iter -- the
- * reference's "Time: X ms" (VR:1270-1278): single-queue frame latency, no overlap between iterations.
- * Every iteration reads input slot 0 and writes output slot 0. */
+ * reference's "Time: X ms" (VR:1270-1278).  Every iteration reads input slot 0 and computes the same frame; output slot 0
+ * holds it afterwards.  The reference records the n_iter pipelines into one command buffer and submits it once (VR:1250-1273);
+ * nothing orders identical iterations, so for n_iter > 1 they alternate on the plan's FFTUP_STREAMS HIP streams (own spectra,
+ * own scratch output per stream beyond the first -- allocated on the first such call) and overlap like the frames of
+ * fftup_execute_ring: bit-identical results, the throughput figure.  n_iter = 1, FFTUP_FLAG_SEQUENTIAL_EXECUTE or
+ * FFTUP_STREAMS=1: one stream, no overlap -- single-frame latency. */
 FFTUP_API int fftup_execute(fftup_plan* plan, uint32_t n_iter, double* ms_per_iter);
 /* batched mode: n_frames pipelines, frame i reads input slot (first_slot+i) % ring and writes
  * output slot (first_slot+i) % ring; returns total device milliseconds. */

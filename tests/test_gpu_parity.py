@@ -888,27 +888,50 @@ def test_fused_output_independent_of_strip_length(W, H, precision):
             assert d.max() <= 4e-3 and (d != 0).mean() <= 2e-4, "pairs_per_strip = %d: %g, %g" % (pairs, d.max(), (d != 0).mean())
 
 
-@pytest.mark.parametrize("W,H,precision,flags", [(256, 128, 0, 0), (640, 480, 0, 2), (2048, 1024, 2, 2), (1920, 1080, 0, 0), (16, 8, 1, 0)])
-def test_recorded_frames_equal_eager_launches(W, H, precision, flags, monkeypatch):
-    """fftup_execute / fftup_execute_ring replay frames recorded once into a hipGraph (the reference records its dispatches
-    into one command buffer, VR:1250-1273); FFTUP_EXPERIMENT graphs=0 issues every launch eagerly.  Same kernels, same
-    arguments: the same bits, for -n 1 (single-frame graph), -n 35 (two graphs of 16 frames + 3 single ones) and a ring."""
-    from vkresample_amd import synth
+@pytest.mark.parametrize("W,H,precision,flags", [(256, 128, 0, 0), (640, 480, 0, 2), (2048, 1024, 2, 2), (2048, 1024, 0, 32), (1920, 1080, 0, 0),
+                                                 (16, 8, 1, 0), (9216, 8, 0, 0), (512, 256, 0, 8)])
+def test_pipelined_execute_is_bit_identical_to_the_single_queue_form(W, H, precision, flags, monkeypatch):
+    """fftup_execute(n > 1) runs its n identical iterations alternately on the plan's streams (own spectra, own scratch output
+    per stream; the reference submits them as one command buffer, VR:1250-1273) -- the same kernels with the same arguments on
+    the same input: output slot 0 holds the bits ONE iteration leaves (n = 1 runs alone on stream 0), for n = 2, 3, 35, on
+    plans with and without a ring, fused, unfused (FFTUP_FLAG_UNFUSED_SHARPEN), 8-bit store (32), -p 1, four-step rows.  The
+    strict single-queue form (FFTUP_FLAG_SEQUENTIAL_EXECUTE, FFTUP_STREAMS=1) gives the same frame: bit for bit wherever the
+    result does not depend on the fused kernel's strip length (a sequential plan cuts two strips per compute unit), to rounding
+    where it does."""
+    from vkresample_amd import FLAG_FUSE_U8_STORE, FLAG_SEQUENTIAL_EXECUTE, synth
+    rgb = synth.frame(70, W, H)
+    get = (lambda up: up.download_rgb8(0).copy()) if flags & FLAG_FUSE_U8_STORE else (lambda up: up.download_planar(0).copy())
     res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("FFTUP_EXPERIMENT", "graphs=" + mode)
-        with _up(W, H, 2.0, precision, 0.2, 0, flags, ring=3) as up:
-            for s in range(3):
-                up.upload_rgb8(synth.frame(70 + s, W, H), slot=s)
-            up.execute(1)
-            a = up.download_planar(0).copy()
-            up.execute(35)
-            b = up.download_planar(0).copy()
-            up.execute_ring(7, 1)
-            res[mode] = [a, b] + [up.download_planar(s).copy() for s in range(3)]
-    for x, y in zip(res["0"], res["1"]):
-        assert np.array_equal(x, y)
-    assert np.array_equal(res["1"][0], res["1"][1]) and not np.array_equal(res["1"][2], res["1"][3])
+    for ring in (1, 3):
+        with _up(W, H, 2.0, precision, 0.2, 0, flags, ring=ring) as up:
+            up.upload_rgb8(rgb)
+            outs = []
+            for n in (1, 2, 3, 35, 1):
+                ms = up.execute(n)
+                assert ms > 0
+                outs.append(get(up))
+            pre = up.download_presharpen().copy() if not flags & FLAG_FUSE_U8_STORE else None
+            for o in outs[1:]:
+                assert np.array_equal(outs[0], o)
+            res[ring] = (outs[0], pre)
+    assert np.array_equal(res[1][0], res[3][0])
+    with _up(W, H, 2.0, precision, 0.2, 0, flags | FLAG_SEQUENTIAL_EXECUTE) as up:
+        up.upload_rgb8(rgb)
+        up.execute(5)
+        seq, seq_pre = get(up), (up.download_presharpen().copy() if not flags & FLAG_FUSE_U8_STORE else None)
+        fused = up.kernel_names[3] == "-"                               # C2R and sharpen in one launch: strips
+    if seq_pre is not None:
+        assert np.array_equal(seq_pre, res[1][1])                        # the transforms do not know about strips
+    if fused:
+        d = np.abs(seq.astype(np.float64) - res[1][0].astype(np.float64))
+        assert d.max() <= (1 if flags & FLAG_FUSE_U8_STORE else 5e-6 if precision == 0 else 4e-3)
+    else:
+        assert np.array_equal(seq, res[1][0])
+    monkeypatch.setenv("FFTUP_STREAMS", "1")
+    with _up(W, H, 2.0, precision, 0.2, 0, flags) as up:
+        up.upload_rgb8(rgb)
+        up.execute(4)
+        assert np.array_equal(get(up), seq)                              # one stream = the sequential plan, cuts included
 
 
 def test_four_step_plans_in_a_ring():

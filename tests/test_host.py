@@ -225,6 +225,26 @@ def test_bench_gpus_flag_starts_ranks_itself():
         assert r.returncode != 0 or json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 2
 
 
+def test_static_counter_figures_belong_to_these_kernel_sources():
+    """bench.py prints HBM bytes and vector-instruction counts from committed rocprofv3 --pmc runs (profiles/hbm_traffic.json) and
+    a second roofline fraction from the committed --kernel-trace --stats summaries (profiles/kernel_stats_index.json): both carry
+    the fingerprint of the kernel sources they were measured on; a kernel change without a refresh (tools/gpu_round_end.sh) fails
+    here instead of leaving stale figures in the line (VERDICT r4 #4)"""
+    import bench
+    h = bench.kernel_sources_sha256()
+    tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    keys = [k for k in tj if not k.startswith("_")]
+    assert {"2048x1024_p0_planar", "2048x1024_p2_u8", "1920x1080_p0_planar", "2048x1024_p2_u8_u8out"} <= set(keys)
+    for k in keys:
+        assert tj[k]["_kernel_sources_sha256"] == h, "%s: measured on other kernel sources -- re-run tools/gpu_pmc.sh" % k
+        assert bench.traffic_is_current(os.path.join(ROOT, "profiles", "hbm_traffic.json"), k) is True
+    idx = json.load(open(os.path.join(ROOT, "profiles", "kernel_stats_index.json")))
+    for k, e in idx.items():
+        assert e["kernel_sources_sha256"] == h and os.path.exists(os.path.join(ROOT, e["file"])), k
+    us, f, fresh = bench.rocprof_kernel_us("2048x1024_p0_planar", "row_c2r_sharpen")
+    assert 30 < us < 80 and fresh is True and f.startswith("profiles/")
+
+
 def test_jit_check_compiles_without_a_device(tmp_path, monkeypatch):
     """csrc/jit.hpp: factorizations are picked and the translation unit is compiled by hipRTC for gfx950 with no GPU
     present; the second request is served from the on-disk cache; a size without a specialised factorization says so."""

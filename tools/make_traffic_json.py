@@ -36,11 +36,13 @@ for line in open(src):
     if m and cur:
         data[cur][m.group(1)] = float(m.group(2))
 import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 allres = json.load(open(out)) if os.path.exists(out) else {}
 if "_method" not in allres or "row_r2c" in allres:      # (round-1 file: not keyed)
     allres = {}
 allres["_method"] = __doc__
-res = {"_source": src}
+res = {"_source": src, "_kernel_sources_sha256": bench.kernel_sources_sha256()}
 for k, c in data.items():
     if k not in names or "FETCH_SIZE" not in c:
         continue

@@ -14,6 +14,7 @@ FLAG_GENERIC_KERNELS = 4
 FLAG_UNFUSED_SHARPEN = 8
 FLAG_TUNE_PLAN = 16
 FLAG_FUSE_U8_STORE = 32
+FLAG_SEQUENTIAL_EXECUTE = 64
 
 # every symbol include/fftup.h declares
 EXPORTS = [

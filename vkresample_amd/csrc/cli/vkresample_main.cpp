@@ -161,6 +161,9 @@ static int launchResample(ResampleConfiguration config)                      // 
     cfg.width = (uint32_t)width; cfg.height = (uint32_t)height; cfg.channels = 3;
     cfg.upscale = config.upscale; cfg.precision = config.precision; cfg.sharpen = config.sharpenConst;
     cfg.device = device; cfg.flags = config.flags; cfg.ring = config.fileUpload ? 2 : 1;
+    // -n 1 (the default): one frame, nothing to pipeline -- the plan is laid out for single-frame latency; -n N > 1: the N
+    // identical iterations alternate on the plan's streams (fftup_execute), "Time:" is the per-iteration throughput figure
+    if (config.numIter == 1) cfg.flags |= FFTUP_FLAG_SEQUENTIAL_EXECUTE;
     // the batched path below runs on the GPU's shared plan: one frame in flight per thread, sixteen slots at most
     // (a slot is busy for ~0.5 ms per frame; a thread comes back after tens of ms of codec work)
     const bool streamed = config.fileUpload && config.numIter == 1 && config.numFiles > 1;

@@ -9,10 +9,8 @@
 #include <cstring>
 #include <atomic>
 #include <condition_variable>
-#include <map>
 #include <mutex>
 #include <string>
-#include <tuple>
 #include <vector>
 
 #include "../../include/fftup.h"
@@ -127,11 +125,6 @@ struct fftup_plan {
     uint64_t* d_sum = nullptr;        // fftup_output_checksum accumulator (created on first use)
     size_t in_plane_stride = 0;
     int executed = 0;
-
-    // One frame's launches recorded once per (lane, input slot, output slot, input kind, repetitions) and replayed with
-    // hipGraphLaunch: the HIP counterpart of the reference's pre-recorded command buffer (VkResample.cpp:1250-1273)
-    std::map<std::tuple<int, uint32_t, uint32_t, int, int>, hipGraphExec_t> graphs;
-    bool use_graphs = true;           // FFTUP_EXPERIMENT graphs=0: every launch issued eagerly (A/B, tests)
 
     std::vector<void*> allocs;
 };
@@ -252,22 +245,40 @@ static int jit_factor_x2(float upscale, uint32_t W, uint32_t H, uint32_t uW, uin
     return D;
 }
 static void tune_fused(fftup_plan* P);
-static std::string wisdom_device_key(const fftup_plan* P);
 
-// Row pairs per workgroup (strip) of the fused C2R+sharpen kernel.
-// Plans whose frames overlap on several streams (ring > 1): ONE strip per compute unit -- the rest of every unit is left
-// to the row and column kernels of the frames on the other streams, and the frame time is what counts.
-// Plans that run one frame after the other (ring = 1: the CLI's single-image mode, the reference's -n timing): nothing
-// runs beside a strip, and a workgroup of at most 512 threads (one or two waves per SIMD) does not hide its own latencies: two
-// strips per unit (1080p 100 -> 91 us per iteration, 1000x1000 75 -> 62, 2048x1024 77.2 -> 76.0, -p 2 82.7 -> 79.7; 768 and 1024
-// threads: 2-7 % slower with two; profiles/r04_s_strips_per_unit_sequential.txt).
-// FFTUP_EXPERIMENT keys g_per_cu / pairs_per_strip override; how many workgroups are resident is the hardware's business.
+// HIP streams ("lanes") the frames of a plan alternate on
+static int lane_count()
+{
+    int nl = 3;
+    if (const char* e = getenv("FFTUP_STREAMS")) nl = atoi(e);
+    return std::max(1, std::min(nl, 4));
+}
+// Do consecutive frames of this plan overlap on several streams?  A ring of slots (fftup_execute_ring, fftup_submit_rgb8) or the
+// pipelined fftup_execute (every plan without FFTUP_FLAG_SEQUENTIAL_EXECUTE) -- as long as there is more than one stream.
+static bool frames_overlap(const fftup_plan* P)
+{
+    return lane_count() > 1 && (P->ring > 1 || !(P->cfg.flags & FFTUP_FLAG_SEQUENTIAL_EXECUTE));
+}
+// what the tuner's findings are filed under: the device and whether consecutive frames overlap (what fits beside a strip
+// decides) or run one after the other (the kernel's own time decides)
+static std::string wisdom_device_key(const fftup_plan* P)
+{
+    return std::string(P->prop.gcnArchName) + (frames_overlap(P) ? " overlapped" : " sequential");
+}
+
+// Row pairs per workgroup (strip) of the fused C2R+sharpen kernel -- a property of the PLAN (results depend on the cuts in
+// their last bits, tests/test_gpu_parity.py: test_fused_output_independent_of_strip_length), chosen by how its frames run.
+// Frames that overlap on several streams: ONE strip per compute unit -- the rest of every unit is left to the row and column
+// kernels of the frames on the other streams, and the frame time is what counts.
+// Frames that run one after the other (FFTUP_FLAG_SEQUENTIAL_EXECUTE on a plan without a ring: the CLI's single image, -n 1):
+// nothing runs beside a strip, and a workgroup of at most 512 threads (one or two waves per SIMD) does not hide its own
+// latencies: two strips per unit (1080p 100 -> 91 us per iteration, 1000x1000 75 -> 62, 2048x1024 77.2 -> 76.0, -p 2
+// 82.7 -> 79.7; 768 and 1024 threads: 2-7 % slower with two; profiles/r04_s_strips_per_unit_sequential.txt).
+// How many workgroups are resident is the hardware's business.
 static void set_strip_length(fftup_plan* P)
 {
     const int fused_threads = P->tuned ? (int)P->uW / 8 : P->mixed == 3 ? P->jit->choice.fused_t : 256;
-    const std::string mode = wisdom_device_key(P);
-    const bool sequential = mode.size() >= 10 && mode.compare(mode.size() - 10, 10, "sequential") == 0;
-    int per_cu = (sequential && fused_threads <= 512) ? 2 : 1;
+    int per_cu = (!frames_overlap(P) && fused_threads <= 512) ? 2 : 1;
     if (const char* e = fftup_jit::experiment("g_per_cu")) per_cu = std::max(1, std::min(4, atoi(e)));
     const int total_pairs = 3 * (int)P->uH / 2, slots = std::max(1, P->prop.multiProcessorCount) * per_cu;
     P->pairs_per_strip = std::max(2, (total_pairs + slots - 1) / slots);
@@ -278,15 +289,6 @@ static void set_strip_length(fftup_plan* P)
         P->pairs_per_strip = std::max(2, (ppp + 8 * per_xcd - 1) / (8 * per_xcd));
     }
     if (const char* e = fftup_jit::experiment("pairs_per_strip")) P->pairs_per_strip = std::max(1, atoi(e));
-}
-// what the tuner's findings are filed under: the device and whether consecutive frames overlap on several streams
-// (ring > 1: what fits beside a strip decides) or run one after the other (ring = 1: the kernel's own time decides)
-static std::string wisdom_device_key(const fftup_plan* P)
-{
-    int nl = 3;
-    if (const char* e = getenv("FFTUP_STREAMS")) nl = atoi(e);
-    nl = std::max(1, std::min(nl, 4));
-    return std::string(P->prop.gcnArchName) + (std::min(nl, (int)P->ring) > 1 ? " overlapped" : " sequential");
 }
 static bool jit_tune_enabled()
 {
@@ -416,7 +418,6 @@ void fftup_plan_destroy(fftup_plan* P)
         if (qs.png.parts_host) (void)hipHostFree(qs.png.parts_host);
     }
     if (P->png_copy) (void)hipStreamDestroy(P->png_copy);
-    for (auto& g : P->graphs) (void)hipGraphExecDestroy(g.second);
     for (void* p : P->allocs) (void)hipFree(p);
     delete P->jit;
     if (P->ev0) (void)hipEventDestroy(P->ev0);
@@ -570,7 +571,6 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         P->fused = (P->tuned || P->mixed) && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
         P->u8out = P->fused && (cfg->flags & FFTUP_FLAG_FUSE_U8_STORE);
         set_strip_length(P);
-        if (const char* e = fftup_jit::experiment("graphs")) P->use_graphs = atoi(e) != 0;
         P->NT = (P->ncols + P->TK - 1) / P->TK;
         P->ldsRowF = 2 * P->csz * (size_t)lpad_size((int)W);
         P->ldsRowI = 2 * P->csz * (size_t)lpad_size((int)uW);
@@ -637,9 +637,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         if (!P->fused) PLAN_RC(dev_alloc(P, &P->R, P->r_bytes));
         if (!P->u8out) PLAN_RC(dev_alloc(P, (void**)&P->out_u8, (size_t)3 * uW * uH + 8));   // staging of the conversion launch (+ 8: k_png_filter reads whole words)
         {
-            int nl = 3;
-            if (const char* e = getenv("FFTUP_STREAMS")) nl = atoi(e);
-            P->nlanes = std::max(1, std::min(nl, 4));
+            P->nlanes = lane_count();
             P->lanes.resize(P->nlanes);
             P->lanes[0].stream = P->stream; P->lanes[0].S1 = P->S1; P->lanes[0].S2 = P->S2; P->lanes[0].R = P->R;
             const size_t t4_bytes = P->csz * 3 * std::max(std::max(P->fourF.on ? (size_t)W * H : 0, P->fourI.on ? (size_t)uW * uH : 0),
@@ -1266,56 +1264,6 @@ static int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int 
     return FFTUP_OK;
 }
 
-// ---- recorded frames.  The reference records its dispatches into ONE command buffer and submits that (VR:1250-1273); here a
-// frame's launches on lane P->cur are captured into a hipGraph the first time that (lane, slots, input kind) combination
-// runs and replayed afterwards; `reps` consecutive frames in one graph.  Used by fftup_execute, the counterpart of
-// performVulkanUpscale.  Measured (profiles/r04_a_graphs.txt): the replay costs what the launches cost -- a 256x128 frame takes
-// 16.3 us either way with kernels of 2-4 us, because a stream's kernels are serialised by the queue's barrier packets
-// (~4 us from the end of one kernel to the start of the next), recorded or not -- and per-frame graphs replayed on the
-// three streams of the batched mode are 1-8 % SLOWER than the launches, so fftup_execute_ring / fftup_submit_rgb8 launch.
-static void graphs_clear(fftup_plan* P)
-{
-    for (auto& g : P->graphs) (void)hipGraphExecDestroy(g.second);
-    P->graphs.clear();
-}
-static int frame_graph(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int reps, hipGraphExec_t* ex)
-{
-    const auto key = std::make_tuple(P->cur, in_slot, out_slot, P->in_kind[in_slot], reps);
-    auto it = P->graphs.find(key);
-    if (it != P->graphs.end()) { *ex = it->second; return FFTUP_OK; }
-    if (P->in_kind[in_slot] == 0) return fail(FFTUP_E_NO_INPUT, "no input uploaded for this slot");
-    hipStream_t st = P->lanes[P->cur].stream;
-    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc = FFTUP_OK;
-    for (int r = 0; r < reps && !rc; r++) rc = launch_frame(P, in_slot, out_slot, -1);
-    hipGraph_t g = nullptr;
-    const hipError_t e = hipStreamEndCapture(st, &g);
-    if (!rc && e != hipSuccess) rc = fail(FFTUP_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    if (!rc) {
-        const hipError_t ei = hipGraphInstantiate(ex, g, nullptr, nullptr, 0);
-        if (ei != hipSuccess) rc = fail(FFTUP_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
-    }
-    if (g) (void)hipGraphDestroy(g);
-    if (!rc) P->graphs[key] = *ex;
-    return rc;
-}
-// `reps` frames (input slot -> output slot) on lane P->cur
-static int run_frames(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int reps)
-{
-    if (!P->use_graphs) {
-        int rc = FFTUP_OK;
-        for (int r = 0; r < reps && !rc; r++) rc = launch_frame(P, in_slot, out_slot, -1);
-        return rc;
-    }
-    hipGraphExec_t ex = nullptr;
-    const int rc = frame_graph(P, in_slot, out_slot, reps, &ex);
-    if (rc) return rc;
-    HIP_TRY(hipGraphLaunch(ex, P->lanes[P->cur].stream));
-    if (P->fused) P->R_valid = false;                       // (what launch_frame notes when it runs)
-    else if (!P->dbl) P->R_valid = true;
-    return FFTUP_OK;
-}
-
 extern "C" {
 
 // shared body of fftup_execute_ring / fftup_execute_ring_timed.  With kernel_ms != NULL a HIP event is recorded
@@ -1456,11 +1404,9 @@ static void tune_fused(fftup_plan* P)
         if (!m) continue;
         P->jit = m;
         set_strip_length(P);
-        graphs_clear(P);                                                        // (recorded frames name the module's kernels)
         const double t = time_plan();
         P->jit = original;
         set_strip_length(P);
-        graphs_clear(P);
         if (getenv("FFTUP_JIT_VERBOSE"))
             fprintf(stderr, "fftup: tuning %s: %s %.1f us/frame (default %s %.1f)\n", key.c_str(), fftup_jit::fused_value(m->choice).c_str(), t * 1e3,
                     fftup_jit::fused_value(base).c_str(), t_base * 1e3);
@@ -1468,7 +1414,6 @@ static void tune_fused(fftup_plan* P)
         else delete m;
     }
     if (best) { delete original; P->jit = best; set_strip_length(P); }
-    graphs_clear(P);
     P->in_kind = kinds;
     P->executed = executed;
     fftup_jit::wisdom_store(key, fftup_jit::fused_value(P->jit->choice));
@@ -1476,34 +1421,49 @@ static void tune_fused(fftup_plan* P)
 
 extern "C" {
 
+// output buffers of the lanes beyond the first for the pipelined fftup_execute (appended to P->out behind the ring's slots,
+// which is all the other entry points can name): created on the first call that needs them
+static int ensure_execute_outputs(fftup_plan* P, int nl)
+{
+    while (P->out.size() < (size_t)P->ring + (size_t)nl - 1) {
+        void* o = nullptr;
+        int rc = dev_alloc(P, &o, (size_t)3 * P->uW * P->uH * (P->u8out ? 1 : P->esz) + 8);
+        if (rc) return rc;
+        P->out.push_back(o);
+    }
+    return FFTUP_OK;
+}
+
 int fftup_execute(fftup_plan* P, uint32_t n_iter, double* ms_per_iter)
 {
     if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
     if (n_iter == 0) return fail(FFTUP_E_INVALID_ARG, "n_iter must be > 0");
     HIP_TRY(hipSetDevice(P->device));
-    // The reference records n_iter identical pipelines in ONE command buffer on ONE queue (VR:1260-1265) and
-    // reports wall time / n_iter (VR:1270-1278): back-to-back frames on the plan's own stream, no overlap between
-    // iterations, every iteration writes output slot 0.  (Overlapped throughput is what fftup_execute_ring and
-    // fftup_submit_rgb8 are for.)
-    // Recorded once, replayed: graphs of 16 frames while that many are left, single frames for the rest.
-    constexpr uint32_t REPS = 16;
-    P->cur = 0;
+    // The reference records n_iter identical pipelines in ONE command buffer, submits it once and reports wall time / n_iter
+    // (VR:1260-1278).  The iterations are identical -- same input slot 0, same result -- so nothing orders them: iteration i
+    // runs on stream i mod nl with that stream's own spectra and, beyond stream 0, its own output buffer (stream 0 writes
+    // output slot 0, which is what fftup_download_* read).  A kernel of one iteration then overlaps other kernels of its
+    // neighbours exactly as consecutive frames of fftup_execute_ring do; every iteration computes the bits a lone one computes.
+    // FFTUP_FLAG_SEQUENTIAL_EXECUTE (or FFTUP_STREAMS=1) keeps the strict single-queue form: one stream, nothing overlaps.
+    const bool sequential = (P->cfg.flags & FFTUP_FLAG_SEQUENTIAL_EXECUTE) != 0;
+    const int nl = sequential ? 1 : (int)std::min<uint32_t>((uint32_t)P->nlanes, n_iter);
+    int rc = ensure_execute_outputs(P, nl);
+    if (rc) return rc;
     P->last_lane = 0;
-    if (P->use_graphs) {                                     // (record before the clock starts, like the reference's command buffer)
-        hipGraphExec_t ex;
-        int rc = n_iter >= REPS ? frame_graph(P, 0, 0, (int)REPS, &ex) : FFTUP_OK;
-        if (!rc && n_iter % REPS) rc = frame_graph(P, 0, 0, 1, &ex);
-        if (rc) return rc;
-    }
     HIP_TRY(hipEventRecord(P->ev0, P->stream));
-    for (uint32_t i = 0; i < n_iter;) {
-        const uint32_t reps = (n_iter - i >= REPS) ? REPS : 1;
-        int rc = run_frames(P, 0, 0, (int)reps);
-        if (rc) return rc;
-        i += reps;
+    for (int l = 1; l < nl; l++) HIP_TRY(hipStreamWaitEvent(P->lanes[l].stream, P->ev0, 0));
+    for (uint32_t i = 0; i < n_iter && !rc; i++) {
+        P->cur = (int)(i % (uint32_t)nl);
+        rc = launch_frame(P, 0, P->cur == 0 ? 0 : P->ring + (uint32_t)P->cur - 1, -1);
     }
-    HIP_TRY(hipEventRecord(P->ev1, P->stream));
-    HIP_TRY(hipEventSynchronize(P->ev1));
+    P->cur = 0;
+    for (int l = 1; l < nl; l++) {
+        (void)hipEventRecord(P->lanes[l].done, P->lanes[l].stream);
+        (void)hipStreamWaitEvent(P->stream, P->lanes[l].done, 0);
+    }
+    const hipError_t e1 = hipEventRecord(P->ev1, P->stream), e2 = hipEventSynchronize(P->ev1);
+    if (rc) return rc;
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(FFTUP_E_HIP, std::string("sync: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, P->ev0, P->ev1));
     if (ms_per_iter) *ms_per_iter = (double)ms / n_iter;

@@ -23,16 +23,17 @@ def frames_for_rank(num_files, world, rank):
 
 def reduce_summary(dist, frames_done, checksum, elapsed_s, device=None):
     """All-reduce {sum frames, sum checksum, max elapsed} over the job.  `dist` is torch.distributed (or None
-    for a single process).  Returns python scalars; exact for checksums < 2**53."""
+    for a single process).  Returns python scalars; the sums are 64-bit integer sums (exact while the job's total stays below
+    2**63: 2**11 ranks with checksums below 2**52)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return int(frames_done), int(checksum), float(elapsed_s)
     import torch
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    s = torch.tensor([float(frames_done), float(checksum)], dtype=torch.float64, device=dev)
+    s = torch.tensor([int(frames_done), int(checksum)], dtype=torch.int64, device=dev)
     m = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=dev)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
-    return int(round(s[0].item())), int(round(s[1].item())), float(m[0].item())
+    return int(s[0].item()), int(s[1].item()), float(m[0].item())
 
 
 class FrameQueue:
