@@ -38,7 +38,11 @@ enum {
     FFTUP_E_HIP = 5,            /* a HIP runtime call failed (message in fftup_last_error)              */
     FFTUP_E_OUT_OF_MEMORY = 6,  /* device allocation failed (allocateFFTBuffer VR:361-384)              */
     FFTUP_E_NO_INPUT = 7,       /* execute/download before any upload                                   */
-    FFTUP_E_INCOMPLETE = 8      /* "Image not found" class of errors in the host mirror (VR:1366)       */
+    FFTUP_E_INCOMPLETE = 8,     /* "Image not found" class of errors in the host mirror (VR:1366)       */
+    FFTUP_E_WOULD_BLOCK = 9,    /* fftup_submit_png: the ring slot it needs holds a PNG ticket of the CALLING thread that has
+                                   not been collected (fftup_wait_png) -- waiting would never end                */
+    FFTUP_E_OVERFLOW = 10       /* fftup_wait_png: the frame's deflate stream did not fit the encoder's buffer; nothing was
+                                   written beyond it, the frame is not encoded                                   */
 };
 
 /* ---- flags ---- */
@@ -219,8 +223,11 @@ FFTUP_API int fftup_drain(fftup_plan* plan);
  * named at submission already (a 16-byte aligned buffer of fftup_host_alloc; NULL: not yet) the GPU writes the stream into it
  * itself, sized by the count it knows, and fftup_wait_png(.., the same buffer, ..) only waits, adds the framing and the CRC --
  * no size round trip through the host: several frames of one thread stream back to back.  A ticket of
- * fftup_submit_png must be collected by fftup_wait_png (a later submission of its ring slot waits for that); -p 0 and -p 2
- * plans; thread-safe like fftup_submit_rgb8 / fftup_wait. */
+ * fftup_submit_png must be collected by fftup_wait_png: a later submission (fftup_submit_png or fftup_submit_rgb8, any thread)
+ * that comes round to its ring slot waits for that -- unless the uncollected ticket belongs to the submitting thread itself,
+ * which would wait forever: that call fails with FFTUP_E_WOULD_BLOCK instead (a thread keeps at most `ring` PNG tickets open;
+ * with the default ring of 1: collect each one before the next submission).  -p 0 and -p 2 plans whose stream bound fits one
+ * IDAT chunk (2^31 - 1 bytes: FFTUP_E_UNSUPPORTED_SIZE beyond); thread-safe like fftup_submit_rgb8 / fftup_wait. */
 FFTUP_API size_t fftup_png_bound(fftup_plan* plan);
 FFTUP_API int fftup_submit_png(fftup_plan* plan, const uint8_t* rgb_in, size_t in_stride_bytes, uint8_t* png_out, size_t capacity,
                                uint64_t* ticket);

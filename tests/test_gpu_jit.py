@@ -121,6 +121,13 @@ def test_specialisation_can_be_switched_off(monkeypatch):
         assert not up.tuned
 
 
+def _knobs(monkeypatch, text):
+    """FFTUP_EXPERIMENT is parsed by the test build of the library only (libfftup_knobs.so, -DFFTUP_TEST_KNOBS): load that one"""
+    from vkresample_amd import _lib
+    monkeypatch.setenv("FFTUP_LIBRARY", _lib.KNOBS_LIB_PATH)
+    monkeypatch.setenv("FFTUP_EXPERIMENT", text)
+
+
 def test_pinned_factorizations(monkeypatch):
     """FFTUP_EXPERIMENT keys jit_row / jit_col / jit_fused pin a factorization: other valid choices give the same pixels up to
     fp32 rounding"""
@@ -134,7 +141,7 @@ def test_pinned_factorizations(monkeypatch):
             up.execute(1)
             return up.download_planar().astype(np.float64)
     ref = run()
-    monkeypatch.setenv("FFTUP_EXPERIMENT", "jit_row=5,8,16;jit_col=15,4,8;jit_fused=192:8,10,16")
+    _knobs(monkeypatch, "jit_row=5,8,16;jit_col=15,4,8;jit_fused=192:8,10,16")
     got = run()
     assert np.percentile(np.abs(ref - got), 99.99) <= 1e-5 and np.abs(ref - got).max() <= 2e-4
 

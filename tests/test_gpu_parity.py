@@ -343,6 +343,8 @@ def test_fused_sharpen_equals_unfused(precision, pps, monkeypatch):
     sample) against the two-launch path on the same frame, for strip lengths that do / do not divide the
     plane, cross plane boundaries, or swallow whole planes."""
     from vkresample_amd import FLAG_UNFUSED_SHARPEN
+    from vkresample_amd import _lib
+    monkeypatch.setenv("FFTUP_LIBRARY", _lib.KNOBS_LIB_PATH)       # (the knob exists in the test build of the library only)
     monkeypatch.setenv("FFTUP_EXPERIMENT", "pairs_per_strip=%d" % pps)
     (pre, out, u8), _ = _run(512, 256, 2.0, precision, "U", seed=3)
     (pre2, out2, u82), _ = _run(512, 256, 2.0, precision, "U", flags=FLAG_UNFUSED_SHARPEN, seed=3)
@@ -849,6 +851,11 @@ def test_plans_in_concurrent_host_threads():
             assert np.array_equal(a, b)
 
 
+def _knobs_lib():
+    from vkresample_amd import _lib
+    return _lib.KNOBS_LIB_PATH
+
+
 def _run_env(env, W, H, precision, dist="N", flags=0):
     """Output planes of one frame with plan-creation environment switches set (read by fftup_plan_create)."""
     from vkresample_amd import synth
@@ -880,7 +887,7 @@ def test_fused_output_independent_of_strip_length(W, H, precision):
     <= 1.8e-6 (fp32), 61 pixels in 1.5 M one or two binary16 ulps apart (-p 2).  A wrong halo, tap or cut costs >= 1e-3."""
     ref = _run_env({}, W, H, precision).astype(np.float64)
     for pairs in ((1, 2, 3, 5, 7, 50) if W == 512 else (3, 5, 7, 50)):
-        got = _run_env({"FFTUP_EXPERIMENT": "pairs_per_strip=%d" % pairs}, W, H, precision).astype(np.float64)
+        got = _run_env({"FFTUP_EXPERIMENT": "pairs_per_strip=%d" % pairs, "FFTUP_LIBRARY": _knobs_lib()}, W, H, precision).astype(np.float64)
         d = np.abs(ref - got)
         if precision == 0:
             assert d.max() <= 5e-6, "pairs_per_strip = %d: %g" % (pairs, d.max())

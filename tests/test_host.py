@@ -276,10 +276,31 @@ def test_jit_check_compiles_without_a_device(tmp_path, monkeypatch):
     assert lib.fftup_jit_check(2450, 1080, 2, 0, None, buf, 256) == 2          # FFTUP_E_UNSUPPORTED_SIZE: the generic kernels run it
     assert lib.fftup_jit_check(640, 480, 2, 1, None, buf, 256) == 3            # FFTUP_E_UNSUPPORTED_PRECISION
     # a pinned factorization that does not multiply to the size is ignored; a valid one is used
+    monkeypatch.setenv("FFTUP_LIBRARY", _lib.KNOBS_LIB_PATH)       # the FFTUP_EXPERIMENT parser exists in the test build only
+    lib = _lib.load()
     monkeypatch.setenv("FFTUP_EXPERIMENT", "jit_row=5,8,16")
     assert lib.fftup_jit_check(640, 480, 2, 0, None, buf, 256) == 0 and "row 5*8*16" in buf.value.decode()
     monkeypatch.setenv("FFTUP_EXPERIMENT", "jit_row=5,8,8")
     assert lib.fftup_jit_check(640, 480, 2, 0, None, buf, 256) == 0 and "row 10*8*8" in buf.value.decode()
+
+
+def test_shipping_library_has_no_experiment_parser(monkeypatch):
+    """FFTUP_EXPERIMENT is a test knob.  The shipping libfftup.so does not parse it (the same pin that changes
+    libfftup_knobs.so's choice leaves the product's untouched); nothing else in csrc/ reads the variable."""
+    from vkresample_amd import _lib
+    buf = C.create_string_buffer(256)
+    monkeypatch.setenv("FFTUP_EXPERIMENT", "jit_row=5,8,16")
+    monkeypatch.delenv("FFTUP_LIBRARY", raising=False)
+    lib = _lib.load()
+    assert lib.fftup_jit_check(640, 480, 2, 0, b"", buf, 256) == 0 and "row 5*8*16" not in buf.value.decode()
+    monkeypatch.setenv("FFTUP_LIBRARY", _lib.KNOBS_LIB_PATH)
+    assert _lib.load().fftup_jit_check(640, 480, 2, 0, b"", buf, 256) == 0 and "row 5*8*16" in buf.value.decode()
+    csrc = os.path.join(ROOT, "vkresample_amd", "csrc")
+    readers = [f for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".hpp")) and 'getenv("FFTUP_EXPERIMENT")' in open(os.path.join(csrc, f)).read()]
+    assert readers == ["jit.cpp"]
+    src = open(os.path.join(csrc, "jit.cpp")).read()
+    k = src.index("#ifdef FFTUP_TEST_KNOBS")
+    assert k < src.index('getenv("FFTUP_EXPERIMENT")') < src.index("#else", k)
 
 
 def test_jit_cache_rejects_torn_files_and_coalesces_concurrent_compiles(tmp_path):

@@ -2,7 +2,7 @@
 # A/B on the GPU box (one gpurun call = one box, so the comparison is fair):
 #   [BENCH_ARGS="--preset config3"] [PROF=1] [REPS=2] tools/gpu_ab.sh variant...
 # a variant is a library build (path ending in .so, relative to the repo root), a set of environment variables
-# ("FFTUP_STREAMS=2 FFTUP_EXPERIMENT=g_per_cu=2"), or the word "base" (the in-tree library as it is).
+# ("FFTUP_STREAMS=2 FFTUP_LIBRARY=.../libfftup_knobs.so FFTUP_EXPERIMENT=g_per_cu=2": the knobs need the test build of the library), or the word "base" (the in-tree library as it is).
 # Prints ms/frame (overlapped, the bench's `value`) and the kernels' sequential durations (HIP events; PROF=1: rocprofv3 averages).
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

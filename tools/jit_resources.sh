@@ -3,7 +3,7 @@
 #   tools/jit_resources.sh <W> <H> [precision] [upscale]      (FFTUP_EXPERIMENT jit_row / jit_col / jit_fused pins are honoured)
 W=$1; H=$2; P=${3:-0}; U=${4:-2}
 cd "$(dirname "$0")/.."
-FFTUP_CACHE_DIR=/tmp/jit_res_cache FFTUP_EXPERIMENT="${FFTUP_EXPERIMENT:+$FFTUP_EXPERIMENT;}jit_dump=/tmp/jit_res_$$.hip" python - <<PY
+FFTUP_CACHE_DIR=/tmp/jit_res_cache FFTUP_LIBRARY=$(dirname $0)/../vkresample_amd/libfftup_knobs.so FFTUP_EXPERIMENT="${FFTUP_EXPERIMENT:+$FFTUP_EXPERIMENT;}jit_dump=/tmp/jit_res_$$.hip" python - <<PY
 import ctypes as C, sys
 sys.path.insert(0, ".")
 from vkresample_amd import _lib

@@ -43,18 +43,22 @@ class Info(C.Structure):
                 ("kernel_min_bytes", C.c_double * FFTUP_NUM_KERNELS), ("abi_version", C.c_uint32), ("u8_store", C.c_uint32)]
 
 
-_lib = None
+KNOBS_LIB_PATH = os.path.join(HERE, "libfftup_knobs.so")       # the same objects + the FFTUP_EXPERIMENT parser (tests, tools)
+_libs = {}
 
 
 def load():
-    """Load libfftup.so (built by __graft_entry__.build()).  Raises if it is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    """Load libfftup.so (built by __graft_entry__.build()).  Raises if it is absent.
+    FFTUP_LIBRARY=<path> names another build of the library (tests that pin factorizations or strip lengths through
+    FFTUP_EXPERIMENT load libfftup_knobs.so this way: the shipping library has no such parser); read at every call, one
+    handle per path."""
+    path = os.environ.get("FFTUP_LIBRARY") or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise RuntimeError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "(there is no CPU fallback)" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+                           "(there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
     vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
     lib.fftup_device_count.restype = C.c_int
     lib.fftup_device_name.argtypes = [C.c_int, C.c_char_p, sz]
@@ -92,5 +96,5 @@ def load():
     lib.fftup_jit_check.argtypes = [u32, u32, C.c_float, u32, C.c_char_p, C.c_char_p, sz]
     lib.fftup_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, sz]
     lib.fftup_output_checksum.argtypes = [vp, u32, C.POINTER(C.c_uint64)]
-    _lib = lib
+    _libs[path] = lib
     return lib

@@ -193,15 +193,22 @@ bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& width, i
     if (!f) { err = "cannot open " + path; return false; }
     std::vector<uint8_t>& file = scratch().file;
     file.clear();
-    if (fseek(f, 0, SEEK_END) == 0) {
-        const long sz = ftell(f);
-        rewind(f);
-        if (sz > 0) {
-            try { file.resize((size_t)sz); } catch (const std::bad_alloc&) { fclose(f); err = "image too large"; return false; }
+    long sz = -1;
+    if (fseek(f, 0, SEEK_END) == 0) { sz = ftell(f); rewind(f); }
+    try {
+        if (sz > 0) {                                   // a regular file: one read of its size
+            file.resize((size_t)sz);
             file.resize(fread(file.data(), 1, (size_t)sz, f));
+        } else {                                        // a pipe, /dev/stdin, a process substitution: read until the end
+            clearerr(f);
+            uint8_t chunk[65536];
+            size_t n;
+            while ((n = fread(chunk, 1, sizeof chunk, f)) > 0) file.insert(file.end(), chunk, chunk + n);
         }
-    }
+    } catch (const std::bad_alloc&) { fclose(f); err = "image too large"; return false; }
+    const bool read_error = ferror(f) != 0;
     fclose(f);
+    if (read_error) { err = "read error on " + path; return false; }
     static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     if (file.size() < 8 || memcmp(file.data(), sig, 8)) { err = "not a PNG file"; return false; }
     Header hd{};
@@ -315,7 +322,11 @@ bool load_rgb8(const std::string& path, std::vector<uint8_t>& rgb, int& width, i
 //    histogram, length-limited canonical codes, and two symbols per 64-bit store.  3-6 x zlib's rate, same size within 1 %.
 namespace {
 
+#if defined(__x86_64__) && defined(__GNUC__)
 #define PNGIO_SIMD __attribute__((target_clones("avx2", "default")))
+#else
+#define PNGIO_SIMD
+#endif
 
 inline uint8_t mag8(uint8_t r) { const uint8_t n = (uint8_t)(0 - r); return r < n ? r : n; }      // |(int8_t) r|
 
@@ -396,6 +407,7 @@ PNGIO_SIMD void apply_filter(int ft, const uint8_t* cur, const uint8_t* up, size
 
 // -- Huffman-only deflate: code construction and the block header are shared with the device-side encoder (../huffman.hpp) --
 
+static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "BitWriter stores its 64-bit accumulator as the stream's next eight bytes");
 struct BitWriter {                    // LSB-first bit stream; every put stores 8 bytes at the write position (little-endian host)
     uint8_t* p;
     uint64_t buf = 0;
@@ -526,7 +538,7 @@ bool write_rgb8(const std::string& path, const uint8_t* rgb, int width, int heig
         deflateEnd(&zs);
         if (zr != Z_STREAM_END) { err = "zlib deflate failed"; return false; }
     } else cl = huffman_zlib(raw.data(), raw.size(), comp.data());
-    if (cl > 0xffffffffu - 16) { err = "image too large for one IDAT chunk"; return false; }
+    if (cl > 0x7fffffffu) { err = "image too large for one IDAT chunk (PNG chunks hold at most 2^31 - 1 bytes)"; return false; }
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { err = "cannot create " + path; return false; }
     static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};

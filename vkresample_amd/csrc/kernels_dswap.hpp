@@ -176,7 +176,7 @@ template <int WV, int DIR> __device__ __forceinline__ void bfly_groups(float2 (&
 // H = 128 WV rows on 64 WV threads, WV = 8, 4, 2 waves (H = 1024, 512, 256): n = (H/8) r + 16 w + 2 g + h0 -- registers r, wave w, lane
 // bits 5-3 g, lane bit 2 h0 (lane bits 1-0: the tile's column) -- and k = k0 + 8 k1 + 8 WV k2 + 64 WV k3 (k1: WV values).
 template <int TK, int H = 1024>
-__global__ void __launch_bounds__(H / 2, FFTUP_COL_WAVES) k_col_v(ColTParams p)
+__global__ void __launch_bounds__(H / 2, kColWaves) k_col_v(ColTParams p)
 {
     static_assert(TK == 4, "four columns of H/8 threads: lane bits 0-1 = column, bits 2-5 and the wave = pp");
     static_assert(H == 1024 || H == 512 || H == 256, "8, 4 or 2 waves");

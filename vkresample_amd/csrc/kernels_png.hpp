@@ -18,27 +18,11 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include "crc32.hpp"
 #include "huffman.hpp"
+#include "png_params.hpp"
 
 namespace fftup {
-
-struct PngParams {
-    const uint8_t* rgb;          // [uH][uW][3], the frame's 8-bit image
-    uint8_t* raw;                // [uH][1 + 3 uW] filter type + residuals
-    uint32_t* rowhist;           // [uH][257]   (symbol 256 unused: the end-of-block symbol is counted per block)
-    unsigned long long* rowsum;  // [uH][2]: sum of the row's stream bytes, sum of (L - i) * byte_i  (Adler-32 partials)
-    uint32_t* tab;               // [nblocks][257] code | length << 16
-    uint32_t* hdr;               // [nblocks][64] block header bits
-    uint32_t* hdr_bits;          // [nblocks]
-    unsigned long long* block_bits;   // [nblocks] header + symbols + end of block
-    unsigned long long* block_start;  // [nblocks] bit offset in the stream
-    unsigned long long* row_off; // [uH] bit offset of the row inside its block (header included)
-    uint32_t* stream;            // zlib stream, zeroed before the frame
-    unsigned long long* meta;    // [0] bytes of the stream (with header and trailer), [1] Adler-32
-    uint32_t* crc_parts;         // CRC-32 of every whole 4 KB piece of the stream (k_png_crc)
-    int uW, uH, rows_per_block, nblocks;
-    int row_in_lds;              // k_png_pack was given LDS for a whole row
-};
 
 __device__ __forceinline__ unsigned png_mag8(unsigned r) { r &= 255u; return r < 256u - r ? r : 256u - r; }
 
@@ -225,6 +209,11 @@ __global__ __launch_bounds__(256) void k_png_layout(PngParams p)
     unsigned long long bsum;
     (void)png_scan256(part % M, buf, &bsum);
     if (t == 0) {
+        // The code lengths come out of a heuristic length limit; the buffer's bound (9 1/8 bits per symbol) is an argument, not
+        // a guarantee the device can lean on: a stream that would not fit is not written at all (k_png_pack, k_png_crc and
+        // k_png_deliver read the verdict from meta), fftup_wait_png reports it.  (+ 8: the words the last atomicOr may touch)
+        if (data_bytes + 4 + 8 > p.capacity) { p.meta[0] = 0; p.meta[1] = 0; p.meta[2] = data_bytes + 4; return; }
+        p.meta[2] = 0;
         const uint32_t adler = (uint32_t)(((bsum % M) << 16) | ((1 + all1) % M));
         atomicOr(&p.stream[0], 0x0178u);                     // bytes 0x78 0x01: deflate, 32 KB window, fastest level
         for (int k = 0; k < 4; k++) {                        // trailer, most significant byte first
@@ -240,6 +229,7 @@ __global__ __launch_bounds__(256) void k_png_pack(PngParams p)
 {
     const int y = blockIdx.x, t = threadIdx.x, blk = y / p.rows_per_block;
     const unsigned L = 3u * (unsigned)p.uW + 1;
+    if (p.meta[2]) return;                                // (uniform) the stream does not fit its buffer: k_png_layout
     __shared__ uint32_t tab[257];
     __shared__ unsigned long long scan[256];
     tab[t] = p.tab[(size_t)blk * 257 + t];
@@ -316,11 +306,7 @@ __global__ __launch_bounds__(256) void k_png_crc(PngParams p)
 {
     __shared__ uint32_t T[4][256];
     const int t = threadIdx.x;
-    {
-        uint32_t c = (uint32_t)t;
-        for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-        T[0][t] = c;
-    }
+    T[0][t] = fftup_crc::crc32_table_entry((uint32_t)t);
     __syncthreads();
     for (int k = 1; k < 4; k++) {
         T[k][t] = (T[k - 1][t] >> 8) ^ T[0][T[k - 1][t] & 255];

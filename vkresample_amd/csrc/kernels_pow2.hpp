@@ -18,14 +18,11 @@
 #include "fft_engine.hpp"
 #include "kernels_generic.hpp"
 
-
-
-
-#ifndef FFTUP_COL_WAVES
-#define FFTUP_COL_WAVES 8     // k_col_t: 8 waves per SIMD = 64 VGPRs: four 512-thread workgroups per CU, all 771 of a frame resident at once
-#endif
-
 namespace fftup {
+
+// launch bound of the column kernels (k_col_t, k_col_v): 8 waves per SIMD = 64 VGPRs: four 512-thread workgroups per compute
+// unit, all 771 of a frame resident at once
+constexpr int kColWaves = 8;
 
 constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n / 2); }
 // radix of the stage that starts at sub-transform length Ns: the largest allowed one (RMAX = 8, or 16 for
@@ -481,7 +478,7 @@ __device__ __forceinline__ void col_phase(float2 (&v)[8], const float2* __restri
 // from S1.  Both halves are kept at TWICE the reference's normalisation (S1 as it is, odd rows D/H instead of D/2H);
 // the consumers fold the 1/2 into their final scale.  Exact for every column vector, Nyquist row included.
 template <int H, int TK>
-__global__ void __launch_bounds__(TK* H / 8, FFTUP_COL_WAVES) k_col_t(ColTParams p)
+__global__ void __launch_bounds__(TK* H / 8, kColWaves) k_col_t(ColTParams p)
 {
     constexpr int Tc = H / 8;                        // threads per column
     extern __shared__ __attribute__((aligned(128))) char smem[];
@@ -1172,9 +1169,6 @@ template <int N, int DIR, int TK, int R0, int R1, int R2, bool FINAL_TO_LDS> str
     }
 };
 
-#ifndef FFTUP_3840_PKTW
-#define FFTUP_3840_PKTW 1
-#endif
 // ---- any number of stages, at most 8 points per butterfly except the last: T threads run ceil(NB/T) butterflies per
 // stage, index map lswz.  What the run-time specialised plans (jit.hpp) instantiate for lengths without a three-stage plan.
 template <int N, int DIR, int T, int TK, int... RS> struct MrFftNT {
@@ -1228,7 +1222,7 @@ template <int N, int DIR, int T, int TK, int... RS> struct MrFftNT {
             for (int b = 0; b < BPT; b++) {
                 const int jb = j + T * b;
                 if (jb < NB) {
-                    if constexpr (S > 0) twiddle_all<R, FFTUP_3840_PKTW != 0>(&v[b * R], twid<DIR>(w.w[S > 0 ? S - 1 : 0][b]));
+                    if constexpr (S > 0) twiddle_all<R>(&v[b * R], twid<DIR>(w.w[S > 0 ? S - 1 : 0][b]));
                     bfly_reg<R, DIR>(&v[b * R]);
                     if constexpr (S + 1 < NST) {
                         const int k = jb % Ns, j0 = (jb - k) * R + k;
@@ -1286,12 +1280,6 @@ template <int UW_, int T_, int NBUF_, int WPE_, bool RR_, int... RS> struct Fuse
         F::template run<NBUF == 2>(v, buf, zbuf, j, t);
     }
 };
-#ifndef FFTUP_3840X16_NBUF
-#define FFTUP_3840X16_NBUF 2
-#endif
-#ifndef FFTUP_3840X16_RR
-#define FFTUP_3840X16_RR 1
-#endif
 // Rows of UW = 16 * 16 * R2 = 256 * R2 points on 256 threads -- one wave per SIMD -- R2 points per thread in the last stage
 // (3840: R2 = 15, the default for 1920x1080; 2560: R2 = 10 for 1280x720).  120 VGPRs + the ring rows.
 template <int UW_, int R2_> struct FusedPlanMr16 {
@@ -1304,8 +1292,8 @@ template <int UW_, int R2_> struct FusedPlanMr16 {
     static __device__ __forceinline__ void load_tw(Tw& w, const float2* __restrict__ tw, int j) { F::load_tw(w, tw, j); }
     // NBUF = 3 (first exchange through z, second through the L-row buffer: 4 barriers per step instead of 6) changes
     // nothing for the kernel alone (77 us at 3840) and costs 98 instead of 65 KB of LDS: frame 75 -> 87 us.  Kept at 2.
-    static constexpr int NBUF = FFTUP_3840X16_NBUF;
-    static constexpr bool RING_REGS = FFTUP_3840X16_RR;
+    static constexpr int NBUF = 2;
+    static constexpr bool RING_REGS = true;
     static constexpr int WPE = 2;
     static constexpr bool MIRROR_SHARE = false;
     static __device__ __forceinline__ void fft(float2 (&v)[VN], float2* __restrict__ buf, float2* __restrict__ zbuf, int j, const Tw& w, int = 0)
@@ -1327,15 +1315,12 @@ using FusedPlan3840x16 = FusedPlanMr16<3840, 15>;
 //   of a step (FusedPlanPow2).  The spectrum rows of pair s+1 are prefetched into REGISTERS while pair s is
 //   processed (every thread loads the 8 values its first butterfly needs, mirrored ones included), so no LDS staging
 //   and -- loads being older than the output stores of the same step -- no wait on a store, ever (vmcnt is in order).
-#ifndef FFTUP_RING_REGS
-#define FFTUP_RING_REGS 1
-#endif
 template <class PL> struct FusedGLds {
     static constexpr size_t XB = PL::XB;
     // RR: the ring rows (the L rows of the previous pair) stay in the registers of the threads that read them as taps in
     // the previous step -- no second L-row buffer: LDS = the L rows of the current pair + the transform's z buffer.
     // (12 registers per sharpen pass for fp32, 10 for binary16; plans opt in with RING_REGS, at most four passes.)
-    static constexpr bool RR = FFTUP_RING_REGS && PL::RING_REGS && (PL::UW + 4 * PL::T - 1) / (4 * PL::T) <= 4;
+    static constexpr bool RR = PL::RING_REGS && (PL::UW + 4 * PL::T - 1) / (4 * PL::T) <= 4;
     static constexpr size_t NX = RR ? 1 : 2;                                // L-row buffers
     static constexpr size_t ZOFF = NX * XB;                                 // the transform's z buffer (three-buffer plans)
     static constexpr size_t RED = NX * XB;                                  // corner partial sums: in z when there is one (free at strip start)
