@@ -111,6 +111,48 @@ def test_png_encode_roundtrip_through_stb_and_variants(tmp_path):
         assert np.array_equal(mine, theirs), name
 
 
+@needs_ref
+def test_png_file_size_against_the_reference_writer(tmp_path):
+    """the reference writes its output with stbi_write_png (stb_image_write.h:1185: LZ matching at level 8 behind
+    FIXED Huffman codes); the CLI's encoder is Huffman-only with dynamic codes per 256 KB block.  Same frames (what the upscaler
+    produces from natural images: the oracle's 8-bit output), both writers: on such frames -- filtered residuals of an
+    interpolated image, no repeats worth a match -- the dynamic codes win by a third (measured 0.60-0.66, profiles/
+    r05_d_png_size_vs_stb.txt); the bound says the CLI never writes larger files than the reference would."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib as O
+    from vkresample_amd import synth
+    tool = _build_png_tool(tmp_path)
+    ref = _stb()
+    frames = {"no_upscaling.png crop 960x540 x2": np.load(os.path.join(ROOT, "tests", "golden", "no_upscaling_rgb.npz"))["rgb"][270:810, 480:1440],
+              "README car strip 512x512 x2": np.load(os.path.join(ROOT, "tests", "golden", "readme_car.npz"))["rgb"],
+              "synthetic N 1024x512 x2": synth.frame(1, 1024, 512, "N")}
+    for name, rgb in frames.items():
+        _, _, u8 = O.upscale_rgb8(np.ascontiguousarray(rgb), 2.0, 0, 0.2)
+        u8 = np.ascontiguousarray(u8)
+        h, w, _ = u8.shape
+        raw = tmp_path / "f.rgb"
+        u8.tofile(raw)
+        subprocess.check_call([tool, "enc", str(raw), str(tmp_path / "mine.png"), str(w), str(h)])
+        assert ref.ref_png_write_rgb(str(tmp_path / "stb.png").encode(), w, h, u8.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        a, b = os.path.getsize(tmp_path / "mine.png"), os.path.getsize(tmp_path / "stb.png")
+        print("MEASURED png size %s (%dx%d): CLI encoder %d bytes, stbi_write_png %d bytes, ratio %.3f" % (name, w, h, a, b, a / b))
+        back, _ = _stb_load(ref, str(tmp_path / "mine.png"))
+        assert np.array_equal(back, u8)
+        assert a <= 1.0 * b, (name, a, b)
+    # flat and synthetic-gradient frames are where matching wins: there the encoder takes its zlib path (not larger than 1.15x)
+    yy, xx = np.mgrid[0:512, 0:1024]
+    grad = np.stack([xx % 256, yy % 256, (xx + yy) % 256], axis=2).astype(np.uint8)
+    for name, im in (("flat", np.full((512, 1024, 3), 77, np.uint8)), ("gradient", grad)):
+        im = np.ascontiguousarray(im)
+        im.tofile(tmp_path / "g.rgb")
+        subprocess.check_call([tool, "enc", str(tmp_path / "g.rgb"), str(tmp_path / "g_mine.png"), "1024", "512"])
+        assert ref.ref_png_write_rgb(str(tmp_path / "g_stb.png").encode(), 1024, 512, im.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        a, b = os.path.getsize(tmp_path / "g_mine.png"), os.path.getsize(tmp_path / "g_stb.png")
+        print("MEASURED png size %s 1024x512: CLI encoder %d bytes, stbi_write_png %d bytes, ratio %.3f" % (name, a, b, a / b))
+        assert a <= 1.15 * b, (name, a, b)
+
+
 @needs_cli
 def test_cli_flag_handling_without_gpu(tmp_path):
     def run(*args):

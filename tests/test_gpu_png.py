@@ -170,3 +170,65 @@ def test_png_tickets_from_several_threads():
         for x in th:
             x.join()
         assert not errors, errors
+
+
+def test_a_thread_waiting_for_its_own_png_ticket_is_an_error_not_a_hang():
+    """a submission that comes round to a ring slot whose PNG ticket has not been collected waits for the collector --
+    unless the collector is the submitting thread itself, which would wait forever: FFTUP_E_WOULD_BLOCK (9).  ring = 1 (the
+    default): the second fftup_submit_png of one thread; ring = 2: the third; fftup_submit_rgb8 behind an open ticket likewise.
+    After fftup_wait_png the slot is free again and nothing was lost."""
+    import vkresample_amd as v
+    from vkresample_amd import synth
+    W, H = 128, 64
+    f = [synth.frame(40 + k, W, H, "N") for k in range(3)]
+    for ring in (1, 2):
+        with v.Upscaler(W, H, 2.0, 0, 0.2, 0, 0, ring) as up:
+            buf = v.PinnedArray((up.png_bound(),))
+            out = v.PinnedArray((2 * H, 2 * W, 3))
+            want = []
+            for x in f:
+                up.wait(up.submit_rgb8(x, out.array))
+                want.append(out.array.copy())
+            tickets = [up.submit_png(f[k]) for k in range(ring)]
+            for call in (lambda: up.submit_png(f[2]), lambda: up.submit_rgb8(f[2], out.array)):
+                with pytest.raises(v.FftupError) as e:
+                    call()
+                assert e.value.code == 9 and "fftup_wait_png" in str(e.value)
+            for k, t in enumerate(tickets):                              # nothing was lost: every open ticket still delivers its frame
+                assert np.array_equal(_decode(bytes(buf.array[:up.wait_png(t, buf.array)])), want[k])
+            assert np.array_equal(_decode(bytes(buf.array[:up.wait_png(up.submit_png(f[2]), buf.array)])), want[2])
+            buf.close()
+            out.close()
+
+
+def test_device_png_size_against_the_reference_writer():
+    """VERDICT r4 #6 for the device-side encoder: the same 8-bit frames written by the reference's stbi_write_png
+    (oracle/_ref/libref_host.so = the reference's stb_image_write compiled in place; built where /root/reference exists, it travels
+    with the snapshot).  Natural frames: the device's Huffman-only stream with per-block dynamic codes is smaller than
+    stb's LZ + fixed codes."""
+    import ctypes as C
+    import os
+    import tempfile
+    import vkresample_amd as v
+    from vkresample_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    refso = os.path.join(root, "oracle", "_ref", "libref_host.so")
+    if not os.path.exists(refso):
+        pytest.skip("oracle/_ref/libref_host.so not built (no reference tree where build() ran)")
+    ref = C.CDLL(refso)
+    frames = {"README car strip": np.load(os.path.join(root, "tests", "golden", "readme_car.npz"))["rgb"],
+              "no_upscaling.png crop": np.ascontiguousarray(np.load(os.path.join(root, "tests", "golden", "no_upscaling_rgb.npz"))["rgb"][284:796, 448:1472]),
+              "synthetic N": synth.frame(1, 1024, 512, "N")}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, rgb in frames.items():
+            H, W, _ = rgb.shape
+            with v.Upscaler(W, H, 2.0, 0, 0.2, 0, 0, 1) as up:
+                buf = np.empty(up.png_bound(), np.uint8)
+                n = up.wait_png(up.submit_png(rgb), buf)
+                img = _decode(bytes(buf[:n]))
+            img = np.ascontiguousarray(img)
+            path = os.path.join(tmp, "stb.png")
+            assert ref.ref_png_write_rgb(path.encode(), img.shape[1], img.shape[0], img.ctypes.data_as(C.POINTER(C.c_ubyte)))
+            b = os.path.getsize(path)
+            print("MEASURED device png size %s (%dx%d): fftup_submit_png %d bytes, stbi_write_png %d bytes, ratio %.3f" % (name, img.shape[1], img.shape[0], n, b, n / b))
+            assert n <= 1.0 * b, (name, n, b)
