@@ -30,23 +30,27 @@ int kernels_aot_mixed_plan(uint32_t W, uint32_t H)
 size_t kernels_tuned_col_lds(uint32_t H) { return sizeof(float2) * (size_t)lswz_size((int)H * TUNED_TK); }   // both transforms of the column kernel have length H
 
 // four-step rows (k_row4_a / k_row4_b): launch both passes; ATTR: only allow their dynamic LDS sizes (plan creation)
-template <typename C, int DIR, int MODE, int OUT, int TKS, bool ATTR>
-static hipError_t four_passes(const fftup_plan::Four& f, const Row4Params<C>& q, int rows, hipStream_t st)
+template <typename C, int DIR, int MODE, int TKA> static hipError_t four_pass_a(const fftup_plan::Four& f, const Row4Params<C>& q, int rows, hipStream_t st, bool attr)
 {
-    if constexpr (ATTR) {
-        hipError_t e = hipFuncSetAttribute((const void*)(k_row4_a<DIR, TKS, MODE, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.ldsA);
-        if (e != hipSuccess) return e;
-        return hipFuncSetAttribute((const void*)(k_row4_b<DIR, TKS, OUT, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.ldsB);
-    } else {
-        hipLaunchKernelGGL((k_row4_a<DIR, TKS, MODE, C>), dim3(rows, f.n2 / TKS, 3), dim3(f.thrA), f.ldsA, st, q);
-        hipLaunchKernelGGL((k_row4_b<DIR, TKS, OUT, C>), dim3(rows, f.n1 / TKS, 3), dim3(f.thrB), f.ldsB, st, q);
-        return hipSuccess;
-    }
+    if (attr) return hipFuncSetAttribute((const void*)(k_row4_a<DIR, TKA, MODE, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.ldsA);
+    hipLaunchKernelGGL((k_row4_a<DIR, TKA, MODE, C>), dim3(rows, f.n2 / TKA, 3), dim3(f.thrA), f.ldsA, st, q);
+    return hipSuccess;
 }
+template <typename C, int DIR, int OUT, int TKB> static hipError_t four_pass_b(const fftup_plan::Four& f, const Row4Params<C>& q, int rows, hipStream_t st, bool attr)
+{
+    if (attr) return hipFuncSetAttribute((const void*)(k_row4_b<DIR, TKB, OUT, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.ldsB);
+    hipLaunchKernelGGL((k_row4_b<DIR, TKB, OUT, C>), dim3(rows, f.n1 / TKB, 3), dim3(f.thrB), f.ldsB, st, q);
+    return hipSuccess;
+}
+// (the two passes pick their tile widths independently: kernels are instantiated per pass and width, not per pair)
 template <typename C, int DIR, int MODE, int OUT, bool ATTR>
 static hipError_t four_run(const fftup_plan::Four& f, const Row4Params<C>& q, int rows, hipStream_t st)
 {
-    return f.tk == 4 ? four_passes<C, DIR, MODE, OUT, 4, ATTR>(f, q, rows, st) : four_passes<C, DIR, MODE, OUT, 1, ATTR>(f, q, rows, st);
+    hipError_t e = f.tka == 4 ? four_pass_a<C, DIR, MODE, 4>(f, q, rows, st, ATTR) : f.tka == 2 ? four_pass_a<C, DIR, MODE, 2>(f, q, rows, st, ATTR)
+                                                                                                 : four_pass_a<C, DIR, MODE, 1>(f, q, rows, st, ATTR);
+    if (e != hipSuccess) return e;
+    return f.tkb == 4 ? four_pass_b<C, DIR, OUT, 4>(f, q, rows, st, ATTR) : f.tkb == 2 ? four_pass_b<C, DIR, OUT, 2>(f, q, rows, st, ATTR)
+                                                                                       : four_pass_b<C, DIR, OUT, 1>(f, q, rows, st, ATTR);
 }
 // forward rows of a plan: input mode from the slot's kind and the precision; inverse rows: output type from the precision
 template <typename C, bool ATTR> static hipError_t four_forward(fftup_plan* P, const Row4Params<C>& q, int kind, hipStream_t st)

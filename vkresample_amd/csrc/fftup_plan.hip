@@ -38,18 +38,27 @@ static bool is_smooth(uint32_t n)
     return n == 1;
 }
 
-// Four-step split of a row of n points that does not fit the LDS (k_row4_a / k_row4_b): n = n1 * n2, both transforms with
-// their two Stockham buffers of tk interleaved sequences in 160 KB, as square as possible, tk = 4 where both factors allow it
-static bool split_four(uint32_t n, size_t el, int* n1, int* n2, int* tk)
+// Four-step split of a row of n points that does not fit the LDS (k_row4_a / k_row4_b): n = n1 * n2.  Pass A transforms tka
+// sequences of n1 points side by side -- tka consecutive elements of the row per piece it reads and of the transposed row per
+// piece it writes -- pass B tkb sequences of n2 points (tkb consecutive output elements per piece): each the widest of 4, 2, 1
+// that divides the other factor and whose two Stockham buffers fit 160 KB.  Widest tiles first (8-byte pieces are a quarter
+// of the bandwidth of 32-byte ones, profiles/r05_*_four_step.txt), then as square as possible.
+static bool split_four(uint32_t n, size_t el, int* n1, int* n2, int* tka, int* tkb)
 {
     long best = -1;
+    auto widest = [&](uint32_t len, uint32_t other) -> int {        // sequences of `len` points, tile width must divide `other`
+        for (int t : {4, 2, 1})
+            if (other % (uint32_t)t == 0 && 2 * el * (size_t)lpad_size((int)len * t) <= (size_t)160 * 1024) return t;
+        return 0;
+    };
     for (uint32_t d = 2; d * d <= n; d++) {
         if (n % d) continue;
         const uint32_t a = d, b = n / d;                     // a <= b
-        const int t = (a % 4 == 0 && b % 4 == 0) ? 4 : 1;
-        if (2 * el * (size_t)lpad_size((int)b * t) > (size_t)160 * 1024) continue;
-        const long score = (t == 4 ? 0 : (1l << 40)) + (long)(b - a);
-        if (best < 0 || score < best) { best = score; *n1 = (int)a; *n2 = (int)b; *tk = t; }
+        const int ta = widest(a, b), tb = widest(b, a);
+        if (!ta || !tb) continue;
+        // time ~ bytes / piece width: pass A reads and writes the row in pieces of ta elements, pass B writes it in pieces of tb
+        const long score = (long)(2000 / ta + 1000 / tb) * (1l << 32) + (long)(b - a);
+        if (best < 0 || score < best) { best = score; *n1 = (int)a; *n2 = (int)b; *tka = ta; *tkb = tb; }
     }
     return best >= 0;
 }
@@ -307,9 +316,9 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
     };
     // ... and rows beyond one buffer run in four steps through HBM (k_row4_a / k_row4_b), as the reference's multi-upload plans
     {
-        int a, b, t;
+        int a, b, t, t2;
         const size_t el = cfg->precision == 1 ? 16 : 8;
-        if (cplx && ((!rows_fit(uW) && !split_four(uW, el, &a, &b, &t)) || (!rows_fit(W) && !split_four(W, el, &a, &b, &t))))
+        if (cplx && ((!rows_fit(uW) && !split_four(uW, el, &a, &b, &t, &t2)) || (!rows_fit(W) && !split_four(W, el, &a, &b, &t, &t2))))
             return fail(FFTUP_E_UNSUPPORTED_SIZE, "row too long: no four-step split of the row length fits the LDS");
     }
 
@@ -385,13 +394,13 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             P->TK = 1; P->ldsCol = 0;
             for (auto fh : {std::make_pair(&P->colF, H), std::make_pair(&P->colI, uH)}) {
                 fftup_plan::Four& f = *fh.first;
-                f.on = split_four(fh.second, P->csz, &f.n1, &f.n2, &f.tk);
+                f.on = split_four(fh.second, P->csz, &f.n1, &f.n2, &f.tka, &f.tkb);
                 if (!f.on) { rc = fail(FFTUP_E_UNSUPPORTED_SIZE, "column too long: no four-step split of the height fits the LDS"); goto bad; }
                 f.p1 = make_stage_plan((uint32_t)f.n1); f.p2 = make_stage_plan((uint32_t)f.n2);
-                f.ldsA = 2 * P->csz * (size_t)lpad_size(f.n1 * f.tk); f.ldsB = 2 * P->csz * (size_t)lpad_size(f.n2 * f.tk);
+                f.ldsA = 2 * P->csz * (size_t)lpad_size(f.n1 * f.tka); f.ldsB = 2 * P->csz * (size_t)lpad_size(f.n2 * f.tkb);
                 const int tmax = kernels_generic_max_threads(P->dbl);
-                f.thrA = std::min(tmax, std::max(64, round_up(f.n1 * f.tk / 8, 64)));
-                f.thrB = std::min(tmax, std::max(64, round_up(f.n2 * f.tk / 8, 64)));
+                f.thrA = std::min(tmax, std::max(64, round_up(f.n1 * f.tka / 8, 64)));
+                f.thrB = std::min(tmax, std::max(64, round_up(f.n2 * f.tkb / 8, 64)));
             }
         }
         if (aot && !P->dbl && !cplx && !P->tuned && !(cfg->flags & FFTUP_FLAG_GENERIC_KERNELS) && uW == 2 * W && uH == 2 * H && P->TK >= 4) {
@@ -424,12 +433,12 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             if (P->inplaceF) P->ldsRowF /= 2;
             if (P->inplaceI) P->ldsRowI /= 2;
             auto four = [&](fftup_plan::Four& f, uint32_t n) {           // ... or four steps through HBM
-                f.on = split_four(n, P->csz, &f.n1, &f.n2, &f.tk);
+                f.on = split_four(n, P->csz, &f.n1, &f.n2, &f.tka, &f.tkb);
                 f.p1 = make_stage_plan((uint32_t)f.n1); f.p2 = make_stage_plan((uint32_t)f.n2);
-                f.ldsA = 2 * P->csz * (size_t)lpad_size(f.n1 * f.tk); f.ldsB = 2 * P->csz * (size_t)lpad_size(f.n2 * f.tk);
+                f.ldsA = 2 * P->csz * (size_t)lpad_size(f.n1 * f.tka); f.ldsB = 2 * P->csz * (size_t)lpad_size(f.n2 * f.tkb);
                 const int tmax = kernels_generic_max_threads(P->dbl);
-                f.thrA = std::min(tmax, std::max(64, round_up(f.n1 * f.tk / 8, 64)));
-                f.thrB = std::min(tmax, std::max(64, round_up(f.n2 * f.tk / 8, 64)));
+                f.thrA = std::min(tmax, std::max(64, round_up(f.n1 * f.tka / 8, 64)));
+                f.thrB = std::min(tmax, std::max(64, round_up(f.n2 * f.tkb / 8, 64)));
             };
             if (!rows_fit(W)) { four(P->fourF, W); P->ldsRowF = 0; }
             if (!rows_fit(uW)) { four(P->fourI, uW); P->ldsRowI = 0; }
@@ -520,7 +529,7 @@ int fftup_plan_describe(const fftup_plan* P, char* buf, size_t buflen)
     else if (P->cplx) s = "size-generic kernels, non-R2C path (full complex transforms)";
     else s = std::string("size-generic kernels (LDS ping-pong, run-time radix lists)") + (P->dbl ? ", double" : "");
     auto four = [&](const char* what, const fftup_plan::Four& f) {
-        if (f.on) s += std::string("; ") + what + " in four steps " + std::to_string(f.n1) + "*" + std::to_string(f.n2) + (f.tk == 4 ? "" : " (one sequence per workgroup)");
+        if (f.on) s += std::string("; ") + what + " in four steps " + std::to_string(f.n1) + "*" + std::to_string(f.n2) + " (tiles of " + std::to_string(f.tka) + " / " + std::to_string(f.tkb) + ")";
     };
     four("forward rows", P->fourF); four("inverse rows", P->fourI); four("forward columns", P->colF); four("inverse columns", P->colI);
     if (P->u8out) s += "; fused 8-bit RGB store";

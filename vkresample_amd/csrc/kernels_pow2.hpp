@@ -983,7 +983,7 @@ __device__ __forceinline__ h2v sharpen_eval_pair_half(h2v N, h2v S, h2v Wv, h2v 
     const h2v s4 = ((N + Wv) + E) + S;
     const h2v prod = scale * s4;
     const h2v num = C + prod;
-    const h2v den = one + scale * four;                // 4 * scale is exact: one rounding either way
+    const h2v den = __builtin_elementwise_fma(scale, four, one);      // 4 * scale is exact: one rounding either way, one instruction
     return pk_div(num, den);
 }
 // one window (three rows) of four pixels: P[r] = the five column pairs (-1,0) (0,1) (1,2) (2,3) (3,4) of row r

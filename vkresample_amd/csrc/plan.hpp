@@ -82,7 +82,8 @@ struct fftup_plan {
     bool cplx = false;                // non-R2C path (VR:1424 false): full complex transforms, uW beyond the R2C limit
     bool inplaceF = false, inplaceI = false;   // ... whose forward / inverse rows are too long for two LDS buffers: fft_lds_inplace
     // ... and rows too long for ONE buffer: four steps through HBM (k_row4_a / k_row4_b), row length = n1 * n2
-    struct Four { bool on = false; int n1 = 0, n2 = 0, tk = 1; StagePlan p1{}, p2{}; float2 *tw1 = nullptr, *tw2 = nullptr; size_t ldsA = 0, ldsB = 0; int thrA = 64, thrB = 64; };
+    struct Four { bool on = false; int n1 = 0, n2 = 0, tka = 1, tkb = 1;    // N = n1 * n2; sequences per workgroup of pass A / pass B
+                  StagePlan p1{}, p2{}; float2 *tw1 = nullptr, *tw2 = nullptr; size_t ldsA = 0, ldsB = 0; int thrA = 64, thrB = 64; };
     Four fourF, fourI;
     Four colF, colI;                  // columns longer than the LDS (TK = 1): the same two kernels on dense columns
     int ncols = 0;                    // spectrum columns kept: W/2 + 1, or W on the non-R2C path
