@@ -497,7 +497,7 @@ def test_non_r2c_limits():
         assert up.kernel_names == ["row_c2c", "col_fwd_pad_inv", "row_c2c_inv", "sharpen"] and not up.tuned
     for W, u, p, what in ((9216, 2.0, 0, "inverse rows in four steps 128*144"), (8064, 2.0, 0, "inverse rows in four steps 112*144"),
                           (2560, 2.0, 1, "inverse rows in four steps 64*80"), (17280, 1.0, 0, "forward rows in four steps 120*144"),
-                          (8748, 2.0, 0, "inverse rows in four steps 108*162 (tiles of 2 / 4)")):
+                          (8748, 2.0, 0, "inverse rows in four steps 54*324 (tiles of 4 / 2)")):
         with _up(W, 16, u, p) as up:               # beyond one LDS buffer: four steps (refused until round 4)
             assert up.kernel_names[0] == "row_c2c" and not up.tuned and what in up.description, up.description
     with _up(16, 4900, 2.0) as up:
@@ -510,7 +510,7 @@ FOUR_STEP = [(9216, 8, 2.0, 0, 0),       # inverse rows of 18432 = 128 * 144 poi
              (8064, 8, 2.0, 0, 0),       # 16128 = 2^8 * 63: the one-buffer form has no radix-7 stage that long
              (20000, 4, 1.5, 0, 0),      # 30000-point inverse rows, 20000-point forward rows
              (2560, 8, 2.0, 1, 0),       # -p 1: two buffers of 5120 double2 do not fit
-             (8748, 4, 2.0, 0, 0)]       # 17496 = 2^3 3^7 = 108 * 162: no factor pair with 4 | both -- pass A in tiles of 2, pass B in tiles of 4
+             (8748, 4, 2.0, 0, 0)]       # 17496 = 2^3 3^7 = 54 * 324: no factor pair with 4 | both -- pass A in tiles of 4, pass B in tiles of 2
 
 
 @pytest.mark.parametrize("W,H,u,precision,flags", FOUR_STEP)
