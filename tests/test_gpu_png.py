@@ -232,3 +232,26 @@ def test_device_png_size_against_the_reference_writer():
             b = os.path.getsize(path)
             print("MEASURED device png size %s (%dx%d): fftup_submit_png %d bytes, stbi_write_png %d bytes, ratio %.3f" % (name, img.shape[1], img.shape[0], n, b, n / b))
             assert n <= 1.0 * b, (name, n, b)
+
+
+def test_a_stream_that_would_not_fit_is_refused_on_the_device(monkeypatch):
+    """the stream buffer's size rests on an argument about the length-limited Huffman codes; the device checks the real
+    size against the capacity before a bit is packed.  With the capacity knob of the test build set below what a noise frame needs,
+    fftup_wait_png reports FFTUP_E_OVERFLOW (10) with the size that was needed, nothing is written (the words behind the
+    pretended capacity stay zero: the buffer is zeroed per frame), the slot is free again, and a frame that fits still encodes."""
+    import vkresample_amd as v
+    from vkresample_amd import _lib, synth
+    monkeypatch.setenv("FFTUP_LIBRARY", _lib.KNOBS_LIB_PATH)
+    monkeypatch.setenv("FFTUP_EXPERIMENT", "png_capacity=60000")
+    W, H = 128, 64
+    noise, flat = synth.frame(7, W, H, "U"), np.full((H, W, 3), 90, np.uint8)
+    with v.Upscaler(W, H, 2.0, 0, 0.2, 0, 0, 1) as up:
+        buf = np.empty(up.png_bound(), np.uint8)
+        out = np.empty((2 * H, 2 * W, 3), np.uint8)
+        t = up.submit_png(noise)                                  # ~ 190 KB of residuals: does not fit 60 000 bytes
+        with pytest.raises(v.FftupError) as e:
+            up.wait_png(t, buf)
+        assert e.value.code == 10 and "exceeds" in str(e.value)
+        n = up.wait_png(up.submit_png(flat), buf)                 # a flat frame fits; the slot was released by the failed wait
+        up.wait(up.submit_rgb8(flat, out))
+        assert n < 60000 and np.array_equal(_decode(bytes(buf[:n])), out)

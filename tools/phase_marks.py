@@ -66,25 +66,28 @@ rep("        F::fft(v, buf, NBUF == 3 ? zbuf : buf, j, w);", "        F::fft(v, 
 rep("reg_fft_pp<UW, 8, -1>(v, buf, zbuf, j, w.t);", "reg_fft_pp<UW, 8, -1>(v, buf, zbuf, j, w.t, dn);")
 rep("    int lt = threadIdx.x;                       // (made opaque", "    int dn = -100000;\n    int lt = threadIdx.x;                       // (made opaque")
 open(p, "w").write(s)
-p = tmp + "/vkresample_amd/csrc/fftup.hip"
-s = open(p).read()
-rep('''void fftup_plan_destroy(fftup_plan* P)
+# the marks live in the launch unit (the one that includes kernels_pow2.hpp): it gets an exported dump routine, plan destruction calls it
+p = tmp + "/vkresample_amd/csrc/fftup_launch.hip"
+s = open(p).read() + '''
+void fftup_dbg_dump()
 {
-    if (!P) return;
-    (void)hipSetDevice(P->device);
-    if (P->stream) (void)hipStreamSynchronize(P->stream);''','''void fftup_plan_destroy(fftup_plan* P)
-{
-    if (!P) return;
-    (void)hipSetDevice(P->device);
-    if (P->stream) (void)hipStreamSynchronize(P->stream);
     if (const char* f = getenv("FFTUP_DBG_OUT")) {
         static unsigned long long h[4096];
         (void)hipDeviceSynchronize();
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(fftup::g_dbg), sizeof h) == hipSuccess) { FILE* o = fopen(f, "wb"); if (o) { fwrite(h, 1, sizeof h, o); fclose(o); } }
-    }''')
+    }
+}
+'''
+open(p, "w").write(s)
+p = tmp + "/vkresample_amd/csrc/fftup_plan.hip"
+s = open(p).read()
+rep('''    if (P->stream) (void)hipStreamSynchronize(P->stream);
+    for (size_t l = 1;''', '''    if (P->stream) (void)hipStreamSynchronize(P->stream);
+    { void fftup_dbg_dump(); fftup_dbg_dump(); }
+    for (size_t l = 1;''')
 open(p, "w").write(s)
 tid = sys.argv[1] if len(sys.argv) > 1 else "0"
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=on",
-                       "-Wno-unused-function", "-DDBG_TID=" + tid, "-shared", "-o", ROOT + "/tools/scratch/lib_dbg%s.so" % tid,
-                       tmp + "/vkresample_amd/csrc/fftup.hip"], stderr=subprocess.DEVNULL)
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g
+g.build_variant(ROOT + "/tools/scratch/lib_dbg%s.so" % tid, csrc=tmp + "/vkresample_amd/csrc", extra=["-DDBG_TID=" + tid])
 print("built dbg", tid)

@@ -55,13 +55,13 @@ def build(name):
         assert s.count(a) == 1, (name, a, s.count(a))
         open(p, "w").write(s.replace(a, b))
     if name == "tk8":        # spectrum tiles of 8 columns instead of 4 (64-byte row pieces)
-        q = tmp + "/vkresample_amd/csrc/fftup.hip"
+        q = tmp + "/vkresample_amd/csrc/plan.hpp"
         t = open(q).read()
         assert t.count("static constexpr int TUNED_TK = 4;") == 1
         open(q, "w").write(t.replace("static constexpr int TUNED_TK = 4;", "static constexpr int TUNED_TK = 8;"))
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=on",
-                           "-Wno-unused-function", "-shared", "-o", ROOT + "/tools/scratch/lib_%s.so" % name, tmp + "/vkresample_amd/csrc/fftup.hip"],
-                          stderr=subprocess.DEVNULL)
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build_variant(ROOT + "/tools/scratch/lib_%s.so" % name, csrc=tmp + "/vkresample_amd/csrc")
     print("built", name)
 if __name__ == "__main__":
     from concurrent.futures import ThreadPoolExecutor

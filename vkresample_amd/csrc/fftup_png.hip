@@ -57,6 +57,8 @@ int png_slot_init(fftup_plan* P, fftup_plan::QSlot& Q)
     if (!rc) rc = need(&p.stream, P->png_stream_bytes);
     if (rc) return rc;
     p.capacity = P->png_stream_bytes;
+    // (test knob, libfftup_knobs.so only: a smaller capacity than the buffer has, so that the overflow path can be exercised)
+    if (const char* e = fftup_jit::experiment("png_capacity")) p.capacity = std::min<unsigned long long>(p.capacity, strtoull(e, nullptr, 10));
     p.uW = (int)P->uW; p.uH = (int)P->uH; p.rows_per_block = P->png_rpb; p.nblocks = P->png_nblocks;
     if (!G.meta_host) HIP_TRY(hipHostMalloc((void**)&G.meta_host, 3 * sizeof(unsigned long long), hipHostMallocDefault));
     if (!G.parts_host) HIP_TRY(hipHostMalloc((void**)&G.parts_host, (P->png_stream_bytes / 4096 + 1) * sizeof(uint32_t), hipHostMallocDefault));

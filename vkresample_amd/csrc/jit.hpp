@@ -17,7 +17,7 @@
 // keyed by a hash of the translation unit, the instantiated names, the compiler options, the hipRTC version and the
 // kernel headers' text.
 // With FFTUP_FLAG_TUNE_PLAN the plan is also timed with the alternative factorizations of its dominant kernel
-// (fused_candidates(), tune_fused() in fftup.hip) and the decision kept in <cache dir>/wisdom.txt.
+// (fused_candidates(), tune_fused() in fftup_plan.hip) and the decision kept in <cache dir>/wisdom.txt.
 //
 // The kernel headers' text is embedded in the library at build time (kernel_sources.inc, written by
 // __graft_entry__.build() from the very files the ahead-of-time kernels are compiled from) and handed to hipRTC as
