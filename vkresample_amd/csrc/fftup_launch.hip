@@ -46,11 +46,22 @@ template <typename C, int DIR, int OUT, int TKB> static hipError_t four_pass_b(c
 template <typename C, int DIR, int MODE, int OUT, bool ATTR>
 static hipError_t four_run(const fftup_plan::Four& f, const Row4Params<C>& q, int rows, hipStream_t st)
 {
-    hipError_t e = f.tka == 4 ? four_pass_a<C, DIR, MODE, 4>(f, q, rows, st, ATTR) : f.tka == 2 ? four_pass_a<C, DIR, MODE, 2>(f, q, rows, st, ATTR)
-                                                                                                 : four_pass_a<C, DIR, MODE, 1>(f, q, rows, st, ATTR);
+    hipError_t e;
+    switch (f.tka) {
+    case 16: e = four_pass_a<C, DIR, MODE, 16>(f, q, rows, st, ATTR); break;
+    case 8: e = four_pass_a<C, DIR, MODE, 8>(f, q, rows, st, ATTR); break;
+    case 4: e = four_pass_a<C, DIR, MODE, 4>(f, q, rows, st, ATTR); break;
+    case 2: e = four_pass_a<C, DIR, MODE, 2>(f, q, rows, st, ATTR); break;
+    default: e = four_pass_a<C, DIR, MODE, 1>(f, q, rows, st, ATTR); break;
+    }
     if (e != hipSuccess) return e;
-    return f.tkb == 4 ? four_pass_b<C, DIR, OUT, 4>(f, q, rows, st, ATTR) : f.tkb == 2 ? four_pass_b<C, DIR, OUT, 2>(f, q, rows, st, ATTR)
-                                                                                       : four_pass_b<C, DIR, OUT, 1>(f, q, rows, st, ATTR);
+    switch (f.tkb) {
+    case 16: return four_pass_b<C, DIR, OUT, 16>(f, q, rows, st, ATTR);
+    case 8: return four_pass_b<C, DIR, OUT, 8>(f, q, rows, st, ATTR);
+    case 4: return four_pass_b<C, DIR, OUT, 4>(f, q, rows, st, ATTR);
+    case 2: return four_pass_b<C, DIR, OUT, 2>(f, q, rows, st, ATTR);
+    default: return four_pass_b<C, DIR, OUT, 1>(f, q, rows, st, ATTR);
+    }
 }
 // forward rows of a plan: input mode from the slot's kind and the precision; inverse rows: output type from the precision
 template <typename C, bool ATTR> static hipError_t four_forward(fftup_plan* P, const Row4Params<C>& q, int kind, hipStream_t st)

@@ -40,14 +40,14 @@ static bool is_smooth(uint32_t n)
 
 // Four-step split of a row of n points that does not fit the LDS (k_row4_a / k_row4_b): n = n1 * n2.  Pass A transforms tka
 // sequences of n1 points side by side -- tka consecutive elements of the row per piece it reads and of the transposed row per
-// piece it writes -- pass B tkb sequences of n2 points (tkb consecutive output elements per piece): each the widest of 4, 2, 1
+// piece it writes -- pass B tkb sequences of n2 points (tkb consecutive output elements per piece): each the widest of 16, 8, 4, 2, 1
 // that divides the other factor and whose two Stockham buffers fit 160 KB.  Widest tiles first (8-byte pieces are a quarter
 // of the bandwidth of 32-byte ones, profiles/r05_*_four_step.txt), then as square as possible.
 static bool split_four(uint32_t n, size_t el, int* n1, int* n2, int* tka, int* tkb)
 {
     long best = -1;
     auto widest = [&](uint32_t len, uint32_t other) -> int {        // sequences of `len` points, tile width must divide `other`
-        for (int t : {4, 2, 1})
+        for (int t : {16, 8, 4, 2, 1})
             if (other % (uint32_t)t == 0 && 2 * el * (size_t)lpad_size((int)len * t) <= (size_t)160 * 1024) return t;
         return 0;
     };
