@@ -78,7 +78,7 @@ def _sweep_case(W, H, u, p, flags, sharpen, seed, expect_specialised=False):
             # the size-generic kernels are a legitimate answer only where no factorization exists
             assert _lib.load().fftup_jit_check(W, H, float(u), p, None, buf, 256) == 2, "plan fell back although a specialised plan exists"
         up.upload_rgb8(rgb)
-        up.execute(1)
+        up.execute(1 + seed % 3)                        # one, two or three iterations: alone on stream 0, or alternating on the plan's streams
         pre = up.download_presharpen().astype(np.float64)
         out = up.download_planar().astype(np.float64)
         u8_planes = up.download_rgb8()                  # (k_pack_u8: four pixels per thread, scalar tail where 4 does not divide uW)
