@@ -57,15 +57,16 @@ enum {
     FFTUP_FLAG_TUNE_PLAN = 16u,      /* plans specialised at plan time (below): compile and time the alternatives for the fused
                                         kernel's factorization on the device, keep the fastest, remember it in
                                         <cache dir>/wisdom.txt (a few seconds, once per row length and device)            */
-    FFTUP_FLAG_FUSE_U8_STORE = 32u   /* 8-bit pipelines (the reference's own: PNG in, PNG out): the fused C2R+sharpen kernel stores
+    FFTUP_FLAG_FUSE_U8_STORE = 32u,  /* 8-bit pipelines (the reference's own: PNG in, PNG out): the fused C2R+sharpen kernel stores
                                         the interleaved 8-bit RGB image itself (the conversion of VR:1708-1748 in registers); the
                                         float / half planes are never written, fftup_download_rgb8 / fftup_submit_rgb8 need no
                                         conversion launch, fftup_download_planar fails with FFTUP_E_INVALID_ARG.  Plans without a
                                         fused kernel (size-generic, -p 1, non-R2C, FFTUP_FLAG_UNFUSED_SHARPEN) ignore the flag:
                                         fftup_info.u8_store says which it is                                               */
-    , FFTUP_FLAG_SEQUENTIAL_EXECUTE = 64u /* fftup_execute keeps every iteration on the plan's ONE stream (the strict single-queue
-                                        form of performVulkanUpscale); default: the identical iterations of an n_iter > 1 call
-                                        alternate on the plan's streams, same bits, overlapped                              */
+    FFTUP_FLAG_SEQUENTIAL_EXECUTE = 64u /* fftup_execute keeps every iteration on the plan's ONE stream (the strict single-queue
+                                        form of performVulkanUpscale: single-frame latency; a plan without a ring is then laid out
+                                        for it); default: the identical iterations of an n_iter > 1 call alternate on the plan's
+                                        streams, same bits, overlapped                                                        */
 };
 
 /* Replaces VkResampleConfiguration (VR:45-59) + the part of VkFFTConfiguration (VF:22-94) that
