@@ -21,9 +21,10 @@ def main():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--precision", type=int, default=0)
+    ap.add_argument("--depths", default="1,2,4,8", help="frames in flight to try (1: a frame's kernels run alone -- isolated durations under rocprofv3)")
     a = ap.parse_args()
     W, H = a.width, a.height
-    for depth in (1, 2, 4, 8):
+    for depth in (int(x) for x in a.depths.split(",")):
         with v.Upscaler(W, H, 2.0, a.precision, 0.2, 0, 0, max(depth, 2)) as up:
             pin = v.PinnedArray((depth, H, W, 3))
             for k in range(depth):

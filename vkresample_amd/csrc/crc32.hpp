@@ -44,27 +44,43 @@ inline uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n)
     return ~crc;
 }
 
-// crc(A || B) from crc(A) and crc(B) for |B| = 4096: crc32_shift_4096(crc(A)) ^ crc(B).  The operator "append 4096 zero bytes" is
-// linear over GF(2) -- the matrix of one zero bit (the polynomial and a shift), squared fifteen times
+// The operator "append 2^log2_bits zero bits" on a CRC value is linear over GF(2): a 32 x 32 bit matrix, column n = image of bit n.
+// The matrix of one zero bit is the polynomial and a shift; squaring it log2_bits times gives the operator.
+inline uint32_t crc32_matrix_times(const uint32_t* m, uint32_t v)
+{
+    uint32_t s = 0;
+    for (int i = 0; v; v >>= 1, i++)
+        if (v & 1) s ^= m[i];
+    return s;
+}
+inline void crc32_shift_matrix(int log2_bits, uint32_t out[32])
+{
+    uint32_t a[32], b[32];
+    a[0] = kPoly;
+    for (int n = 1; n < 32; n++) a[n] = 1u << (n - 1);
+    for (int k = 0; k < log2_bits; k++) {
+        for (int n = 0; n < 32; n++) b[n] = crc32_matrix_times(a, a[n]);
+        memcpy(a, b, sizeof a);
+    }
+    memcpy(out, a, sizeof a);
+}
+// crc(A || B) from crc(A) and crc(B) for |B| = 4096: crc32_shift_4096(crc(A)) ^ crc(B)   (2^15 bits = 4096 bytes)
 inline uint32_t crc32_shift_4096(uint32_t crc)
 {
     static uint32_t M[32];
     static std::once_flag once;
-    std::call_once(once, [] {
-        uint32_t a[32], b[32];
-        a[0] = kPoly;
-        for (int n = 1; n < 32; n++) a[n] = 1u << (n - 1);
-        auto times = [](const uint32_t* m, uint32_t v) { uint32_t s = 0; for (int i = 0; v; v >>= 1, i++) if (v & 1) s ^= m[i]; return s; };
-        for (int k = 0; k < 15; k++) {                          // 2^15 bits = 4096 bytes
-            for (int n = 0; n < 32; n++) b[n] = times(a, a[n]);
-            memcpy(a, b, sizeof a);
-        }
-        memcpy(M, a, sizeof M);
-    });
-    uint32_t s = 0;
-    for (int i = 0; crc; crc >>= 1, i++)
-        if (crc & 1) s ^= M[i];
-    return s;
+    std::call_once(once, [] { crc32_shift_matrix(15, M); });
+    return crc32_matrix_times(M, crc);
+}
+// powers 0 .. 15 of the operator "append 256 zero bytes" (2^11 bits): what the sixteen threads of a 4 KB piece apply to their
+// 256-byte values before the exclusive-or across lanes (k_png_crc)
+inline void crc32_shift_256_powers(uint32_t out[16][32])
+{
+    uint32_t m1[32];
+    crc32_shift_matrix(11, m1);
+    for (int n = 0; n < 32; n++) { out[0][n] = 1u << n; out[1][n] = m1[n]; }
+    for (int j = 2; j < 16; j++)
+        for (int n = 0; n < 32; n++) out[j][n] = crc32_matrix_times(m1, out[j - 1][n]);
 }
 
 }  // namespace fftup_crc

@@ -56,6 +56,14 @@ int png_slot_init(fftup_plan* P, fftup_plan::QSlot& Q)
     if (!rc) rc = need(&p.crc_parts, (P->png_stream_bytes / 4096 + 1) * sizeof(uint32_t));
     if (!rc) rc = need(&p.stream, P->png_stream_bytes);
     if (rc) return rc;
+    if (!P->png_crc_shift) {                                      // one table per plan: shift_256^0..15 (crc32.hpp), 2 KB
+        uint32_t m[16][32];
+        fftup_crc::crc32_shift_256_powers(m);
+        rc = dev_alloc(P, (void**)&P->png_crc_shift, sizeof m);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(P->png_crc_shift, m, sizeof m, hipMemcpyHostToDevice));
+    }
+    p.crc_shift = P->png_crc_shift;
     p.capacity = P->png_stream_bytes;
     // (test knob, libfftup_knobs.so only: a smaller capacity than the buffer has, so that the overflow path can be exercised)
     if (const char* e = fftup_jit::experiment("png_capacity")) p.capacity = std::min<unsigned long long>(p.capacity, strtoull(e, nullptr, 10));
@@ -85,7 +93,7 @@ int png_enqueue(fftup_plan* P, fftup_plan::QSlot& Q, hipStream_t cs, uint8_t* pn
     hipLaunchKernelGGL(k_png_layout, dim3(1), dim3(256), 0, cs, pp);
     hipLaunchKernelGGL(k_png_pack, dim3(P->uH), dim3(256), lds_pack, cs, pp);
     const size_t max_pieces = P->png_stream_bytes / 4096;
-    if (max_pieces) hipLaunchKernelGGL(k_png_crc, dim3((unsigned)((max_pieces + 255) / 256)), dim3(256), 0, cs, pp);
+    if (max_pieces) hipLaunchKernelGGL(k_png_crc, dim3((unsigned)((max_pieces * 16 + 255) / 256)), dim3(256), 0, cs, pp);      // sixteen threads per 4 KB piece
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(Q.png.meta_host, pp.meta, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, cs));
     if (max_pieces) HIP_TRY(hipMemcpyAsync(Q.png.parts_host, pp.crc_parts, max_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));

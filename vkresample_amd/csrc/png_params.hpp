@@ -20,6 +20,7 @@ struct PngParams {
                                  //     `capacity` -- nothing was packed, [0] is 0 and [2] the bytes it needs
     unsigned long long capacity; // bytes of `stream`
     uint32_t* crc_parts;         // CRC-32 of every whole 4 KB piece of the stream (k_png_crc)
+    const uint32_t* crc_shift;   // [16][32]: powers of the operator "append 256 zero bytes" (crc32.hpp: crc32_shift_256_powers)
     int uW, uH, rows_per_block, nblocks;
     int row_in_lds;              // k_png_pack was given LDS for a whole row
 };
