@@ -61,6 +61,9 @@ def parse_args():
     ap.add_argument("--tune", action="store_true", help="FFTUP_FLAG_TUNE_PLAN: plan-time tuner for sizes specialised at plan time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rccl-check", action="store_true", help="skip the one-rank RCCL bring-up of N = 1 lines (`rccl_selfcheck`)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over this very configuration that measure "
+                         "`roofline.traffic` live at N = 1; the committed figures of profiles/hbm_traffic.json are reported instead")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the bounded CPU-baseline sample (~11 s on 128 threads)")
     ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other BASELINE configurations (`others`)")
     ap.add_argument("--job", action="store_true",
@@ -314,6 +317,64 @@ class PowerSampler:
         return {"socket_power_w_median": med(pw), "socket_power_w_max": max(pw) if pw else None, "power_cap_w": cap * 1e-6 if cap else None,
                 "sclk_mhz_median": med(fr), "sclk_mhz_min": min(fr) if fr else None, "samples": len(self.samples),
                 "note": "sampled during the timed regions; at the cap the shader clock is throttled (DESIGN.md section 4)"}
+
+
+# kernel name (as rocprofv3 prints it, template arguments cut) -> the plan's kernel slot, and the FETCH_SIZE correction of its access
+# pattern: on gfx950 a 128-byte read request is tallied as 64 bytes, so fully coalesced streaming reads (the row and column kernels:
+# whole rows / whole 64 KB tiles) report half their bytes; the C2R kernels read the blocked spectrum in 32/64-byte pieces (factor 1).
+# Calibrated on known byte counts, profiles/hbm_traffic.json `_method`; WRITE_SIZE matched every kernel's known output within 1 %.
+PMC_KERNELS = (("k_row_r2c", "row_r2c", 2.0), ("k_row_c2c_fwd", "row_c2c", 2.0), ("k_col", "col_fwd_pad_inv", 2.0),
+               ("k_c2r_sharpen", "row_c2r_sharpen", 1.0), ("k_row_c2c_inv", "row_c2c_inv", 1.0), ("k_row_c2r", "row_c2r", 1.0), ("k_sharpen", "sharpen", 1.0))
+
+
+def live_traffic(argv_config):
+    """HBM bytes per launch of this configuration's kernels, measured NOW: two short runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE do not fit one pass; counters only, with --kernel-trace, as the microarchitecture
+    guide prescribes), averaged per kernel over the run's launches, corrected as PMC_KERNELS says.  None where rocprofv3 is missing,
+    fails or takes too long -- the committed figures then stand in (`traffic_source` says which it is)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rp:
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself being profiled"
+    child = [sys.executable, os.path.abspath(__file__)] + argv_config + ["--steps", "1", "--warmup", "1", "--repeats", "1", "--frames-per-step", "8",
+                                                                        "--profile-iters", "2", "--no-cpu-baseline", "--no-others", "--no-rccl-check", "--no-live-traffic"]
+    acc = {}
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(prefix="fftup_pmc_") as tmp:
+        env = dict(os.environ, TMPDIR=tmp)
+        for i, counters in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"])):
+            out = os.path.join(tmp, "pass%d" % i)
+            try:
+                r = subprocess.run([rp, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out, "-o", "pmc", "--"] + child,
+                                   cwd=tmp, env=env, capture_output=True, text=True, timeout=240)
+            except Exception as e:
+                return None, "rocprofv3 pass %d: %s" % (i, type(e).__name__)
+            files = glob.glob(out + "/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 pass %d failed (exit code %d)" % (i, r.returncode)
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    name = row["Kernel_Name"].replace("void ", "").replace("fftup::", "")
+                    a = acc.setdefault(name.split("<")[0].split("(")[0], {}).setdefault(row["Counter_Name"], [0.0, 0])
+                    a[0] += float(row["Counter_Value"])
+                    a[1] += 1
+    per = {}
+    for kname, c in acc.items():
+        for prefix, slot, factor in PMC_KERNELS:
+            if kname.startswith(prefix) and slot not in per and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                rd = c["FETCH_SIZE"][0] / c["FETCH_SIZE"][1] * 1024 * factor          # (KiB of 64-byte fabric requests)
+                wr = c["WRITE_SIZE"][0] / c["WRITE_SIZE"][1] * 1024
+                per[slot] = {"kernel": kname, "fetch_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr, "fetch_correction": factor,
+                             "launches_averaged": c["FETCH_SIZE"][1]}
+                break
+    if not per:
+        return None, "no kernel of the plan in the counter files"
+    return per, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes over this configuration in this run (%.0f s)" % (time.perf_counter() - t0)
 
 
 def launch_command(n, argv, port):
@@ -600,6 +661,19 @@ def main():
         key = config_key(args) + ("_u8out" if up.u8_store else "")
         per, frame_hbm, tsrc = frame_traffic(args.traffic_json, key, up.kernel_names)
         traffic = per.get(up.kernel_names[dom]) if per else None
+        static_traffic, live = traffic, None
+        if world == 1 and not args.no_live_traffic and not args.host_streamed and not args.queue:
+            # ... and measured now (the static figures stay in the line for comparison)
+            cfg_argv = ["--width", str(args.width), "--height", str(args.height), "--upscale", repr(args.upscale), "--precision", str(args.precision),
+                        "--ring", str(args.ring), "--streams", str(args.streams)] + (["--fuse-u8"] if args.fuse_u8 else []) + \
+                       (["--fuse-u8-store"] if args.fuse_u8_store else []) + (["--generic"] if args.generic else [])
+            live, live_src = live_traffic(cfg_argv)
+            if live and all(n in live for n in up.kernel_names if n != "-"):
+                per = {n: live[n]["hbm_bytes_per_launch"] for n in up.kernel_names if n != "-"}
+                frame_hbm, tsrc, traffic = sum(per.values()), live_src, per[up.kernel_names[dom]]
+            else:
+                tsrc = (tsrc or "none") + " [live measurement unavailable: %s]" % (live_src if not live else "kernels missing")
+                live = None
         esz = {0: 4, 1: 8, 2: 2}[args.precision]
         b_in = 1 if (args.fuse_u8 and args.precision != 1) else esz
         b_min = 3.0 * (args.width * args.height * b_in + up.out_width * up.out_height * (1 if up.u8_store else esz))
@@ -636,7 +710,8 @@ def main():
                          "frame_achieved": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 1e9,      # per GPU
                          "frame_frac": up.alg_bytes_per_frame / (wall_frame_ms * 1e-3) / 8e12,
                          # do the static figures (traffic, vector instructions) belong to the kernel sources that just ran?
-                         "traffic_kernel_sources_current": traffic_is_current(args.traffic_json, key)},
+                         "traffic_kernel_sources_current": traffic_is_current(args.traffic_json, key),
+                         "traffic_static": static_traffic, "traffic_live": live},
         }
         # the same fraction from the committed rocprofv3 --kernel-trace --stats summary of this configuration, when there is one
         rp_us, rp_file, rp_fresh = rocprof_kernel_us(key, up.kernel_names[dom])

@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --repeats 1 --frames-per-step 8 --profile-iters 2 --no-cpu-baseline --no-others $@"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --repeats 1 --frames-per-step 8 --profile-iters 2 --no-cpu-baseline --no-others --no-live-traffic --no-rccl-check $@"
 i=0
 for SET in \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" \

@@ -30,7 +30,7 @@ prof fp32_s1 --width 2048 --height 1024
 prof fp16_u8_s1 --width 2048 --height 1024 --precision 2 --flags 2
 prof 1080p_s1 --width 1920 --height 1080
 prof fp16_u8_u8store_s1 --width 2048 --height 1024 --precision 2 --flags 34
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s3 -o bench -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-others > $R/$OUT/rocprof_fp32_s3.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s3 -o bench -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-others --no-live-traffic --no-rccl-check > $R/$OUT/rocprof_fp32_s3.log 2>&1)
 mkdir -p $R/$OUT/prof_fp32_s3; cp $(find /tmp/prof_s3 -name "*kernel_stats.csv" | head -1) $R/$OUT/prof_fp32_s3/; rm -rf /tmp/prof_s3
 head -5 $(find $OUT/prof_fp32_s1 -name "*kernel_stats.csv" | head -1)
 bash tools/gpu_pmc.sh $TAG/pmc_fp32 > /dev/null 2>&1
