@@ -207,7 +207,7 @@ def valu_busy(traffic_json, key, kernel_names, ms_per_frame, sclk_mhz, n_cu):
         return None, None
 
 
-def other_configs(v, synth, dev, traffic_json, n_cu, ring=8):
+def other_configs(v, synth, dev, traffic_json, n_cu, ring=8, live=True):
     """Short runs of the other single-GPU BASELINE configurations on the same GPU, same method as the headline (ring of
     resident frames, three streams, HIP events per kernel), and the reference's -n 1000 figure on ring-less plans.  Every entry
     carries, beside the B_alg fractions, the numbers that can still move: the fraction by MEASURED HBM bytes
@@ -231,6 +231,12 @@ def other_configs(v, synth, dev, traffic_json, n_cu, ring=8):
             b_min = 3.0 * (c["width"] * c["height"] * (1 if c["fuse_u8"] else esz) + up.out_width * up.out_height * (1 if up.u8_store else esz))
             key = "%dx%d_p%d_%s%s" % (c["width"], c["height"], c["precision"], "u8" if c["fuse_u8"] else "planar", "_u8out" if up.u8_store else "")
             per, frame_hbm, tsrc = frame_traffic(traffic_json, key, up.kernel_names)
+            if live:                                  # measured now, like the headline's (live_traffic); the committed figures otherwise
+                lv, lsrc = live_traffic(["--width", str(c["width"]), "--height", str(c["height"]), "--precision", str(c["precision"]), "--ring", str(ring)]
+                                        + (["--fuse-u8"] if c["fuse_u8"] else []) + (["--fuse-u8-store"] if up.u8_store else []))
+                if lv and all(n in lv for n in up.kernel_names if n != "-"):
+                    per = {n: lv[n]["hbm_bytes_per_launch"] for n in up.kernel_names if n != "-"}
+                    frame_hbm, tsrc = sum(per.values()), lsrc
             out[name] = {"workload": "%dx%d -u 2 -p %d%s%s" % (c["width"], c["height"], c["precision"], ", fused uint8 load" if c["fuse_u8"] else "",
                                                                   ", fused 8-bit RGB store (8-bit in, 8-bit out)" if up.u8_store else ""),
                          "ms_per_frame": t, "frames_per_s": 1e3 / t,
@@ -747,7 +753,7 @@ def main():
     up.close()
     if rank == 0 and world == 1 and not args.no_others and not args.host_streamed and (args.preset or "config2") == "config2" \
             and (args.width, args.height, args.precision) == (2048, 1024, 0):
-        line["others"] = o = other_configs(v, synth, dev, args.traffic_json, n_cu)
+        line["others"] = o = other_configs(v, synth, dev, args.traffic_json, n_cu, live=not args.no_live_traffic)
         # the figures a reader of the one line needs without opening `others`: the reference's -n 1000 number per configuration
         # and the frame fractions of configs 3 and 4
         line["execute_n1000"] = {k: {m: e[m] for m in ("ms_per_iter", "frame_frac", "sequential_ms_per_iter", "sequential_frame_frac")}

@@ -58,7 +58,7 @@ def test_bench_single_rank_line():
                     ("config3_u8_store", 3.0 * (2048 * 1024 + 4096 * 2048))):
         e = o[k]
         assert e["B_min"] == bmin and abs(e["b_min_frac"] - bmin / (e["ms_per_frame"] * 1e-3) / 8e12) < 1e-9 and e["b_min_frac"] < e["frame_frac"]
-        assert e["frame_hbm_bytes_measured"] is not None and "static" in e["traffic_source"], k
+        assert e["frame_hbm_bytes_measured"] is not None and e["traffic_source"].startswith("live: rocprofv3 --pmc"), k
         assert bmin <= e["frame_hbm_bytes_measured"] < 4e8 and e["b_min_frac"] <= e["real_traffic_frac"] < 1.0
         assert set(e["kernel_hbm_bytes_measured"]) == {"row_r2c", "col_fwd_pad_inv", "row_c2r_sharpen"}
         assert e["energy_mj_per_frame"] is None or 10 < e["energy_mj_per_frame"] < 500
