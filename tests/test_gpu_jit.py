@@ -78,6 +78,12 @@ U_CASES = [
     (1280, 2160, 1.5),   # uH = 3240: k_col_pad with two columns per workgroup
     (640, 3000, 3.0),    # k_col_u with two columns per workgroup
     (5120, 2880, 1.5),   # 5K -> 8K: the widest input (7680 output columns), uH = 4320 (FFTUP_BIG_TESTS=1)
+    # quarter-integer factors (round 5): the factor is D / (2 DD) with DD = 2 -- the fused kernel's first radix makes R0 DD / D whole
+    (1280, 720, 1.25),   # 5/4: fused 10*10*16, NI = 4 of 10 first-stage inputs non-zero
+    (1024, 512, 1.25),   # row pow2/8, fused 10*8*16
+    (1920, 1080, 1.25),  # 1080p -> 2400 x 1350
+    (1024, 768, 1.75),   # 7/4: first radix 7, NI = 2
+    (1280, 720, 2.25),   # 9/4: first radix 9, NI = 4
 ]
 
 

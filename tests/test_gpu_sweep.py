@@ -46,8 +46,10 @@ def _cases_specialised():
     out = []
     while len(out) < int(os.environ.get("FFTUP_SWEEP_JIT_N", "16")):  # (a one-off 400-case run is logged in profiles/)
         W, H = int(rng.choice(SMOOTH_BIG)), int(rng.choice(SMOOTH_BIG))
-        u = float(rng.choice([2.0, 2.0, 2.0, 3.0, 4.0, 5.0, 1.5, 1.5, 2.5]))
+        u = float(rng.choice([2.0, 2.0, 2.0, 3.0, 4.0, 5.0, 1.5, 1.5, 2.5, 1.25, 1.75, 2.25]))
         if u * W > 8192 or u * u * W * H > 3 << 20 or (2 * u * W) % 4 or (2 * u * H) % 4 or not _smooth(int(u * W)) or not _smooth(int(u * H)):
+            continue
+        if (4 * u) % 2 and ((u * W) % 4 or (u * H) % 2):                       # quarter-integer factors: whole, even output sizes
             continue
         p = int(rng.choice([0, 0, 2]))
         out.append((W, H, u, p, int(rng.choice([0, 2])), float(rng.choice([0.2, 0.2, 0.05])), len(out)))

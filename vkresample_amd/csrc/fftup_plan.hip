@@ -137,15 +137,20 @@ static bool jit_enabled()
     const char* e = getenv("FFTUP_JIT");
     return !e || atoi(e) != 0;
 }
-// 2 x the upscale factor when the specialised kernels' assumptions hold: the factor is an integer or a half-integer in
-// [1.5, 8], the output sizes are exactly u W and u H, and the reference's zero-padding guard of the column pass
-// (float arithmetic, VkResample.cpp:1494-1495) is exactly [H/2, uH - H/2).  0 otherwise.
-static int jit_factor_x2(float upscale, uint32_t W, uint32_t H, uint32_t uW, uint32_t uH, int zly, int zry)
+// The upscale factor as D / (2 DD) when the specialised kernels' assumptions hold: an integer or half-integer factor in [1.5, 8]
+// (DD = 1, D = 2u) or a quarter-integer one (DD = 2, D = 4u odd: -u 1.25, 1.75, 2.25 ...; round 5), output sizes exactly u W and u H,
+// and the reference's zero-padding guard of the column pass (float arithmetic, VkResample.cpp:1494-1495) exactly
+// [H/2, uH - H/2).  Returns D (0: none of that) and sets *DD.
+static int jit_factor(float upscale, uint32_t W, uint32_t H, uint32_t uW, uint32_t uH, int zly, int zry, int* DD)
 {
-    const float two_u = 2.0f * upscale;
-    const int D = (int)two_u;
-    if ((float)D != two_u || D < 3 || D > 16) return 0;
-    if (2 * (uint64_t)uW != (uint64_t)D * W || 2 * (uint64_t)uH != (uint64_t)D * H) return 0;
+    int D = 0;
+    *DD = 1;
+    const float two_u = 2.0f * upscale, four_u = 4.0f * upscale;
+    if ((float)(int)two_u == two_u) D = (int)two_u;
+    else if ((float)(int)four_u == four_u) { D = (int)four_u; *DD = 2; }
+    else return 0;
+    if (D < 3 || D > 16 * *DD) return 0;
+    if (2 * (uint64_t)*DD * uW != (uint64_t)D * W || 2 * (uint64_t)*DD * uH != (uint64_t)D * H) return 0;
     if (zly != (int)(H / 2) || zry != (int)(uH - H / 2)) return 0;
     return D;
 }
@@ -245,9 +250,10 @@ int fftup_jit_check(uint32_t width, uint32_t height, float upscale, uint32_t pre
     fftup_jit::Choice ch;
     if (!(upscale >= 1.0f && upscale <= 8.0f)) return fail(FFTUP_E_INVALID_ARG, "upscale out of range");
     const uint32_t uW = (uint32_t)(upscale * (float)width), uH = (uint32_t)(upscale * (float)height);
+    int DD = 1;
     const int D = (uW & 1) || (uH & 1) || !is_smooth(uW) || !is_smooth(uH) || uW > 8192 ? 0 :
-                  jit_factor_x2(upscale, width, height, uW, uH, (int)(uint32_t)((float)uH / (2 * upscale)), (int)(uint32_t)((2 * upscale - 1) * (float)uH / (2 * upscale)));
-    if (!D || !fftup_jit::choose((int)width, (int)height, D, precision == 2, stage_radices(make_stage_plan(uW)), ch))
+                  jit_factor(upscale, width, height, uW, uH, (int)(uint32_t)((float)uH / (2 * upscale)), (int)(uint32_t)((2 * upscale - 1) * (float)uH / (2 * upscale)), &DD);
+    if (!D || !fftup_jit::choose((int)width, (int)height, D, precision == 2, stage_radices(make_stage_plan(uW)), ch, "", true, DD))
         return fail(FFTUP_E_UNSUPPORTED_SIZE, "no specialised factorization for this size: the size-generic kernels run it");
     if (desc && desclen) snprintf(desc, desclen, "%s", fftup_jit::describe(ch).c_str());
     if (arch && !*arch) return FFTUP_OK;                     // "": the factorizations only, nothing is compiled
@@ -410,11 +416,12 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
         // any other size with an integer or half-integer upscale factor: kernels specialised for it now (the counterpart
         // of VkFFT generating its shaders at plan time)
         if (!P->dbl && !cplx && !P->tuned && !P->mixed && !(cfg->flags & (FFTUP_FLAG_GENERIC_KERNELS | FFTUP_FLAG_UNFUSED_SHARPEN)) && jit_enabled()) {
-            const int D = jit_factor_x2(cfg->upscale, W, H, uW, uH, P->zly, P->zry);
+            int DD = 1;
+            const int D = jit_factor(cfg->upscale, W, H, uW, uH, P->zly, P->zry, &DD);
             if (D) {
                 fftup_jit::Choice ch;
                 std::string jerr;
-                if (fftup_jit::choose((int)W, (int)H, D, P->half, stage_radices(P->planUW), ch, wisdom_device_key(P))) {
+                if (fftup_jit::choose((int)W, (int)H, D, P->half, stage_radices(P->planUW), ch, wisdom_device_key(P), true, DD)) {
                     ch.u8out = (cfg->flags & FFTUP_FLAG_FUSE_U8_STORE) != 0;         // (such a plan is always fused)
                     P->jit = fftup_jit::load(ch, P->prop.gcnArchName, jerr);
                     if (P->jit) { P->mixed = 3; P->U = ch.U; P->TK = 4; P->ldsCol = P->jit->choice.col_lds; }
@@ -647,13 +654,13 @@ static void tune_fused(fftup_plan* P)
     std::vector<fftup_jit::Choice> cands;
     {
         fftup_jit::Choice d;
-        if (fftup_jit::choose(base.W, base.H, base.D, base.half, stage_radices(P->planUW), d, "", false) &&
+        if (fftup_jit::choose(base.W, base.H, base.D, base.half, stage_radices(P->planUW), d, "", false, base.DD) &&
             fftup_jit::fused_value(d) != fftup_jit::fused_value(base)) {
             d.u8out = base.u8out;
             cands.push_back(d);
         }
     }
-    for (const auto& cand : fftup_jit::fused_candidates(base.UW, base.D, 5)) {
+    for (const auto& cand : fftup_jit::fused_candidates(base.UW, base.D, 5, base.DD)) {
         if (base.fused_kind == 2 && cand.T == base.fused_t && cand.r == base.fr) continue;
         fftup_jit::Choice c = base;
         fftup_jit::set_fused_n(c, cand.T, cand.r);

@@ -123,14 +123,14 @@ static bool choose3(int n, int tk, int tmax, int r[3], int* threads, const char*
 // eight inputs -- beats 16 (half the threads idle in the prefetch and in the first stage) by 10-25 %, even at one stage
 // more; after that the fewest stages (every stage is an LDS exchange with two workgroup barriers), the fewest lane
 // slots, the largest smallest radix.
-static bool choose_fused_n(int n, int D, std::vector<int>& out, int* threads)
+static bool choose_fused_n(int n, int D, int DD, std::vector<int>& out, int* threads)
 {
     {
         int T = 0;
         std::vector<int> pin;
         if (env_radices("jit_fused", pin, &T) && T >= 64 && T <= 1024 && T % 64 == 0) {
             long prod = 1;
-            bool ok = pin.size() >= 2 && pin[0] % D == 0;
+            bool ok = pin.size() >= 2 && (pin[0] * DD) % D == 0;
             for (int q : pin) { ok &= is_radix(q); prod *= q; }
             if (ok && prod == n && T >= n / pin[0] && T >= n / pin.back()) { out = pin; *threads = T; return true; }
         }
@@ -142,7 +142,7 @@ static bool choose_fused_n(int n, int D, std::vector<int>& out, int* threads)
     auto r0_rank = [](int r0) { return r0 == 8 ? 0 : r0 == 12 ? 1 : r0 == 16 ? 2 : 3; };
     auto eval = [&]() {
         const int ns = (int)cur.size();
-        if (ns < 2 || cur[0] % D) return;
+        if (ns < 2 || (cur[0] * DD) % D) return;
         const int tmin = std::max(n / cur[0], n / cur[ns - 1]);
         // whole multiples of 256 threads (the waves spread evenly over the four SIMDs, fewer sharpen passes) beat the
         // minimum in 30 of 43 tuner decisions; small workgroups take one wave more than they need
@@ -187,14 +187,14 @@ static bool choose_fused_n(int n, int D, std::vector<int>& out, int* threads)
 static std::string cache_dir();
 static bool read_file(const std::string& path, std::string& out);
 static std::string join(const std::vector<int>& v);
-std::vector<FusedCand> fused_candidates(int n, int D, size_t max)
+std::vector<FusedCand> fused_candidates(int n, int D, size_t max, int DD)
 {
     struct Best { int r0, ns, T, mn; double cost; std::vector<int> r; };
     std::vector<Best> classes;
     std::vector<int> cur;
     auto eval = [&]() {
         const int ns = (int)cur.size();
-        if (ns < 2 || ns > 4 || cur[0] % D) return;
+        if (ns < 2 || ns > 4 || (cur[0] * DD) % D) return;
         const int tmin = std::max(n / cur[0], n / cur[ns - 1]);
         for (int T = (tmin + 63) / 64 * 64, tries = 0; T <= 1024 && tries < 2; T += 64) {
             int vn = 0, mn = 99;
@@ -385,7 +385,7 @@ void set_fused_n(Choice& c, int T, const std::vector<int>& radices)
 }
 std::string fused_key(const Choice& c, const std::string& arch)
 {
-    return "fused v1 " + arch + " " + std::to_string(c.UW) + " " + std::to_string(c.D) + (c.half ? " h" : " f");
+    return "fused v1 " + arch + " " + std::to_string(c.UW) + " " + std::to_string(c.D) + (c.DD != 1 ? "/" + std::to_string(c.DD) : "") + (c.half ? " h" : " f");
 }
 std::string fused_value(const Choice& c)
 {
@@ -399,11 +399,13 @@ std::string fused_value(const Choice& c)
 // then stays on the size-generic kernels).  ct_radices: the stage list of the size-generic plan for the output width
 // (radices <= 8); arch: device + mode key of the tuner's wisdom file ("" = built-in wisdom only); use_wisdom = false: the
 // structural default (pow2 / 16*16*R / the chooser's pick), whatever the wisdom says -- the tuner times it as a candidate.
-bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, Choice& c, const std::string& arch, bool use_wisdom)
+bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, Choice& c, const std::string& arch, bool use_wisdom, int DD)
 {
-    const int U = D % 2 == 0 ? D / 2 : 1;
-    c.W = W; c.H = H; c.U = U; c.D = D; c.UW = D * W / 2; c.UH = D * H / 2; c.half = half;
-    if (W < 64 || H < 64 || W > 8192 || H > 4096 || D < 3 || c.UW > 8192 || (D * W) % 2 || (D * H) % 2) return false;
+    // (DD = 2: quarter-integer factor D / 4, D odd -- like the half-integer ones one spectrum buffer with all rows, U = 1)
+    const int U = (DD == 1 && D % 2 == 0) ? D / 2 : 1;
+    c.W = W; c.H = H; c.U = U; c.D = D; c.DD = DD; c.UW = D * W / (2 * DD); c.UH = D * H / (2 * DD); c.half = half;
+    if (W < 64 || H < 64 || W > 8192 || H > 4096 || D < 3 || c.UW > 8192 || (D * W) % (2 * DD) || (D * H) % (2 * DD)) return false;
+    if (DD != 1 && (DD != 2 || D % 2 == 0 || D < 5)) return false;
     if (c.UW % 4) return false;        // the sharpen works on quads of pixels (-u 5 with W = 2 * odd: the size-generic kernels)
     // ---- row R2C
     if (is_pow2(W) && W >= 256) { c.row_kind = 0; c.row_block = W / 8; }
@@ -439,13 +441,13 @@ bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, 
     const int UW = c.UW;
     size_t xb = sizeof(float2) * (size_t)((UW + 15) & ~15);                    // lswz_size(UW)
     int nbuf = 2;
-    if ((UW == 1024 || UW == 2048 || UW == 4096) && 8 % D == 0) { c.fused_kind = 0; c.fused_t = UW / 8; nbuf = 3; }
+    if ((UW == 1024 || UW == 2048 || UW == 4096) && (8 * DD) % D == 0) { c.fused_kind = 0; c.fused_t = UW / 8; nbuf = 3; }
     else {
-        const bool mr16 = UW % 256 == 0 && is_radix(UW / 256) && 16 % D == 0 && !experiment("jit_fused");
+        const bool mr16 = UW % 256 == 0 && is_radix(UW / 256) && (16 * DD) % D == 0 && !experiment("jit_fused");
         if (mr16) {
             c.fused_kind = 1; c.fused_t = 256;
             xb = (sizeof(float2) * (size_t)(UW + (UW >> 4) + 1) + 15) & ~(size_t)15;                               // lpad_size(UW)
-        } else if (choose_fused_n(UW, D, c.fr, &c.fused_t)) {
+        } else if (choose_fused_n(UW, D, DD, c.fr, &c.fused_t)) {
             set_fused_n(c, c.fused_t, std::vector<int>(c.fr));
             if (const char* e = experiment("jit_fused_opt")) { int w = 0, r = 1; if (sscanf(e, "%d,%d", &w, &r) == 2) { c.fused_wpe = std::max(1, w); c.fused_rr = r != 0; } }
         } else return false;
@@ -462,7 +464,7 @@ bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, 
         bool have = !arch.empty() && wisdom_lookup(fused_key(c, arch), w);
         if (!have && !experiment("jit_no_builtin_wisdom"))
             for (const auto& e : kBuiltinWisdom)
-                if (e.uw == UW && e.d == D) { w = e.plan; have = true; }
+                if (e.uw == UW && e.d == D && DD == 1) { w = e.plan; have = true; }
         if (have && w != fused_value(c) && w != "pow2" && w != "mr16") {
             int T = 0;
             std::vector<int> r;
@@ -473,7 +475,7 @@ bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, 
                 while (pos < w.size()) { r.push_back(atoi(w.c_str() + pos)); const size_t cm = w.find(',', pos); if (cm == std::string::npos) break; pos = cm + 1; }
             }
             long prod = 1;
-            bool ok = r.size() >= 2 && T >= 64 && T <= 1024 && T % 64 == 0 && r[0] % D == 0;
+            bool ok = r.size() >= 2 && T >= 64 && T <= 1024 && T % 64 == 0 && (r[0] * DD) % D == 0;
             for (int q : r) { ok &= is_radix(q); prod *= q; }
             // (a hand-edited or stale entry must pass the chooser's own bound: at most 16 points per thread in every stage --
             // 16,3,16 on UW/16 threads needs 18 and would not compile, leaving the plan on the size-generic kernels for good)
@@ -550,15 +552,16 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT], int 
          ", \"host and device disagree on the fused kernel's geometry\");\n";
     s += "}\n";
     const std::string hb = c.half ? "true" : "false";
-    const std::string U = std::to_string(c.U) + ", " + std::to_string(c.D);
-    names[K_FUSED] = "fftup::k_c2r_sharpen_g<fftup::JitFused, " + hb + ", 4, " + U + (c.u8out ? ", true>" : ">");
-    names[K_C2R_CT] = "fftup::k_row_c2r_ct<fftup::JitCT, " + hb + ", " + U + ">";
+    const std::string U = std::to_string(c.U) + ", " + std::to_string(c.D), DD = std::to_string(c.DD);
+    names[K_FUSED] = "fftup::k_c2r_sharpen_g<fftup::JitFused, " + hb + ", 4, " + U + (c.u8out ? ", true, " : ", false, ") + DD + ">";
+    names[K_C2R_CT] = "fftup::k_row_c2r_ct<fftup::JitCT, " + hb + ", " + U + ", " + DD + ">";
     return s;
 }
 
 std::string describe(const Choice& c)
 {
-    std::string s = c.D == 4 ? "row " : (c.D % 2 ? "u" + std::to_string(c.D / 2) + ".5 row " : "u" + std::to_string(c.U) + " row ");
+    std::string s = c.DD == 2 ? "u" + std::to_string(c.D / 4) + (c.D % 4 == 1 ? ".25 row " : ".75 row ")
+                    : c.D == 4 ? "row " : (c.D % 2 ? "u" + std::to_string(c.D / 2) + ".5 row " : "u" + std::to_string(c.U) + " row ");
     auto star = [](const std::vector<int>& v) { std::string t; for (size_t i = 0; i < v.size(); i++) t += (i ? "*" : "") + std::to_string(v[i]); return t; };
     s += c.row_kind == 2 ? "generic" : c.row_kind == 0 ? "pow2/8" : c.row_kind == 3 ? star(c.rn) : std::to_string(c.rr[0]) + "*" + std::to_string(c.rr[1]) + "*" + std::to_string(c.rr[2]);
     s += " x" + std::to_string(c.row_block) + ", col ";

@@ -39,7 +39,8 @@ namespace fftup_jit {
 struct Choice {
     int W = 0, H = 0, UW = 0;
     int U = 2;                         // integer upscale factor; 1 = half-integer factor D/2 (one spectrum buffer with all rows)
-    int D = 4;                         // 2 x upscale factor: the spectrum rows hold kx = 0..UW/D
+    int D = 4;                         // 2 DD x upscale factor: the spectrum rows hold kx = 0..UW DD / D
+    int DD = 1;                        // 1: integer and half-integer factors (D = 2u); 2: quarter-integer ones (D = 4u, odd: -u 1.25 -> 5)
     int UH = 0;
     bool half = false;
     int row_kind = -1;                 // 0: k_row_r2c_t<W> (power of two, 8 points per thread); 1: k_row_r2c_m (three stages); 2: k_row_r2c (not specialised); 3: k_row_r2c_n
@@ -88,10 +89,10 @@ struct Module {
 
 // factorizations for a W x H plan with upscale factor D/2 (radices of the stand-alone C2R given); `arch`: the wisdom key's
 // device part ("" = none); false: no specialised factorization exists
-bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, Choice& c, const std::string& arch = "", bool use_wisdom = true);
+bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, Choice& c, const std::string& arch = "", bool use_wisdom = true, int DD = 1);
 std::string describe(const Choice& c);
 // alternatives for the fused kernel of a row length (the tuner's candidates), the chooser's pick first
-std::vector<FusedCand> fused_candidates(int n, int D, size_t max);
+std::vector<FusedCand> fused_candidates(int n, int D, size_t max, int DD = 1);
 void set_fused_n(Choice& c, int T, const std::vector<int>& radices);
 std::string fused_key(const Choice& c, const std::string& arch);
 std::string fused_value(const Choice& c);

@@ -36,10 +36,12 @@ __device__ __forceinline__ float2* run_plan(CtPlan<N, T, R...>, float2* a, float
 
 // ---- row C2R (see k_row_c2r), u = 2.  grid (uH/2, 3), block PUW::T, dynamic LDS 2*lpad_size(UW) float2
 // (U: integer upscale factor, see k_c2r_sharpen_g; output row y = row y/U of spectrum buffer y%U, buffers p.S2 - p.S1 apart)
-template <class PUW, bool HALF_OUT, int U = 2, int D = 2 * U>
+// (the upscale factor is D / (2 DD): DD = 1 for integer and half-integer factors, 2 for quarter-integer ones -- -u 1.25 = 5/4: D = 5, DD = 2)
+template <class PUW, bool HALF_OUT, int U = 2, int D = 2 * U, int DD = 1>
 __global__ void __launch_bounds__(PUW::T) k_row_c2r_ct(RowC2RParams p)
 {
-    constexpr int UW = PUW::N, T = PUW::T, KH = UW / D;       // kx = 0..W/2 = UW/2u non-zero
+    constexpr int UW = PUW::N, T = PUW::T, KH = UW * DD / D;  // kx = 0..W/2 = UW/2u non-zero
+    static_assert((UW * DD) % D == 0, "the output width is the upscale factor times an even input width");
     static_assert(UW % 4 == 0, "four consecutive points per thread in the store loop");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* a = (float2*)smem;

@@ -1369,11 +1369,13 @@ __device__ __forceinline__ void deferred_pixel(const FusedParams& p, long of, fl
 // What the variant costs against the planes (68 vs 56 us at 4096x2048 -p 2, profiles/r04_d_*): 14 instead of 13 steps per
 // strip, and four store instructions per thread and row instead of one -- lines touched per instruction do not matter
 // (a wave-transposed form with 3-4 instead of 12 lines per instruction, ds_bpermute, ran 1 % slower: removed).
-template <class PL, bool HALF, int TK, int U = 2, int D = 2 * U, bool OUT_U8 = false>
+// Quarter-integer factors (-u 1.25, 1.75, 2.25, 3.75; round 5): the factor is D / (2 DD) with DD = 2 -- 5/4: D = 5 -- the spectrum
+// rows hold kx = 0..UW DD / D, and the first radix R0 must make R0 DD / D whole (5, 10, 15 for 5/4; 7 for 7/4; 9 for 9/4).
+template <class PL, bool HALF, int TK, int U = 2, int D = 2 * U, bool OUT_U8 = false, int DD = 1>
 __global__ void __launch_bounds__(PL::T, PL::WPE) k_c2r_sharpen_g(FusedParams p)
 {
-    constexpr int UW = PL::UW, T = PL::T, R0 = PL::R0, NB0 = PL::NB0, NI = R0 / D, KH = UW / D;
-    static_assert(R0 % D == 0, "the first radix must be a multiple of 2u");
+    constexpr int UW = PL::UW, T = PL::T, R0 = PL::R0, NB0 = PL::NB0, NI = R0 * DD / D, KH = UW * DD / D;
+    static_assert((R0 * DD) % D == 0, "the first radix must be a multiple of 2u");
     static_assert(UW % 4 == 0, "the sharpen passes work on quads of pixels");
     constexpr int EOUT = PL::EOUT, SOUT = PL::SOUT, VN = PL::VN;
     constexpr int NPASS = (UW + 4 * T - 1) / (4 * T);           // sharpen passes of 4 pixels per thread
