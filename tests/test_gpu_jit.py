@@ -84,6 +84,9 @@ U_CASES = [
     (1920, 1080, 1.25),  # 1080p -> 2400 x 1350
     (1024, 768, 1.75),   # 7/4: first radix 7, NI = 2
     (1280, 720, 2.25),   # 9/4: first radix 9, NI = 4
+    (640, 480, 7.0),     # -u 7: first radix 14 = 2 x 7 (round 5), six residue transforms in the column kernel
+    (320, 240, 7.0),
+    (640, 480, 3.5),     # 7/2: first radix 14 as well
 ]
 
 
@@ -203,5 +206,7 @@ def test_plan_describe():
         assert up.description.startswith("specialised at plan time: row 10*10*10") and "fused 8*5*5*10" in up.description
     with _up(2048, 1024, 2.0, 0) as up:
         assert up.description.startswith("ahead-of-time power-of-two")
-    with _up(240, 128, 1.25, 0) as up:
+    with _up(256, 128, 1.25, 0) as up:                 # quarter-integer factors are specialised since round 5
+        assert up.description.startswith("specialised at plan time: u1.25")
+    with _up(250, 120, 1.2, 0) as up:                  # 6/5: not a multiple of 1/4
         assert up.description.startswith("size-generic")

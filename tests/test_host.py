@@ -363,7 +363,7 @@ def test_jit_chooser_invariants_over_all_sizes():
     buf = C.create_string_buffer(512)
     smooth = sorted({2 ** a * 3 ** b * 5 ** c * 7 ** d for a in range(1, 13) for b in range(6) for c in range(5) for d in range(4)
                      if 64 <= 2 ** a * 3 ** b * 5 ** c * 7 ** d <= 4096})
-    radices = {2, 3, 4, 5, 7, 8, 9, 10, 12, 15, 16}
+    radices = {2, 3, 4, 5, 7, 8, 9, 10, 12, 14, 15, 16}
 
     def prod(xs):
         p = 1
@@ -377,14 +377,15 @@ def test_jit_chooser_invariants_over_all_sizes():
     seen = 0
     for i, W in enumerate(smooth):
         H = smooth[(i * 7 + 3) % len(smooth)]
-        for u in (1.5, 2.0, 2.5, 3.0, 4.0, 5.0, 8.0):
+        for u in (1.25, 1.5, 1.75, 2.0, 2.5, 3.0, 4.0, 5.0, 7.0, 8.0):
             rc = lib.fftup_jit_check(W, H, u, 0, b"", buf, 512)
             assert rc in (0, 2, 1), (W, H, u, rc)
             if rc != 0:
                 continue
             seen += 1
             d = buf.value.decode()
-            UW, UH, D = int(u * W), int(u * H), int(2 * u)
+            UW, UH = int(u * W), int(u * H)
+            D, DD = (int(2 * u), 1) if 2 * u == int(2 * u) else (int(4 * u), 2)     # the factor as D / (2 DD)
             assert UW % 4 == 0 and UW <= 8192
             m = re.search(r"row (.*?), col (.*?), fused (.*?) \((\d+) B LDS", d)
             assert m, d
@@ -407,7 +408,7 @@ def test_jit_chooser_invariants_over_all_sizes():
                     assert prod(r) == H and set(r) <= radices and t <= 1024 and t >= cols * max(H // r[0], H // r[-1]), d
             if not fused.startswith("pow2"):
                 r, t = parse(fused)
-                assert prod(r) == UW and set(r) <= radices and r[0] % D == 0 and t <= 1024 and t % 64 == 0, d
+                assert prod(r) == UW and set(r) <= radices and (r[0] * DD) % D == 0 and t <= 1024 and t % 64 == 0, d
                 assert t >= UW // r[0] and t >= UW // r[-1], d
                 assert max(-(-(UW // q) // t) * q for q in r) <= 16, d          # points per thread
     assert seen > 400

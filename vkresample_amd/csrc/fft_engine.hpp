@@ -333,6 +333,24 @@ template <int DIR, typename C> __device__ __forceinline__ void bfly10(C* v)
         for (int k2 = 0; k2 < 5; k2++) v[(5 * k1 + 6 * k2) % 10] = z[k2];
     }
 }
+// radix 14 = 2 x 7 (first radix of the fused kernel for -u 7: a multiple of 2u): n = (7 n1 + 2 n2) mod 14, k = (7 k1 + 8 k2) mod 14
+template <int DIR, typename C> __device__ __forceinline__ void bfly14(C* v)
+{
+    C y[7][2];
+#pragma unroll
+    for (int n2 = 0; n2 < 7; n2++) {
+        y[n2][0] = v[(2 * n2) % 14];                // n1 = 0
+        y[n2][1] = v[(7 + 2 * n2) % 14];            // n1 = 1
+        bfly2<DIR>(y[n2]);                          // -> y[n2][k1]
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 2; k1++) {
+        C z[7] = {y[0][k1], y[1][k1], y[2][k1], y[3][k1], y[4][k1], y[5][k1], y[6][k1]};
+        bfly7<DIR>(z);                              // -> z[k2]
+#pragma unroll
+        for (int k2 = 0; k2 < 7; k2++) v[(7 * k1 + 8 * k2) % 14] = z[k2];
+    }
+}
 template <int DIR, typename C> __device__ __forceinline__ void bfly12(C* v)
 {
     C y[4][3];
@@ -362,6 +380,7 @@ template <int R, int DIR, typename C> __device__ __forceinline__ void bfly(C* v)
     else if constexpr (R == 9) bfly9<DIR>(v);
     else if constexpr (R == 10) bfly10<DIR>(v);
     else if constexpr (R == 12) bfly12<DIR>(v);
+    else if constexpr (R == 14) bfly14<DIR>(v);
     else if constexpr (R == 15) bfly15<DIR>(v);
     else if constexpr (R == 16) bfly16<DIR>(v);
 }

@@ -34,7 +34,7 @@ static const char* const kHeaderNames[] = {"fft_engine.hpp", "kernels_generic.hp
 static constexpr int kNumHeaders = (int)(sizeof kHeaderNames / sizeof kHeaderNames[0]);
 
 // radices the register engines have butterflies for (fft_engine.hpp bfly<R>, kernels_pow2.hpp twiddle_all<R>)
-static const int kRadices[] = {2, 3, 4, 5, 7, 8, 9, 10, 12, 15, 16};
+static const int kRadices[] = {2, 3, 4, 5, 7, 8, 9, 10, 12, 14, 15, 16};
 
 
 static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
