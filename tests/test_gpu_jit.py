@@ -87,6 +87,10 @@ U_CASES = [
     (640, 480, 7.0),     # -u 7: first radix 14 = 2 x 7 (round 5), six residue transforms in the column kernel
     (320, 240, 7.0),
     (640, 480, 3.5),     # 7/2: first radix 14 as well
+    # inputs taller than 4096 rows (round 5: up to 8192): two columns of a spectrum tile per workgroup (four no longer fit the LDS)
+    (256, 8192, 2.0),    # col 16*2*16*16, 1024 threads
+    (400, 6000, 2.0),
+    (640, 4800, 3.0),    # k_col_u with two columns of 4800 points
 ]
 
 

@@ -45,4 +45,6 @@ python tools/make_traffic_json.py $OUT/pmc_fp16u8_u8store/summary.txt $OUT/hbm_t
 grep -A12 "k_c2r_sharpen_g" $OUT/pmc_fp32/summary.txt | grep -E "==|SQ_INSTS_VALU|FETCH_SIZE|WRITE_SIZE" | head -8
 # the bench-line test needs the refreshed figures: run it last, against them (the suite above ran without it)
 cp $OUT/hbm_traffic.json profiles/hbm_traffic.json
+python tools/index_kernel_stats.py 2048x1024_p0_planar $(find $OUT/prof_fp32_s1 -name "*kernel_stats.csv" | head -1) 2048x1024_p2_u8 $(find $OUT/prof_fp16_u8_s1 -name "*kernel_stats.csv" | head -1) \
+       1920x1080_p0_planar $(find $OUT/prof_1080p_s1 -name "*kernel_stats.csv" | head -1) 2048x1024_p2_u8_u8out $(find $OUT/prof_fp16_u8_u8store_s1 -name "*kernel_stats.csv" | head -1) > /dev/null
 python -m pytest tests/test_gpu_bench.py::test_bench_single_rank_line -q -m gpu > $OUT/pytest_bench_line.txt 2>&1; tail -2 $OUT/pytest_bench_line.txt

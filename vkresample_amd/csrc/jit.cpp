@@ -404,7 +404,7 @@ bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, 
     // (DD = 2: quarter-integer factor D / 4, D odd -- like the half-integer ones one spectrum buffer with all rows, U = 1)
     const int U = (DD == 1 && D % 2 == 0) ? D / 2 : 1;
     c.W = W; c.H = H; c.U = U; c.D = D; c.DD = DD; c.UW = D * W / (2 * DD); c.UH = D * H / (2 * DD); c.half = half;
-    if (W < 64 || H < 64 || W > 8192 || H > 4096 || D < 3 || c.UW > 8192 || (D * W) % (2 * DD) || (D * H) % (2 * DD)) return false;
+    if (W < 64 || H < 64 || W > 8192 || H > 8192 || D < 3 || c.UW > 8192 || (D * W) % (2 * DD) || (D * H) % (2 * DD)) return false;
     if (DD != 1 && (DD != 2 || D % 2 == 0 || D < 5)) return false;
     if (c.UW % 4) return false;        // the sharpen works on quads of pixels (-u 5 with W = 2 * odd: the size-generic kernels)
     // ---- row R2C
@@ -413,9 +413,11 @@ bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, 
     else if (choose_n(W, 1024, 64, c.rn, &c.row_t, "jit_row")) { c.row_kind = 3; c.row_block = c.row_t; }
     else c.row_kind = 2;               // no supported factorization: the size-generic row kernel (same S1 layout) stays
     // ---- column (four columns of a spectrum tile per workgroup; two when a stage of a long column needs more than 256 threads)
+    // (columns beyond 5120 points: four of them no longer fit the 160 KB of LDS side by side -- two per workgroup, up to 8192 points)
+    auto col_lds = [](int len, int cols) { return sizeof(float2) * (size_t)((len * cols + 15) & ~15); };
     auto col_n = [&](int len, std::vector<int>& r, int* tpc, const char* env) {
-        if (choose_n(len, 256, 16, r, tpc, env)) return 4;
-        if (choose_n(len, 512, 32, r, tpc, env)) return 2;
+        if (col_lds(len, 4) <= 160 * 1024 && choose_n(len, 256, 16, r, tpc, env)) return 4;
+        if (col_lds(len, 2) <= 160 * 1024 && choose_n(len, 512, 32, r, tpc, env)) return 2;
         return 0;
     };
     if (U == 1) {
@@ -432,7 +434,7 @@ bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, 
         c.col_kind = 4; c.col_block = c.col_cols * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * c.col_cols + 15) & ~15);
     } else if (is_pow2(H) && H >= 128 && H <= 2048) {
         c.col_kind = 0; c.col_block = 4 * H / 8; c.col_lds = sizeof(float2) * (size_t)((H * 4 + 15) & ~15);      // lswz_size
-    } else if (!experiment("jit_col_nstage") && choose3(H, 4, 256, c.cr, &c.col_tpc, "jit_col")) {
+    } else if (!experiment("jit_col_nstage") && col_lds(H, 4) <= 160 * 1024 && choose3(H, 4, 256, c.cr, &c.col_tpc, "jit_col")) {
         c.col_kind = 1; c.col_block = 4 * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)H * 4;
     } else if ((c.col_cols = col_n(H, c.cn, &c.col_tpc, "jit_col"))) {
         c.col_kind = 3; c.col_block = c.col_cols * c.col_tpc; c.col_lds = sizeof(float2) * (size_t)((H * c.col_cols + 15) & ~15);
