@@ -424,7 +424,12 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
                 if (fftup_jit::choose((int)W, (int)H, D, P->half, stage_radices(P->planUW), ch, wisdom_device_key(P), true, DD)) {
                     ch.u8out = (cfg->flags & FFTUP_FLAG_FUSE_U8_STORE) != 0;         // (such a plan is always fused)
                     P->jit = fftup_jit::load(ch, P->prop.gcnArchName, jerr);
-                    if (P->jit) { P->mixed = 3; P->U = ch.U; P->TK = 4; P->ldsCol = P->jit->choice.col_lds; }
+                    if (P->jit) {
+                        P->mixed = 3; P->U = ch.U; P->TK = 4; P->ldsCol = P->jit->choice.col_lds;
+                        // (inputs taller than 4800 rows: the size-generic plan above would have run its columns in four steps through
+                        // HBM -- the specialised column kernel holds two whole columns in LDS instead)
+                        P->colF = fftup_plan::Four{}; P->colI = fftup_plan::Four{};
+                    }
                     else if (getenv("FFTUP_JIT_VERBOSE")) fprintf(stderr, "fftup: run-time specialisation failed, size-generic kernels in use: %s\n", jerr.c_str());
                 }
             }
