@@ -225,10 +225,12 @@ FFTUP_API int fftup_drain(fftup_plan* plan);
  * named at submission already (a 16-byte aligned buffer of fftup_host_alloc; NULL: not yet) the GPU writes the stream into it
  * itself, sized by the count it knows, and fftup_wait_png(.., the same buffer, ..) only waits, adds the framing and the CRC --
  * no size round trip through the host: several frames of one thread stream back to back.  A ticket of
- * fftup_submit_png must be collected by fftup_wait_png: a later submission (fftup_submit_png or fftup_submit_rgb8, any thread)
- * that comes round to its ring slot waits for that -- unless the uncollected ticket belongs to the submitting thread itself,
- * which would wait forever: that call fails with FFTUP_E_WOULD_BLOCK instead (a thread keeps at most `ring` PNG tickets open;
- * with the default ring of 1: collect each one before the next submission).  -p 0 and -p 2 plans whose stream bound fits one
+ * fftup_submit_png must be collected by fftup_wait_png: its ring slot stays with it until then.  Submissions (fftup_submit_png
+ * or fftup_submit_rgb8, any thread) take the next slot that holds no uncollected stream -- so threads that keep tickets open
+ * while they submit cannot wait for each other in a circle as long as fewer than `ring` streams are uncollected in total; with
+ * every slot held a submission waits for a collector, unless every uncollected stream is the submitting thread's own, which would
+ * wait forever: that call fails with FFTUP_E_WOULD_BLOCK instead (with the default ring of 1: collect each ticket before the
+ * next submission).  -p 0 and -p 2 plans whose stream bound fits one
  * IDAT chunk (2^31 - 1 bytes: FFTUP_E_UNSUPPORTED_SIZE beyond); thread-safe like fftup_submit_rgb8 / fftup_wait. */
 FFTUP_API size_t fftup_png_bound(fftup_plan* plan);
 FFTUP_API int fftup_submit_png(fftup_plan* plan, const uint8_t* rgb_in, size_t in_stride_bytes, uint8_t* png_out, size_t capacity,

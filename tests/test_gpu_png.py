@@ -255,3 +255,46 @@ def test_a_stream_that_would_not_fit_is_refused_on_the_device(monkeypatch):
         n = up.wait_png(up.submit_png(flat), buf)                 # a flat frame fits; the slot was released by the failed wait
         up.wait(up.submit_rgb8(flat, out))
         assert n < 60000 and np.array_equal(_decode(bytes(buf[:n])), out)
+
+
+def test_threads_that_keep_png_tickets_open_do_not_wait_in_a_circle():
+    """Round 4's queue took its ring slots strictly in turn: two threads that each keep a PNG ticket open while submitting the
+    next could end up waiting for each other's slots (found by tools/png_threads.py: the run never ended).  Submissions now take
+    the next slot WITHOUT an uncollected stream: with ring = threads x depth and depth tickets open per thread a slot is always
+    free.  Four threads, two tickets open each, 40 frames each -- every file decodes to its frame, and the run ends."""
+    import vkresample_amd as v
+    W, H, T, depth, per = 128, 64, 4, 2, 40
+    frames = _frames(W, H, 10)
+    with v.Upscaler(W, H, 2.0, 0, 0.2, 0, 0, T * depth) as up:
+        want, out = [], np.empty((2 * H, 2 * W, 3), np.uint8)
+        for f in frames:
+            up.wait(up.submit_rgb8(f, out))
+            want.append(out.copy())
+        errors, done = [], []
+
+        def worker(t):
+            try:
+                bufs = [v.PinnedArray((up.png_bound(),)) for _ in range(depth)]
+                tk = [(up.submit_png(frames[(t + k) % 10], bufs[k].array), (t + k) % 10) for k in range(depth)]
+                for i in range(per):
+                    k = i % depth
+                    n = up.wait_png(tk[k][0], bufs[k].array)
+                    if not np.array_equal(_decode(bytes(bufs[k].array[:n])), want[tk[k][1]]):
+                        errors.append((t, i, "pixels differ"))
+                    g = (t + i + depth) % 10
+                    tk[k] = (up.submit_png(frames[g], bufs[k].array), g)
+                for k in range(depth):
+                    up.wait_png(tk[(per + k) % depth][0], bufs[(per + k) % depth].array)
+                for b in bufs:
+                    b.close()
+                done.append(t)
+            except Exception as e:                                     # noqa: BLE001
+                errors.append((t, repr(e)))
+
+        th = [threading.Thread(target=worker, args=(t,), daemon=True) for t in range(T)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join(timeout=120)
+        assert not any(x.is_alive() for x in th), "threads still waiting for each other's ring slots"
+        assert not errors and sorted(done) == list(range(T)), errors

@@ -125,15 +125,17 @@ int fftup_wait_png(fftup_plan* P, uint64_t ticket, uint8_t* png_out, size_t capa
 {
     using fftup_crc::crc32_update;
     if (!P || !png_out || !png_bytes) return fail(FFTUP_E_INVALID_ARG, "null argument");
-    const uint64_t next = P->q_next.load(std::memory_order_acquire);
-    if (ticket >= next) return fail(FFTUP_E_INVALID_ARG, "ticket was never issued");
-    fftup_plan::QSlot& Q = P->q[ticket % P->ring];
+    fftup_plan::QSlot* Qp = nullptr;
     {
-        // (state and ticket are written by submit_frame under the queue's lock: read them under it)
+        // (slot state is written by submit_frame under the queue's lock: read it under it)
         std::lock_guard<std::mutex> lock(P->q_mu);
-        if (ticket + P->ring < next || Q.png.state != 1 || Q.png.ticket != ticket)
-            return fail(FFTUP_E_INVALID_ARG, "no PNG stream is waiting under this ticket");
+        if (ticket >= P->q_next.load(std::memory_order_relaxed)) return fail(FFTUP_E_INVALID_ARG, "ticket was never issued");
+        for (auto& c : P->q)
+            if (c.used && c.ticket == ticket && c.png.state == 1 && c.png.ticket == ticket) Qp = &c;
+        if (!Qp) return fail(FFTUP_E_INVALID_ARG, "no PNG stream is waiting under this ticket");
+        Qp->png.state = 2;                                            // being collected: a second collector of the same ticket finds nothing
     }
+    fftup_plan::QSlot& Q = *Qp;
     // From here on the ticket is this caller's: whatever happens below, the slot is handed back (a slot left in state 1 would
     // block every later submission that comes round to it).
     struct Release {

@@ -84,21 +84,29 @@ int submit_frame(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, uint8_t
     std::unique_lock<std::mutex> lock(P->q_mu);
     int rc = queue_init(P);
     if (rc) return rc;
-    uint64_t t;
-    for (;;) {                                                        // (the lock is released while waiting: the ticket is re-read)
-        t = P->q_next.load(std::memory_order_relaxed);
-        const fftup_plan::PngSlot& G = P->q[t % P->ring].png;
-        if (G.state == 0) break;
-        // A PNG stream of this slot is still to be collected.  By the thread that is asking for the slot now: it would wait for
-        // itself, forever (ring + 1 fftup_submit_png calls of one thread without a fftup_wait_png; ring = 1: the second call).
-        if (G.owner == std::this_thread::get_id())
-            return fail(FFTUP_E_WOULD_BLOCK, "ring slot " + std::to_string(t % P->ring) + " holds this thread's PNG ticket " + std::to_string(G.ticket) +
-                                                 ": collect it with fftup_wait_png before submitting again (ring = " + std::to_string(P->ring) + ")");
-        P->q_cv.wait(lock);                                           // another thread's: it will be collected
+    // The slot: the next one in turn that holds no uncollected PNG stream (a slot is a set of device buffers; which one a frame
+    // goes through is the queue's business -- tickets count submissions).  Taking slots strictly in turn, as round 4 did, lets
+    // two threads that each keep a ticket open while submitting wait for each other's slots in a circle; skipping held slots
+    // cannot: while fewer than `ring` streams are uncollected a slot is free.  Every slot held: wait for a collector -- unless
+    // every uncollected stream is this thread's own, which would be waiting for itself (FFTUP_E_WOULD_BLOCK).
+    uint32_t s = 0;
+    for (;;) {                                                        // (the lock is released while waiting: the search starts over)
+        bool found = false, others = false;
+        for (uint32_t i = 0; i < P->ring && !found; i++) {
+            s = (P->q_cursor + i) % P->ring;
+            if (P->q[s].png.state == 0) found = true;
+            else if (P->q[s].png.owner != std::this_thread::get_id()) others = true;
+        }
+        if (found) break;
+        if (!others)
+            return fail(FFTUP_E_WOULD_BLOCK, "all " + std::to_string(P->ring) + " ring slot(s) hold PNG tickets of this thread: collect one with "
+                                             "fftup_wait_png before submitting again");
+        P->q_cv.wait(lock);
     }
-    const uint32_t s = (uint32_t)(t % P->ring);
+    const uint64_t t = P->q_next.load(std::memory_order_relaxed);
+    P->q_cursor = (s + 1) % P->ring;
     fftup_plan::QSlot& Q = P->q[s];
-    if (t >= P->ring) HIP_TRY(hipEventSynchronize(Q.done));          // the slot's previous frame has left the device
+    if (Q.used) HIP_TRY(hipEventSynchronize(Q.done));                // the slot's previous frame has left the device
     if (png && (rc = png_slot_init(P, Q)) != FFTUP_OK) return rc;
     // The whole frame -- H2D, conversion, kernels, conversion, D2H -- goes to ONE stream (lane t % nlanes), so no
     // cross-stream dependency exists and nothing can stall behind a neighbour's wait when streams share a hardware
@@ -139,6 +147,8 @@ int submit_frame(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, uint8_t
         (void)hipStreamSynchronize(cs);
         return rc ? rc : fail(FFTUP_E_HIP, std::string("hipEventRecord: ") + hipGetErrorString(rec));
     }
+    Q.used = true;
+    Q.ticket = t;
     if (png) {
         Q.png.state = 1;
         Q.png.ticket = t;
@@ -160,20 +170,30 @@ int fftup_submit_rgb8(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, ui
     return submit_frame(P, rgb_in, in_stride, rgb_out, out_stride, false, ticket);
 }
 
+// the slot a ticket went through, or nullptr when that slot has carried a later frame since (the ticket's frame is then long done);
+// q_mu held
+static fftup_plan::QSlot* slot_of(fftup_plan* P, uint64_t ticket)
+{
+    for (auto& Q : P->q)
+        if (Q.used && Q.ticket == ticket) return &Q;
+    return nullptr;
+}
+
 int fftup_wait(fftup_plan* P, uint64_t ticket)
 {
     if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
-    const uint64_t next = P->q_next.load(std::memory_order_acquire);
-    if (ticket >= next) return fail(FFTUP_E_INVALID_ARG, "ticket was never issued");
-    if (ticket + P->ring < next) return FFTUP_OK;             // its slot has been reused: submit already waited for it
+    hipEvent_t done = nullptr;
     {
-        std::lock_guard<std::mutex> lock(P->q_mu);                // (written by submit_frame under the lock)
-        const fftup_plan::QSlot& Q = P->q[ticket % P->ring];
-        if (Q.png.state == 1 && Q.png.ticket == ticket) return fail(FFTUP_E_INVALID_ARG, "a ticket of fftup_submit_png is collected by fftup_wait_png");
+        std::lock_guard<std::mutex> lock(P->q_mu);                // (slot state is written by submit_frame under the lock)
+        if (ticket >= P->q_next.load(std::memory_order_relaxed)) return fail(FFTUP_E_INVALID_ARG, "ticket was never issued");
+        const fftup_plan::QSlot* Q = slot_of(P, ticket);
+        if (!Q) return FFTUP_OK;                                  // its slot has been reused: submit already waited for it
+        if (Q->png.state == 1 && Q->png.ticket == ticket) return fail(FFTUP_E_INVALID_ARG, "a ticket of fftup_submit_png is collected by fftup_wait_png");
+        done = Q->done;
     }
     // (a submission of another thread may re-record this slot's event right now: the wait then covers the later frame too)
     HIP_TRY(hipSetDevice(P->device));
-    HIP_TRY(hipEventSynchronize(P->q[ticket % P->ring].done));
+    HIP_TRY(hipEventSynchronize(done));
     return FFTUP_OK;
 }
 

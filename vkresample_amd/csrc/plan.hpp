@@ -106,12 +106,14 @@ struct fftup_plan {
     uint8_t* out_u8 = nullptr;        // staging for download_rgb8
     // host-streamed queue (fftup_submit_rgb8): created on first use
     // (png: the device-side PNG encoder's buffers of the slot, created on the first fftup_submit_png; state 1 = a stream waits for
-    // its fftup_wait_png -- a later submission of the slot waits for that on q_cv)
+    // its fftup_wait_png, 2 = being collected -- submissions skip such a slot, and wait on q_cv when every slot is held)
     struct PngSlot { PngParams p{}; bool ready = false; unsigned long long* meta_host = nullptr; uint32_t* parts_host = nullptr; hipEvent_t copied = nullptr;
                      int state = 0; uint64_t ticket = 0; std::thread::id owner{}; uint8_t* dest = nullptr; size_t dest_cap = 0; };
-    struct QSlot { uint8_t* out_u8 = nullptr; hipEvent_t done = nullptr; PngSlot png; };
+    struct QSlot { uint8_t* out_u8 = nullptr; hipEvent_t done = nullptr; PngSlot png;
+                   bool used = false; uint64_t ticket = 0; };        // the latest submission that went through this slot
     std::vector<QSlot> q;
-    std::atomic<uint64_t> q_next{0};   // next ticket; written under q_mu, read by fftup_wait without it
+    std::atomic<uint64_t> q_next{0};   // next ticket (tickets count the plan's submissions); written under q_mu
+    uint32_t q_cursor = 0;             // where the search for a free slot starts (slots are taken in turn, skipping uncollected PNG streams)
     std::mutex q_mu;                   // fftup_submit_rgb8 may be called by several host threads (codec workers sharing a plan)
     std::condition_variable q_cv;
     hipStream_t png_copy = nullptr;    // the sized D2H copies of fftup_wait_png
