@@ -352,7 +352,9 @@ static int launch_frame_f64(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, 
     if (which < 0 || which == 3) {
         SharpenParams p{};
         p.R = P->lanes[P->cur].R; p.out = P->out[out_slot]; p.uW = (int)P->uW; p.uH = (int)P->uH; p.upsq = P->upsq; p.coef = P->coef;
-        hipLaunchKernelGGL(k_sharpen_f64, dim3((P->uW + 255) / 256, P->uH, 3), dim3(256), 0, st, p);
+        const dim3 sgrid((P->uW + 511) / 512, (P->uH + SHARPEN_F64_RPT - 1) / SHARPEN_F64_RPT, 3);
+        if (P->uW % 2 == 0) hipLaunchKernelGGL(k_sharpen_f64<true>, sgrid, dim3(64, 4), 0, st, p);
+        else hipLaunchKernelGGL(k_sharpen_f64<false>, sgrid, dim3(64, 4), 0, st, p);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FFTUP_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));

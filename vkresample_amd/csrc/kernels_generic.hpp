@@ -588,28 +588,136 @@ __device__ __forceinline__ double sharpen_px_f64(const double* len, double coef)
     return (len[4] + scale * (((len[1] + len[3]) + len[5]) + len[7])) / (1.0 + scale * 4.0);
 }
 
-// one thread = one pixel; grid (ceil(uW/256), uH, 3)
+// The filter's three divisions and its root without IEEE division sequences (3 x ~14 + ~20 instructions per pixel made
+// k_sharpen_f64 a 170 us kernel for 402 MB of traffic).  As in the fp32 kernels (sharpen_eval_pair): a < b <=> mn + mx < 1, so ONE
+// quotient n / d is formed, n = min(mn, 1 - mx), d = 1 - n in [0.5, 1], everything carried doubled; sqrt(n / d) = n rsq(n d).
+// v_rsq_f64 / v_rcp_f64 deliver ~2^-23: two coupled Newton steps for the root (Goldschmidt form), one for the reciprocal plus the
+// residual correction of the quotient: <= 2 ulp of the correctly rounded sequence (GLSL asks 2.5 ulp of one double division;
+// tests: 1e-9 against the oracle after the filter's sqrt amplification near 0).
+__device__ __forceinline__ double min_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double max_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double sharpen_eval_f64(double s4, double C, double mn0, double mn1, double mx0, double mx1, double m2coef)
+{
+    const double smn = mn0 + mn1, smx = mx0 + mx1;           // 2 mn, 2 mx
+    const double n2 = min_f64(smn, 2.0 - smx);               // 2 n
+    const double d2 = 2.0 - n2;                              // 2 d (exact: see sharpen_eval_pair)
+    const double pr = fma(n2, d2, 1e-300);                   // 4 n d; n = 0 -> root 0, no NaN
+    const double y = __builtin_amdgcn_rsq(pr);
+    double g = pr * y, h = 0.5 * y;                          // g -> sqrt(pr), h -> 1 / (2 sqrt(pr))
+    double r = fma(-g, h, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-g, h, 0.5);
+    h = fma(h, r, h);
+    const double scale = m2coef * (n2 * h);                  // -coef sqrt(n / d) = -coef n2 / sqrt(4 n d) = (-2 coef) n2 h
+    const double num = fma(scale, s4, C), den = fma(scale, 4.0, 1.0);
+    double yd = __builtin_amdgcn_rcp(den);
+    yd = fma(fma(-den, yd, 1.0), yd, yd);
+    const double q = num * yd;
+    return fma(fma(-den, q, num), yd, q);
+}
+
+// min(|upsq x|, 1) = |upsq| |x| clamped to [0, 1] by the output modifier: one instruction per tap (written with fmin / fmax the
+// compiler adds a canonicalising v_max x, x in front of every chain -- it cannot know the loaded value is no signalling NaN)
+__device__ __forceinline__ double tap_f64(double upsq, double x)
+{
+    double r;
+    asm("v_mul_f64 %0, |%1|, |%2| clamp" : "=v"(r) : "v"(upsq), "v"(x));
+    return r;
+}
+// one thread = 2 consecutive pixels x RPT rows (the three tap rows slide down); block (64, 4), grid (ceil(uW/512), ceil(uH/RPT), 3).
+// Even widths: ONE 16-byte load and ONE 16-byte store per thread and row -- a wave reads and writes 1 KB runs -- the left / right
+// taps come from the neighbouring lanes (DPP wave shifts, as the fp32 kernels do), only the lanes at the ends of a wave or a row
+// load theirs.  (8-byte loads and stores at a 16-byte stride -- four loads per pair, every 64-byte line of the output written in
+// two instructions -- held the kernel at 107 us whatever its arithmetic.)  Odd widths: element-wise taps.  Planes below 2^31 elements.
+constexpr int SHARPEN_F64_RPT = 16;
+__device__ __forceinline__ double dpp_f64(double v, double edge, bool from_below)
+{
+    const int2 a = __builtin_bit_cast(int2, v), e = __builtin_bit_cast(int2, edge);
+    int2 r;
+    if (from_below) { r.x = __builtin_amdgcn_update_dpp(e.x, a.x, 0x138, 0xf, 0xf, false); r.y = __builtin_amdgcn_update_dpp(e.y, a.y, 0x138, 0xf, 0xf, false); }
+    else { r.x = __builtin_amdgcn_update_dpp(e.x, a.x, 0x130, 0xf, 0xf, false); r.y = __builtin_amdgcn_update_dpp(e.y, a.y, 0x130, 0xf, 0xf, false); }
+    return __builtin_bit_cast(double, r);
+}
+template <bool EVEN>
+__device__ __forceinline__ void sharpen_f64_row(double (&L)[4], const double* __restrict__ R, unsigned plane, unsigned uW, int uH, int row,
+                                                const unsigned (&xo)[4], bool edge_l, bool edge_r, double upsq)
+{
+    // taps x0-1 (clamped at 0, VkResample.cpp:889) .. x0+2 (no upper clamp: x == uW is the next row's first pixel, quirk B5);
+    // reads past the plane: same column, last written row (see oracle) -- row <= uH and x <= uW here, so clamping the row and one
+    // conditional step back (only the right taps can need it) cover every case the oracle's loop does
+    const unsigned base = (unsigned)(row < uH ? row : uH - 1) * uW;
+    if constexpr (EVEN) {
+        const double2 v = *(const double2*)(R + base + xo[1]);
+        L[1] = tap_f64(upsq, v.x);
+        L[2] = tap_f64(upsq, v.y);
+        L[0] = dpp_f64(L[2], 0.0, true);
+        L[3] = dpp_f64(L[1], 0.0, false);
+        if (edge_l) L[0] = tap_f64(upsq, R[base + xo[0]]);
+        if (edge_r) {
+            unsigned f = base + xo[3];
+            f = f >= plane ? f - uW : f;
+            L[3] = tap_f64(upsq, R[f]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned f = base + xo[i];
+            if (i >= 2) f = f >= plane ? f - uW : f;
+            L[i] = tap_f64(upsq, R[f]);
+        }
+    }
+}
+template <bool EVEN>
 __global__ void __launch_bounds__(256) k_sharpen_f64(SharpenParams p)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y, c = blockIdx.z;
+    constexpr int RPT = SHARPEN_F64_RPT;
+    const int lane = threadIdx.x;
+    const int x0 = ((blockIdx.x * 4 + threadIdx.y) * 64 + lane) * 2;      // (a workgroup: 512 pixels = 4 KB of RPT rows)
+    const int y0 = blockIdx.y * RPT;
+    const int c = blockIdx.z;
     const int uW = p.uW, uH = p.uH;
-    if (x >= uW) return;
-    const long plane = (long)uW * uH;
-    const double* R = (const double*)p.R + c * plane;
-    const int xs[3] = {x > 0 ? x - 1 : x, x, x + 1};
-    const int ys[3] = {y > 0 ? y - 1 : y, y, y + 1};
-    double len[9];
+    if (x0 >= uW) return;
+    const unsigned plane = (unsigned)uW * (unsigned)uH;
+    const double* R = (const double*)p.R + (long)c * plane;
+    double* out = (double*)p.out + (long)c * plane;
+    const double upsq = (double)p.upsq, m2coef = -2.0 * (double)p.coef;
+    // (x0 + 2 > uW: the tap of a pixel beyond the row -- odd widths -- unused)
+    const unsigned xo[4] = {(unsigned)(x0 > 0 ? x0 - 1 : 0), (unsigned)x0, (unsigned)(x0 + 1), (unsigned)(x0 + 2 > uW ? uW : x0 + 2)};
+    const bool edge_l = lane == 0, edge_r = lane == 63 || x0 + 2 >= uW;      // (the lane above has left the kernel)
+    double a[4], b[4], cc[4];
+    sharpen_f64_row<EVEN>(a, R, plane, uW, uH, y0 > 0 ? y0 - 1 : 0, xo, edge_l, edge_r, upsq);
+    sharpen_f64_row<EVEN>(b, R, plane, uW, uH, y0, xo, edge_l, edge_r, upsq);
+#pragma unroll 2
+    for (int r = 0; r < RPT; r++) {
+        const int y = y0 + r;
+        if (y >= uH) break;
+        sharpen_f64_row<EVEN>(cc, R, plane, uW, uH, y + 1, xo, edge_l, edge_r, upsq);
+        double vmn[4], vmx[4], o[2];
 #pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int b = 0; b < 3; b++) {
-            long f = (long)ys[a] * uW + xs[b];
-            while (f >= plane) f -= uW;
-            double t = fabs((double)p.upsq * R[f]);
-            len[a * 3 + b] = fmin(fmax(t, 0.0), 1.0);
+        for (int i = 0; i < 4; i++) {
+            vmn[i] = min_f64(min_f64(a[i], b[i]), cc[i]);
+            vmx[i] = max_f64(max_f64(a[i], b[i]), cc[i]);
         }
-    ((double*)p.out)[c * plane + (long)y * uW + x] = sharpen_px_f64(len, (double)p.coef);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const double mn1 = min_f64(min_f64(vmn[k], vmn[k + 1]), vmn[k + 2]), mx1 = max_f64(max_f64(vmx[k], vmx[k + 1]), vmx[k + 2]);
+            const double mn0 = min_f64(min_f64(vmn[k + 1], b[k]), b[k + 2]), mx0 = max_f64(max_f64(vmx[k + 1], b[k]), b[k + 2]);
+            // (len[1] + len[3]) + len[5]) + len[7] = ((N + W) + E) + S, left to right as the shader (VkResample.cpp:921)
+            const double s4 = ((a[k + 1] + b[k]) + b[k + 2]) + cc[k + 1];
+            o[k] = sharpen_eval_f64(s4, b[k + 1], mn0, mn1, mx0, mx1, m2coef);
+        }
+        double* dst = out + ((unsigned)y * (unsigned)uW + (unsigned)x0);
+        if constexpr (EVEN) {
+            typedef double d2v __attribute__((ext_vector_type(2)));
+            d2v val = {o[0], o[1]};
+            __builtin_nontemporal_store(val, (d2v*)dst);
+        } else {
+            dst[0] = o[0];
+            if (x0 + 1 < uW) dst[1] = o[1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a[i] = b[i]; b[i] = cc[i]; }
+    }
 }
 
 // VkResample.cpp:1650-1668: x = (double)v / 255.0
