@@ -679,8 +679,8 @@ def test_one_plan_fed_by_several_host_threads(W, H, precision, flags, ring):
         up.drain()
 
 
-@pytest.mark.parametrize("W,H,u", [(16, 8, 2.0), (60, 42, 2.0), (24, 16, 3.0), (16, 8, 1.5), (256, 128, 2.0),
-                                   (240, 270, 2.0), (1024, 512, 2.0), (2048, 64, 2.0)])
+@pytest.mark.parametrize("W,H,u", [(16, 8, 2.0), (60, 42, 2.0), (24, 16, 3.0), (16, 8, 1.5), (32, 16, 1.25), (256, 128, 2.0),
+                                   (240, 270, 2.0), (1024, 512, 2.0), (2048, 64, 2.0), (64, 2048, 2.0), (96, 1200, 2.5)])
 @pytest.mark.parametrize("dist", ["U", "N"])
 def test_fp64_parity(W, H, u, dist):
     """-p 1: double buffers and double arithmetic end to end; the oracle is fp64 too, so the two

@@ -520,6 +520,62 @@ __device__ __forceinline__ void stage_lds_inplace(C* __restrict__ buf, int N, in
 }
 __host__ __device__ constexpr bool stage_fits_inplace(int N, int R, int T, int PT) { return N / R <= (PT / R) * T; }
 
+// ... and on TK interleaved sequences (element n of sequence col at lpad(n * TK + col)): the column kernel's form.  A thread runs
+// up to PT / R butterflies of the N / R * TK of a stage: needs N / R * TK <= (PT / R) * T.
+template <int R, int DIR, int PT, int TK, typename C>
+__device__ __forceinline__ void stage_lds_inplace_tk(C* __restrict__ buf, int N, int Ns, const C* __restrict__ tw, int tid, int T)
+{
+    constexpr int NBT = PT / R;
+    const int nb = N / R;
+    const int tstep = nb / Ns;
+    const bool ns_pow2 = (Ns & (Ns - 1)) == 0;
+    C v[NBT][R];
+#pragma unroll
+    for (int b = 0; b < NBT; b++) {
+        const int g = tid + b * T;
+        if (g < nb * TK) {
+            const int col = g % TK, j = g / TK;
+#pragma unroll
+            for (int m = 0; m < R; m++) v[b][m] = buf[lpad((j + m * nb) * TK + col)];
+        }
+    }
+    __syncthreads();                            // every input of the stage is in somebody's registers
+#pragma unroll
+    for (int b = 0; b < NBT; b++) {
+        const int g = tid + b * T;
+        if (g < nb * TK) {
+            const int col = g % TK, j = g / TK;
+            const int k = ns_pow2 ? (j & (Ns - 1)) : (j % Ns);
+            if (Ns > 1) apply_twiddles<R, DIR>(v[b], tw, k * tstep);
+            bfly<R, DIR>(v[b]);
+            const int j0 = (j - k) * R + k;
+#pragma unroll
+            for (int m = 0; m < R; m++) buf[lpad((j0 + m * Ns) * TK + col)] = v[b][m];
+        }
+    }
+    __syncthreads();
+}
+constexpr int COL_INPLACE_PT = 8;        // points per thread of the in-place column kernel (k_col<TK, double2, true>; the plan checks with it)
+__host__ __device__ constexpr bool stage_fits_inplace_tk(int N, int TK, int R, int T, int PT) { return (N / R) * TK <= (PT / R) * T; }
+template <int DIR, int PT, int TK, typename C>
+__device__ __forceinline__ void fft_lds_inplace_tk(C* a, const StagePlan& P, const C* __restrict__ tw, int tid, int T)
+{
+    const int N = P.n;
+    int Ns = 1;
+    for (int s = 0; s < P.nstages; s++) {
+        const int R = P.radix[s];
+        switch (R) {
+        case 8: stage_lds_inplace_tk<8, DIR, PT, TK>(a, N, Ns, tw, tid, T); break;
+        case 4: stage_lds_inplace_tk<4, DIR, PT, TK>(a, N, Ns, tw, tid, T); break;
+        case 2: stage_lds_inplace_tk<2, DIR, PT, TK>(a, N, Ns, tw, tid, T); break;
+        case 3: stage_lds_inplace_tk<3, DIR, PT, TK>(a, N, Ns, tw, tid, T); break;
+        case 5: stage_lds_inplace_tk<5, DIR, PT, TK>(a, N, Ns, tw, tid, T); break;
+        default: stage_lds_inplace_tk<7, DIR, PT, TK>(a, N, Ns, tw, tid, T); break;
+        }
+        Ns *= R;
+    }
+}
+
 // Data in `a` (valid after a barrier executed by the caller); the result is left in `a` (synced).
 template <int DIR, int PT, typename C>
 __device__ __forceinline__ void fft_lds_inplace(C* a, const StagePlan& P, const C* __restrict__ tw, int tid, int T)

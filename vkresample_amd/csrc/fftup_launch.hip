@@ -152,8 +152,17 @@ int kernels_set_attributes(fftup_plan* P)
             }
         }
         if (P->dbl) {
-            if (!cplx) { SET_LDS((k_row_r2c<IN_F64, double2>), P->ldsRowF); SET_LDS((k_row_c2r<false, double2>), P->ldsRowI); }
-            if (!P->colF.on) switch (P->TK) {
+            if (!cplx) {
+                if (P->inplaceF) SET_LDS((k_row_r2c<IN_F64, double2, true>), P->ldsRowF); else SET_LDS((k_row_r2c<IN_F64, double2>), P->ldsRowF);
+                if (P->inplaceI) SET_LDS((k_row_c2r<false, double2, true>), P->ldsRowI); else SET_LDS((k_row_c2r<false, double2>), P->ldsRowI);
+            }
+            if (P->inplaceC) switch (P->TK) {
+            case 8: SET_LDS((k_col<8, double2, true>), P->ldsCol); break;
+            case 4: SET_LDS((k_col<4, double2, true>), P->ldsCol); break;
+            case 2: SET_LDS((k_col<2, double2, true>), P->ldsCol); break;
+            default: SET_LDS((k_col<1, double2, true>), P->ldsCol); break;
+            }
+            else if (!P->colF.on) switch (P->TK) {
             case 8: SET_LDS((k_col<8, double2>), P->ldsCol); break;
             case 4: SET_LDS((k_col<4, double2>), P->ldsCol); break;
             case 2: SET_LDS((k_col<2, double2>), P->ldsCol); break;
@@ -325,7 +334,8 @@ static int launch_frame_f64(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, 
         p.S1 = (double2*)P->lanes[P->cur].S1; p.tw = (const double2*)P->twW; p.plan = P->planW; p.W = (int)P->W; p.H = (int)P->H;
         p.TK = P->TK; p.NT = P->NT;
         p.in = P->in_planar[in_slot]; p.in_row_stride = P->W; p.in_plane_stride = (long)P->in_plane_stride;
-        hipLaunchKernelGGL((k_row_r2c<IN_F64, double2>), dim3(P->H / 2, 3), dim3(P->thrW), P->ldsRowF, st, p);
+        if (P->inplaceF) hipLaunchKernelGGL((k_row_r2c<IN_F64, double2, true>), dim3(P->H / 2, 3), dim3(P->thrW), P->ldsRowF, st, p);
+        else hipLaunchKernelGGL((k_row_r2c<IN_F64, double2>), dim3(P->H / 2, 3), dim3(P->thrW), P->ldsRowF, st, p);
     }
     if ((which < 0 || which == 1) && P->colF.on) (void)four_columns<double2, false>(P, st);
     else if (which < 0 || which == 1) {
@@ -335,7 +345,13 @@ static int launch_frame_f64(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, 
         p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.ncols = P->ncols; p.zly = P->zly; p.zry = P->zry;
         p.inv_norm = 1.0 / (double)P->uH;
         dim3 grid(P->NT, 3), block(P->thrCol);
-        switch (P->TK) {
+        if (P->inplaceC) switch (P->TK) {
+        case 8: hipLaunchKernelGGL((k_col<8, double2, true>), grid, block, P->ldsCol, st, p); break;
+        case 4: hipLaunchKernelGGL((k_col<4, double2, true>), grid, block, P->ldsCol, st, p); break;
+        case 2: hipLaunchKernelGGL((k_col<2, double2, true>), grid, block, P->ldsCol, st, p); break;
+        default: hipLaunchKernelGGL((k_col<1, double2, true>), grid, block, P->ldsCol, st, p); break;
+        }
+        else switch (P->TK) {
         case 8: hipLaunchKernelGGL((k_col<8, double2>), grid, block, P->ldsCol, st, p); break;
         case 4: hipLaunchKernelGGL((k_col<4, double2>), grid, block, P->ldsCol, st, p); break;
         case 2: hipLaunchKernelGGL((k_col<2, double2>), grid, block, P->ldsCol, st, p); break;
@@ -347,7 +363,8 @@ static int launch_frame_f64(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, 
         p.S2 = (const double2*)P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = (const double2*)P->twUW; p.plan = P->planUW;
         p.W = (int)P->W; p.uW = (int)P->uW; p.uH = (int)P->uH; p.TK = P->TK; p.NT = P->NT; p.zlx = P->zlx; p.zrx = P->zrx;
         p.inv_norm = 1.0 / (double)P->uW;
-        hipLaunchKernelGGL((k_row_c2r<false, double2>), dim3(P->uH / 2, 3), dim3(P->thrUW), P->ldsRowI, st, p);
+        if (P->inplaceI) hipLaunchKernelGGL((k_row_c2r<false, double2, true>), dim3(P->uH / 2, 3), dim3(P->thrUW), P->ldsRowI, st, p);
+        else hipLaunchKernelGGL((k_row_c2r<false, double2>), dim3(P->uH / 2, 3), dim3(P->thrUW), P->ldsRowI, st, p);
     }
     if (which < 0 || which == 3) {
         SharpenParams p{};

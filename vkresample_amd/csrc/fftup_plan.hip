@@ -389,8 +389,19 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             P->TK = TUNED_TK;
             P->ldsCol = kernels_tuned_col_lds(H);
         } else {
+            // -p 1 R2C plans: ONE buffer where every stage of both column transforms runs in place with COL_INPLACE_PT points per thread (k_col<.., true>)
+            if (P->dbl && !cplx) {
+                for (int tk : {8, 4, 2, 1}) {
+                    const size_t need = P->csz * (size_t)lpad_size((int)uH * tk);
+                    const int thr = std::min(kernels_generic_max_threads(true), std::max(64, round_up((int)uH * tk / 8, 64)));
+                    bool ok = need <= lds_max / 2 && (size_t)(H / 2) * tk <= (size_t)COL_INPLACE_PT * thr;       // (two workgroups per compute unit)
+                    for (const StagePlan* sp : {&P->planH, &P->planUH})
+                        for (int st = 0; st < sp->nstages && ok; st++) ok = stage_fits_inplace_tk(sp->n, tk, sp->radix[st], thr, COL_INPLACE_PT);
+                    if (ok) { P->TK = tk; P->ldsCol = need; P->inplaceC = true; break; }
+                }
+            }
             // column tile width: widest of 8,4,2,1 whose ping-pong buffers fit in LDS
-            for (int tk : {8, 4, 2, 1}) {
+            if (!P->TK) for (int tk : {8, 4, 2, 1}) {
                 size_t need = 2 * P->csz * (size_t)lpad_size((int)uH * tk);
                 if (need <= lds_max) { P->TK = tk; P->ldsCol = need; break; }
             }
@@ -461,6 +472,17 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             P->thrW = std::min(tmax, std::max(64, round_up((int)W / 8, 64)));
             P->thrUW = std::min(tmax, std::max(64, round_up((int)uW / 8, 64)));
             P->thrCol = std::min(tmax, std::max(64, round_up((int)uH * P->TK / 8, 64)));
+            // -p 1 R2C rows: one LDS buffer where every stage runs in place with 8 points per thread (two workgroups per compute unit)
+            if (P->dbl && !cplx) {
+                auto fits = [](const StagePlan& sp, int thr) {
+                    for (int st = 0; st < sp.nstages; st++)
+                        if (!stage_fits_inplace(sp.n, sp.radix[st], thr, 8)) return false;
+                    return true;
+                };
+                P->inplaceF = fits(P->planW, P->thrW); P->inplaceI = fits(P->planUW, P->thrUW);
+                if (P->inplaceF) P->ldsRowF /= 2;
+                if (P->inplaceI) P->ldsRowI /= 2;
+            }
         }
 
         P->upsq = const_via_percent_f((double)(cfg->upscale * cfg->upscale), P->half);   // VkResample.cpp:1615

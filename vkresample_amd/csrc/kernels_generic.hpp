@@ -64,8 +64,11 @@ template <int MODE, typename P> __device__ __forceinline__ auto load_px(const P&
 }
 
 // grid (H/2, 3); dynamic LDS = 2 * lpad_size(W) complex
-template <int MODE, typename C = float2>
-__global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_r2c(RowR2CParamsT<C> p)
+// INPLACE (-p 1 plans whose stages allow it, stage_fits_inplace with 8 points per thread): ONE buffer, two workgroups per compute
+// unit instead of one (a 4096-point double2 row pair: 70 instead of 139 KB) -- these kernels wait for LDS and twiddle loads
+// most of the time, a second resident workgroup fills the gaps
+template <int MODE, typename C = float2, bool INPLACE = false>
+__global__ void __launch_bounds__(GenericMaxThreads<C>::value, INPLACE ? 4 : 1) k_row_r2c(RowR2CParamsT<C> p)
 {
     using S = scalar_t<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,7 +80,9 @@ __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_r2c(RowR2CP
     for (int n = tid; n < W; n += T)
         a[lpad(n)] = mk<C>(load_px<MODE>(p, c, 2 * j, n), load_px<MODE>(p, c, 2 * j + 1, n));
     __syncthreads();
-    const C* Z = fft_lds<+1, 1>(a, b, p.plan, p.tw, tid, T);
+    const C* Z = a;
+    if constexpr (INPLACE) fft_lds_inplace<+1, 8>(a, p.plan, p.tw, tid, T);
+    else Z = fft_lds<+1, 1>(a, b, p.plan, p.tw, tid, T);
     // unpack two real rows (vkFFT.h:4292-4323): A = (Z[k]+conj Z[W-k])/2, B = (Z[k]-conj Z[W-k])/(2i)
     const long tile_stride = (long)p.H * p.TK;
     C* base = p.S1 + (long)c * p.NT * tile_stride;
@@ -106,8 +111,11 @@ template <typename C> struct ColParamsT {
 using ColParams = ColParamsT<float2>;
 
 // grid (NT, 3); dynamic LDS = 2 * lpad_size(uH*TK) complex
-template <int TK, typename C = float2>
-__global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_col(ColParamsT<C> p)
+// INPLACE (-p 1 plans whose stages allow it, stage_fits_inplace_tk with COL_INPLACE_PT points per thread): ONE buffer of uH * TK -- twice the tile
+// width in the same LDS (64-byte instead of 32-byte pieces for the row kernels on either side), and the shift between the two
+// transforms moves the upper half of the spectrum through registers instead of copying everything into the second buffer.
+template <int TK, typename C = float2, bool INPLACE = false>
+__global__ void __launch_bounds__(GenericMaxThreads<C>::value, INPLACE ? 4 : 1) k_col(ColParamsT<C> p)
 {
     using S = scalar_t<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,21 +132,51 @@ __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_col(ColParamsT<
         a[lpad(e)] = v;
     }
     __syncthreads();
-    C* F = fft_lds<+1, TK>(a, b, p.planH, p.twH, tid, T);
-    C* G = (F == a) ? b : a;
-    // shift (VkResample.cpp:514-526): buffer row ky' holds F[ky'-(uH-H)] for ky' >= uH-H/2, else the
-    // un-shifted F[ky'] while ky' < H; then the zero-padding read guard of the inverse plan.
-    for (int e = tid; e < uH * TK; e += T) {
-        const int ky = e / TK, col = e % TK;
-        C v = mk<C>(S(0), S(0));
-        if (!(ky >= p.zly && ky < p.zry)) {
-            if (ky >= uH - H / 2) v = F[lpad((ky - (uH - H)) * TK + col)];
-            else if (ky < H) v = F[lpad(e)];
+    const C* D;
+    if constexpr (INPLACE) {
+        fft_lds_inplace_tk<+1, COL_INPLACE_PT, TK>(a, p.planH, p.twH, tid, T);
+        // shift (VkResample.cpp:514-526) and the zero-padding read guard of the inverse plan, as below, within the one buffer:
+        // rows [H/2, H) of F go to [uH - H/2, uH) -- through registers, the two ranges overlap for factors below 1.5 -- the
+        // rows in [zly, zry) are read as zero, rows below H keep the un-shifted F
+        constexpr int PT = COL_INPLACE_PT;
+        C up[PT];
+        const int nup = (H - H / 2) * TK, e0 = (H / 2) * TK;
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            const int e = tid + i * T;
+            if (e < nup) up[i] = a[lpad(e0 + e)];
         }
-        G[lpad(e)] = v;
+        __syncthreads();
+        for (int e = H * TK + tid; e < uH * TK; e += T) a[lpad(e)] = mk<C>(S(0), S(0));    // (rows of F never written: H <= ky < uH)
+        __syncthreads();
+        const int d0 = (uH - (H - H / 2)) * TK;                                             // row uH - H + H/2
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            const int e = tid + i * T;
+            if (e < nup) a[lpad(d0 + e)] = up[i];
+        }
+        __syncthreads();
+        for (int e = p.zly * TK + tid; e < p.zry * TK; e += T) a[lpad(e)] = mk<C>(S(0), S(0));
+        __syncthreads();
+        fft_lds_inplace_tk<-1, COL_INPLACE_PT, TK>(a, p.planUH, p.twUH, tid, T);
+        D = a;
+    } else {
+        C* F = fft_lds<+1, TK>(a, b, p.planH, p.twH, tid, T);
+        C* G = (F == a) ? b : a;
+        // shift (VkResample.cpp:514-526): buffer row ky' holds F[ky'-(uH-H)] for ky' >= uH-H/2, else the
+        // un-shifted F[ky'] while ky' < H; then the zero-padding read guard of the inverse plan.
+        for (int e = tid; e < uH * TK; e += T) {
+            const int ky = e / TK, col = e % TK;
+            C v = mk<C>(S(0), S(0));
+            if (!(ky >= p.zly && ky < p.zry)) {
+                if (ky >= uH - H / 2) v = F[lpad((ky - (uH - H)) * TK + col)];
+                else if (ky < H) v = F[lpad(e)];
+            }
+            G[lpad(e)] = v;
+        }
+        __syncthreads();
+        D = fft_lds<-1, TK>(G, F, p.planUH, p.twUH, tid, T);
     }
-    __syncthreads();
-    const C* D = fft_lds<-1, TK>(G, F, p.planUH, p.twUH, tid, T);
     C* dst = p.S2 + ((long)c * p.NT + tile) * uH * TK;
     for (int e = tid; e < uH * TK; e += T)
         if ((e % TK) < ncol_valid) dst[e] = cscale(D[lpad(e)], p.inv_norm);
@@ -158,8 +196,8 @@ template <typename C> struct RowC2RParamsT {
 using RowC2RParams = RowC2RParamsT<float2>;
 
 // grid (uH/2, 3); dynamic LDS = 2 * lpad_size(uW) complex
-template <bool HALF_OUT, typename C = float2>
-__global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_c2r(RowC2RParamsT<C> p)
+template <bool HALF_OUT, typename C = float2, bool INPLACE = false>
+__global__ void __launch_bounds__(GenericMaxThreads<C>::value, INPLACE ? 4 : 1) k_row_c2r(RowC2RParamsT<C> p)
 {
     using S = scalar_t<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -187,7 +225,9 @@ __global__ void __launch_bounds__(GenericMaxThreads<C>::value) k_row_c2r(RowC2RP
         a[lpad(0)] = mk<C>(A.x - B.y, A.y + B.x);
     }
     __syncthreads();
-    const C* z = fft_lds<-1, 1>(a, b, p.plan, p.tw, tid, T);
+    const C* z = a;
+    if constexpr (INPLACE) fft_lds_inplace<-1, 8>(a, p.plan, p.tw, tid, T);
+    else z = fft_lds<-1, 1>(a, b, p.plan, p.tw, tid, T);
     const long plane = (long)uW * p.uH;
     for (int n = tid; n < uW; n += T) {
         C v = cscale(z[lpad(n)], p.inv_norm);
