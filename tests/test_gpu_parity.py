@@ -961,3 +961,16 @@ def test_four_step_plans_in_a_ring():
             for s in range(3):
                 assert np.array_equal(up.download_planar(s), single[s])
         assert not np.array_equal(single[0], single[1])
+
+
+def test_two_pixel_wide_image():
+    """uW = 2 (the smallest width the reference's even-size rule admits): the two-launch sharpen computed its grid as uW / 4 / 256
+    rounded up -- zero workgroups, a launch error -- until round 5."""
+    from vkresample_amd import synth
+    rgb = synth.frame(1, 2, 4, "N")
+    with _up(2, 4, 1.0, 0, 0.2, 0) as up:
+        up.upload_rgb8(rgb)
+        up.execute(1)
+        out = up.download_planar().astype(np.float64)
+    _, oout, _ = O.upscale_rgb8(rgb, 1.0, 0, 0.2)
+    assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 2e-5

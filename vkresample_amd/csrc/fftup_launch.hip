@@ -595,7 +595,7 @@ int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
     } else if (which < 0 || which == 3) {
         SharpenParams p{};
         p.R = P->lanes[P->cur].R; p.out = P->out[out_slot]; p.uW = (int)P->uW; p.uH = (int)P->uH; p.upsq = P->upsq; p.coef = P->coef;
-        dim3 grid((P->uW / 4 + 255) / 256, P->uH, 3), block(256);
+        dim3 grid((P->uW + 1023) / 1024, P->uH, 3), block(256);      // (four pixels per thread; a width of 2 gave an empty grid until round 5)
         if (P->half) hipLaunchKernelGGL(k_sharpen<true>, grid, block, 0, P->lanes[P->cur].stream, p);
         else hipLaunchKernelGGL(k_sharpen<false>, grid, block, 0, P->lanes[P->cur].stream, p);
     }
