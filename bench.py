@@ -440,6 +440,9 @@ def rccl_selfcheck(dev):
 
 def main():
     args = parse_args()
+    # the pool's host driver supports dmabuf IPC only: without this RCCL's multi-process bring-up fails in hipIpcGetMemHandle
+    # (exported on the boxes already; kept in every environment built here, ranks started by spawn_ranks included)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
