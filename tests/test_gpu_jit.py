@@ -84,6 +84,10 @@ U_CASES = [
     (1920, 1080, 1.25),  # 1080p -> 2400 x 1350
     (1024, 768, 1.75),   # 7/4: first radix 7, NI = 2
     (1280, 720, 2.25),   # 9/4: first radix 9, NI = 4
+    # an odd number of eighths (round 5, DD = 4): the two such factors whose numerator is a radix of the engine
+    (1280, 720, 1.125),  # 9/8: 720p -> 1440 x 810, first radix 9, NI = 4 of 9 first-stage inputs non-zero
+    (1024, 576, 1.875),  # 15/8: -> 1920 x 1080, first radix 15, NI = 4 of 15
+    (2048, 1024, 1.125), # -> 2304 x 1152
     (640, 480, 7.0),     # -u 7: first radix 14 = 2 x 7 (round 5), six residue transforms in the column kernel
     (320, 240, 7.0),
     (640, 480, 3.5),     # 7/2: first radix 14 as well

@@ -377,7 +377,7 @@ def test_jit_chooser_invariants_over_all_sizes():
     seen = 0
     for i, W in enumerate(smooth):
         H = smooth[(i * 7 + 3) % len(smooth)]
-        for u in (1.25, 1.5, 1.75, 2.0, 2.5, 3.0, 4.0, 5.0, 7.0, 8.0):
+        for u in (1.125, 1.25, 1.5, 1.75, 1.875, 2.0, 2.5, 3.0, 4.0, 5.0, 7.0, 8.0):
             rc = lib.fftup_jit_check(W, H, u, 0, b"", buf, 512)
             assert rc in (0, 2, 1), (W, H, u, rc)
             if rc != 0:
@@ -385,7 +385,7 @@ def test_jit_chooser_invariants_over_all_sizes():
             seen += 1
             d = buf.value.decode()
             UW, UH = int(u * W), int(u * H)
-            D, DD = (int(2 * u), 1) if 2 * u == int(2 * u) else (int(4 * u), 2)     # the factor as D / (2 DD)
+            D, DD = (int(2 * u), 1) if 2 * u == int(2 * u) else (int(4 * u), 2) if 4 * u == int(4 * u) else (int(8 * u), 4)     # the factor as D / (2 DD)
             assert UW % 4 == 0 and UW <= 8192
             m = re.search(r"row (.*?), col (.*?), fused (.*?) \((\d+) B LDS", d)
             assert m, d

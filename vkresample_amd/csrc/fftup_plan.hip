@@ -138,16 +138,17 @@ static bool jit_enabled()
     return !e || atoi(e) != 0;
 }
 // The upscale factor as D / (2 DD) when the specialised kernels' assumptions hold: an integer or half-integer factor in [1.5, 8]
-// (DD = 1, D = 2u) or a quarter-integer one (DD = 2, D = 4u odd: -u 1.25, 1.75, 2.25 ...; round 5), output sizes exactly u W and u H,
+// (DD = 1, D = 2u), a quarter-integer one (DD = 2, D = 4u odd: -u 1.25, 1.75, 2.25 ...; round 5) or an odd number of eighths (DD = 4: -u 1.125, 1.875), output sizes exactly u W and u H,
 // and the reference's zero-padding guard of the column pass (float arithmetic, VkResample.cpp:1494-1495) exactly
 // [H/2, uH - H/2).  Returns D (0: none of that) and sets *DD.
 static int jit_factor(float upscale, uint32_t W, uint32_t H, uint32_t uW, uint32_t uH, int zly, int zry, int* DD)
 {
     int D = 0;
     *DD = 1;
-    const float two_u = 2.0f * upscale, four_u = 4.0f * upscale;
+    const float two_u = 2.0f * upscale, four_u = 4.0f * upscale, eight_u = 8.0f * upscale;
     if ((float)(int)two_u == two_u) D = (int)two_u;
     else if ((float)(int)four_u == four_u) { D = (int)four_u; *DD = 2; }
+    else if ((float)(int)eight_u == eight_u) { D = (int)eight_u; *DD = 4; }      // eighths: -u 1.125 = 9/8, 1.875 = 15/8 (first radix 9, 15)
     else return 0;
     if (D < 3 || D > 16 * *DD) return 0;
     if (2 * (uint64_t)*DD * uW != (uint64_t)D * W || 2 * (uint64_t)*DD * uH != (uint64_t)D * H) return 0;

@@ -401,11 +401,11 @@ std::string fused_value(const Choice& c)
 // structural default (pow2 / 16*16*R / the chooser's pick), whatever the wisdom says -- the tuner times it as a candidate.
 bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, Choice& c, const std::string& arch, bool use_wisdom, int DD)
 {
-    // (DD = 2: quarter-integer factor D / 4, D odd -- like the half-integer ones one spectrum buffer with all rows, U = 1)
+    // (DD = 2 / 4: quarter- / eighth-integer factor D / 4, D / 8, D odd -- like the half-integer ones one spectrum buffer with all rows, U = 1)
     const int U = (DD == 1 && D % 2 == 0) ? D / 2 : 1;
     c.W = W; c.H = H; c.U = U; c.D = D; c.DD = DD; c.UW = D * W / (2 * DD); c.UH = D * H / (2 * DD); c.half = half;
     if (W < 64 || H < 64 || W > 8192 || H > 8192 || D < 3 || c.UW > 8192 || (D * W) % (2 * DD) || (D * H) % (2 * DD)) return false;
-    if (DD != 1 && (DD != 2 || D % 2 == 0 || D < 5)) return false;
+    if (DD != 1 && ((DD != 2 && DD != 4) || D % 2 == 0 || D <= 2 * DD)) return false;      // (the factor in lowest terms, above 1: D odd)
     if (c.UW % 4) return false;        // the sharpen works on quads of pixels (-u 5 with W = 2 * odd: the size-generic kernels)
     // ---- row R2C
     if (is_pow2(W) && W >= 256) { c.row_kind = 0; c.row_block = W / 8; }
@@ -562,7 +562,8 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT], int 
 
 std::string describe(const Choice& c)
 {
-    std::string s = c.DD == 2 ? "u" + std::to_string(c.D / 4) + (c.D % 4 == 1 ? ".25 row " : ".75 row ")
+    std::string s = c.DD == 4 ? "u" + std::to_string(c.D / 8) + "." + std::to_string(c.D % 8 * 125) + " row "
+                    : c.DD == 2 ? "u" + std::to_string(c.D / 4) + (c.D % 4 == 1 ? ".25 row " : ".75 row ")
                     : c.D == 4 ? "row " : (c.D % 2 ? "u" + std::to_string(c.D / 2) + ".5 row " : "u" + std::to_string(c.U) + " row ");
     auto star = [](const std::vector<int>& v) { std::string t; for (size_t i = 0; i < v.size(); i++) t += (i ? "*" : "") + std::to_string(v[i]); return t; };
     s += c.row_kind == 2 ? "generic" : c.row_kind == 0 ? "pow2/8" : c.row_kind == 3 ? star(c.rn) : std::to_string(c.rr[0]) + "*" + std::to_string(c.rr[1]) + "*" + std::to_string(c.rr[2]);
