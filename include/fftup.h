@@ -137,7 +137,7 @@ FFTUP_API int fftup_plan_describe(const fftup_plan* plan, char* buf, size_t bufl
 
 /* Run-time specialised plans (csrc/jit.hpp; the counterpart of VkFFT generating and compiling its shaders for the
  * requested size at plan time, VF:4707-5189 + the GLSL generator, glslang in VkResample's link line).  A plan with an
- * integer, half-integer or quarter-integer upscale factor (-u 1.25, 1.5, 1.75, 2, 2.25, 2.5, 3, 3.5, 4, 5, 6, 7, 8; -p 0 / -p 2; H <= 8192,
+ * integer, half-, quarter- or eighth-integer upscale factor or a ratio over 3, 5 or 7 whose sizes come out exact (-u 1.125, 1.2, 1.25, 4/3, 1.4, 1.5, 1.6, 5/3, 1.75, 1.875, 2, 2.25, 2.5, 8/3, 3, 3.5, 4, 5, 6, 7, 8; -p 0 / -p 2; H <= 8192,
  * u*W <= 8192, 4 | u*W, u*H even)
  * whose size has no ahead-of-time
  * kernels gets its row, column and fused C2R+sharpen kernels

@@ -88,6 +88,16 @@ U_CASES = [
     (1280, 720, 1.125),  # 9/8: 720p -> 1440 x 810, first radix 9, NI = 4 of 9 first-stage inputs non-zero
     (1024, 576, 1.875),  # 15/8: -> 1920 x 1080, first radix 15, NI = 4 of 15
     (2048, 1024, 1.125), # -> 2304 x 1152
+    # ratios with denominator 3, 5, 7 (round 5, DD = 3, 5, 7): whatever float the caller passes, where the reference's float arithmetic
+    # gives exact output sizes and the symmetric guard for THIS size (fftup_plan.hip: jit_factor)
+    (1920, 1080, float(np.float32(4.0 / 3.0))),   # 1080p -> 1440p: fused 16*16*10, NI = 6 of 16 first-stage inputs non-zero
+    (960, 540, float(np.float32(4.0 / 3.0))),     # -> 720p
+    (1600, 900, 1.6),                             # 8/5: 900p -> 1440p
+    (1000, 500, 1.4),                             # 7/5: first radix 14
+    (1152, 648, float(np.float32(5.0 / 3.0))),    # 5/3: -> 1080p, first radix 10
+    (1280, 720, 1.2),                             # 6/5: first radix 12
+    (768, 432, float(np.float32(8.0 / 3.0))),     # 8/3
+    (1120, 630, float(np.float32(8.0 / 7.0))),    # 8/7: -> 720p
     (640, 480, 7.0),     # -u 7: first radix 14 = 2 x 7 (round 5), six residue transforms in the column kernel
     (320, 240, 7.0),
     (640, 480, 3.5),     # 7/2: first radix 14 as well

@@ -47,6 +47,16 @@ def _cases_specialised():
     while len(out) < int(os.environ.get("FFTUP_SWEEP_JIT_N", "16")):  # (a one-off 400-case run is logged in profiles/)
         W, H = int(rng.choice(SMOOTH_BIG)), int(rng.choice(SMOOTH_BIG))
         u = float(rng.choice([2.0, 2.0, 2.0, 3.0, 4.0, 5.0, 1.5, 1.5, 2.5, 1.25, 1.75, 2.25]))
+        if os.environ.get("FFTUP_SWEEP_RATIOS", "0") != "0":                    # (one-off runs: eighths and ratios over 3, 5, 7 as well)
+            u = float(np.float32(rng.choice([1.125, 1.875, 4 / 3, 5 / 3, 8 / 3, 1.2, 1.4, 1.6, 8 / 7, 2.0, 1.5])))
+            uW, uH = int(np.float32(u) * np.float32(W)), int(np.float32(u) * np.float32(H))
+            num, den = next((round(2 * dd * u), 2 * dd) for dd in (1, 2, 4, 3, 5, 7) if abs(2 * dd * u - round(2 * dd * u)) < 1e-5 * 2 * dd * u)
+            # (exact sizes, even, smooth, whole quads; the guard's float arithmetic may still say no: then the case checks the fallback's parity)
+            if uW * den != num * W or uH * den != num * H or uW % 4 or uH % 2 or uW > 8192 or uW * uH > 3 << 20 or not _smooth(uW) or not _smooth(uH):
+                continue
+            p = int(rng.choice([0, 0, 2]))
+            out.append((W, H, u, p, int(rng.choice([0, 2])), float(rng.choice([0.2, 0.2, 0.05])), len(out)))
+            continue
         if u * W > 8192 or u * u * W * H > 3 << 20 or (2 * u * W) % 4 or (2 * u * H) % 4 or not _smooth(int(u * W)) or not _smooth(int(u * H)):
             continue
         if (4 * u) % 2 and ((u * W) % 4 or (u * H) % 2):                       # quarter-integer factors: whole, even output sizes

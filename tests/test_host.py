@@ -358,6 +358,7 @@ def test_jit_chooser_invariants_over_all_sizes():
     160 KB, at most 1024 threads.  (No compilation: arch = "".)"""
     import ctypes as C
     import re
+    import numpy as np
     from vkresample_amd import _lib
     lib = _lib.load()
     buf = C.create_string_buffer(512)
@@ -377,15 +378,16 @@ def test_jit_chooser_invariants_over_all_sizes():
     seen = 0
     for i, W in enumerate(smooth):
         H = smooth[(i * 7 + 3) % len(smooth)]
-        for u in (1.125, 1.25, 1.5, 1.75, 1.875, 2.0, 2.5, 3.0, 4.0, 5.0, 7.0, 8.0):
+        for u in (1.125, 1.25, 1.5, 1.75, 1.875, 2.0, 2.5, 3.0, 4.0, 5.0, 7.0, 8.0, float(np.float32(4 / 3)), 1.6, 1.4, float(np.float32(5 / 3))):
             rc = lib.fftup_jit_check(W, H, u, 0, b"", buf, 512)
             assert rc in (0, 2, 1), (W, H, u, rc)
             if rc != 0:
                 continue
             seen += 1
             d = buf.value.decode()
-            UW, UH = int(u * W), int(u * H)
-            D, DD = (int(2 * u), 1) if 2 * u == int(2 * u) else (int(4 * u), 2) if 4 * u == int(4 * u) else (int(8 * u), 4)     # the factor as D / (2 DD)
+            UW, UH = int(np.float32(u) * np.float32(W)), int(np.float32(u) * np.float32(H))      # (float arithmetic, as VR:1417)
+            DD = next(dd for dd in (1, 2, 4, 3, 5, 7) if abs(2 * dd * u - round(2 * dd * u)) < 1e-5 * 2 * dd * u)       # the factor as D / (2 DD)
+            D = round(2 * DD * u)
             assert UW % 4 == 0 and UW <= 8192
             m = re.search(r"row (.*?), col (.*?), fused (.*?) \((\d+) B LDS", d)
             assert m, d

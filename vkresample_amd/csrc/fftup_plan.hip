@@ -138,22 +138,28 @@ static bool jit_enabled()
     return !e || atoi(e) != 0;
 }
 // The upscale factor as D / (2 DD) when the specialised kernels' assumptions hold: an integer or half-integer factor in [1.5, 8]
-// (DD = 1, D = 2u), a quarter-integer one (DD = 2, D = 4u odd: -u 1.25, 1.75, 2.25 ...; round 5) or an odd number of eighths (DD = 4: -u 1.125, 1.875), output sizes exactly u W and u H,
+// (DD = 1, D = 2u), a quarter-integer one (DD = 2, D = 4u odd: -u 1.25, 1.75, 2.25 ...; round 5), an odd number of eighths (DD = 4: -u 1.125, 1.875)
+// or a ratio with denominator 3, 5 or 7 (DD: -u 4/3, 5/3, 1.4, 1.6 ...), output sizes exactly u W and u H,
 // and the reference's zero-padding guard of the column pass (float arithmetic, VkResample.cpp:1494-1495) exactly
 // [H/2, uH - H/2).  Returns D (0: none of that) and sets *DD.
 static int jit_factor(float upscale, uint32_t W, uint32_t H, uint32_t uW, uint32_t uH, int zly, int zry, int* DD)
 {
-    int D = 0;
+    // denominators in the order of their use; lowest terms follow from taking the first that fits (2 DD uW = D W rules out the rest).
+    // A factor that is no binary fraction (4/3, 1.6 ...) is whatever float the caller passed: it joins when the reference's float
+    // arithmetic makes the output sizes and the guard come out exact for THIS size (-u 1.3333334 at 1920x1080 does, -u 1.2 at
+    // 1600x900 puts the guard at [449, ..): the size-generic kernels reproduce that)
     *DD = 1;
-    const float two_u = 2.0f * upscale, four_u = 4.0f * upscale, eight_u = 8.0f * upscale;
-    if ((float)(int)two_u == two_u) D = (int)two_u;
-    else if ((float)(int)four_u == four_u) { D = (int)four_u; *DD = 2; }
-    else if ((float)(int)eight_u == eight_u) { D = (int)eight_u; *DD = 4; }      // eighths: -u 1.125 = 9/8, 1.875 = 15/8 (first radix 9, 15)
-    else return 0;
-    if (D < 3 || D > 16 * *DD) return 0;
-    if (2 * (uint64_t)*DD * uW != (uint64_t)D * W || 2 * (uint64_t)*DD * uH != (uint64_t)D * H) return 0;
-    if (zly != (int)(H / 2) || zry != (int)(uH - H / 2)) return 0;
-    return D;
+    for (int dd : {1, 2, 4, 3, 5, 7}) {
+        const float t = 2.0f * (float)dd * upscale;
+        const int d = (int)lrintf(t);
+        if (fabsf(t - (float)d) > 1e-5f * t) continue;
+        if (d < 3 || d > 16 * dd || d <= 2 * dd - (dd == 1)) continue;
+        if (2 * (uint64_t)dd * uW != (uint64_t)d * W || 2 * (uint64_t)dd * uH != (uint64_t)d * H) continue;
+        if (zly != (int)(H / 2) || zry != (int)(uH - H / 2)) return 0;
+        *DD = dd;
+        return d;
+    }
+    return 0;
 }
 static void tune_fused(fftup_plan* P);
 

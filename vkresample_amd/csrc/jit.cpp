@@ -405,7 +405,11 @@ bool choose(int W, int H, int D, bool half, const std::vector<int>& ct_radices, 
     const int U = (DD == 1 && D % 2 == 0) ? D / 2 : 1;
     c.W = W; c.H = H; c.U = U; c.D = D; c.DD = DD; c.UW = D * W / (2 * DD); c.UH = D * H / (2 * DD); c.half = half;
     if (W < 64 || H < 64 || W > 8192 || H > 8192 || D < 3 || c.UW > 8192 || (D * W) % (2 * DD) || (D * H) % (2 * DD)) return false;
-    if (DD != 1 && ((DD != 2 && DD != 4) || D % 2 == 0 || D <= 2 * DD)) return false;      // (the factor in lowest terms, above 1: D odd)
+    {   // (the factor D / (2 DD) in lowest terms as far as DD goes, above 1)
+        int a = D, b = DD;
+        while (b) { const int t = a % b; a = b; b = t; }
+        if (DD < 1 || DD > 7 || (DD != 1 && (a != 1 || D <= 2 * DD))) return false;
+    }
     if (c.UW % 4) return false;        // the sharpen works on quads of pixels (-u 5 with W = 2 * odd: the size-generic kernels)
     // ---- row R2C
     if (is_pow2(W) && W >= 256) { c.row_kind = 0; c.row_block = W / 8; }
@@ -562,7 +566,8 @@ static std::string make_source(const Choice& c, std::string names[K_COUNT], int 
 
 std::string describe(const Choice& c)
 {
-    std::string s = c.DD == 4 ? "u" + std::to_string(c.D / 8) + "." + std::to_string(c.D % 8 * 125) + " row "
+    std::string s = (c.DD == 3 || c.DD >= 5) ? "u" + std::to_string(c.D % 2 ? c.D : c.D / 2) + "/" + std::to_string(c.D % 2 ? 2 * c.DD : c.DD) + " row "
+                    : c.DD == 4 ? "u" + std::to_string(c.D / 8) + "." + std::to_string(c.D % 8 * 125) + " row "
                     : c.DD == 2 ? "u" + std::to_string(c.D / 4) + (c.D % 4 == 1 ? ".25 row " : ".75 row ")
                     : c.D == 4 ? "row " : (c.D % 2 ? "u" + std::to_string(c.D / 2) + ".5 row " : "u" + std::to_string(c.U) + " row ");
     auto star = [](const std::vector<int>& v) { std::string t; for (size_t i = 0; i < v.size(); i++) t += (i ? "*" : "") + std::to_string(v[i]); return t; };
