@@ -98,6 +98,11 @@ U_CASES = [
     (1280, 720, 1.2),                             # 6/5: first radix 12
     (768, 432, float(np.float32(8.0 / 3.0))),     # 8/3
     (1120, 630, float(np.float32(8.0 / 7.0))),    # 8/7: -> 720p
+    # ... and where that arithmetic puts the guard a row off the symmetric one (k_col_pad takes the guard as a parameter)
+    (1600, 900, 1.2),                             # guard [449, 630) instead of [450, 630)
+    (200, 100, 1.2),                              # [49, 70)
+    (400, 270, 1.4),                              # [135, 242) instead of [135, 243): row 242 reads the UN-shifted F[242] (below H)
+    (224, 98, float(np.float32(8.0 / 7.0))),      # [48, 63)
     (640, 480, 7.0),     # -u 7: first radix 14 = 2 x 7 (round 5), six residue transforms in the column kernel
     (320, 240, 7.0),
     (640, 480, 3.5),     # 7/2: first radix 14 as well
@@ -226,5 +231,7 @@ def test_plan_describe():
         assert up.description.startswith("ahead-of-time power-of-two")
     with _up(256, 128, 1.25, 0) as up:                 # quarter-integer factors are specialised since round 5
         assert up.description.startswith("specialised at plan time: u1.25")
-    with _up(250, 120, 1.2, 0) as up:                  # 6/5: not a multiple of 1/4
+    with _up(250, 120, 1.2, 0) as up:                  # 6/5: ratios over 3, 5, 7 joined later in round 5 (the guard here: [59, 84), a row off)
+        assert up.description.startswith("specialised at plan time: u6/5")
+    with _up(250, 120, 1.8, 0) as up:                  # 9/5 = 18/10: the fused kernel's first radix would have to be 18
         assert up.description.startswith("size-generic")

@@ -289,6 +289,7 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
     if (which < 0 || which == 1) {
         ColTParams p{};
         p.S1 = P->lanes[P->cur].S1; p.S2 = P->lanes[P->cur].S2; p.twH = P->twH; p.twUH = P->twUH; p.W = (int)P->W; p.NT = P->NT;
+        p.zly = P->zly; p.zry = P->zry;
         switch (P->H) {
         case 256: hipLaunchKernelGGL((k_col_v<TUNED_TK, 256>), dim3(P->NT, 3), dim3(128), 8192, P->lanes[P->cur].stream, p); break;
         case 512: hipLaunchKernelGGL((k_col_v<TUNED_TK, 512>), dim3(P->NT, 3), dim3(256), 16384, P->lanes[P->cur].stream, p); break;
@@ -549,6 +550,7 @@ int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
         if (P->mixed) {
             ColTParams q{};
             q.S1 = P->lanes[P->cur].S1; q.S2 = P->lanes[P->cur].S2; q.twH = P->twH; q.twUH = P->twUH; q.W = (int)P->W; q.NT = P->NT;
+            q.zly = P->zly; q.zry = P->zry;
             if (P->mixed == 3) {
                 const auto& ch = P->jit->choice;
                 const dim3 jgrid(P->NT * (ch.col_kind >= 3 ? 4 / ch.col_cols : 1), 3);        // (long columns: two per workgroup)

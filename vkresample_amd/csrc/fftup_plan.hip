@@ -146,8 +146,8 @@ static int jit_factor(float upscale, uint32_t W, uint32_t H, uint32_t uW, uint32
 {
     // denominators in the order of their use; lowest terms follow from taking the first that fits (2 DD uW = D W rules out the rest).
     // A factor that is no binary fraction (4/3, 1.6 ...) is whatever float the caller passed: it joins when the reference's float
-    // arithmetic makes the output sizes and the guard come out exact for THIS size (-u 1.3333334 at 1920x1080 does, -u 1.2 at
-    // 1600x900 puts the guard at [449, ..): the size-generic kernels reproduce that)
+    // arithmetic makes the output sizes come out exact for THIS size (-u 1.3333334 at 1920x1080 does); the guard may sit a row off
+    // the symmetric one (-u 1.2 at 1600x900: [449, 630)): k_col_pad takes it as it is
     *DD = 1;
     for (int dd : {1, 2, 4, 3, 5, 7}) {
         const float t = 2.0f * (float)dd * upscale;
@@ -155,7 +155,10 @@ static int jit_factor(float upscale, uint32_t W, uint32_t H, uint32_t uW, uint32
         if (fabsf(t - (float)d) > 1e-5f * t) continue;
         if (d < 3 || d > 16 * dd || d <= 2 * dd - (dd == 1)) continue;
         if (2 * (uint64_t)dd * uW != (uint64_t)d * W || 2 * (uint64_t)dd * uH != (uint64_t)d * H) continue;
-        if (zly != (int)(H / 2) || zry != (int)(uH - H / 2)) return 0;
+        // integer factors run the polyphase column kernels (k_col_u: residues of the symmetric guard only); every other factor runs
+        // k_col_pad, which takes the guard as the reference's float arithmetic puts it -- as long as it leaves the halves apart
+        const bool polyphase = dd == 1 && d % 2 == 0;
+        if (polyphase ? (zly != (int)(H / 2) || zry != (int)(uH - H / 2)) : (zly < 1 || zly > (int)H || zry < zly || zry > (int)uH)) return 0;
         *DD = dd;
         return d;
     }

@@ -355,8 +355,8 @@ __global__ void __launch_bounds__(CFG::COL_COLS * CFG::COL_TPC) k_col_u(ColTPara
 // ---- column for a half-integer upscale factor (-u 1.5, 2.5): forward transform of length H, the reference's shift and
 // zero-padding (VkResample.cpp:514-526, read guard vkFFT.h:1670-1695) as the gather of the inverse's first stage, inverse
 // transform of length UH = u H, ALL rows written to one buffer at the reference's normalisation (no residue split: the
-// rows of the zero-padded inverse are not subsequences of equal length here).  The plan guarantees the guard
-// [H/2, UH - H/2) (fftup_plan_create checks the reference's float arithmetic gives exactly that).
+// rows of the zero-padded inverse are not subsequences of equal length here).  The guard [p.zly, p.zry) is the reference's, as its
+// float arithmetic puts it: [H/2, UH - H/2) for every binary-fraction factor, sometimes a row off that for the others (-u 1.2 ...).
 // CFG::ColF = MrFftNT<H, +1, COL_TPC, 4, ...>, CFG::ColIU = MrFftNT<UH, -1, COL_TPC, 4, ...>.  LDS lswz_size(4 UH) float2.
 template <class CFG>
 __global__ void __launch_bounds__(CFG::COL_COLS * CFG::COL_TPC) k_col_pad(ColTParams p)
@@ -393,8 +393,11 @@ __global__ void __launch_bounds__(CFG::COL_COLS * CFG::COL_TPC) k_col_pad(ColTPa
         for (int m = 0; m < Q0; m++) {
             const int ky = j + MB0 * m;                                             // row of the zero-padded buffer
             float2 g = make_float2(0.f, 0.f);
-            if (ky < H / 2) g = buf[lidx<CC>(ky, col)];
+            // (as k_col: the guard first, then the shifted upper half, then the un-shifted rows below H -- with the symmetric guard
+            // [H/2, UH - H/2) that is rows below H/2 and the upper half; a guard that starts a row early zeroes that row)
+            if (ky >= p.zly && ky < p.zry) {}
             else if (ky >= UH - H / 2) g = buf[lidx<CC>(ky - (UH - H), col)];
+            else if (ky < H) g = buf[lidx<CC>(ky, col)];
             w[m] = g;
         }
     }

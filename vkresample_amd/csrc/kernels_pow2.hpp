@@ -451,6 +451,8 @@ struct ColTParams {
     float2* S2;
     const float2 *twH, *twUH;
     int W, NT;
+    int zly, zry;            // k_col_pad: rows [zly, zry) of the zero-padded spectrum read as zero (the reference's guard as ITS float arithmetic
+                             // puts it, VkResample.cpp:1494-1495: [H/2, UH - H/2) or a row off that for factors that are no binary fraction)
 };
 
 // v[i] = F[pp + Tc*i] * w * exp(-2 pi i * q/16), q = i (i < 4) or i + 8 (i >= 4: the extra half turn is the -1)
