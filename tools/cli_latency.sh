@@ -14,8 +14,10 @@ export FFTUP_CACHE_DIR=$T/cache
 for s in 2048x1024:2 1920x1080:2 1280x720:1.5 1920x1080:1.3333334; do
   sz=${s%%:*}; u=${s##*:}
   for rep in 1 2 3; do
-    /usr/bin/time -f "%e s wall  %U s user  %S s sys" $R/vkresample_amd/vkresample -i in_$sz.png -o out.png -u $u -n 1 > log.txt 2> time.txt
-    echo "$sz -u $u run $rep: $(tail -1 time.txt) | $(grep -o 'Time: [0-9.]* ms' log.txt) | $(grep -o 'Total time: [0-9.]* ms' log.txt)"
+    t0=$(date +%s.%N)
+    $R/vkresample_amd/vkresample -i in_$sz.png -o out.png -u $u -n 1 > log.txt 2>&1
+    t1=$(date +%s.%N)
+    echo "$sz -u $u run $rep: $(python -c "print('%.3f' % ($t1 - $t0))") s wall | $(grep -o 'Time: [0-9.]* ms' log.txt) | $(grep -io 'total time[^,]*' log.txt | head -1)"
   done
 done
 rm -rf $T
