@@ -571,7 +571,8 @@ int fftup_plan_describe(const fftup_plan* P, char* buf, size_t buflen)
                            + "; column kernel with digit-swap exchanges";
     else if (P->mixed) s = std::string("ahead-of-time mixed-radix kernels: ") + (P->mixed == 1 ? "row 15*8*16, col 9*10*12, fused 16*16*15" : "row 5*16*16, col 9*8*10, fused 16*16*10");
     else if (P->cplx) s = "size-generic kernels, non-R2C path (full complex transforms)";
-    else s = std::string("size-generic kernels (LDS ping-pong, run-time radix lists)") + (P->dbl ? ", double" : "");
+    else s = std::string("size-generic kernels (") + ((P->inplaceF || P->inplaceI || P->inplaceC) ? "in place in one LDS buffer" : "LDS ping-pong") + ", run-time radix lists)"
+             + (P->dbl ? ", double" : "");
     auto four = [&](const char* what, const fftup_plan::Four& f) {
         if (f.on) s += std::string("; ") + what + " in four steps " + std::to_string(f.n1) + "*" + std::to_string(f.n2) + " (tiles of " + std::to_string(f.tka) + " / " + std::to_string(f.tkb) + ")";
     };
