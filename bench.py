@@ -269,6 +269,18 @@ def other_configs(v, synth, dev, traffic_json, n_cu, ring=8, live=True):
                 e[mode + "ms_per_iter"] = ms
                 e[mode + "frame_frac"] = up.alg_bytes_per_frame / (ms * 1e-3) / 8e12
         n1000[name] = e
+    # outside BASELINE's list, one line each (short runs, ring of 3, no counters): the reference's third precision (-p 1, SURVEY 8 f4:
+    # size-generic kernels) and a size / factor the plan-time compiler serves (1080p -> 1440p, -u 4/3)
+    import numpy as _np
+    for name, (w, h, u, prec) in (("fp64", (2048, 1024, 2.0, 1)), ("fhd_to_qhd_u4_3", (1920, 1080, float(_np.float32(4.0 / 3.0)), 0))):
+        with v.Upscaler(w, h, u, prec, 0.2, dev, 0, 3) as up:
+            for s in range(3):
+                up.upload_rgb8(synth.frame(s, w, h, "U"), slot=s)
+            up.execute_ring(48, 0)
+            t = sorted(up.execute_ring(192, 0) / 192 for _ in range(5))[2]
+            out[name] = {"workload": "%dx%d -> %dx%d -p %d" % (w, h, up.out_width, up.out_height, prec), "ms_per_frame": t, "frames_per_s": 1e3 / t,
+                         "frame_frac": up.alg_bytes_per_frame / (t * 1e-3) / 8e12, "kernel_ms": dict(zip(up.kernel_names, up.profile_kernels(10))),
+                         "plan": up.description}
     out["execute_n1000"] = dict(n1000, note="fftup_execute(plan, 1000) on a plan without a ring = performVulkanUpscale(.., 1000), "
                                             "VkResample.cpp:1260-1278; the CLI prints ms_per_iter as Time: (-n 1000); sequential_* = one "
                                             "queue, nothing overlaps (FFTUP_FLAG_SEQUENTIAL_EXECUTE)")

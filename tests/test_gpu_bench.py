@@ -70,6 +70,9 @@ def test_bench_single_rank_line():
     # (the 8-bit image is written once: the fused kernel's launch moves 91 MB -- 25 MB of writes, the spectra, and the L2's
     # reads of the lines it merges the three planes' bytes into -- not the 111 MB of round 3 with 76 MB of writes)
     assert o["config3_u8_store"]["kernel_hbm_bytes_measured"]["row_c2r_sharpen"] < 1.0e8
+    # (outside BASELINE's list: the reference's third precision on the size-generic kernels, a plan-time size at -u 4/3)
+    assert 0.15 < o["fp64"]["ms_per_frame"] < 0.5 and o["fp64"]["plan"].startswith("size-generic")
+    assert 0.03 < o["fhd_to_qhd_u4_3"]["ms_per_frame"] < 0.12 and o["fhd_to_qhd_u4_3"]["plan"].startswith("specialised at plan time: u4/3")
     n = o["execute_n1000"]
     for k in ("config2", "config3", "config4"):
         assert 0.01 < n[k]["ms_per_iter"] < 1.0 and 0.01 < n[k]["sequential_ms_per_iter"] < 1.0
