@@ -500,8 +500,10 @@ def test_non_r2c_limits():
                           (8748, 2.0, 0, "inverse rows in four steps 54*324 (tiles of 4 / 2)")):
         with _up(W, 16, u, p) as up:               # beyond one LDS buffer: four steps (refused until round 4)
             assert up.kernel_names[0] == "row_c2c" and not up.tuned and what in up.description, up.description
-    with _up(16, 4900, 2.0) as up:
-        assert "forward columns in four steps 70*70" in up.description and "inverse columns in four steps 98*100" in up.description, up.description
+    with _up(16, 4900, 3.0) as up:
+        assert "forward columns in four steps 70*70" in up.description and "inverse columns in four steps" in up.description, up.description
+    with _up(16, 4900, 2.0) as up:                 # u = 2: the polyphase column kernel needs ONE buffer of 4900 points (round 5; four steps before)
+        assert "polyphase column pass" in up.description and "four steps" not in up.description, up.description
 
 
 FOUR_STEP = [(9216, 8, 2.0, 0, 0),       # inverse rows of 18432 = 128 * 144 points in four steps, forward rows (9216) in one launch
@@ -538,7 +540,9 @@ def test_four_step_rows_vs_oracle(W, H, u, precision, flags):
 
 
 TALL = [(16, 4900, 2.0, 0, 0),          # uH = 9800: two Stockham buffers of one column do not fit 160 KB; 4900 = 70 * 70, 9800 = 98 * 100
-        (16, 4900, 2.0, 0, 2), (32, 4900, 2.0, 2, 2),
+        (16, 4900, 2.0, 0, 2), (32, 4900, 2.0, 2, 2),      # (u = 2: since round 5 the polyphase column kernel, ONE buffer of 4900 points, no four steps)
+        (16, 4900, 3.0, 0, 0),          # uH = 14700: both column transforms in four steps
+        (16, 2500, 3.0, 1, 0),          # -p 1: uH = 7500 in double2, four steps
         (20, 9800, 1.5, 0, 0),          # H itself beyond one column's LDS, uH = 14700 = 105 * 140, non-integer factor
         (16, 2500, 2.0, 1, 0),          # -p 1: uH = 5000 in double2
         (2100, 2500, 2.0, 1, 0)]        # ... on the non-R2C path (uW = 4200 > 4096 for -p 1)
@@ -945,15 +949,15 @@ def test_four_step_plans_in_a_ring():
     """rows and columns in four steps with frames overlapping on the plan's streams: every lane has its own transposition
     buffer -- three distinct frames through fftup_execute_ring equal the same frames one at a time"""
     from vkresample_amd import synth
-    for (W, H) in ((9216, 8), (16, 4900)):
+    for (W, H, u) in ((9216, 8, 2.0), (16, 4900, 3.0)):       # (16 x 4900 at u = 2 is a one-launch polyphase plan since round 5)
         frames = [synth.frame(90 + k, W, H) for k in range(3)]
         single = []
-        with _up(W, H, 2.0, 0) as up:
+        with _up(W, H, u, 0) as up:
             for f in frames:
                 up.upload_rgb8(f)
                 up.execute(1)
                 single.append(up.download_planar().copy())
-        with _up(W, H, 2.0, 0, ring=3) as up:
+        with _up(W, H, u, 0, ring=3) as up:
             assert "four steps" in up.description
             for s, f in enumerate(frames):
                 up.upload_rgb8(f, slot=s)
@@ -974,3 +978,32 @@ def test_two_pixel_wide_image():
         out = up.download_planar().astype(np.float64)
     _, oout, _ = O.upscale_rgb8(rgb, 1.0, 0, 0.2)
     assert np.abs(out[:, :-1] - oout[:, :-1]).max() <= 2e-5
+
+
+@pytest.mark.parametrize("W,H,precision,flags", [(16, 8, 0, 4), (60, 42, 0, 4), (240, 270, 0, 4), (1000, 600, 0, 4), (2048, 1024, 0, 4), (640, 480, 2, 6),
+                                                 (16, 8, 1, 0), (60, 42, 1, 0), (240, 270, 1, 0), (1024, 512, 1, 0), (2048, 64, 1, 0), (64, 2048, 1, 0)])
+def test_generic_polyphase_column_pass(W, H, precision, flags, monkeypatch):
+    """Round 5: size-generic plans with u = 2 run the column pass in polyphase form (k_col_poly: the even rows of the zero-padded
+    inverse ARE the rows of S1 over 2 and are never computed; the odd rows are a length-H inverse of the phase-shifted spectrum)
+    and the C2R kernel reads the even rows from S1.  Against the full-length form (generic_poly=0 in the test build of the
+    library) to rounding, and both against the oracle at the bars of the other tests."""
+    from vkresample_amd import _lib, synth
+    rgb = synth.frame(21, W, H, "N")
+    res = []
+    for poly in (1, 0):
+        if not poly:
+            monkeypatch.setenv("FFTUP_LIBRARY", _lib.KNOBS_LIB_PATH)
+            monkeypatch.setenv("FFTUP_EXPERIMENT", "generic_poly=0")
+        with _up(W, H, 2.0, precision, 0.2, 0, flags) as up:
+            assert ("polyphase" in up.description) == bool(poly), up.description
+            up.upload_rgb8(rgb)
+            up.execute(2)
+            res.append((up.download_presharpen().astype(np.float64), up.download_planar().astype(np.float64)))
+    opre, oout, _ = O.upscale_rgb8(rgb, 2.0, precision, 0.2)
+    # (-p 2: the pre-sharpen image is binary16 -- one ulp of the value, as the sweeps' bound)
+    tol_pre = {0: 2e-6, 1: 1e-12}.get(precision, np.maximum(np.abs(opre), 2.0 ** -14) * 2.0 ** -10 * 1.0001 + 5e-7)
+    for pre, out in res:
+        assert (np.abs(pre - opre) <= tol_pre).all()
+    assert (np.abs(res[0][0] - res[1][0]) <= tol_pre).all()
+    if precision != 2:
+        assert np.abs(res[0][1][:, :-1] - oout[:, :-1]).max() <= (1e-9 if precision == 1 else 5e-5)

@@ -115,7 +115,21 @@ int kernels_set_attributes(fftup_plan* P)
         if (P->colF.on) {                                    // columns in four steps (k_row4_a / k_row4_b on dense columns)
             if (P->dbl) PLAN_TRY((four_columns<double2, true>(P, nullptr))); else PLAN_TRY((four_columns<float2, true>(P, nullptr)));
         }
-        if (generic && !P->dbl && !P->colF.on) {
+        if (generic && P->poly) {
+            if (P->dbl) switch (P->TK) {
+            case 8: SET_LDS((k_col_poly<8, double2>), P->ldsCol); break;
+            case 4: SET_LDS((k_col_poly<4, double2>), P->ldsCol); break;
+            case 2: SET_LDS((k_col_poly<2, double2>), P->ldsCol); break;
+            default: SET_LDS((k_col_poly<1, double2>), P->ldsCol); break;
+            }
+            else switch (P->TK) {
+            case 8: SET_LDS(k_col_poly<8>, P->ldsCol); break;
+            case 4: SET_LDS(k_col_poly<4>, P->ldsCol); break;
+            case 2: SET_LDS(k_col_poly<2>, P->ldsCol); break;
+            default: SET_LDS(k_col_poly<1>, P->ldsCol); break;
+            }
+        }
+        else if (generic && !P->dbl && !P->colF.on) {
             switch (P->TK) {
             case 8: SET_LDS(k_col<8>, P->ldsCol); break;
             case 4: SET_LDS(k_col<4>, P->ldsCol); break;
@@ -156,7 +170,8 @@ int kernels_set_attributes(fftup_plan* P)
                 if (P->inplaceF) SET_LDS((k_row_r2c<IN_F64, double2, true>), P->ldsRowF); else SET_LDS((k_row_r2c<IN_F64, double2>), P->ldsRowF);
                 if (P->inplaceI) SET_LDS((k_row_c2r<false, double2, true>), P->ldsRowI); else SET_LDS((k_row_c2r<false, double2>), P->ldsRowI);
             }
-            if (P->inplaceC) switch (P->TK) {
+            if (P->poly) {}
+            else if (P->inplaceC) switch (P->TK) {
             case 8: SET_LDS((k_col<8, double2, true>), P->ldsCol); break;
             case 4: SET_LDS((k_col<4, double2, true>), P->ldsCol); break;
             case 2: SET_LDS((k_col<2, double2, true>), P->ldsCol); break;
@@ -346,7 +361,13 @@ static int launch_frame_f64(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, 
         p.W = (int)P->W; p.H = (int)P->H; p.uH = (int)P->uH; p.NT = P->NT; p.ncols = P->ncols; p.zly = P->zly; p.zry = P->zry;
         p.inv_norm = 1.0 / (double)P->uH;
         dim3 grid(P->NT, 3), block(P->thrCol);
-        if (P->inplaceC) switch (P->TK) {
+        if (P->poly) switch (P->TK) {
+        case 8: hipLaunchKernelGGL((k_col_poly<8, double2>), grid, block, P->ldsCol, st, p); break;
+        case 4: hipLaunchKernelGGL((k_col_poly<4, double2>), grid, block, P->ldsCol, st, p); break;
+        case 2: hipLaunchKernelGGL((k_col_poly<2, double2>), grid, block, P->ldsCol, st, p); break;
+        default: hipLaunchKernelGGL((k_col_poly<1, double2>), grid, block, P->ldsCol, st, p); break;
+        }
+        else if (P->inplaceC) switch (P->TK) {
         case 8: hipLaunchKernelGGL((k_col<8, double2, true>), grid, block, P->ldsCol, st, p); break;
         case 4: hipLaunchKernelGGL((k_col<4, double2, true>), grid, block, P->ldsCol, st, p); break;
         case 2: hipLaunchKernelGGL((k_col<2, double2, true>), grid, block, P->ldsCol, st, p); break;
@@ -361,9 +382,9 @@ static int launch_frame_f64(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, 
     }
     if (which < 0 || which == 2) {
         RowC2RParamsT<double2> p{};
-        p.S2 = (const double2*)P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = (const double2*)P->twUW; p.plan = P->planUW;
+        p.S1 = (const double2*)P->lanes[P->cur].S1; p.S2 = (const double2*)P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = (const double2*)P->twUW; p.plan = P->planUW;
         p.W = (int)P->W; p.uW = (int)P->uW; p.uH = (int)P->uH; p.TK = P->TK; p.NT = P->NT; p.zlx = P->zlx; p.zrx = P->zrx;
-        p.inv_norm = 1.0 / (double)P->uW;
+        p.inv_norm = 1.0 / (double)P->uW; p.poly = P->poly;
         if (P->inplaceI) hipLaunchKernelGGL((k_row_c2r<false, double2, true>), dim3(P->uH / 2, 3), dim3(P->thrUW), P->ldsRowI, st, p);
         else hipLaunchKernelGGL((k_row_c2r<false, double2>), dim3(P->uH / 2, 3), dim3(P->thrUW), P->ldsRowI, st, p);
     }
@@ -558,6 +579,11 @@ int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
             }
             else if (P->mixed == 1) hipLaunchKernelGGL(k_col_m<MixedCfg1080>, grid, dim3(4 * MixedCfg1080::COL_TPC), P->ldsCol, P->lanes[P->cur].stream, q);
             else hipLaunchKernelGGL(k_col_m<MixedCfg720>, grid, dim3(4 * MixedCfg720::COL_TPC), P->ldsCol, P->lanes[P->cur].stream, q);
+        } else if (P->poly) switch (P->TK) {
+        case 8: hipLaunchKernelGGL(k_col_poly<8>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
+        case 4: hipLaunchKernelGGL(k_col_poly<4>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
+        case 2: hipLaunchKernelGGL(k_col_poly<2>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
+        default: hipLaunchKernelGGL(k_col_poly<1>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
         } else switch (P->TK) {
         case 8: hipLaunchKernelGGL(k_col<8>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
         case 4: hipLaunchKernelGGL(k_col<4>, grid, block, P->ldsCol, P->lanes[P->cur].stream, p); break;
@@ -577,7 +603,7 @@ int launch_frame(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, int which)
         RowC2RParams p{};
         p.S1 = P->lanes[P->cur].S1; p.S2 = P->lanes[P->cur].S2; p.R = P->lanes[P->cur].R; p.tw = P->twUW; p.plan = P->planUW; p.W = (int)P->W; p.uW = (int)P->uW;
         p.uH = (int)P->uH; p.TK = P->TK; p.NT = P->NT; p.zlx = P->zlx; p.zrx = P->zrx;
-        p.inv_norm = 1.0f / (float)P->uW;
+        p.inv_norm = 1.0f / (float)P->uW; p.poly = P->poly && !P->mixed;
         dim3 grid(P->uH / 2, 3), block(P->thrUW);
         if (P->mixed) {
             if (P->mixed == 3) {

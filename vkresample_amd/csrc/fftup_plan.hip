@@ -297,6 +297,21 @@ void fftup_plan_destroy(fftup_plan* P)
     delete P;
 }
 
+// Threads a workgroup needs to run every stage of `sp` in place on `tk` interleaved sequences with `pt` points per thread
+// (stage_fits_inplace_tk; at least one eighth of the points: the loads and stores around the transform), a multiple of 64 --
+// or 0 when that is more than `tmax`.  Radices 3, 5, 7 need more threads than N / 8: one butterfly of 5 or 7 per thread.
+static int inplace_threads(const StagePlan& sp, int tk, int pt, int tmax)
+{
+    long need = (long)sp.n * tk / 8;
+    for (int st = 0; st < sp.nstages; st++) {
+        const int r = sp.radix[st], per = pt / r;
+        if (per < 1) return 0;
+        need = std::max(need, ((long)(sp.n / r) * tk + per - 1) / per);
+    }
+    const long thr = std::max(64l, (need + 63) / 64 * 64);
+    return thr <= tmax ? (int)thr : 0;
+}
+
 int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
 {
     if (!out || !cfg) return fail(FFTUP_E_INVALID_ARG, "null argument");
@@ -399,15 +414,25 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             P->TK = TUNED_TK;
             P->ldsCol = kernels_tuned_col_lds(H);
         } else {
+            // u = 2 with the symmetric guard: the polyphase column kernel (k_col_poly: forward, phase, length-H inverse in ONE buffer of
+            // H TK points, odd rows out; the C2R kernel takes the even rows from S1) where its stages run in place
+            const char* const poly_e = fftup_jit::experiment("generic_poly");
+            if (!cplx && uW == 2 * W && uH == 2 * H && P->zly == (int)(H / 2) && P->zry == (int)(uH - H / 2) && !(poly_e && atoi(poly_e) == 0)) {
+                for (int tk : {8, 4, 2, 1}) {
+                    const size_t need = P->csz * (size_t)lpad_size((int)H * tk);
+                    const int thr = inplace_threads(P->planH, tk, COL_INPLACE_PT, kernels_generic_max_threads(P->dbl));
+                    if (thr && need <= lds_max / 2) { P->TK = tk; P->ldsCol = need; P->poly = true; P->thrCol = thr; break; }    // (two workgroups per compute unit)
+                }
+            }
             // -p 1 R2C plans: ONE buffer where every stage of both column transforms runs in place with COL_INPLACE_PT points per thread (k_col<.., true>)
-            if (P->dbl && !cplx) {
+            if (!P->TK && P->dbl && !cplx) {
                 for (int tk : {8, 4, 2, 1}) {
                     const size_t need = P->csz * (size_t)lpad_size((int)uH * tk);
-                    const int thr = std::min(kernels_generic_max_threads(true), std::max(64, round_up((int)uH * tk / 8, 64)));
-                    bool ok = need <= lds_max / 2 && (size_t)(H / 2) * tk <= (size_t)COL_INPLACE_PT * thr;       // (two workgroups per compute unit)
-                    for (const StagePlan* sp : {&P->planH, &P->planUH})
-                        for (int st = 0; st < sp->nstages && ok; st++) ok = stage_fits_inplace_tk(sp->n, tk, sp->radix[st], thr, COL_INPLACE_PT);
-                    if (ok) { P->TK = tk; P->ldsCol = need; P->inplaceC = true; break; }
+                    const int tmax = kernels_generic_max_threads(true);
+                    const int thr = std::max(inplace_threads(P->planH, tk, COL_INPLACE_PT, tmax), inplace_threads(P->planUH, tk, COL_INPLACE_PT, tmax));
+                    const bool ok = inplace_threads(P->planH, tk, COL_INPLACE_PT, tmax) && inplace_threads(P->planUH, tk, COL_INPLACE_PT, tmax) &&
+                                    need <= lds_max / 2 && (size_t)(H / 2) * tk <= (size_t)COL_INPLACE_PT * thr;  // (two workgroups per compute unit)
+                    if (ok) { P->TK = tk; P->ldsCol = need; P->inplaceC = true; P->thrCol = thr; break; }
                 }
             }
             // column tile width: widest of 8,4,2,1 whose ping-pong buffers fit in LDS
@@ -455,6 +480,7 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
                 }
             }
         }
+        if (P->tuned || P->mixed) P->poly = false;               // (their own column kernels)
         P->fused = (P->tuned || P->mixed) && !(cfg->flags & FFTUP_FLAG_UNFUSED_SHARPEN);
         P->u8out = P->fused && (cfg->flags & FFTUP_FLAG_FUSE_U8_STORE);
         set_strip_length(P);
@@ -481,17 +507,12 @@ int fftup_plan_create(fftup_plan** out, const fftup_config* cfg)
             const int tmax = kernels_generic_max_threads(P->dbl);
             P->thrW = std::min(tmax, std::max(64, round_up((int)W / 8, 64)));
             P->thrUW = std::min(tmax, std::max(64, round_up((int)uW / 8, 64)));
-            P->thrCol = std::min(tmax, std::max(64, round_up((int)uH * P->TK / 8, 64)));
+            if (!(P->poly || P->inplaceC)) P->thrCol = std::min(tmax, std::max(64, round_up((int)uH * P->TK / 8, 64)));     // (in-place column plans chose theirs above)
             // -p 1 R2C rows: one LDS buffer where every stage runs in place with 8 points per thread (two workgroups per compute unit)
             if (P->dbl && !cplx) {
-                auto fits = [](const StagePlan& sp, int thr) {
-                    for (int st = 0; st < sp.nstages; st++)
-                        if (!stage_fits_inplace(sp.n, sp.radix[st], thr, 8)) return false;
-                    return true;
-                };
-                P->inplaceF = fits(P->planW, P->thrW); P->inplaceI = fits(P->planUW, P->thrUW);
-                if (P->inplaceF) P->ldsRowF /= 2;
-                if (P->inplaceI) P->ldsRowI /= 2;
+                const int tf = inplace_threads(P->planW, 1, 8, tmax), ti = inplace_threads(P->planUW, 1, 8, tmax);
+                if (tf) { P->inplaceF = true; P->thrW = tf; P->ldsRowF /= 2; }
+                if (ti) { P->inplaceI = true; P->thrUW = ti; P->ldsRowI /= 2; }
             }
         }
 
@@ -571,7 +592,8 @@ int fftup_plan_describe(const fftup_plan* P, char* buf, size_t buflen)
                            + "; column kernel with digit-swap exchanges";
     else if (P->mixed) s = std::string("ahead-of-time mixed-radix kernels: ") + (P->mixed == 1 ? "row 15*8*16, col 9*10*12, fused 16*16*15" : "row 5*16*16, col 9*8*10, fused 16*16*10");
     else if (P->cplx) s = "size-generic kernels, non-R2C path (full complex transforms)";
-    else s = std::string("size-generic kernels (") + ((P->inplaceF || P->inplaceI || P->inplaceC) ? "in place in one LDS buffer" : "LDS ping-pong") + ", run-time radix lists)"
+    else s = std::string("size-generic kernels (") + ((P->inplaceF || P->inplaceI || P->inplaceC) ? "in place in one LDS buffer" : "LDS ping-pong") + ", run-time radix lists"
+             + (P->poly ? ", polyphase column pass)" : ")")
              + (P->dbl ? ", double" : "");
     auto four = [&](const char* what, const fftup_plan::Four& f) {
         if (f.on) s += std::string("; ") + what + " in four steps " + std::to_string(f.n1) + "*" + std::to_string(f.n2) + " (tiles of " + std::to_string(f.tka) + " / " + std::to_string(f.tkb) + ")";

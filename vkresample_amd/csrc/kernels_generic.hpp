@@ -182,6 +182,43 @@ __global__ void __launch_bounds__(GenericMaxThreads<C>::value, INPLACE ? 4 : 1) 
         if ((e % TK) < ncol_valid) dst[e] = cscale(D[lpad(e)], p.inv_norm);
 }
 
+// ---- the same column pass for u = 2 in polyphase form (round 5; what k_col_t / k_col_n are for the specialised plans): with the
+// symmetric guard [H/2, uH - H/2) row 2j of the zero-padded inverse is row j of S1 over 2 -- never computed, never written: the
+// C2R kernel reads S1 -- and row 2j+1 is the length-H inverse of F[k] t[k], t[k] = exp(-2 pi i k / 2H) (k < H/2), minus that above
+// (the upper half of the spectrum sits uH - H rows higher: a half turn).  Half the inverse transform, half the writes, and a buffer
+// of H TK instead of uH TK points: in place (fft_lds_inplace_tk), twice the tile width in the same LDS.  Odd rows at the
+// reference's normalisation (1 / uH), H rows per tile.  grid (NT, 3), dynamic LDS lpad_size(H TK) complex.
+template <int TK, typename C = float2>
+__global__ void __launch_bounds__(GenericMaxThreads<C>::value, 4) k_col_poly(ColParamsT<C> p)
+{
+    using S = scalar_t<C>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    C* a = (C*)smem;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int tile = blockIdx.x, c = blockIdx.y;
+    const int H = p.H;
+    const int ncol_valid = min(TK, p.ncols - tile * TK);
+    const C* src = p.S1 + ((long)c * p.NT + tile) * H * TK;
+    for (int e = tid; e < H * TK; e += T) {
+        C v = mk<C>(S(0), S(0));
+        if ((e % TK) < ncol_valid) v = src[e];
+        a[lpad(e)] = v;
+    }
+    __syncthreads();
+    fft_lds_inplace_tk<+1, COL_INPLACE_PT, TK>(a, p.planH, p.twH, tid, T);
+    for (int e = tid; e < H * TK; e += T) {
+        const int k = e / TK;
+        C t = twid<-1>(p.twUH[k]);                            // exp(-2 pi i k / uH), uH = 2H
+        if (k >= H / 2) t = mk<C>(-t.x, -t.y);
+        a[lpad(e)] = cmul(a[lpad(e)], t);
+    }
+    __syncthreads();
+    fft_lds_inplace_tk<-1, COL_INPLACE_PT, TK>(a, p.planH, p.twH, tid, T);
+    C* dst = p.S2 + ((long)c * p.NT + tile) * H * TK;
+    for (int e = tid; e < H * TK; e += T)
+        if ((e % TK) < ncol_valid) dst[e] = cscale(a[lpad(e)], p.inv_norm);
+}
+
 template <typename C> struct RowC2RParamsT {
     const C* S1;             // polyphase plans only (k_row_c2r_ct): even spectrum rows; S2 then holds the odd rows
     const C* S2;
@@ -192,6 +229,7 @@ template <typename C> struct RowC2RParamsT {
     int TK, NT;
     int zlx, zrx;            // column-index read guard [zlx,zrx) (VkResample.cpp:1492-1493)
     scalar_t<C> inv_norm;    // 1/uW
+    int poly;                // size-generic plans with u = 2 (k_col_poly): row 2j is row j of S1 (times 1/2), row 2j+1 row j of S2, H rows per tile each
 };
 using RowC2RParams = RowC2RParamsT<float2>;
 
@@ -206,22 +244,26 @@ __global__ void __launch_bounds__(GenericMaxThreads<C>::value, INPLACE ? 4 : 1) 
     const int tid = threadIdx.x, T = blockDim.x;
     const int j = blockIdx.x, c = blockIdx.y;
     const int uW = p.uW;
-    const long tile_stride = (long)p.uH * p.TK;
-    const C* base = p.S2 + (long)c * p.NT * tile_stride + (long)(2 * j) * p.TK;
+    // rows 2j and 2j+1 of the spectrum after the column pass: consecutive rows of S2 -- or (poly: k_col_poly wrote the odd rows only)
+    // row j of S1, which IS row 2j of the zero-padded inverse up to the factor 1/u = 1/2 (exact), and row j of the odd rows
+    const long tile_stride = (long)(p.poly ? p.uH / 2 : p.uH) * p.TK;
+    const C* baseA = (p.poly ? p.S1 + (long)j * p.TK : p.S2 + (long)(2 * j) * p.TK) + (long)c * p.NT * tile_stride;
+    const C* baseB = (p.poly ? p.S2 + (long)j * p.TK : p.S2 + (long)(2 * j + 1) * p.TK) + (long)c * p.NT * tile_stride;
+    const S sa = p.poly ? S(0.5) : S(1);
     // vkFFT.h:2059-2131: Z[k] = A + iB, Z[uW-k] = conj(A) + i conj(B); column index cidx = k-1
     for (int cidx = tid; cidx < uW / 2; cidx += T) {
         const int k = cidx + 1;
         C A = mk<C>(S(0), S(0)), B = A;
         if ((cidx < p.zlx || cidx >= p.zrx) && k <= p.W / 2) {
-            const C* s = base + (long)(k / p.TK) * tile_stride + (k % p.TK);
-            A = s[0];
-            B = s[p.TK];
+            const long o = (long)(k / p.TK) * tile_stride + (k % p.TK);
+            A = cscale(baseA[o], sa);
+            B = baseB[o];
         }
         a[lpad(k)] = mk<C>(A.x - B.y, A.y + B.x);
         a[lpad(uW - k)] = mk<C>(A.x + B.y, -A.y + B.x);
     }
     if (tid == 0) {
-        C A = base[0], B = base[p.TK];
+        C A = cscale(baseA[0], sa), B = baseB[0];
         a[lpad(0)] = mk<C>(A.x - B.y, A.y + B.x);
     }
     __syncthreads();

@@ -80,6 +80,7 @@ struct fftup_plan {
     fftup_jit::Module* jit = nullptr;
     int U = 2;                        // integer upscale factor of a polyphase plan (tuned / mixed): S1 + U-1 residue buffers
     bool cplx = false;                // non-R2C path (VR:1424 false): full complex transforms, uW beyond the R2C limit
+    bool poly = false;                         // size-generic u = 2 plan: polyphase column kernel (k_col_poly), the C2R kernel reads the even rows from S1
     bool inplaceC = false;                     // -p 1 R2C plans: the column kernel's two transforms in one LDS buffer (k_col<TK, double2, true>)
     bool inplaceF = false, inplaceI = false;   // ... whose forward / inverse rows are too long for two LDS buffers: fft_lds_inplace
     // ... and rows too long for ONE buffer: four steps through HBM (k_row4_a / k_row4_b), row length = n1 * n2
