@@ -15,10 +15,11 @@ python bench.py --preset config3 --fuse-u8-store --no-cpu-baseline > $OUT/bench_
 python bench.py --fuse-u8 --fuse-u8-store --no-cpu-baseline > $OUT/bench_fp32_u8_u8store.json 2>> $OUT/bench.err
 python bench.py --preset config5 --no-cpu-baseline > $OUT/bench_config5_1gpu.json 2>> $OUT/bench.err
 python bench.py --streams 1 --no-cpu-baseline --no-others > $OUT/bench_fp32_streams1.json 2>> $OUT/bench.err
+python bench.py --precision 1 --no-cpu-baseline --no-others --no-rccl-check --frames-per-step 64 --steps 5 > $OUT/bench_fp64.json 2>> $OUT/bench.err
 python bench.py --host-streamed --no-cpu-baseline --ring 4 > $OUT/bench_host_streamed_fp32.json 2>> $OUT/bench.err
 python bench.py --host-streamed --fuse-u8 --fuse-u8-store --no-cpu-baseline --ring 4 > $OUT/bench_host_streamed_u8store.json 2>> $OUT/bench.err
 python bench.py --host-streamed --png --no-cpu-baseline --ring 4 > $OUT/bench_host_streamed_png.json 2>> $OUT/bench.err
-for f in fp16_u8 1080p fp16_u8_u8store fp32_u8_u8store config5_1gpu fp32_streams1 host_streamed_fp32 host_streamed_u8store host_streamed_png; do
+for f in fp16_u8 1080p fp16_u8_u8store fp32_u8_u8store config5_1gpu fp32_streams1 fp64 host_streamed_fp32 host_streamed_u8store host_streamed_png; do
   python -c "import json,sys; d=json.load(open('$OUT/bench_$f.json')); print('%-24s %9.0f frames/s %.2f us/frame frac %.3f' % ('$f', d['value'], d['ms_per_frame']*1e3, d['frame_roofline_frac']), {k: round(v*1e3,1) for k,v in d['kernel_ms'].items()})"
 done
 prof() {  # tag, clock_check.py args: rocprofv3 ON fftup_profile_kernels of the DEFAULT plan (ring of 8, three streams: one strip per compute unit), the
