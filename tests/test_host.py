@@ -428,3 +428,37 @@ def test_without_the_runtime_compiler_the_library_says_so(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("5 ") and "not available" in r.stdout, r.stdout
+
+
+def test_jit_check_takes_any_float_factor():
+    """fftup_jit_check (no device, no compilation) over factors that are whatever float a caller may pass -- just off an integer, off a
+    ratio, irrational, huge: it answers 0 (a specialised plan exists: then the output sizes are exactly D / (2 DD) times the input
+    sizes for the D, DD its description names), 1 (not a configuration at all) or 2 (the size-generic kernels run it); it never faults."""
+    import ctypes as C
+    import re
+    import numpy as np
+    from fractions import Fraction
+    from vkresample_amd import _lib
+    lib = _lib.load()
+    buf = C.create_string_buffer(512)
+    rng = np.random.default_rng(7)
+    sizes = [64, 96, 100, 120, 128, 250, 256, 270, 480, 600, 720, 900, 1000, 1080, 1280, 1600, 1920, 2048]
+    base = [1.0, 1.125, 1.2, 1.25, 4 / 3, 1.4, 1.5, 1.6, 5 / 3, 1.75, 1.8, 1.875, 2.0, 2.25, 2.4, 2.5, 8 / 3, 3.0, 3.5, 4.0, 5.0, 7.0, 8.0, 9.0, 16.0, np.pi, np.e]
+    seen = 0
+    for k in range(3000):
+        W, H = int(rng.choice(sizes)), int(rng.choice(sizes))
+        u = np.float32(rng.choice(base))
+        if k % 3 == 1:
+            u = np.nextafter(u, np.float32(0 if k % 2 else 100), dtype=np.float32)       # one float off
+        elif k % 3 == 2:
+            u = np.float32(u * (1 + rng.normal() * 1e-6))
+        rc = lib.fftup_jit_check(W, H, C.c_float(float(u)), int(rng.choice([0, 2])), b"", buf, 512)
+        assert rc in (0, 1, 2), (W, H, float(u), rc)
+        if rc == 0:
+            seen += 1
+            uW, uH = int(np.float32(u) * np.float32(W)), int(np.float32(u) * np.float32(H))
+            fr = Fraction(uW, W)
+            assert Fraction(uH, H) == fr and fr.limit_denominator(16) == fr, (W, H, float(u), uW, uH)
+            m = re.search(r"fused ([\d*]+|pow2/8)", buf.value.decode())
+            assert m, buf.value
+    assert seen > 300
