@@ -235,3 +235,32 @@ def test_plan_describe():
         assert up.description.startswith("specialised at plan time: u6/5")
     with _up(250, 120, 1.8, 0) as up:                  # 9/5 = 18/10: the fused kernel's first radix would have to be 18
         assert up.description.startswith("size-generic")
+
+
+@pytest.mark.parametrize("W,H,u", [
+    (96, 72, float(np.nextafter(np.float32(4 / 3), np.float32(2)))),     # one float above the nearest float of 4/3: sizes 128 x 96 still exact
+    (96, 72, float(np.nextafter(np.float32(4 / 3), np.float32(1)))),     # one below: 127 x 95 -- odd, not a configuration
+    (128, 64, float(np.nextafter(np.float32(2), np.float32(3)))),        # just above 2
+    (128, 64, float(np.nextafter(np.float32(2), np.float32(1)))),        # just below 2: 255 x 127
+    (120, 100, float(np.nextafter(np.float32(1.5), np.float32(2)))),
+    (250, 120, 1.2), (250, 120, float(np.nextafter(np.float32(1.2), np.float32(2)))),
+    (200, 100, 1.6), (140, 70, 1.4), (168, 84, float(np.float32(7 / 6))), (224, 112, float(np.float32(15 / 14)))])
+def test_float_factors_at_the_edges(W, H, u):
+    """The factor is a float and the reference multiplies, truncates and divides in float (VR:1417, 1494-1495): a factor one ulp off a
+    ratio may give the same sizes, sizes one pixel short, or a guard a row off.  Whatever the plan decides -- specialised, size-generic,
+    or no configuration at all -- the result agrees with the oracle, which repeats that arithmetic."""
+    import vkresample_amd as v
+    from vkresample_amd import synth
+    if O.check(W, H, u, 0) != 0:
+        with pytest.raises(v.FftupError):
+            v.Upscaler(W, H, u, 0, 0.2, 0)
+        return
+    rgb = synth.frame(31, W, H, "N")
+    for flags in (0, v.FLAG_GENERIC_KERNELS):
+        with v.Upscaler(W, H, u, 0, 0.2, 0, flags) as up:
+            up.upload_rgb8(rgb)
+            up.execute(1)
+            pre, out = up.download_presharpen().astype(np.float64), up.download_planar().astype(np.float64)
+        opre, oout, _ = O.upscale_rgb8(rgb, u, 0, 0.2)
+        assert pre.shape == opre.shape
+        assert np.abs(pre - opre).max() * u * u <= 1e-5 and np.abs(out[:, :-1] - oout[:, :-1]).max() <= 5e-4
