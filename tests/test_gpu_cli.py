@@ -39,6 +39,23 @@ def test_cli_single_image_1080p(tmp_path):
     assert out.shape == (2160, 3840, 3) and d.max() <= 1 and (d != 0).mean() <= 5e-3
 
 
+def test_cli_upscale_factor_as_a_ratio(tmp_path):
+    """-u 4/3 (extension: the ratio divided in float): 960 x 540 -> exactly 1280 x 720, the result of -u 1.3333334"""
+    from vkresample_amd import synth
+    rgb = synth.frame(13, 960, 540, "N")
+    _png_write(tmp_path / "in.png", rgb)
+    outs = []
+    for u in ("4/3", "1.3333334"):
+        r = subprocess.run([CLI, "-i", "in.png", "-o", "out.png", "-u", u, "-n", "1"], capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert re.search(r"upscale: 960x540 to 1280x720 Time: [0-9.]+ ms", r.stdout), r.stdout
+        outs.append(_png_read(tmp_path / "out.png"))
+    assert outs[0].shape == (720, 1280, 3) and np.array_equal(outs[0], outs[1])
+    _, _, ou8 = O.upscale_rgb8(rgb, float(np.float32(4.0 / 3.0)), 0, 0.2)
+    d = np.abs(outs[0][:-1].astype(int) - ou8[:-1].astype(int))
+    assert d.max() <= 1 and (d != 0).mean() <= 5e-3
+
+
 @pytest.mark.parametrize("W,H,u,p", [(800, 600, "2", "0"), (1280, 720, "1.5", "0"), (960, 540, "4", "2")])
 def test_cli_sizes_specialised_at_plan_time(tmp_path, W, H, u, p):
     """sizes and factors the CLI gets plan-time specialised kernels for (csrc/jit.hpp): 800x600 -u 2, 720p -> 1080p,

@@ -358,7 +358,11 @@ int main(int argc, char* argv[])
     }
     if (findFlag(B, E, "-u")) {
         char* v = getFlagValue(B, E, "-u");
-        if (v) sscanf(v, "%f", &config.upscale);
+        // (VR:1883: "%f".  Extension: "-u 4/3" -- a ratio, divided in float: the nearest float of 4/3 is what makes 1920 x 1080 come out
+        // as exactly 2560 x 1440 in the reference's float arithmetic; typed as a decimal it takes eight digits, 1.3333334)
+        float num = 0.f, den = 0.f;
+        if (v && sscanf(v, "%f/%f", &num, &den) == 2 && den != 0.f) config.upscale = num / den;
+        else if (v) sscanf(v, "%f", &config.upscale);
         else printf("No proper upscale factor is selected with -u flag, default 1\n");
     } else {
         printf("No upscale factor is selected with -u flag, default 1\n");
