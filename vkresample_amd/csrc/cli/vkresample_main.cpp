@@ -311,7 +311,7 @@ int main(int argc, char* argv[])
         printf("	-h: this help\n");
         printf("	-devices: list the available GPUs\n");
         printf("	-d X: GPU to use (default 0)\n");
-        printf("	-u X: upscale factor (float; the upscaled sizes must factor into 2s, 3s, 5s and 7s)\n");
+        printf("	-u X: upscale factor (float, or a ratio like 4/3; the upscaled sizes must factor into 2s, 3s, 5s and 7s)\n");
         printf("	-p X: specify precision (0 - single, 1 - double, 2 - half, default - single)\n");
         printf("	-s X: sharpening factor, 0.0-0.2 (default 0.2)\n");
         printf("	-n X: how many times to run the upscale; removes launch overhead from the reported time (default 1)\n");
