@@ -19,7 +19,7 @@ for cfg in "640 480" "720 480" "720 576" "800 600" "1000 1000" "1024 768" "1280 
   set -- $cfg
   for mode in jit generic; do
     if [ $mode = generic ]; then FL="--generic"; else FL=""; fi
-    python bench.py --width $1 --height $2 --no-cpu-baseline --steps 3 --warmup 1 --repeats 3 --frames-per-step 256 --ring 4 $FL > $OUT/b_$1x$2_$mode.json 2>> $OUT/err.txt
+    python bench.py --width $1 --height $2 --no-cpu-baseline --no-others --no-rccl-check --no-live-traffic --steps 3 --warmup 1 --repeats 3 --frames-per-step 256 --ring 4 $FL > $OUT/b_$1x$2_$mode.json 2>> $OUT/err.txt
     k=$(python -c "import json;d=json.loads(open('$OUT/b_$1x$2_$mode.json').read().strip().splitlines()[-1]);print(d['config']['kernels'])" 2>/dev/null)
     line $OUT/b_$1x$2_$mode.json "$k"
   done
@@ -27,7 +27,7 @@ done
 echo "# other upscale factors"
 for cfg in "1920 1080 1.5" "2048 1024 1.5" "2048 1024 3" "960 540 4"; do
   set -- $cfg
-  python bench.py --width $1 --height $2 --upscale $3 --no-cpu-baseline --steps 3 --warmup 1 --repeats 3 --frames-per-step 256 --ring 4 > $OUT/b_$1x$2_u$3.json 2>> $OUT/err.txt
+  python bench.py --width $1 --height $2 --upscale $3 --no-cpu-baseline --no-others --no-rccl-check --no-live-traffic --steps 3 --warmup 1 --repeats 3 --frames-per-step 256 --ring 4 > $OUT/b_$1x$2_u$3.json 2>> $OUT/err.txt
   k=$(python -c "import json;d=json.loads(open('$OUT/b_$1x$2_u$3.json').read().strip().splitlines()[-1]);print(d['config']['kernels'])" 2>/dev/null)
   line $OUT/b_$1x$2_u$3.json "$k"
 done
