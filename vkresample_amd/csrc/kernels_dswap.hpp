@@ -273,8 +273,10 @@ __global__ void __launch_bounds__(H / 2, kColWaves) k_col_v(ColTParams p)
     float2* dst = p.S2 + ((long)c * p.NT + tile) * H * TK;
     constexpr float inv = 1.0f / (float)H;
     if (valid) {
+        // (8-byte write-through stores, 512 contiguous bytes per wave and instruction.  Lane pairs trading elements for 16-byte stores --
+        // DPP quad_perm, 32 more vector instructions per thread -- measured no faster: profiles/r06_c_wt_default.txt)
 #pragma unroll
-        for (int i = 0; i < 8; i++) dst[tid + T * i] = cscale(v[i], inv);
+        for (int i = 0; i < 8; i++) spec_store8(dst + tid + T * i, cscale(v[i], inv));
     }
 }
 

@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(CFG::ROW_T) k_row_r2c_m(RowR2CTParams p)
             }
             o[e] = r;
         }
-        *(float4*)(base + (long)tile * tile_stride + (isB ? TK : 0) + kk) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+        spec_store16(base + (long)tile * tile_stride + (isB ? TK : 0) + kk, o[0], o[1]);
     }
 }
 
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(4 * CFG::COL_TPC) k_col_m(ColTParams p)
     constexpr float inv = 1.0f / (float)H;
     if (j < FI::NB2 && valid) {
 #pragma unroll
-        for (int m = 0; m < R2; m++) dst[(j + FI::NB2 * m) * TK + col] = cscale(v[m], inv);
+        for (int m = 0; m < R2; m++) spec_store8(dst + (j + FI::NB2 * m) * TK + col, cscale(v[m], inv));
     }
 }
 
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(CFG::ROW_T) k_row_r2c_n(RowR2CTParams p)
             }
             o[e] = r;
         }
-        *(float4*)(base + (long)tile * tile_stride + (isB ? TK : 0) + kk) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+        spec_store16(base + (long)tile * tile_stride + (isB ? TK : 0) + kk, o[0], o[1]);
     }
 }
 
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(CFG::COL_COLS * CFG::COL_TPC) k_col_n(ColTPara
     constexpr float inv = 1.0f / (float)H;
     if (j < NBL && valid) {
 #pragma unroll
-        for (int m = 0; m < RL; m++) dst[(j + NBL * m) * TK + gcol] = cscale(v[m], inv);
+        for (int m = 0; m < RL; m++) spec_store8(dst + (j + NBL * m) * TK + gcol, cscale(v[m], inv));
     }
 }
 
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(CFG::COL_COLS * CFG::COL_TPC) k_col_u(ColTPara
         float2* dst = p.S2 + (r - 1) * buf_stride + ((long)c * p.NT + tile) * H * TK;
         if (j < NBL && valid) {
 #pragma unroll
-            for (int m = 0; m < RL; m++) dst[(j + NBL * m) * TK + gcol] = cscale(v[m], inv);
+            for (int m = 0; m < RL; m++) spec_store8(dst + (j + NBL * m) * TK + gcol, cscale(v[m], inv));
         }
         __syncthreads();                                                            // the buffer is free for the next residue
     }
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(CFG::COL_COLS * CFG::COL_TPC) k_col_pad(ColTPa
     constexpr float inv = 1.0f / (float)UH;
     if (j < MBL && valid) {
 #pragma unroll
-        for (int m = 0; m < QL; m++) dst[(j + MBL * m) * TK + gcol] = cscale(w[m], inv);
+        for (int m = 0; m < QL; m++) spec_store8(dst + (j + MBL * m) * TK + gcol, cscale(w[m], inv));
     }
 }
 
