@@ -1019,6 +1019,66 @@ __device__ __forceinline__ h2v sharpen_eval_pair_half(h2v N, h2v S, h2v Wv, h2v 
     const h2v den = __builtin_elementwise_fma(scale, four, one);      // 4 * scale is exact: one rounding either way, one instruction
     return pk_div(num, den);
 }
+// ---- the same on the FOUR pixels of a quad at once (two register pairs per value): every operation becomes two independent
+// v_pk_*_f16 instructions back to back.  On gfx950 a packed binary16 result needs one wait state before the next vector
+// instruction may read it, and the filter is ONE dependency chain from the minima to the quotient: evaluated pair by pair the
+// compiler pads it with an s_nop behind nearly every instruction (33 per row of quads, 132 of the 880 instructions of a step);
+// with the two pairs of a quad interleaved the other pair's instruction IS the wait state.  (Measured, round 6: 187 -> 71 s_nop in
+// the kernel and the same time -- the padding costs the wave issue cycles, the vector ALU none, and it is the ALU the kernel is
+// short of; profiles/r06_d_quad.txt.  Tabulating the weight scale(d) over its ONE binary16 argument d = min(smn, 2 - smx) in LDS --
+// 15361 entries, 30 KB, the shader's per-operation roundings exactly; 10 packed + 8 transcendental instructions fewer per row
+// of quads -- makes the kernel alone 6 % faster (57.5 -> 54.0 us) and the overlapped frame 1.4 % slower: 94 instead of 64 KB
+// of LDS per strip leave the other frames' row and column workgroups less room on the unit.  Not kept: profiles/r06_e_lut.txt,
+// the patch beside it.)
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h4v h4_cat(h2v a, h2v b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); }
+__device__ __forceinline__ h2v h4_lo(h4v a) { return __builtin_shufflevector(a, a, 0, 1); }
+__device__ __forceinline__ h2v h4_hi(h4v a) { return __builtin_shufflevector(a, a, 2, 3); }
+// v_rcp_f16 / v_sqrt_f16 of four halves: the lower halves of both registers first, then the upper ones through SDWA (each reads
+// the lower half its predecessor-but-one wrote: the instruction between them is the wait state a transcendental result needs)
+__device__ __forceinline__ h4v pk4_rcp_h(h4v b)
+{
+    h2v r0, r1;
+    const h2v b0 = h4_lo(b), b1 = h4_hi(b);
+    asm("v_rcp_f16_e32 %0, %2\n\tv_rcp_f16_e32 %1, %3\n\t"
+        "v_rcp_f16_sdwa %0, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+        "v_rcp_f16_sdwa %1, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "=&v"(r0), "=&v"(r1) : "v"(b0), "v"(b1));
+    return h4_cat(r0, r1);
+}
+__device__ __forceinline__ h4v pk4_sqrt_h(h4v b)
+{
+    h2v r0, r1;
+    const h2v b0 = h4_lo(b), b1 = h4_hi(b);
+    asm("v_sqrt_f16_e32 %0, %2\n\tv_sqrt_f16_e32 %1, %3\n\t"
+        "v_sqrt_f16_sdwa %0, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+        "v_sqrt_f16_sdwa %1, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "=&v"(r0), "=&v"(r1) : "v"(b0), "v"(b1));
+    return h4_cat(r0, r1);
+}
+__device__ __forceinline__ h4v pk4_div(h4v a, h4v b)
+{
+#pragma clang fp contract(off)
+    const h4v rc = pk4_rcp_h(b);
+    const h4v q = a * rc;
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(-q, b, a), rc, q);
+}
+__device__ __forceinline__ h4v sharpen_eval_quad_half(h4v N, h4v S, h4v Wv, h4v E, h4v C, h4v mn0, h4v mn1, h4v mx0, h4v mx1, h4v ncoef)
+{
+#pragma clang fp contract(off)
+    const _Float16 f1 = (_Float16)1.0f, f2 = (_Float16)2.0f, f4 = (_Float16)4.0f;
+    const h4v one = {f1, f1, f1, f1}, two = {f2, f2, f2, f2}, four = {f4, f4, f4, f4};
+    const h4v smn = mn0 + mn1, smx = mx0 + mx1;
+    const h4v u = two - smx;
+    const h4v n2 = __builtin_elementwise_min(smn, u);
+    const h4v d2 = two - n2;
+    const h4v q = pk4_div(n2, d2);
+    const h4v r = pk4_sqrt_h(q);
+    const h4v scale = ncoef * r;
+    const h4v s4 = ((N + Wv) + E) + S;
+    const h4v prod = scale * s4;
+    const h4v num = C + prod;
+    const h4v den = __builtin_elementwise_fma(scale, four, one);
+    return pk4_div(num, den);
+}
 // one window (three rows) of four pixels: P[r] = the five column pairs (-1,0) (0,1) (1,2) (2,3) (3,4) of row r
 struct H2Row { h2v sa, h01, sb, h23, sc; };
 __device__ __forceinline__ void sharpen_quad_half(const H2Row& r0, const H2Row& r1, const H2Row& r2, h2v ncoef, h2v& o01, h2v& o23)
@@ -1032,11 +1092,14 @@ __device__ __forceinline__ void sharpen_quad_half(const H2Row& r0, const H2Row& 
     // pixels 0,1: columns (-1,0) (0,1) (1,2); cross = N, C, S (the vertical triple of the centre pair) and W, E
     const h2v mn1a = pk_min3(na, nb, nc), mx1a = pk_max3(xa, xb, xc);
     const h2v mn0a = pk_min3(nb, r1.sa, r1.sb), mx0a = pk_max3(xb, r1.sa, r1.sb);
-    o01 = sharpen_eval_pair_half(r0.h01, r2.h01, r1.sa, r1.sb, r1.h01, mn0a, mn1a, mx0a, mx1a, ncoef);
     // pixels 2,3: columns (1,2) (2,3) (3,4)
     const h2v mn1b = pk_min3(nc, nd, ne), mx1b = pk_max3(xc, xd, xe);
     const h2v mn0b = pk_min3(nd, r1.sb, r1.sc), mx0b = pk_max3(xd, r1.sb, r1.sc);
-    o23 = sharpen_eval_pair_half(r0.h23, r2.h23, r1.sb, r1.sc, r1.h23, mn0b, mn1b, mx0b, mx1b, ncoef);
+    // both pairs through the filter's arithmetic together (sharpen_eval_quad_half: same operations, interleaved)
+    const h4v o = sharpen_eval_quad_half(h4_cat(r0.h01, r0.h23), h4_cat(r2.h01, r2.h23), h4_cat(r1.sa, r1.sb), h4_cat(r1.sb, r1.sc), h4_cat(r1.h01, r1.h23),
+                                         h4_cat(mn0a, mn0b), h4_cat(mn1a, mn1b), h4_cat(mx0a, mx0b), h4_cat(mx1a, mx1b), h4_cat(ncoef, ncoef));
+    o01 = h4_lo(o);
+    o23 = h4_hi(o);
 }
 
 // =================================================================================== transform plans of the fused kernel
