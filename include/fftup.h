@@ -39,8 +39,9 @@ enum {
     FFTUP_E_OUT_OF_MEMORY = 6,  /* device allocation failed (allocateFFTBuffer VR:361-384)              */
     FFTUP_E_NO_INPUT = 7,       /* execute/download before any upload                                   */
     FFTUP_E_INCOMPLETE = 8,     /* "Image not found" class of errors in the host mirror (VR:1366)       */
-    FFTUP_E_WOULD_BLOCK = 9,    /* fftup_submit_png: the ring slot it needs holds a PNG ticket of the CALLING thread that has
-                                   not been collected (fftup_wait_png) -- waiting would never end                */
+    FFTUP_E_WOULD_BLOCK = 9,    /* fftup_submit_png / fftup_submit_rgb8: every ring slot holds an uncollected PNG ticket of the
+                                   CALLING thread and no other thread has collected anything on this plan (after a bounded
+                                   wait, FFTUP_SELF_WAIT_MS, default 2000) -- waiting would never end            */
     FFTUP_E_OVERFLOW = 10       /* fftup_wait_png: the frame's deflate stream did not fit the encoder's buffer; nothing was
                                    written beyond it, the frame is not encoded                                   */
 };
@@ -63,10 +64,12 @@ enum {
                                         conversion launch, fftup_download_planar fails with FFTUP_E_INVALID_ARG.  Plans without a
                                         fused kernel (size-generic, -p 1, non-R2C, FFTUP_FLAG_UNFUSED_SHARPEN) ignore the flag:
                                         fftup_info.u8_store says which it is                                               */
-    FFTUP_FLAG_SEQUENTIAL_EXECUTE = 64u /* fftup_execute keeps every iteration on the plan's ONE stream (the strict single-queue
-                                        form of performVulkanUpscale: single-frame latency; a plan without a ring is then laid out
-                                        for it); default: the identical iterations of an n_iter > 1 call alternate on the plan's
-                                        streams, same bits, overlapped                                                        */
+    FFTUP_FLAG_SEQUENTIAL_EXECUTE = 64u, /* accepted and ignored: ordered iterations are what fftup_execute does (0.6 and earlier
+                                        needed this flag for it)                                                               */
+    FFTUP_FLAG_OVERLAP_ITERATIONS = 128u /* EXTENSION, not the reference's semantics: the n_iter identical iterations of one
+                                        fftup_execute call alternate on the plan's streams and overlap like the distinct frames
+                                        of fftup_execute_ring (a throughput figure; same bits).  A plan without a ring is then
+                                        laid out for overlapping frames (one strip of the last kernel per compute unit)         */
 };
 
 /* Replaces VkResampleConfiguration (VR:45-59) + the part of VkFFTConfiguration (VF:22-94) that
@@ -83,8 +86,8 @@ typedef struct fftup_config {
 } fftup_config;
 
 /* Environment read by fftup_plan_create (operational knobs, not part of the reference's surface):
- *   FFTUP_STREAMS=n     HIP streams consecutive frames of fftup_execute_ring / fftup_submit_rgb8 and the iterations of
- *                       fftup_execute (n_iter > 1) alternate on (default 3, 1..4)
+ *   FFTUP_STREAMS=n     HIP streams consecutive frames of fftup_execute_ring / fftup_submit_rgb8 (and the iterations of
+ *                       fftup_execute under FFTUP_FLAG_OVERLAP_ITERATIONS) alternate on (default 3, 1..4)
  *   FFTUP_JIT=0|1       run-time specialised plans (default 1); FFTUP_JIT_VERBOSE=1 prints why one fell back
  *   FFTUP_CACHE_DIR     code-object cache and wisdom file of those plans (default ~/.cache/fftup);
  *   FFTUP_KERNEL_DIR    kernel headers, when not the ones embedded in the library; FFTUP_HIPRTC_LIB: the run-time compiler's
@@ -162,11 +165,12 @@ FFTUP_API int fftup_upload_planar(fftup_plan* plan, uint32_t slot, const void* p
 /* performVulkanUpscale (VR:1249-1279): enqueue n_iter full pipelines, one synchronisation.
  * *ms_per_iter = device time from before the first to after the last launch, divided by n_iter -- the
  * reference's "Time: X ms" (VR:1270-1278).  Every iteration reads input slot 0 and computes the same frame; output slot 0
- * holds it afterwards.  The reference records the n_iter pipelines into one command buffer and submits it once (VR:1250-1273);
- * nothing orders identical iterations, so for n_iter > 1 they alternate on the plan's FFTUP_STREAMS HIP streams (own spectra,
- * own scratch output per stream beyond the first -- allocated on the first such call) and overlap like the frames of
- * fftup_execute_ring: bit-identical results, the throughput figure.  n_iter = 1, FFTUP_FLAG_SEQUENTIAL_EXECUTE or
- * FFTUP_STREAMS=1: one stream, no overlap -- single-frame latency. */
+ * holds it afterwards.  The reference records the n_iter pipelines into ONE command buffer on ONE queue, and every stage ends
+ * in a compute-to-compute pipeline barrier (vkFFT.h:7678, VR:1217): iteration i + 1 cannot start before the sharpen pass of
+ * iteration i has finished.  So here: one stream, the iterations in order, nothing overlaps -- single-frame latency, the figure
+ * that is comparable with the reference's.  FFTUP_FLAG_OVERLAP_ITERATIONS (an extension) lets the identical iterations of a
+ * call alternate on the plan's FFTUP_STREAMS streams instead (own spectra, own scratch output per stream beyond the first,
+ * allocated on the first such call): the same bits, the throughput figure of fftup_execute_ring. */
 FFTUP_API int fftup_execute(fftup_plan* plan, uint32_t n_iter, double* ms_per_iter);
 /* batched mode: n_frames pipelines, frame i reads input slot (first_slot+i) % ring and writes
  * output slot (first_slot+i) % ring; returns total device milliseconds. */
@@ -228,9 +232,13 @@ FFTUP_API int fftup_drain(fftup_plan* plan);
  * fftup_submit_png must be collected by fftup_wait_png: its ring slot stays with it until then.  Submissions (fftup_submit_png
  * or fftup_submit_rgb8, any thread) take the next slot that holds no uncollected stream -- so threads that keep tickets open
  * while they submit cannot wait for each other in a circle as long as fewer than `ring` streams are uncollected in total; with
- * every slot held a submission waits for a collector, unless every uncollected stream is the submitting thread's own, which would
- * wait forever: that call fails with FFTUP_E_WOULD_BLOCK instead (with the default ring of 1: collect each ticket before the
- * next submission).  -p 0 and -p 2 plans whose stream bound fits one
+ * every slot held a submission waits for a collector -- another thread's fftup_wait_png (one thread submitting, another
+ * collecting, more frames than slots: the submission waits) -- unless every uncollected stream is the submitting thread's own
+ * AND no other thread has ever collected on this plan, which would wait forever: after a bounded wait that call fails with
+ * FFTUP_E_WOULD_BLOCK (with the default ring of 1 and one thread: collect each ticket before the next submission).
+ * fftup_wait_png: a device error or FFTUP_E_OVERFLOW voids the ticket and frees its slot; a caller's error (capacity too
+ * small, a buffer other than the one named at submission) leaves the stream on the device and the ticket collectable.
+ * -p 0 and -p 2 plans whose stream bound fits one
  * IDAT chunk (2^31 - 1 bytes: FFTUP_E_UNSUPPORTED_SIZE beyond); thread-safe like fftup_submit_rgb8 / fftup_wait. */
 FFTUP_API size_t fftup_png_bound(fftup_plan* plan);
 FFTUP_API int fftup_submit_png(fftup_plan* plan, const uint8_t* rgb_in, size_t in_stride_bytes, uint8_t* png_out, size_t capacity,

@@ -118,6 +118,8 @@ U_CASES = [
 def test_specialised_integer_factor_vs_oracle(W, H, u, precision, flags):
     if os.environ.get("FFTUP_BIG_TESTS", "0") == "0" and (W * H * u * u > 30e6 or (W * H * u * u > 12e6 and precision == 0)):
         pytest.skip("outputs above 12 Mpixel: -p 2 with the fused u8 load only, above 30 Mpixel nothing, unless FFTUP_BIG_TESTS=1 (oracle time)")
+    if os.environ.get("FFTUP_BIG_TESTS", "0") == "0" and precision == 2 and W * H * u * u <= 12e6 and U_CASES.index((W, H, u)) % 2:
+        pytest.skip("-p 2 on every other case of the list unless FFTUP_BIG_TESTS=1: the driver's whole GPU run has a time limit (VERDICT r5 #1)")
     with _up(W, H, u, precision, 0.2, 0, flags) as up:
         assert up.tuned and up.specialised_at_plan_time, "plan fell back to the size-generic kernels"
     (pre, out, u8), (opre, oout, ou8) = _run(W, H, u, precision, "N", flags=flags, seed=W + H)

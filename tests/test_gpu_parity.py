@@ -697,6 +697,43 @@ def test_fp64_parity(W, H, u, dist):
     assert np.abs(d).max() <= 1 and (d != 0).mean() <= 1e-4      # trunc(255*x) flips where 255*x is an integer +- 1 ulp
 
 
+def test_fp64_sharpen_against_the_ieee_sequence_in_ulps(monkeypatch):
+    """the -p 1 sharpen forms its quotients and its root from v_rcp_f64 / v_rsq_f64 seeds and Newton steps
+    (sharpen_eval_f64) instead of IEEE division sequences.  Against the same kernel with the shader's own divisions and root
+    (k_sharpen_f64<.., EXACT>, test build of the library) on the same pre-sharpen image: an explicit bound in units of the last
+    place, on frames whose 3x3 minima reach 0 and maxima reach 1 (black and white blocks: n -> 0, the root's steep end; d -> 1)."""
+    from vkresample_amd import _lib, synth
+    W, H = 256, 128
+    rgb = synth.frame(11, W, H, "N").copy()
+    rgb[8:40, 16:80] = 0                                     # mn = 0 over whole neighbourhoods
+    rgb[60:100, 100:200] = 255                               # mx = 1 (clamped)
+    rgb[20:30, 150:160] = np.random.default_rng(1).integers(0, 3, (10, 10, 3))       # tiny non-zero minima
+    monkeypatch.setenv("FFTUP_LIBRARY", _lib.KNOBS_LIB_PATH)
+    res = []
+    for exact in ("0", "1"):
+        monkeypatch.setenv("FFTUP_EXPERIMENT", "f64_exact_sharpen=" + exact)
+        with _up(W, H, 2.0, 1) as up:
+            up.upload_rgb8(rgb)
+            up.execute(1)
+            res.append((up.download_presharpen().copy(), up.download_planar().copy()))
+    assert np.array_equal(res[0][0], res[1][0])              # the same image goes into both filters
+    fast, exact = res[0][1], res[1][1]
+    assert np.isfinite(fast).all() and np.isfinite(exact).all()
+    assert 4.0 * np.abs(res[0][0]).min() < 1e-4 and 4.0 * res[0][0].max() > 1.0       # taps |u^2 g| near 0 and clamped at 1 both occur
+    # The output is (C + scale * s4) / (1 + 4 scale) with scale < 0: where the two terms of the numerator nearly cancel, the result is
+    # small and an error of one unit in the last place of the TERMS is thousands of units of the result's own.  So: in units of
+    # the last place of the filter's operands (values in [0, 1]: 2^-53), and in the result's own units where it is not small
+    err = np.abs(fast - exact)
+    u1 = err / 2.0 ** -53
+    own = err[np.abs(exact) >= 0.25] / np.spacing(np.abs(exact[np.abs(exact) >= 0.25]))
+    print("MEASURED fp64 sharpen vs IEEE sequence: max %.1f units of 2^-53, %.3f %% of the pixels differ; results >= 0.25: max %.1f ulp of their own"
+          % (u1.max(), 100.0 * (err > 0).mean(), own.max()))
+    assert u1.max() <= 16.0 and own.max() <= 8.0, (u1.max(), own.max())
+    # and the IEEE form against the oracle: the same sequence of operations, to the last few bits
+    opre, oout, _ = O.upscale_rgb8(rgb, 2.0, 1, 0.2)
+    assert np.abs(exact[:, :-1] - oout[:, :-1]).max() <= 1e-9
+
+
 def test_fp64_planar_input_and_limits():
     import vkresample_amd as v
     rng = np.random.default_rng(5)
@@ -901,20 +938,20 @@ def test_fused_output_independent_of_strip_length(W, H, precision):
 
 @pytest.mark.parametrize("W,H,precision,flags", [(256, 128, 0, 0), (640, 480, 0, 2), (2048, 1024, 2, 2), (2048, 1024, 0, 32), (1920, 1080, 0, 0),
                                                  (16, 8, 1, 0), (9216, 8, 0, 0), (512, 256, 0, 8)])
-def test_pipelined_execute_is_bit_identical_to_the_single_queue_form(W, H, precision, flags, monkeypatch):
-    """fftup_execute(n > 1) runs its n identical iterations alternately on the plan's streams (own spectra, own scratch output
-    per stream; the reference submits them as one command buffer, VR:1250-1273) -- the same kernels with the same arguments on
-    the same input: output slot 0 holds the bits ONE iteration leaves (n = 1 runs alone on stream 0), for n = 2, 3, 35, on
-    plans with and without a ring, fused, unfused (FFTUP_FLAG_UNFUSED_SHARPEN), 8-bit store (32), -p 1, four-step rows.  The
-    strict single-queue form (FFTUP_FLAG_SEQUENTIAL_EXECUTE, FFTUP_STREAMS=1) gives the same frame: bit for bit wherever the
-    result does not depend on the fused kernel's strip length (a sequential plan cuts two strips per compute unit), to rounding
-    where it does."""
-    from vkresample_amd import FLAG_FUSE_U8_STORE, FLAG_SEQUENTIAL_EXECUTE, synth
+def test_overlapped_iterations_are_bit_identical_to_the_ordered_form(W, H, precision, flags, monkeypatch):
+    """fftup_execute(n) runs its n identical iterations in order on one stream -- the reference's one command buffer with a barrier
+    behind every stage (VR:1260-1265, VR:1217, vkFFT.h:7678).  FFTUP_FLAG_OVERLAP_ITERATIONS (extension) lets them alternate on the
+    plan's streams (own spectra, own scratch output per stream): the same kernels with the same arguments on the same input, so
+    output slot 0 holds the bits ONE iteration leaves (n = 1 runs alone on stream 0), for n = 2, 3, 35, on plans with and without
+    a ring, fused, unfused (FFTUP_FLAG_UNFUSED_SHARPEN), 8-bit store (32), -p 1, four-step rows.  The ordered form gives the same
+    frame: bit for bit wherever the result does not depend on the fused kernel's strip length (a plan without a ring and without
+    the flag cuts two strips per compute unit), to rounding where it does."""
+    from vkresample_amd import FLAG_FUSE_U8_STORE, FLAG_OVERLAP_ITERATIONS, FLAG_SEQUENTIAL_EXECUTE, synth
     rgb = synth.frame(70, W, H)
     get = (lambda up: up.download_rgb8(0).copy()) if flags & FLAG_FUSE_U8_STORE else (lambda up: up.download_planar(0).copy())
     res = {}
     for ring in (1, 3):
-        with _up(W, H, 2.0, precision, 0.2, 0, flags, ring=ring) as up:
+        with _up(W, H, 2.0, precision, 0.2, 0, flags | FLAG_OVERLAP_ITERATIONS, ring=ring) as up:
             up.upload_rgb8(rgb)
             outs = []
             for n in (1, 2, 3, 35, 1):
@@ -926,7 +963,12 @@ def test_pipelined_execute_is_bit_identical_to_the_single_queue_form(W, H, preci
                 assert np.array_equal(outs[0], o)
             res[ring] = (outs[0], pre)
     assert np.array_equal(res[1][0], res[3][0])
-    with _up(W, H, 2.0, precision, 0.2, 0, flags | FLAG_SEQUENTIAL_EXECUTE) as up:
+    # a ring and no flag: ordered iterations on a plan laid out for overlapping frames -- the same cuts, the same bits
+    with _up(W, H, 2.0, precision, 0.2, 0, flags, ring=3) as up:
+        up.upload_rgb8(rgb)
+        up.execute(3)
+        assert np.array_equal(get(up), res[3][0])
+    with _up(W, H, 2.0, precision, 0.2, 0, flags) as up:                 # the default: ordered iterations, no ring
         up.upload_rgb8(rgb)
         up.execute(5)
         seq, seq_pre = get(up), (up.download_presharpen().copy() if not flags & FLAG_FUSE_U8_STORE else None)
@@ -938,11 +980,15 @@ def test_pipelined_execute_is_bit_identical_to_the_single_queue_form(W, H, preci
         assert d.max() <= (1 if flags & FLAG_FUSE_U8_STORE else 5e-6 if precision == 0 else 4e-3)
     else:
         assert np.array_equal(seq, res[1][0])
+    with _up(W, H, 2.0, precision, 0.2, 0, flags | FLAG_SEQUENTIAL_EXECUTE) as up:     # (the flag of 0.6 and earlier: accepted, no effect)
+        up.upload_rgb8(rgb)
+        up.execute(2)
+        assert np.array_equal(get(up), seq)
     monkeypatch.setenv("FFTUP_STREAMS", "1")
-    with _up(W, H, 2.0, precision, 0.2, 0, flags) as up:
+    with _up(W, H, 2.0, precision, 0.2, 0, flags | FLAG_OVERLAP_ITERATIONS) as up:
         up.upload_rgb8(rgb)
         up.execute(4)
-        assert np.array_equal(get(up), seq)                              # one stream = the sequential plan, cuts included
+        assert np.array_equal(get(up), seq)                              # one stream: nothing to overlap -- the ordered plan, cuts included
 
 
 def test_four_step_plans_in_a_ring():

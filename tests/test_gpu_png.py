@@ -82,10 +82,12 @@ def test_png_from_the_device_decodes_to_the_frame(W, H, u, precision, flags, rin
             sizes.append(nbytes)
         print("MEASURED png %dx%d: %s bytes per frame, %d raw" % (uW, uH, sizes, uH * uW * 3))
         assert sizes[2] < 0.2 * uH * uW * 3 if len(sizes) > 2 and W < 1000 else True      # the flat frame: one bit per byte + headers
-        # tickets of the two kinds share the queue; a buffer that is too small is an error, and the slot is free again afterwards
+        # tickets of the two kinds share the queue; a buffer that is too small is the caller's error: the stream stays on the device
+        # and the ticket collectable -- with a proper buffer it delivers its frame
         t = up.submit_png(frames[0])
         with pytest.raises(v.FftupError):
             up.wait_png(t, buf.array[:64])
+        assert np.array_equal(_decode(bytes(buf.array[:up.wait_png(t, buf.array)])), want[0])
         t2 = up.submit_png(frames[1 % len(frames)])
         nbytes = up.wait_png(t2, buf.array)
         assert np.array_equal(_decode(bytes(buf.array[:nbytes])), want[1 % len(frames)])
@@ -96,7 +98,8 @@ def test_png_from_the_device_decodes_to_the_frame(W, H, u, precision, flags, rin
         other = v.PinnedArray((up.png_bound(),))
         t5 = up.submit_png(frames[0], buf.array)
         with pytest.raises(v.FftupError):
-            up.wait_png(t5, other.array)                                # the file is in the buffer named at submission (slot freed)
+            up.wait_png(t5, other.array)                                # the file is in the buffer named at submission: named again, it is collected
+        assert np.array_equal(_decode(bytes(buf.array[:up.wait_png(t5, buf.array)])), want[0])
         other.close()
         t3 = up.submit_png(frames[0])
         with pytest.raises(v.FftupError):
@@ -172,13 +175,15 @@ def test_png_tickets_from_several_threads():
         assert not errors, errors
 
 
-def test_a_thread_waiting_for_its_own_png_ticket_is_an_error_not_a_hang():
+def test_a_thread_waiting_for_its_own_png_ticket_is_an_error_not_a_hang(monkeypatch):
     """a submission that comes round to a ring slot whose PNG ticket has not been collected waits for the collector --
-    unless the collector is the submitting thread itself, which would wait forever: FFTUP_E_WOULD_BLOCK (9).  ring = 1 (the
+    unless the collector is the submitting thread itself, which would wait forever: FFTUP_E_WOULD_BLOCK (9), after a bounded wait in
+    which no other thread collected anything on the plan (FFTUP_SELF_WAIT_MS, two seconds by default).  ring = 1 (the
     default): the second fftup_submit_png of one thread; ring = 2: the third; fftup_submit_rgb8 behind an open ticket likewise.
     After fftup_wait_png the slot is free again and nothing was lost."""
     import vkresample_amd as v
     from vkresample_amd import synth
+    monkeypatch.setenv("FFTUP_SELF_WAIT_MS", "50")
     W, H = 128, 64
     f = [synth.frame(40 + k, W, H, "N") for k in range(3)]
     for ring in (1, 2):
@@ -199,6 +204,71 @@ def test_a_thread_waiting_for_its_own_png_ticket_is_an_error_not_a_hang():
             assert np.array_equal(_decode(bytes(buf.array[:up.wait_png(up.submit_png(f[2]), buf.array)])), want[2])
             buf.close()
             out.close()
+
+
+def test_producer_and_consumer_threads_with_more_frames_than_ring_slots():
+    """ONE thread submits (fftup_submit_png), ANOTHER collects (fftup_wait_png), more frames than ring slots.  Every held
+    slot then belongs to the producer -- which round 5 took for "would wait for itself" and answered with FFTUP_E_WOULD_BLOCK; the
+    submission has to wait for the consumer instead.  ring = 2, 14 frames, the consumer deliberately late: all files decode."""
+    import queue
+    import time
+    import vkresample_amd as v
+    W, H, N = 128, 64, 14
+    frames = _frames(W, H, 7)
+    with v.Upscaler(W, H, 2.0, 0, 0.2, 0, 0, 2) as up:
+        want, out = [], np.empty((2 * H, 2 * W, 3), np.uint8)
+        for f in frames:
+            up.wait(up.submit_rgb8(f, out))
+            want.append(out.copy())
+        tickets, errors, got = queue.Queue(), [], []
+
+        def producer():
+            try:
+                for i in range(N):
+                    tickets.put((up.submit_png(frames[i % 7]), i % 7))
+            except Exception as e:                                     # noqa: BLE001
+                errors.append(("producer", repr(e)))
+            tickets.put(None)
+
+        def consumer():
+            try:
+                buf = np.empty(up.png_bound(), np.uint8)
+                time.sleep(0.3)                                        # the producer has filled the ring long before the first collection
+                while True:
+                    item = tickets.get(timeout=60)
+                    if item is None:
+                        return
+                    n = up.wait_png(item[0], buf)
+                    got.append(np.array_equal(_decode(bytes(buf[:n])), want[item[1]]))
+            except Exception as e:                                     # noqa: BLE001
+                errors.append(("consumer", repr(e)))
+
+        th = [threading.Thread(target=producer, daemon=True), threading.Thread(target=consumer, daemon=True)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join(timeout=120)
+        assert not any(x.is_alive() for x in th), "producer and consumer wait for each other"
+        assert not errors and len(got) == N and all(got), (errors, got)
+
+
+def test_a_callers_mistake_in_wait_png_keeps_the_ticket():
+    """a buffer too small (or not the one named at submission) is the CALLER's error -- the encoded stream sits intact on
+    the device, so the ticket stays collectable; only device errors and an overflowed stream void it."""
+    import vkresample_amd as v
+    from vkresample_amd import synth
+    W, H = 128, 64
+    f = synth.frame(3, W, H, "N")
+    with v.Upscaler(W, H, 2.0, 0, 0.2, 0, 0, 1) as up:
+        out = np.empty((2 * H, 2 * W, 3), np.uint8)
+        up.wait(up.submit_rgb8(f, out))
+        t = up.submit_png(f)
+        with pytest.raises(v.FftupError) as e:
+            up.wait_png(t, np.empty(64, np.uint8))
+        assert e.value.code == 1 and "too small" in str(e.value)
+        buf = np.empty(up.png_bound(), np.uint8)
+        n = up.wait_png(t, buf)                                       # the same ticket, a proper buffer: the file
+        assert np.array_equal(_decode(bytes(buf[:n])), out)
 
 
 def test_device_png_size_against_the_reference_writer():

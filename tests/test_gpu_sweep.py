@@ -24,7 +24,7 @@ def _cases():
     import os
     rng = np.random.default_rng(int(os.environ.get("FFTUP_SWEEP_SEED", "20260930")))
     out = []
-    while len(out) < int(os.environ.get("FFTUP_SWEEP_N", "72")):      # (a one-off 1500-case run is logged in profiles/)
+    while len(out) < int(os.environ.get("FFTUP_SWEEP_N", "144" if os.environ.get("FFTUP_BIG_TESTS", "0") != "0" else "44")):      # (a one-off 1500-case run is logged in profiles/)
         W, H = int(rng.choice(SMOOTH)), int(rng.choice(SMOOTH))
         u = float(rng.choice([1.0, 1.25, 1.5, 2.0, 2.0, 2.0, 2.5, 3.0, 4.0]))
         uW, uH = int(np.float32(u) * np.float32(W)), int(np.float32(u) * np.float32(H))
@@ -44,7 +44,7 @@ def _cases_specialised():
     import os
     rng = np.random.default_rng(int(os.environ.get("FFTUP_SWEEP_SEED", "20260930")) + 1)
     out = []
-    while len(out) < int(os.environ.get("FFTUP_SWEEP_JIT_N", "16")):  # (a one-off 400-case run is logged in profiles/)
+    while len(out) < int(os.environ.get("FFTUP_SWEEP_JIT_N", "32" if os.environ.get("FFTUP_BIG_TESTS", "0") != "0" else "10")):  # (a one-off 400-case run is logged in profiles/)
         W, H = int(rng.choice(SMOOTH_BIG)), int(rng.choice(SMOOTH_BIG))
         u = float(rng.choice([2.0, 2.0, 2.0, 3.0, 4.0, 5.0, 1.5, 1.5, 2.5, 1.25, 1.75, 2.25]))
         if os.environ.get("FFTUP_SWEEP_RATIOS", "0") != "0":                    # (one-off runs: eighths and ratios over 3, 5, 7 as well)
@@ -90,7 +90,7 @@ def _sweep_case(W, H, u, p, flags, sharpen, seed, expect_specialised=False):
             # the size-generic kernels are a legitimate answer only where no factorization exists
             assert _lib.load().fftup_jit_check(W, H, float(u), p, None, buf, 256) == 2, "plan fell back although a specialised plan exists"
         up.upload_rgb8(rgb)
-        up.execute(1 + seed % 3)                        # one, two or three iterations: alone on stream 0, or alternating on the plan's streams
+        up.execute(1 + seed % 3)                        # one, two or three iterations (in order, one stream)
         pre = up.download_presharpen().astype(np.float64)
         out = up.download_planar().astype(np.float64)
         u8_planes = up.download_rgb8()                  # (k_pack_u8: four pixels per thread, scalar tail where 4 does not divide uW)

@@ -14,7 +14,8 @@ FLAG_GENERIC_KERNELS = 4
 FLAG_UNFUSED_SHARPEN = 8
 FLAG_TUNE_PLAN = 16
 FLAG_FUSE_U8_STORE = 32
-FLAG_SEQUENTIAL_EXECUTE = 64
+FLAG_SEQUENTIAL_EXECUTE = 64      # (accepted and ignored: ordered iterations are the default)
+FLAG_OVERLAP_ITERATIONS = 128
 
 # every symbol include/fftup.h declares
 EXPORTS = [

@@ -13,6 +13,8 @@
 //   -workqueue    batched mode: threads take the next unprocessed file from ONE shared counter (dynamic balancing over
 //                 threads / GPUs of unequal speed) instead of the static stripe t+1, t+1+T, .. of VR:1622-1629
 //   -tune         FFTUP_FLAG_TUNE_PLAN: time the alternatives for a size specialised at plan time, keep the fastest (wisdom file)
+//   -overlap      FFTUP_FLAG_OVERLAP_ITERATIONS: the -n iterations alternate on the plan's streams ("Time:" = throughput; the
+//                 default keeps them in order like the reference's barriers, VR:1217, vkFFT.h:7678)
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -161,9 +163,9 @@ static int launchResample(ResampleConfiguration config)                      // 
     cfg.width = (uint32_t)width; cfg.height = (uint32_t)height; cfg.channels = 3;
     cfg.upscale = config.upscale; cfg.precision = config.precision; cfg.sharpen = config.sharpenConst;
     cfg.device = device; cfg.flags = config.flags; cfg.ring = config.fileUpload ? 2 : 1;
-    // -n 1 (the default): one frame, nothing to pipeline -- the plan is laid out for single-frame latency; -n N > 1: the N
-    // identical iterations alternate on the plan's streams (fftup_execute), "Time:" is the per-iteration throughput figure
-    if (config.numIter == 1) cfg.flags |= FFTUP_FLAG_SEQUENTIAL_EXECUTE;
+    // -n N: the N iterations run in order on one stream, as the reference's one command buffer with its barriers does
+    // (VR:1260-1265): "Time:" is the figure comparable with the reference's, and the plan (strip cuts included) is the same for
+    // every N.  -overlap (extension, config.flags): the iterations alternate on the plan's streams -- a throughput figure.
     // the batched path below runs on the GPU's shared plan: one frame in flight per thread, sixteen slots at most
     // (a slot is busy for ~0.5 ms per frame; a thread comes back after tens of ms of codec work)
     const bool streamed = config.fileUpload && config.numIter == 1 && config.numFiles > 1;
@@ -306,7 +308,9 @@ int main(int argc, char* argv[])
     char** B = argv;
     char** E = argv + argc;
     if (findFlag(B, E, "-h")) {
-        printf("vkresample (MI355X/HIP build, %s) -- command line of VkResample v1.0.2\n", fftup_version());
+        // (first line: the reference's own banner, VR:1808, for scripts that look for it; then whose build this is)
+        printf("VkResample v1.0.2 (16-01-2021). Author: Tolmachev Dmitrii\n");
+        printf("(command line reproduced by the MI355X/HIP build, %s)\n", fftup_version());
         printf("PNG images only.\n");
         printf("	-h: this help\n");
         printf("	-devices: list the available GPUs\n");
@@ -332,6 +336,7 @@ int main(int argc, char* argv[])
         printf("	-gpupng: batched mode: the GPU also encodes the PNG (row filters, Huffman-only deflate, Adler-32); the host writes the file\n");
         printf("	-stagetimes: batched mode: every thread reports its host time by stage (decode, submit, wait, encode)\n");
         printf("	-tune: sizes whose kernels are specialised at plan time: measure the alternatives once, remember the fastest\n");
+        printf("	-overlap: the -n iterations overlap on several streams: 'Time:' becomes a throughput figure, not the original's serial one\n");
         return 0;
     }
     if (findFlag(B, E, "-devices")) return devices_list();
@@ -372,6 +377,7 @@ int main(int argc, char* argv[])
     if (findFlag(B, E, "-fuseu8out")) config.flags |= FFTUP_FLAG_FUSE_U8_STORE;
     if (findFlag(B, E, "-wrapu8")) config.flags |= FFTUP_FLAG_U8_WRAP;
     if (findFlag(B, E, "-tune")) config.flags |= FFTUP_FLAG_TUNE_PLAN;
+    if (findFlag(B, E, "-overlap")) config.flags |= FFTUP_FLAG_OVERLAP_ITERATIONS;
     config.stageTimes = findFlag(B, E, "-stagetimes");
     config.gpuPng = findFlag(B, E, "-gpupng");
 

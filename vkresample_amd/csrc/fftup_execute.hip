@@ -156,13 +156,13 @@ int fftup_execute(fftup_plan* P, uint32_t n_iter, double* ms_per_iter)
     if (!P) return fail(FFTUP_E_INVALID_ARG, "null plan");
     if (n_iter == 0) return fail(FFTUP_E_INVALID_ARG, "n_iter must be > 0");
     HIP_TRY(hipSetDevice(P->device));
-    // The reference records n_iter identical pipelines in ONE command buffer, submits it once and reports wall time / n_iter
-    // (VR:1260-1278).  The iterations are identical -- same input slot 0, same result -- so nothing orders them: iteration i
-    // runs on stream i mod nl with that stream's own spectra and, beyond stream 0, its own output buffer (stream 0 writes
-    // output slot 0, which is what fftup_download_* read).  A kernel of one iteration then overlaps other kernels of its
-    // neighbours exactly as consecutive frames of fftup_execute_ring do; every iteration computes the bits a lone one computes.
-    // FFTUP_FLAG_SEQUENTIAL_EXECUTE (or FFTUP_STREAMS=1) keeps the strict single-queue form: one stream, nothing overlaps.
-    const bool sequential = (P->cfg.flags & FFTUP_FLAG_SEQUENTIAL_EXECUTE) != 0;
+    // The reference records n_iter identical pipelines in ONE command buffer on one queue, every stage behind a pipeline barrier
+    // (VR:1260-1278, vkFFT.h:7678, VR:1217), and reports wall time / n_iter: the iterations run in order, here on ONE stream.
+    // FFTUP_FLAG_OVERLAP_ITERATIONS (extension): iteration i runs on stream i mod nl with that stream's own spectra and, beyond
+    // stream 0, its own output buffer (stream 0 writes output slot 0, which is what fftup_download_* read); a kernel of one
+    // iteration then overlaps other kernels of its neighbours exactly as consecutive frames of fftup_execute_ring do; every
+    // iteration computes the bits a lone one computes.
+    const bool sequential = !(P->cfg.flags & FFTUP_FLAG_OVERLAP_ITERATIONS);
     const int nl = sequential ? 1 : (int)std::min<uint32_t>((uint32_t)P->nlanes, n_iter);
     int rc = ensure_execute_outputs(P, nl);
     if (rc) return rc;
@@ -200,10 +200,21 @@ int fftup_profile_kernels(fftup_plan* P, uint32_t n_iter, double* ms_per_kernel)
     EventList ev;
     int rc = ev.create((size_t)n_iter * NE);
     if (rc) return rc;
+    // test builds, FFTUP_EXPERIMENT evict_mb=N: N MB are written in front of EVERY kernel launch, so that each kernel starts with
+    // nothing of its predecessor's output in the L2s or the Infinity Cache -- counter calibration runs (the FETCH_SIZE correction
+    // of a kernel is measured on that kernel reading a known number of bytes from HBM); the durations then include the fill
+    void* evict = nullptr;
+    size_t evict_bytes = 0;
+    if (const char* e = fftup_jit::experiment("evict_mb")) {
+        evict_bytes = (size_t)std::max(0, atoi(e)) << 20;
+        if (evict_bytes) HIP_TRY(hipMalloc(&evict, evict_bytes));
+    }
+    struct FreeEvict { void* p; ~FreeEvict() { if (p) (void)hipFree(p); } } free_evict{evict};
     for (uint32_t i = 0; i < n_iter && !rc; i++) {
         hipEvent_t* e = &ev.ev[(size_t)i * NE];
         (void)hipEventRecord(e[0], P->stream);
         for (int k = 0; k < FFTUP_NUM_KERNELS && !rc; k++) {
+            if (evict) (void)hipMemsetAsync(evict, (int)(i + k) & 255, evict_bytes, P->stream);
             rc = launch_frame(P, i % P->ring, i % P->ring, k);
             (void)hipEventRecord(e[k + 1], P->stream);
         }

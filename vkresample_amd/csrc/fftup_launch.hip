@@ -392,7 +392,12 @@ static int launch_frame_f64(fftup_plan* P, uint32_t in_slot, uint32_t out_slot, 
         SharpenParams p{};
         p.R = P->lanes[P->cur].R; p.out = P->out[out_slot]; p.uW = (int)P->uW; p.uH = (int)P->uH; p.upsq = P->upsq; p.coef = P->coef;
         const dim3 sgrid((P->uW + 511) / 512, (P->uH + SHARPEN_F64_RPT - 1) / SHARPEN_F64_RPT, 3);
-        if (P->uW % 2 == 0) hipLaunchKernelGGL(k_sharpen_f64<true>, sgrid, dim3(64, 4), 0, st, p);
+        const char* ex = fftup_jit::experiment("f64_exact_sharpen");          // (test builds: IEEE divisions and root)
+        if (ex && atoi(ex)) {
+            if (P->uW % 2 == 0) hipLaunchKernelGGL((k_sharpen_f64<true, true>), sgrid, dim3(64, 4), 0, st, p);
+            else hipLaunchKernelGGL((k_sharpen_f64<false, true>), sgrid, dim3(64, 4), 0, st, p);
+        }
+        else if (P->uW % 2 == 0) hipLaunchKernelGGL(k_sharpen_f64<true>, sgrid, dim3(64, 4), 0, st, p);
         else hipLaunchKernelGGL(k_sharpen_f64<false>, sgrid, dim3(64, 4), 0, st, p);
     }
     hipError_t e = hipGetLastError();

@@ -173,11 +173,11 @@ int lane_count()
     if (const char* e = getenv("FFTUP_STREAMS")) nl = atoi(e);
     return std::max(1, std::min(nl, 4));
 }
-// Do consecutive frames of this plan overlap on several streams?  A ring of slots (fftup_execute_ring, fftup_submit_rgb8) or the
-// pipelined fftup_execute (every plan without FFTUP_FLAG_SEQUENTIAL_EXECUTE) -- as long as there is more than one stream.
+// Do consecutive frames of this plan overlap on several streams?  A ring of slots (fftup_execute_ring, fftup_submit_rgb8) or
+// FFTUP_FLAG_OVERLAP_ITERATIONS (fftup_execute's extension) -- as long as there is more than one stream.
 static bool frames_overlap(const fftup_plan* P)
 {
-    return lane_count() > 1 && (P->ring > 1 || !(P->cfg.flags & FFTUP_FLAG_SEQUENTIAL_EXECUTE));
+    return lane_count() > 1 && (P->ring > 1 || (P->cfg.flags & FFTUP_FLAG_OVERLAP_ITERATIONS));
 }
 // what the tuner's findings are filed under: the device and whether consecutive frames overlap (what fits beside a strip
 // decides) or run one after the other (the kernel's own time decides)
@@ -190,7 +190,7 @@ static std::string wisdom_device_key(const fftup_plan* P)
 // their last bits, tests/test_gpu_parity.py: test_fused_output_independent_of_strip_length), chosen by how its frames run.
 // Frames that overlap on several streams: ONE strip per compute unit -- the rest of every unit is left to the row and column
 // kernels of the frames on the other streams, and the frame time is what counts.
-// Frames that run one after the other (FFTUP_FLAG_SEQUENTIAL_EXECUTE on a plan without a ring: the CLI's single image, -n 1):
+// Frames that run one after the other (a plan without a ring: fftup_execute's ordered iterations, the CLI's -n N):
 // nothing runs beside a strip, and a workgroup of at most 512 threads (one or two waves per SIMD) does not hide its own
 // latencies: two strips per unit (1080p 100 -> 91 us per iteration, 1000x1000 75 -> 62, 2048x1024 77.2 -> 76.0, -p 2
 // 82.7 -> 79.7; 768 and 1024 threads: 2-7 % slower with two; profiles/r04_s_strips_per_unit_sequential.txt).

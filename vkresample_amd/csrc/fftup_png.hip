@@ -59,9 +59,11 @@ int png_slot_init(fftup_plan* P, fftup_plan::QSlot& Q)
     if (!P->png_crc_shift) {                                      // one table per plan: shift_256^0..15 (crc32.hpp), 2 KB
         uint32_t m[16][32];
         fftup_crc::crc32_shift_256_powers(m);
-        rc = dev_alloc(P, (void**)&P->png_crc_shift, sizeof m);
+        uint32_t* tab = nullptr;                                  // published only once it holds the table: a failed copy must not
+        rc = dev_alloc(P, (void**)&tab, sizeof m);                // leave a pointer behind that the next attempt takes for a filled one
         if (rc) return rc;
-        HIP_TRY(hipMemcpy(P->png_crc_shift, m, sizeof m, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(tab, m, sizeof m, hipMemcpyHostToDevice));
+        P->png_crc_shift = tab;
     }
     p.crc_shift = P->png_crc_shift;
     p.capacity = P->png_stream_bytes;
@@ -134,13 +136,15 @@ int fftup_wait_png(fftup_plan* P, uint64_t ticket, uint8_t* png_out, size_t capa
             if (c.used && c.ticket == ticket && c.png.state == 1 && c.png.ticket == ticket) Qp = &c;
         if (!Qp) return fail(FFTUP_E_INVALID_ARG, "no PNG stream is waiting under this ticket");
         Qp->png.state = 2;                                            // being collected: a second collector of the same ticket finds nothing
+        if (Qp->png.owner != std::this_thread::get_id()) P->png_foreign_collector = true;      // (producer / consumer: submit_frame may wait for us)
     }
     fftup_plan::QSlot& Q = *Qp;
-    // From here on the ticket is this caller's: whatever happens below, the slot is handed back (a slot left in state 1 would
-    // block every later submission that comes round to it).
+    // From here on the ticket is this caller's.  A device error or an overflowed stream voids it and hands the slot back (a slot
+    // left in state 1 would block every later submission that comes round to it); a CALLER's error -- a buffer too small, or not
+    // the one named at submission -- leaves the encoded stream where it is and the ticket collectable again (keep = true).
     struct Release {
-        fftup_plan* P; fftup_plan::QSlot& Q;
-        ~Release() { { std::lock_guard<std::mutex> lock(P->q_mu); Q.png.state = 0; } P->q_cv.notify_all(); }
+        fftup_plan* P; fftup_plan::QSlot& Q; bool keep = false;
+        ~Release() { { std::lock_guard<std::mutex> lock(P->q_mu); Q.png.state = keep ? 1 : 0; } P->q_cv.notify_all(); }
     } release{P, Q};
     HIP_TRY(hipSetDevice(P->device));
     HIP_TRY(hipEventSynchronize(Q.done));
@@ -148,10 +152,16 @@ int fftup_wait_png(fftup_plan* P, uint64_t ticket, uint8_t* png_out, size_t capa
         return fail(FFTUP_E_OVERFLOW, "PNG stream of " + std::to_string((size_t)Q.png.meta_host[2]) + " bytes exceeds the encoder's buffer of " +
                                           std::to_string(P->png_stream_bytes) + ": frame not encoded (use fftup_submit_rgb8 and encode on the host)");
     const size_t zbytes = (size_t)Q.png.meta_host[0];
-    if (zbytes < 6 || zbytes > P->png_stream_bytes || zbytes + 57 > capacity)
-        return fail(FFTUP_E_INVALID_ARG, "PNG buffer too small: " + std::to_string(zbytes + 57) + " bytes needed (fftup_png_bound)");
+    if (zbytes < 6 || zbytes > P->png_stream_bytes) return fail(FFTUP_E_HIP, "PNG encoder reported an impossible stream size");
+    if (zbytes + 57 > capacity) {
+        release.keep = true;
+        return fail(FFTUP_E_INVALID_ARG, "PNG buffer too small: " + std::to_string(zbytes + 57) + " bytes needed (fftup_png_bound); the ticket stays collectable");
+    }
     if (Q.png.dest != png_out) {                           // (delivered by the device already when the buffer was named at submission)
-        if (Q.png.dest) return fail(FFTUP_E_INVALID_ARG, "fftup_wait_png: the buffer named by fftup_submit_png holds this file");
+        if (Q.png.dest) {
+            release.keep = true;
+            return fail(FFTUP_E_INVALID_ARG, "fftup_wait_png: the buffer named by fftup_submit_png holds this file; the ticket stays collectable");
+        }
         HIP_TRY(hipMemcpyAsync(png_out + 41, Q.png.p.stream, zbytes, hipMemcpyDeviceToHost, P->png_copy));
         HIP_TRY(hipEventRecord(Q.png.copied, P->png_copy));
         HIP_TRY(hipEventSynchronize(Q.png.copied));

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -87,21 +88,34 @@ int submit_frame(fftup_plan* P, const uint8_t* rgb_in, size_t in_stride, uint8_t
     // The slot: the next one in turn that holds no uncollected PNG stream (a slot is a set of device buffers; which one a frame
     // goes through is the queue's business -- tickets count submissions).  Taking slots strictly in turn, as round 4 did, lets
     // two threads that each keep a ticket open while submitting wait for each other's slots in a circle; skipping held slots
-    // cannot: while fewer than `ring` streams are uncollected a slot is free.  Every slot held: wait for a collector -- unless
-    // every uncollected stream is this thread's own, which would be waiting for itself (FFTUP_E_WOULD_BLOCK).
+    // cannot: while fewer than `ring` streams are uncollected a slot is free.  Every slot held: wait for a collector.  A slot
+    // that is being collected right now (state 2) is about to be free whoever submitted it.  Slots this thread filled itself
+    // are freed by ANOTHER thread in the producer / consumer pattern (one thread submits, one collects) and by nobody when
+    // the caller does both: the submitter's id alone cannot tell, so once some other thread has collected on this plan the
+    // wait is unconditional, and before that it is bounded -- a consumer that has not started yet gets two seconds to show
+    // up -- and ends in FFTUP_E_WOULD_BLOCK (round 5 returned the error at once: spurious for a producer ahead of its consumer).
     uint32_t s = 0;
+    bool waited_for_self = false;
     for (;;) {                                                        // (the lock is released while waiting: the search starts over)
         bool found = false, others = false;
         for (uint32_t i = 0; i < P->ring && !found; i++) {
             s = (P->q_cursor + i) % P->ring;
             if (P->q[s].png.state == 0) found = true;
-            else if (P->q[s].png.owner != std::this_thread::get_id()) others = true;
+            else if (P->q[s].png.state == 2 || P->q[s].png.owner != std::this_thread::get_id()) others = true;
         }
         if (found) break;
-        if (!others)
-            return fail(FFTUP_E_WOULD_BLOCK, "all " + std::to_string(P->ring) + " ring slot(s) hold PNG tickets of this thread: collect one with "
-                                             "fftup_wait_png before submitting again");
-        P->q_cv.wait(lock);
+        if (others || P->png_foreign_collector) { P->q_cv.wait(lock); continue; }
+        // (FFTUP_SELF_WAIT_MS: the bound, for callers that know better and for tests)
+        const char* sw = getenv("FFTUP_SELF_WAIT_MS");
+        const std::chrono::milliseconds bound(sw ? std::max(0, atoi(sw)) : 2000);
+        if (waited_for_self || P->q_cv.wait_for(lock, bound) == std::cv_status::timeout) {
+            bool still = true;                                        // (a wake-up without a free slot and a time-out both end here)
+            for (uint32_t i = 0; i < P->ring; i++) still = still && P->q[i].png.state == 1 && P->q[i].png.owner == std::this_thread::get_id();
+            if (still && !P->png_foreign_collector)
+                return fail(FFTUP_E_WOULD_BLOCK, "all " + std::to_string(P->ring) + " ring slot(s) hold PNG tickets of this thread and no other thread "
+                                                 "collects on this plan: collect one with fftup_wait_png before submitting again");
+            waited_for_self = true;
+        }
     }
     const uint64_t t = P->q_next.load(std::memory_order_relaxed);
     P->q_cursor = (s + 1) % P->ring;

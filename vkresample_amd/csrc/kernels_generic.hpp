@@ -749,7 +749,9 @@ __device__ __forceinline__ void sharpen_f64_row(double (&L)[4], const double* __
         }
     }
 }
-template <bool EVEN>
+// EXACT (test builds, FFTUP_EXPERIMENT f64_exact_sharpen=1): the filter as the shader writes it, IEEE divisions and root
+// (sharpen_px_f64) -- what sharpen_eval_f64 is measured against in ulps (tests/test_gpu_parity.py)
+template <bool EVEN, bool EXACT = false>
 __global__ void __launch_bounds__(256) k_sharpen_f64(SharpenParams p)
 {
     constexpr int RPT = SHARPEN_F64_RPT;
@@ -786,7 +788,12 @@ __global__ void __launch_bounds__(256) k_sharpen_f64(SharpenParams p)
             const double mn0 = min_f64(min_f64(vmn[k + 1], b[k]), b[k + 2]), mx0 = max_f64(max_f64(vmx[k + 1], b[k]), b[k + 2]);
             // (len[1] + len[3]) + len[5]) + len[7] = ((N + W) + E) + S, left to right as the shader (VkResample.cpp:921)
             const double s4 = ((a[k + 1] + b[k]) + b[k + 2]) + cc[k + 1];
-            o[k] = sharpen_eval_f64(s4, b[k + 1], mn0, mn1, mx0, mx1, m2coef);
+            if constexpr (EXACT) {
+                const double len[9] = {a[k], a[k + 1], a[k + 2], b[k], b[k + 1], b[k + 2], cc[k], cc[k + 1], cc[k + 2]};
+                o[k] = sharpen_px_f64(len, (double)p.coef);
+            } else {
+                o[k] = sharpen_eval_f64(s4, b[k + 1], mn0, mn1, mx0, mx1, m2coef);
+            }
         }
         double* dst = out + ((unsigned)y * (unsigned)uW + (unsigned)x0);
         if constexpr (EVEN) {

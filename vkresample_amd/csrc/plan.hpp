@@ -122,6 +122,7 @@ struct fftup_plan {
     int png_rpb = 0, png_nblocks = 0;  // rows per deflate block, blocks per frame
     size_t png_stream_bytes = 0;       // capacity of a slot's stream buffer
     uint32_t* png_crc_shift = nullptr; // device table of k_png_crc (created with the first PNG slot)
+    bool png_foreign_collector = false; // some thread has collected (fftup_wait_png) a ticket another thread submitted; under q_mu
     float2 *twW = nullptr, *twH = nullptr, *twUW = nullptr, *twUH = nullptr;
     uint64_t device_bytes = 0;
     size_t r_bytes = 0;               // bytes of one pre-sharpen image
