@@ -344,10 +344,12 @@ class PowerSampler:
 
 # kernel name (as rocprofv3 prints it, template arguments cut) -> the plan's kernel slot, and the FETCH_SIZE correction of its access
 # pattern: on gfx950 a 128-byte read request is tallied as 64 bytes, so fully coalesced streaming reads (the row and column kernels:
-# whole rows / whole 64 KB tiles) report half their bytes; the C2R kernels read the blocked spectrum in 32/64-byte pieces (factor 1).
-# Calibrated on known byte counts, profiles/hbm_traffic.json `_method`; WRITE_SIZE matched every kernel's known output within 1 %.
+# whole rows / whole 64 KB tiles) report half their bytes; the two-launch C2R kernels read the blocked spectrum in 64-byte requests
+# (factor 1); the fused kernel's requests are a mix -- calibrated on itself with the caches evicted (round 6): 593 538 requests for
+# 54.6 MB of distinct bytes, factor 1.44 (tools/make_traffic_json.py `_method`, profiles/r06_f_fetch_calibration_evict.txt).
+# WRITE_SIZE matched every kernel's known output within 1 %.
 PMC_KERNELS = (("k_row_r2c", "row_r2c", 2.0), ("k_row_c2c_fwd", "row_c2c", 2.0), ("k_col", "col_fwd_pad_inv", 2.0),
-               ("k_c2r_sharpen", "row_c2r_sharpen", 1.0), ("k_row_c2c_inv", "row_c2c_inv", 1.0), ("k_row_c2r", "row_c2r", 1.0), ("k_sharpen", "sharpen", 1.0))
+               ("k_c2r_sharpen", "row_c2r_sharpen", 1.44), ("k_row_c2c_inv", "row_c2c_inv", 1.0), ("k_row_c2r", "row_c2r", 1.0), ("k_sharpen", "sharpen", 1.0))
 
 
 def live_traffic(argv_config):
@@ -592,7 +594,7 @@ def main():
 
     # ---- timed regions: EXACTLY --steps steps each, barrier + synchronize on both sides, MAX over ranks; median of --repeats
     power = PowerSampler(v.device_pci_bus_id(dev)).start() if rank == 0 else None
-    region_s, region_dev_ms = [], []
+    region_s, region_dev_ms, region_own_s = [], [], []
     kms = [0.0] * len(up.kernel_names)
     for rep in range(max(1, args.repeats)):
         barrier()
@@ -615,6 +617,7 @@ def main():
                 ms = up.execute_ring(args.frames_per_step, slot)
             dev_ms += ms
             slot = (slot + args.frames_per_step) % args.ring
+        t_own = time.perf_counter() - t0      # this rank's own work, before the closing barrier: a sagging rank shows here
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -622,6 +625,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         region_s.append(dt)
+        region_own_s.append(t_own)
         region_dev_ms.append(dev_ms)
     power_stats = power.stop() if power is not None else None
     order = sorted(range(len(region_s)), key=lambda i: region_s[i])
@@ -630,6 +634,12 @@ def main():
 
     frames_per_region = world * args.steps * args.frames_per_step
     fps = frames_per_region / dt
+    # every rank's own rate in the median region (frames it processed / time until ITS work was done): with N ranks on one host the
+    # host-streamed regime shares PCIe root complexes and DRAM bandwidth -- a rank that sags is visible here, not only in the MAX
+    per_rank = None
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "frames_per_s": args.steps * args.frames_per_step / region_own_s[med], "own_s": region_own_s[med]})
     job = None
     if not args.job and dist is not None:
         # any multi-rank run says what the collective and the devices really were (the driver's scaling runs use the default
@@ -760,6 +770,8 @@ def main():
                 ("finished PNG files (encoded on the device) back" if args.png else "uint8 RGB frames back")
             line["pcie_bytes_per_frame"] = pcie
             line["pcie_GBps"] = pcie / (wall_frame_ms * 1e-3) / 1e9
+        if per_rank is not None:
+            line["per_rank_frames_per_s"] = [round(r["frames_per_s"], 1) for r in sorted(per_rank, key=lambda r: r["rank"])]
         if job is not None:
             line["job"] = job
             line["rccl_ranks"] = job["collective_ranks"]

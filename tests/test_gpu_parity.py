@@ -461,6 +461,9 @@ def test_non_r2c_complex_path_vs_oracle(W, H, u, precision, flags):
     four-quadrant shift (VR:527-546) and sharpens the modulus of the complex image; the imaginary input parts, which the
     reference leaves uninitialised, are defined as 0.  The pre-sharpen tap returns the real part."""
     assert O.uses_complex_path(W, H, u, precision)
+    if (W, H, u, precision, flags) in ((4608, 16, 2.0, 2, 0), (3072, 8, 3.0, 2, 2)) and os.environ.get("FFTUP_BIG_TESTS", "0") == "0":
+        pytest.skip("-p 2 beyond the R2C limit: the planar-input and the u = 3 case only with FFTUP_BIG_TESTS=1 (6 s of oracle each; the "
+                    "fused-u8 u = 2 case and the 7168-wide one run)")
     (pre, out, u8), (opre, oout, ou8) = _run(W, H, u, precision, "N", flags=flags, seed=21)
     usq = u * u
     if precision == 0:

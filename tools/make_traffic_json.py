@@ -7,10 +7,18 @@ fully coalesced streaming reads; other patterns have to be calibrated on a known
   * row_r2c reads whole contiguous input rows (128-byte requests): known 25.17 MB, FETCH_SIZE reports 12.4 MB
     -> factor 2.0 (matches the guide);
   * the column kernel reads whole contiguous 64 KB tiles: known 25.19 MB, FETCH_SIZE reports 12.7 MB -> factor 2.0;
-  * the C2R kernels read the blocked spectrum in 32/64-byte pieces (64-byte requests): the two-launch C2R kernel
-    of round 1 read a known 50.38 MB and FETCH_SIZE reported 49.5 MB -> factor 1.0.  For the fused kernel part of the
-    spectrum is still L2-resident from the column kernel (l2_hit_rate), so its fetch figure is below the
-    54 MB it requests (50.4 MB of spectrum rows + one halo pair per strip).
+  * the C2R kernels read the blocked spectrum in 32/64-byte pieces: the two-launch C2R kernel of round 1 read a known
+    50.38 MB and FETCH_SIZE reported 49.5 MB -> factor 1.0 (k_row_c2r*).
+  * the FUSED kernel, calibrated on itself in round 6 (tools/gpu_fetch_calibration.sh, profiles/r06_f_fetch_calibration_*.txt):
+    1 GB written in front of every launch, so nothing of the column pass's output is left in the L2s or the Infinity Cache --
+    TCC_EA0_RDREQ_sum = 593 538 requests per launch with AND without the fill (the "still L2-resident from the column kernel"
+    reading of rounds 2-5 was wrong), TCC_EA0_RDREQ_32B_sum = 0, FETCH_SIZE = requests x 64 B = 37.99 MB.  The kernel needs
+    54.6 MB of DISTINCT bytes (50.38 MB of spectrum rows x 13/12 for one halo pair per strip of 12 pairs) plus ~2 MB of corner rows:
+    at least 44 % of its requests are 128-byte ones tallied at 64 -- its row pairs sit 64 contiguous bytes per tile, 32 bytes off
+    the 64-byte grid, and two consecutive pairs share a 128-byte line.  Factor 1.44 (the lower bound: every distinct byte once;
+    2.0 would be every request 128 bytes = 76 MB), applied to every k_c2r_sharpen_g instantiation (same access pattern).
+    The same run confirms 2.0 for the row pass (197 206 requests x 128 B = 25.24 MB against 25.17 MB of input) and the column
+    pass (198 561 x 128 B = 25.42 MB against 25.26 MB of S1).
 Since round 2 the column kernel writes only the odd spectrum rows (25.2 MB, the even rows are the rows of S1).
 WRITE_SIZE matched the known output bytes of every kernel within 1 % -> factor 1.0.
 """
@@ -21,7 +29,7 @@ import sys
 src = sys.argv[1]            # gpurun_out/<tag>/summary.txt
 out = sys.argv[2]            # profiles/hbm_traffic.json (merged: one entry per configuration key)
 key = sys.argv[3]            # e.g. 2048x1024_p0_planar (bench.py: config_key)
-factor = {"k_row_r2c_t": 2.0, "k_row_r2c": 2.0, "k_col_t": 2.0, "k_col_v": 2.0, "k_row_r2c_m": 2.0, "k_col_m": 2.0, "k_row_r2c_n": 2.0, "k_col_n": 2.0}
+factor = {"k_c2r_sharpen_g": 1.44, "k_row_r2c_t": 2.0, "k_row_r2c": 2.0, "k_col_t": 2.0, "k_col_v": 2.0, "k_row_r2c_m": 2.0, "k_col_m": 2.0, "k_row_r2c_n": 2.0, "k_col_n": 2.0}
 names = {"k_row_r2c_t": "row_r2c", "k_row_r2c": "row_r2c", "k_row_r2c_m": "row_r2c", "k_row_r2c_n": "row_r2c", "k_col_t": "col_fwd_pad_inv", "k_col_v": "col_fwd_pad_inv",
          "k_col": "col_fwd_pad_inv", "k_col_m": "col_fwd_pad_inv", "k_col_n": "col_fwd_pad_inv", "k_c2r_sharpen_g": "row_c2r_sharpen", "k_c2r_sharpen_v": "row_c2r_sharpen",
          "k_row_c2r_t": "row_c2r", "k_row_c2r": "row_c2r", "k_sharpen_t": "sharpen", "k_sharpen": "sharpen"}

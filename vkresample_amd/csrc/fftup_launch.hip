@@ -237,9 +237,16 @@ void launch_pack(fftup_plan* P, uint32_t slot, uint8_t* dst, hipStream_t st)
     else hipLaunchKernelGGL(k_pack_u8<false>, grid, dim3(256), 0, st, P->out[slot], dst, (int)P->uW, (int)P->uH, wrap);
 }
 
+// (test builds, FFTUP_EXPERIMENT planes=1: the row and column passes of the power-of-two plans on the first colour plane only --
+// what one plane's pass costs alone on the whole GPU, the start-up a frame pipelined by planes cannot hide; results invalid)
+static unsigned pass_planes()
+{
+    const char* e = fftup_jit::experiment("planes");
+    return e ? (unsigned)std::max(1, std::min(3, atoi(e))) : 3u;
+}
 template <int W> static void launch_r2c_t(fftup_plan* P, const RowR2CTParams& p, int mode)
 {
-    dim3 grid(P->H / 2, 3), block(W / 8);
+    dim3 grid(P->H / 2, pass_planes()), block(W / 8);
     switch (mode) {
     case IN_F32: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F32, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
     case IN_F16: hipLaunchKernelGGL((k_row_r2c_t<W, IN_F16, TUNED_TK>), grid, block, 0, P->lanes[P->cur].stream, p); break;
@@ -306,9 +313,9 @@ static int launch_frame_tuned(fftup_plan* P, uint32_t in_slot, uint32_t out_slot
         p.S1 = P->lanes[P->cur].S1; p.S2 = P->lanes[P->cur].S2; p.twH = P->twH; p.twUH = P->twUH; p.W = (int)P->W; p.NT = P->NT;
         p.zly = P->zly; p.zry = P->zry;
         switch (P->H) {
-        case 256: hipLaunchKernelGGL((k_col_v<TUNED_TK, 256>), dim3(P->NT, 3), dim3(128), 8192, P->lanes[P->cur].stream, p); break;
-        case 512: hipLaunchKernelGGL((k_col_v<TUNED_TK, 512>), dim3(P->NT, 3), dim3(256), 16384, P->lanes[P->cur].stream, p); break;
-        default: hipLaunchKernelGGL((k_col_v<TUNED_TK, 1024>), dim3(P->NT, 3), dim3(512), 32768, P->lanes[P->cur].stream, p); break;
+        case 256: hipLaunchKernelGGL((k_col_v<TUNED_TK, 256>), dim3(P->NT, pass_planes()), dim3(128), 8192, P->lanes[P->cur].stream, p); break;
+        case 512: hipLaunchKernelGGL((k_col_v<TUNED_TK, 512>), dim3(P->NT, pass_planes()), dim3(256), 16384, P->lanes[P->cur].stream, p); break;
+        default: hipLaunchKernelGGL((k_col_v<TUNED_TK, 1024>), dim3(P->NT, pass_planes()), dim3(512), 32768, P->lanes[P->cur].stream, p); break;
         }
     }
     if ((which < 0 || which == 2) && P->fused) {
