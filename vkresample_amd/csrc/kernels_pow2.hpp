@@ -59,38 +59,7 @@ __device__ __forceinline__ float2 lds_get(unsigned a0, int C)
     return make_float2(r.x, r.y);
 }
 
-// Spectrum stores of the specialised row and column kernels: WRITE-THROUGH (sc1).  With the default policy the 25 MB of spectrum
-// a row or column pass writes sit dirty in the XCDs' L2s when the kernel ends, and the end-of-kernel write-back is serial time
-// in front of the next launch of the stream: row pass 9.0 -> 7.5 us, column pass 14.0 -> 11.5 us, the frame of ordered
-// iterations 78.0 -> 75 us at 2048x1024 (profiles/r06_b_wt_stores.txt; the frame of overlapped iterations does not move).  The
-// output image keeps its non-temporal stores: written through, its lines leave the L2s no earlier but the NEXT kernel pays (row
-// pass behind it 9.9 -> 18.7 us, overlapped frame +2.3 us; same file).  -DFFTUP_SPECTRUM_WT=0 builds the default-policy stores.
-#ifndef FFTUP_SPECTRUM_WT
-#define FFTUP_SPECTRUM_WT 1
-#endif
-typedef float st_f4 __attribute__((ext_vector_type(4)));
-typedef float st_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void spec_store16(float2* dst, float2 a, float2 b)       // dst 16-byte aligned
-{
-#if FFTUP_SPECTRUM_WT
-    const st_f4 v = {a.x, a.y, b.x, b.y};
-    // (s_nop 1: a store of more than 64 bits reads its data registers late -- the compiler, which does not know that this is a
-    // store, may overwrite them in the very next instruction)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
-#else
-    *(float4*)dst = make_float4(a.x, a.y, b.x, b.y);
-#endif
-}
-__device__ __forceinline__ void spec_store8(float2* dst, float2 a)
-{
-#if FFTUP_SPECTRUM_WT
-    const st_f2 v = {a.x, a.y};
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-#else
-    *dst = a;
-#endif
-}
-
+// (spec_store16 / spec_store8 / spec_store: the write-through spectrum stores, fft_engine.hpp)
 // ---- twiddles.  Stage with Ns > 1 of butterfly j needs exp(DIR*2 pi i*m*k/(Ns*R)), k = j % Ns,
 // m < R.  Every thread fetches ONE base twiddle per stage from the table, all of them up front
 // (TwSet::load, issued next to the first-stage input loads so that no stage waits on memory), and
