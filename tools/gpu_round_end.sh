@@ -6,7 +6,7 @@ TAG=${1:-rXXfinal}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -m gpu -q -s --timeout=900 --deselect tests/test_gpu_bench.py::test_bench_single_rank_line > $OUT/pytest_gpu.txt 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu.txt | tail -8
+timeout 2400 python -m pytest tests -m gpu -x -q -s --timeout=900 --durations=20 > $OUT/pytest_gpu.txt 2>&1; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu.txt | tail -8
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -4 $OUT/smoke.txt
 python bench.py > $OUT/bench_fp32.json 2> $OUT/bench.err; cat $OUT/bench_fp32.json
 python bench.py --preset config3 --no-cpu-baseline > $OUT/bench_fp16_u8.json 2>> $OUT/bench.err
@@ -31,6 +31,9 @@ prof fp32_s1 --width 2048 --height 1024
 prof fp16_u8_s1 --width 2048 --height 1024 --precision 2 --flags 2
 prof 1080p_s1 --width 1920 --height 1080
 prof fp16_u8_u8store_s1 --width 2048 --height 1024 --precision 2 --flags 34
+prof fp32_ordered --width 2048 --height 1024 --ring 1          # the plan fftup_execute's ordered iterations run on (no ring: two strips per unit)
+prof fp16_u8_ordered --width 2048 --height 1024 --precision 2 --flags 2 --ring 1
+prof 1080p_ordered --width 1920 --height 1080 --ring 1
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s3 -o bench -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-others --no-live-traffic --no-rccl-check > $R/$OUT/rocprof_fp32_s3.log 2>&1)
 mkdir -p $R/$OUT/prof_fp32_s3; cp $(find /tmp/prof_s3 -name "*kernel_stats.csv" | head -1) $R/$OUT/prof_fp32_s3/; rm -rf /tmp/prof_s3
 head -5 $(find $OUT/prof_fp32_s1 -name "*kernel_stats.csv" | head -1)
@@ -44,8 +47,8 @@ python tools/make_traffic_json.py $OUT/pmc_fp16u8/summary.txt $OUT/hbm_traffic.j
 python tools/make_traffic_json.py $OUT/pmc_1080p/summary.txt $OUT/hbm_traffic.json 1920x1080_p0_planar > /dev/null
 python tools/make_traffic_json.py $OUT/pmc_fp16u8_u8store/summary.txt $OUT/hbm_traffic.json 2048x1024_p2_u8_u8out > /dev/null
 grep -A12 "k_c2r_sharpen_g" $OUT/pmc_fp32/summary.txt | grep -E "==|SQ_INSTS_VALU|FETCH_SIZE|WRITE_SIZE" | head -8
-# the bench-line test needs the refreshed figures: run it last, against them (the suite above ran without it)
+# the bench-line tests against the refreshed figures (in the suite above the committed ones were those of the previous kernels: reported as xfail there)
 cp $OUT/hbm_traffic.json profiles/hbm_traffic.json
 python tools/index_kernel_stats.py 2048x1024_p0_planar $(find $OUT/prof_fp32_s1 -name "*kernel_stats.csv" | head -1) 2048x1024_p2_u8 $(find $OUT/prof_fp16_u8_s1 -name "*kernel_stats.csv" | head -1) \
        1920x1080_p0_planar $(find $OUT/prof_1080p_s1 -name "*kernel_stats.csv" | head -1) 2048x1024_p2_u8_u8out $(find $OUT/prof_fp16_u8_u8store_s1 -name "*kernel_stats.csv" | head -1) > /dev/null
-python -m pytest tests/test_gpu_bench.py::test_bench_single_rank_line -q -m gpu > $OUT/pytest_bench_line.txt 2>&1; tail -2 $OUT/pytest_bench_line.txt
+python -m pytest tests/test_gpu_bench.py -q -m gpu -k "bench_line or single_rank_line" -rx > $OUT/pytest_bench_line.txt 2>&1; tail -8 $OUT/pytest_bench_line.txt
