@@ -160,6 +160,7 @@ def test_cli_flag_handling_without_gpu(tmp_path):
         return r.returncode, r.stdout
     rc, out = run("-h")
     assert rc == 0 and "-ifolder" in out and "-numthreads" in out and "-u X" in out
+    assert out.startswith("VkResample v1.0.2 (16-01-2021)") and "-overlap" in out      # the reference's banner first (VR:1808); the extension is listed
     rc, out = run("-u", "2")
     assert rc == 1 and "No input file is selected with -i flag" in out
     rc, out = run("-i", "x.png")

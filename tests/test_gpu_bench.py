@@ -111,9 +111,10 @@ def test_bench_line_live_counters(bench_line):
         _soft(e["frame_hbm_bytes_measured"] is not None and e["traffic_source"].startswith("live: rocprofv3 --pmc"), "%s: no live counters" % k)
         assert bmin <= e["frame_hbm_bytes_measured"] < 4e8 and e["b_min_frac"] <= e["real_traffic_frac"] < 1.0
         assert set(e["kernel_hbm_bytes_measured"]) == {"row_r2c", "col_fwd_pad_inv", "row_c2r_sharpen"}
-    # (the 8-bit image is written once: the fused kernel's launch moves ~90 MB -- 25 MB of writes, the spectra, and the L2's
-    # reads of the lines it merges the three planes' bytes into -- not the 111 MB of round 3 with 76 MB of writes)
-    assert o["config3_u8_store"]["kernel_hbm_bytes_measured"]["row_c2r_sharpen"] < 1.0e8
+    # (the 8-bit image is written once: 25 MB of writes -- round 3 wrote 76 MB --, the spectra, and the L2's reads of the lines it
+    # merges the three planes' bytes into: ~84 MB of reads under the fused kernel's FETCH correction of round 6 (x1.44; 64 MB x1.0 before))
+    assert o["config3_u8_store"]["kernel_hbm_bytes_measured"]["row_c2r_sharpen"] < 1.3e8
+    assert o["config3_u8_store"]["kernel_hbm_bytes_measured"]["row_c2r_sharpen"] - 1.44 * 64e6 < 3.2e7      # ... i.e. the writes stay one image
 
 
 def test_bench_line_committed_profiles_are_current(bench_line):

@@ -77,6 +77,25 @@ def test_cli_sizes_specialised_at_plan_time(tmp_path, W, H, u, p):
         assert d.max() <= 2 and (d > 1).mean() <= 1e-3          # fp16 storage: a one-ulp flip can move a code by 2
 
 
+def test_cli_time_is_the_ordered_figure_and_overlap_is_an_extension(tmp_path):
+    """-n N runs its iterations in order (the reference's barriers, VR:1217): the output file does not depend on N -- same plan, same
+    strip cuts -- and `-overlap` (FFTUP_FLAG_OVERLAP_ITERATIONS) gives the same picture to rounding, faster per iteration."""
+    from vkresample_amd import synth
+    rgb = synth.frame(5, 2048, 1024, "N")
+    _png_write(tmp_path / "in.png", rgb)
+    outs, times = {}, {}
+    for tag, extra in (("n1", ["-n", "1"]), ("n40", ["-n", "40"]), ("n40_overlap", ["-n", "40", "-overlap"])):
+        r = subprocess.run([CLI, "-i", "in.png", "-o", tag + ".png", "-u", "2"] + extra, capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        times[tag] = float(re.search(r"Time: ([0-9.]+) ms", r.stdout).group(1))
+        outs[tag] = _png_read(tmp_path / (tag + ".png"))
+    assert np.array_equal(outs["n1"], outs["n40"])
+    d = np.abs(outs["n40"].astype(int) - outs["n40_overlap"].astype(int))
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-3
+    print("MEASURED CLI Time: -n 1 %.3f ms, -n 40 %.3f ms, -n 40 -overlap %.3f ms" % (times["n1"], times["n40"], times["n40_overlap"]))
+    assert times["n40_overlap"] <= times["n40"] * 1.05
+
+
 def test_cli_config1_literal_image(tmp_path):
     """BASELINE config 1 end to end: the pixels of the reference's samples/no_upscaling.png (committed as data,
     tests/golden/no_upscaling_rgb.npz; the reference decodes RGBA to 3 channels, VR:1362) -u 2 -p 0 -n 1."""
