@@ -186,6 +186,8 @@ def test_bench_two_ranks_default_preset_says_what_ran():
     assert r.returncode == 0, r.stderr[-3000:]
     d = _line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["preset"] == "config2" and d["rccl_ranks"] == 2 and d["frames_done"] == 2 * 32
+    # every rank's own rate (frames / time until ITS work was done): a sagging rank is visible, the aggregate is below their sum only by the barrier
+    assert len(d["per_rank_frames_per_s"]) == 2 and all(x > 100 for x in d["per_rank_frames_per_s"]) and d["value"] <= 1.001 * sum(d["per_rank_frames_per_s"])
     j = d["job"]
     assert [x["rank"] for x in j["ranks"]] == [0, 1] and [x["frames"] for x in j["ranks"]] == [[0, 7], [8, 15]]
     assert j["distinct_resident_frames"] == 16 and j["checksum"] > 0 and j["ranks"][0]["checksum"] != j["ranks"][1]["checksum"]
