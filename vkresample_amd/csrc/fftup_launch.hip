@@ -660,3 +660,11 @@ void launch_checksum(fftup_plan* P, uint32_t slot, hipStream_t st)
     const size_t nwords = (size_t)3 * P->uW * P->uH * (P->u8out ? 1 : P->esz) / 4;       // (uW, uH even: whole words for binary16 and bytes too)
     hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, st, (const uint32_t*)P->out[slot], nwords, (unsigned long long*)P->d_sum);
 }
+
+#ifdef FFTUP_PLANE_STAMPS
+// measurement build: the workgroups' begin / end stamps of the last frame's row and column pass (tools/plane_stamps.py)
+extern "C" __attribute__((visibility("default"))) int fftup_debug_plane_stamps(unsigned long long* out)
+{
+    return out && hipMemcpyFromSymbol(out, HIP_SYMBOL(fftup::g_plane_stamps), sizeof(unsigned long long) * 3 * 2048 * 3) != hipSuccess;
+}
+#endif

@@ -194,6 +194,7 @@ __global__ void __launch_bounds__(H / 2, kColWaves) k_col_v(ColTParams p)
     const int kk = Q * wu + s1 / WV + 8 * (s1 % WV);          // k0 + 8 k1 of the thread once lane bits 5-3 hold s = WV b + k1
     const int kt = kk + 32 * WV * lb2;                        // the thread's part of k after the forward transform
     float2 v[8];
+    stamp_begin(1, c);
 #pragma unroll
     for (int i = 0; i < 8; i++) v[i] = valid ? src[tid + T * i] : make_float2(0.f, 0.f);        // row pp + (H/8) i
     // ---- forward, exp(+2 pi i n k / H), decimation in time
@@ -278,6 +279,7 @@ __global__ void __launch_bounds__(H / 2, kColWaves) k_col_v(ColTParams p)
 #pragma unroll
         for (int i = 0; i < 8; i++) spec_store8(dst + tid + T * i, cscale(v[i], inv));
     }
+    stamp_end(1, c);
 }
 
 // (A digit-swap row kernel -- 2048 = 8 (registers) x 4 (waves) x 8 x 8 (lane bits), 3 barriers instead of 7, parity-green --

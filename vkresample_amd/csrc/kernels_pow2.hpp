@@ -372,6 +372,18 @@ __device__ __forceinline__ void reg_fft_pp(float2 (&v)[E], float2* __restrict__ 
     }
 }
 
+#ifdef FFTUP_PLANE_STAMPS
+// measurement build (tools/plane_stamps.py): when does each workgroup of the row / column pass begin and end?
+// [kernel 0..1][workgroup][begin, end, plane], 100 MHz wall clock, plain stores
+__device__ unsigned long long g_plane_stamps[3][2048][3];
+__device__ __forceinline__ unsigned stamp_wg() { return blockIdx.x + blockIdx.y * gridDim.x; }
+__device__ __forceinline__ void stamp_begin(int k, int c) { if (threadIdx.x == 0) { g_plane_stamps[k][stamp_wg()][0] = wall_clock64(); g_plane_stamps[k][stamp_wg()][2] = (unsigned long long)c; } }
+__device__ __forceinline__ void stamp_end(int k, int) { __syncthreads(); if (threadIdx.x == 0) g_plane_stamps[k][stamp_wg()][1] = wall_clock64(); }
+#else
+__device__ __forceinline__ void stamp_begin(int, int) {}
+__device__ __forceinline__ void stamp_end(int, int) {}
+#endif
+
 // =================================================================================== row R2C
 struct RowR2CTParams {
     const void* in;
@@ -432,12 +444,14 @@ __global__ void __launch_bounds__(W / 8) k_row_r2c_t(RowR2CTParams p)
     const int j = blockIdx.x;      // (an XCD-aware pair order -- pairs 2i, 2i+1 on one XCD -- measured no gain)
     float2 v[E];
     TwSet<W, E> tws;
+    stamp_begin(0, c);
     tws.load(p.tw, tid);
 #pragma unroll
     for (int i = 0; i < E; i++)
         v[i] = make_float2(load_px_t<MODE>(p, c, 2 * j, tid + T * i), load_px_t<MODE>(p, c, 2 * j + 1, tid + T * i));
     reg_fft<W, E, +1, 1, true>(v, buf, tid, 0, tws);
     row_unpack_store<W, TK>(buf, p, c, j, tid);
+    stamp_end(0, c);
 }
 
 // (Round 4 measured "read the row pair's 2 x 3 W bytes once, 16 bytes per thread, stage them in LDS, transform the three planes
