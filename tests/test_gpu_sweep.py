@@ -24,7 +24,7 @@ def _cases():
     import os
     rng = np.random.default_rng(int(os.environ.get("FFTUP_SWEEP_SEED", "20260930")))
     out = []
-    while len(out) < int(os.environ.get("FFTUP_SWEEP_N", "144" if os.environ.get("FFTUP_BIG_TESTS", "0") != "0" else "36")):      # (a one-off 1500-case run is logged in profiles/)
+    while len(out) < int(os.environ.get("FFTUP_SWEEP_N", "144" if os.environ.get("FFTUP_BIG_TESTS", "0") != "0" else "28")):      # (a one-off 1500-case run is logged in profiles/)
         W, H = int(rng.choice(SMOOTH)), int(rng.choice(SMOOTH))
         u = float(rng.choice([1.0, 1.25, 1.5, 2.0, 2.0, 2.0, 2.5, 3.0, 4.0]))
         uW, uH = int(np.float32(u) * np.float32(W)), int(np.float32(u) * np.float32(H))
@@ -44,7 +44,7 @@ def _cases_specialised():
     import os
     rng = np.random.default_rng(int(os.environ.get("FFTUP_SWEEP_SEED", "20260930")) + 1)
     out = []
-    while len(out) < int(os.environ.get("FFTUP_SWEEP_JIT_N", "32" if os.environ.get("FFTUP_BIG_TESTS", "0") != "0" else "8")):  # (a one-off 400-case run is logged in profiles/)
+    while len(out) < int(os.environ.get("FFTUP_SWEEP_JIT_N", "32" if os.environ.get("FFTUP_BIG_TESTS", "0") != "0" else "6")):  # (a one-off 400-case run is logged in profiles/)
         W, H = int(rng.choice(SMOOTH_BIG)), int(rng.choice(SMOOTH_BIG))
         u = float(rng.choice([2.0, 2.0, 2.0, 3.0, 4.0, 5.0, 1.5, 1.5, 2.5, 1.25, 1.75, 2.25]))
         if os.environ.get("FFTUP_SWEEP_RATIOS", "0") != "0":                    # (one-off runs: eighths and ratios over 3, 5, 7 as well)
