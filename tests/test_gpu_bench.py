@@ -193,7 +193,17 @@ def test_bench_two_ranks_default_preset_says_what_ran():
     assert j["distinct_resident_frames"] == 16 and j["checksum"] > 0 and j["ranks"][0]["checksum"] != j["ranks"][1]["checksum"]
 
 
+_job_cache = {}
+
+
 def _job(nproc, frames_per_step, port):
+    if (nproc, frames_per_step) in _job_cache:              # (the one-rank reference of 16 frames serves two tests)
+        return _job_cache[(nproc, frames_per_step)]
+    _job_cache[(nproc, frames_per_step)] = d = _job_run(nproc, frames_per_step, port)
+    return d
+
+
+def _job_run(nproc, frames_per_step, port):
     env = dict(os.environ, FFTUP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     args = ["bench.py", "--gpus", str(nproc), "--steps", "1", "--warmup", "1", "--repeats", "1", "--precision", "2", "--fuse-u8", "--job",
             "--frames-per-step", str(frames_per_step), "--ring", str(frames_per_step), "--profile-iters", "2", "--no-cpu-baseline", "--no-others",
@@ -296,6 +306,8 @@ def test_eight_rank_dry_run_of_config5():
     assert [x["rank"] for x in eight["job"]["ranks"]] == list(range(8))
     assert [x["first_frames"] for x in eight["job"]["ranks"]] == [[r, r + 8, r + 16] for r in range(8)]
     assert abs(eight["value"] - 8 * 64 / eight["timed_region_s_median"]) < 1e-6 * eight["value"]
+    if os.environ.get("FFTUP_BIG_TESTS", "0") == "0":
+        return                                               # (the shared counter over 8 ranks: FFTUP_BIG_TESTS=1; over 2 ranks it runs in test_job_through_the_shared_counter..)
     # the shared counter over 8 ranks (every rank keeps the step's 128 frames resident)
     q1 = _config5(1, 0, [], frames_per_step=128)
     q8 = _config5(8, 0, ["--queue", "--queue-chunk", "4"], frames_per_step=16)

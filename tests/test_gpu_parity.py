@@ -267,6 +267,8 @@ def test_full_size_vs_oracle(W, H, precision, flags, dist):
     north_star's 1e-4: fp32 pre-sharpen max 6e-7 .. 1e-6 measured -> 1e-5; sharpened "N" frames max 2e-6, p99.99 1.2e-6 ->
     2e-5 / 1.2e-5 and NO pixel above 1e-4; uniform noise max 8.5e-5 (the filter's sqrt has unbounded slope at 0: a handful
     of pixels whose 3x3 minimum is exactly 0 in fp64 amplify fp32 noise) -> 2e-4, p99.99 2.1e-6 -> 2.5e-5."""
+    if dist == "U" and W == 1280 and os.environ.get("FFTUP_BIG_TESTS", "0") == "0":
+        pytest.skip("uniform noise at 1280x720 (not a BASELINE size): FFTUP_BIG_TESTS=1; the natural-statistics frame runs, and both distributions at the BASELINE sizes")
     _check_full_size(W, H, precision, flags, dist)
 
 
